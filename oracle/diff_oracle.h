@@ -1,0 +1,106 @@
+/*
+ * diff_oracle.h -- CPU ORACLE for grav1synth's `diff` film-grain estimator.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check
+ * in __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The
+ * shipped library (grav1synth_amd/libg1s_diff.so) never links or calls it.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in the third-party crate
+ * av1-grain 0.4.2 (reference Cargo.toml:15, Cargo.lock:92-95), whose source is
+ * NOT under /root/reference and cannot be built here (no rustc/cargo).  This
+ * file restates the published algorithm that crate ports (libaom
+ * aom_dsp/noise_model.c + aom_dsp/mathutils.h, shape=square, lag=3,
+ * bit_depth=8, block_size=32, 20 strength bins), anchored on the reference's
+ * own call sites: src/main.rs:420-427 (new), :442/462/482/502 (diff_frame),
+ * :524 (finish), src/parser/grain.rs:108-133 (output fields) and
+ * src/main.rs:631-696 (.tbl writer).  The reference has no test or golden
+ * vector for `diff`, so oracle-vs-reference parity cannot be pinned here.
+ */
+#ifndef DIFF_ORACLE_H
+#define DIFF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_Y_POINTS 14  /* av1_grain::NUM_Y_POINTS  (src/parser/grain.rs:2,27) */
+#define ORC_MAX_UV_POINTS 10 /* av1_grain::NUM_UV_POINTS (src/parser/grain.rs:2,29) */
+#define ORC_MAX_Y_COEFFS 24  /* av1_grain::NUM_Y_COEFFS  (src/parser/grain.rs:2,46) */
+#define ORC_MAX_UV_COEFFS 25 /* av1_grain::NUM_UV_COEFFS (src/parser/grain.rs:2,48) */
+
+/* One decoded frame, as v_frame::Frame<T> is seen at src/reader.rs:183-209. */
+typedef struct {
+  uint32_t width, height;   /* luma dimensions */
+  uint8_t bytes_per_sample; /* 1 (u8) or 2 (u16 native endian) */
+  uint8_t xdec, ydec;       /* chroma subsampling log2 */
+  uint8_t nplanes;          /* 1 (luma only) or 3 */
+  const void *data[3];
+  size_t stride_bytes[3];
+} orc_frame;
+
+/* Mirror of av1_grain::GrainTableSegment as consumed at
+ * src/parser/grain.rs:108-133 and src/main.rs:705-713. */
+typedef struct {
+  uint64_t start_time, end_time;
+  uint16_t random_seed;
+  uint8_t num_y_points, num_cb_points, num_cr_points;
+  uint8_t scaling_points_y[ORC_MAX_Y_POINTS][2];
+  uint8_t scaling_points_cb[ORC_MAX_UV_POINTS][2];
+  uint8_t scaling_points_cr[ORC_MAX_UV_POINTS][2];
+  uint8_t scaling_shift;
+  uint8_t ar_coeff_lag;
+  uint8_t num_y_coeffs, num_uv_coeffs;
+  int8_t ar_coeffs_y[ORC_MAX_Y_COEFFS];
+  int8_t ar_coeffs_cb[ORC_MAX_UV_COEFFS];
+  int8_t ar_coeffs_cr[ORC_MAX_UV_COEFFS];
+  uint8_t ar_coeff_shift;
+  uint8_t cb_mult, cb_luma_mult;
+  uint16_t cb_offset;
+  uint8_t cr_mult, cr_luma_mult;
+  uint16_t cr_offset;
+  uint8_t chroma_scaling_from_luma;
+  uint8_t grain_scale_shift;
+  uint8_t overlap_flag;
+} orc_segment;
+
+typedef struct orc_diff orc_diff;
+
+/* lag: 3 = reference behaviour; 1,2 are the BASELINE.json extension.
+ * chroma: 1 = estimate chroma when planes exist (reference); 0 = luma only. */
+orc_diff *orc_diff_new(int64_t fps_num, int64_t fps_den, int src_bd, int den_bd,
+                       int lag, int chroma);
+/* 0 = ok, <0 = error (message via orc_diff_last_error). */
+int orc_diff_frame(orc_diff *, const orc_frame *src, const orc_frame *den);
+/* Returns number of segments written (<= cap), or <0 on error. */
+int orc_diff_finish(orc_diff *, orc_segment *out, int cap);
+void orc_diff_free(orc_diff *);
+const char *orc_diff_last_error(const orc_diff *);
+
+/* ---- introspection of the LAST frame (for pinning GPU intermediates) ---- */
+/* flat mask bytes (0 / 1 / 255 / 255|1) in block raster order */
+const uint8_t *orc_last_flat_mask(const orc_diff *, int *nbw, int *nbh);
+/* per-block score (f32) and the 4-threshold flag of the last frame */
+const float *orc_last_scores(const orc_diff *);
+/* exact integer shadow sums of plane c of the last frame:
+ * S[i*n+j] = sum r_i*r_j, Sb[i] = sum r_i*y, with the chroma luma-average
+ * regressor pre-scaled by ns = (1<<xdec)*(1<<ydec).  Returns n. */
+int orc_last_ar_sums(const orc_diff *, int c, int64_t *S, int64_t *Sb,
+                     int64_t *nobs);
+/* per-block integer statistics of the last frame (block raster order):
+ * luma_sum[b], and for plane c: sum_d[b], sum_d2[b]. */
+void orc_last_block_stats(const orc_diff *, int c, uint32_t *luma_sum,
+                          int32_t *sum_d, uint32_t *sum_d2);
+/* number of segments emitted so far (DifferentType cuts) */
+int orc_num_segments(const orc_diff *);
+
+/* .tbl text exactly as src/main.rs:525-529,631-696 writes it.  Returns bytes
+ * written (excluding NUL) or <0 if cap is too small. */
+long orc_format_tbl(const orc_segment *segs, int n, char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

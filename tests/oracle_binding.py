@@ -1,0 +1,191 @@
+"""ctypes binding of the CPU oracle (oracle/liborc_diff.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Never imported by the grav1synth_amd package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB_PATH = os.path.join(ORACLE_DIR, "liborc_diff.so")
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("bytes_per_sample", C.c_uint8),
+        ("xdec", C.c_uint8),
+        ("ydec", C.c_uint8),
+        ("nplanes", C.c_uint8),
+        ("data", C.c_void_p * 3),
+        ("stride_bytes", C.c_size_t * 3),
+    ]
+
+
+class OrcSegment(C.Structure):
+    _fields_ = [
+        ("start_time", C.c_uint64),
+        ("end_time", C.c_uint64),
+        ("random_seed", C.c_uint16),
+        ("num_y_points", C.c_uint8),
+        ("num_cb_points", C.c_uint8),
+        ("num_cr_points", C.c_uint8),
+        ("scaling_points_y", (C.c_uint8 * 2) * 14),
+        ("scaling_points_cb", (C.c_uint8 * 2) * 10),
+        ("scaling_points_cr", (C.c_uint8 * 2) * 10),
+        ("scaling_shift", C.c_uint8),
+        ("ar_coeff_lag", C.c_uint8),
+        ("num_y_coeffs", C.c_uint8),
+        ("num_uv_coeffs", C.c_uint8),
+        ("ar_coeffs_y", C.c_int8 * 24),
+        ("ar_coeffs_cb", C.c_int8 * 25),
+        ("ar_coeffs_cr", C.c_int8 * 25),
+        ("ar_coeff_shift", C.c_uint8),
+        ("cb_mult", C.c_uint8),
+        ("cb_luma_mult", C.c_uint8),
+        ("cb_offset", C.c_uint16),
+        ("cr_mult", C.c_uint8),
+        ("cr_luma_mult", C.c_uint8),
+        ("cr_offset", C.c_uint16),
+        ("chroma_scaling_from_luma", C.c_uint8),
+        ("grain_scale_shift", C.c_uint8),
+        ("overlap_flag", C.c_uint8),
+    ]
+
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    L.orc_diff_new.restype = C.c_void_p
+    L.orc_diff_new.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_diff_frame.restype = C.c_int
+    L.orc_diff_frame.argtypes = [C.c_void_p, C.POINTER(OrcFrame), C.POINTER(OrcFrame)]
+    L.orc_diff_finish.restype = C.c_int
+    L.orc_diff_finish.argtypes = [C.c_void_p, C.POINTER(OrcSegment), C.c_int]
+    L.orc_diff_free.argtypes = [C.c_void_p]
+    L.orc_diff_last_error.restype = C.c_char_p
+    L.orc_diff_last_error.argtypes = [C.c_void_p]
+    L.orc_last_flat_mask.restype = C.POINTER(C.c_uint8)
+    L.orc_last_flat_mask.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_last_scores.restype = C.POINTER(C.c_float)
+    L.orc_last_scores.argtypes = [C.c_void_p]
+    L.orc_last_ar_sums.restype = C.c_int
+    L.orc_last_ar_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    L.orc_last_block_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_num_segments.restype = C.c_int
+    L.orc_num_segments.argtypes = [C.c_void_p]
+    L.orc_format_tbl.restype = C.c_long
+    L.orc_format_tbl.argtypes = [C.POINTER(OrcSegment), C.c_int, C.c_char_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _np_frame(planes: Sequence[np.ndarray], xdec: int, ydec: int) -> OrcFrame:
+    f = OrcFrame()
+    f.width = planes[0].shape[1]
+    f.height = planes[0].shape[0]
+    f.bytes_per_sample = planes[0].dtype.itemsize
+    f.xdec, f.ydec = xdec, ydec
+    f.nplanes = len(planes)
+    for i, p in enumerate(planes):
+        assert p.flags["C_CONTIGUOUS"] or p.strides[1] == p.dtype.itemsize
+        f.data[i] = p.ctypes.data
+        f.stride_bytes[i] = p.strides[0]
+    return f
+
+
+class OracleDiff:
+    """The oracle behind the same three-method shape as av1_grain::DiffGenerator
+    (reference src/main.rs:420-427, :442, :524)."""
+
+    def __init__(self, fps_num: int, fps_den: int, src_bd: int, den_bd: int, lag: int = 3, chroma: bool = True):
+        self.L = lib()
+        self.h = self.L.orc_diff_new(fps_num, fps_den, src_bd, den_bd, lag, int(chroma))
+        if not self.h:
+            raise ValueError("orc_diff_new failed (lag must be 1..3)")
+        self.lag = lag
+
+    def diff_frame(self, src: Sequence[np.ndarray], den: Sequence[np.ndarray], xdec: int = 1, ydec: int = 1) -> None:
+        fs = _np_frame(src, xdec, ydec)
+        fd = _np_frame(den, xdec, ydec)
+        rc = self.L.orc_diff_frame(self.h, C.byref(fs), C.byref(fd))
+        if rc != 0:
+            raise RuntimeError(self.L.orc_diff_last_error(self.h).decode())
+
+    def finish(self) -> List[OrcSegment]:
+        arr = (OrcSegment * 256)()
+        n = self.L.orc_diff_finish(self.h, arr, 256)
+        if n < 0:
+            raise RuntimeError("orc_diff_finish failed")
+        return [arr[i] for i in range(n)]
+
+    # ---- last-frame introspection ----
+    def flat_mask(self) -> np.ndarray:
+        nbw, nbh = C.c_int(), C.c_int()
+        p = self.L.orc_last_flat_mask(self.h, C.byref(nbw), C.byref(nbh))
+        return np.ctypeslib.as_array(p, shape=(nbh.value, nbw.value)).copy()
+
+    def scores(self) -> np.ndarray:
+        m = self.flat_mask()
+        p = self.L.orc_last_scores(self.h)
+        return np.ctypeslib.as_array(p, shape=m.shape).copy()
+
+    def ar_sums(self, c: int):
+        n = (2 * self.lag + 1) ** 2 // 2 + (1 if c else 0)
+        S = np.zeros((n, n), dtype=np.int64)
+        Sb = np.zeros(n, dtype=np.int64)
+        nobs = C.c_int64()
+        self.L.orc_last_ar_sums(self.h, c, S.ctypes.data, Sb.ctypes.data, C.byref(nobs))
+        return S, Sb, nobs.value
+
+    def block_stats(self, c: int):
+        m = self.flat_mask()
+        nb = m.size
+        ls = np.zeros(nb, dtype=np.uint32)
+        sd = np.zeros(nb, dtype=np.int32)
+        sd2 = np.zeros(nb, dtype=np.uint32)
+        self.L.orc_last_block_stats(self.h, c, ls.ctypes.data, sd.ctypes.data, sd2.ctypes.data)
+        return ls, sd, sd2
+
+    def num_segments(self) -> int:
+        return self.L.orc_num_segments(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.orc_diff_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_tbl(segs: Sequence[OrcSegment]) -> bytes:
+    L = lib()
+    arr = (OrcSegment * len(segs))(*segs)
+    buf = C.create_string_buffer(1 << 20)
+    n = L.orc_format_tbl(arr, len(segs), buf, len(buf))
+    if n < 0:
+        raise RuntimeError("orc_format_tbl overflow")
+    return buf.raw[:n]
