@@ -1,0 +1,676 @@
+// engine.hip -- host engine + C-ABI of libg1s_diff.so (see include/g1s_diff.h).
+//
+// Frames are queued into a slot of `batch_frames` pairs; a full slot is one
+// K1 -> K2 -> K3 launch group on the engine's HIP stream followed by one D2H
+// copy of the slot's integer records.  Two slots alternate, so the GPU works on
+// batch k+1 while the host folds batch k in frame order (fold.cpp).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/g1s_diff.h"
+#include "fold.h"
+#include "kernels.hip.h"
+#include "record.h"
+
+using namespace g1s;
+
+namespace {
+
+thread_local std::string g_global_error;
+
+constexpr uint32_t kDefaultBatch = 16;
+constexpr int kK3Chunks = 48;
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      char b_[384];                                                                        \
+      snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return fail_hip(b_);                                                                 \
+    }                                                                                      \
+  } while (0)
+
+struct Slot {
+  FramePlanes *h_planes = nullptr;  // pinned
+  FramePlanes *d_planes = nullptr;
+  uint8_t *d_records = nullptr;
+  uint8_t *h_records = nullptr;  // pinned
+  uint8_t *d_flags = nullptr;
+  uint8_t *d_stage = nullptr;  // device copies of host-resident frames
+  size_t stage_bytes_per_frame = 0;
+  hipEvent_t done = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // timing: k1 start, k2 start, k3 start, k3 end
+  uint32_t count = 0;
+  bool timed = false;
+};
+
+}  // namespace
+
+struct g1s_diff {
+  int64_t fps_num, fps_den;
+  uint32_t src_bd, den_bd;
+  uint32_t lag, n;
+  bool luma_only, records_only;
+  uint32_t batch;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool geometry_set = false;
+  g1s_frame_t shape{};  // geometry of the first frame
+  Geom geom{};
+  RecLayout L{};
+  FlatConsts fc{};
+  double *d_lut = nullptr;
+  Slot slots[2];
+  int cur = 0;
+  std::deque<int> in_flight;
+  NoiseFold *fold = nullptr;
+  std::vector<uint8_t> records_out;
+  size_t records_out_frames = 0;
+  std::vector<uint8_t> last_record;
+  std::string err;
+  int deferred = G1S_OK;
+  int sticky = G1S_OK;  // a fold error kills the generator (the reference `?`-propagates out of main)
+  bool finished = false;
+  bool timing = false;
+  g1s_stats_t stats{};
+
+  int fail(int code, const std::string &msg) {
+    err = msg;
+    return code;
+  }
+  int fail_hip(const char *msg) {
+    err = msg;
+    return G1S_ERR_HIP;
+  }
+
+  int set_geometry(const g1s_frame_t *s, const g1s_frame_t *d);
+  int append(const g1s_frame_t *s, const g1s_frame_t *d);
+  int submit(int si);
+  int drain_one();
+  int drain_all();
+  void release();
+};
+
+// The 3x3 inverse of A^T A for the plane fit, built the way
+// FlatBlockFinder::new does (three solves of the normal equations).
+static void make_flat_consts(FlatConsts &fc) {
+  double AtA[9] = {0};
+  for (int y = 0; y < kBlock; ++y) {
+    const double yd = ((double)y - kBlock / 2.) / (kBlock / 2.);
+    for (int x = 0; x < kBlock; ++x) {
+      const double xd = ((double)x - kBlock / 2.) / (kBlock / 2.);
+      const double co[3] = {yd, xd, 1};
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) AtA[3 * i + j] += co[i] * co[j];
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    double A[9], b[3] = {0, 0, 0}, x[3] = {0, 0, 0};
+    std::memcpy(A, AtA, sizeof(A));
+    b[i] = 1;
+    gauss_solve(3, A, b, x);
+    for (int j = 0; j < 3; ++j) fc.ata_inv[j * 3 + i] = x[j];
+  }
+}
+
+int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
+  shape = *s;
+  const uint32_t np = luma_only ? 1u : (uint32_t)s->nplanes;
+  L = make_layout(s->width, s->height, np, lag);
+  Geom &g = geom;
+  g.W = (int)s->width;
+  g.H = (int)s->height;
+  g.xdec = s->xdec;
+  g.ydec = s->ydec;
+  g.nplanes = (int)np;
+  g.nbw = (g.W + kBlock - 1) / kBlock;
+  g.nbh = (g.H + kBlock - 1) / kBlock;
+  g.nblocks = g.nbw * g.nbh;
+  g.src_bps = s->bytes_per_sample;
+  g.den_bps = d->bytes_per_sample;
+  g.src_shift = s->bytes_per_sample == 2 ? (int)src_bd - 8 : 0;
+  g.den_shift = d->bytes_per_sample == 2 ? (int)den_bd - 8 : 0;
+  g.lag = (int)lag;
+  g.n = (int)n;
+  g.rec_size = (uint32_t)L.size;
+  for (int c = 0; c < 3; ++c) {
+    g.off_ar[c] = (uint32_t)L.off_ar[c];
+    g.off_sum_d[c] = (uint32_t)L.off_sum_d[c];
+    g.off_sum_d2[c] = (uint32_t)L.off_sum_d2[c];
+  }
+  g.off_luma_sum = (uint32_t)L.off_luma_sum;
+  g.off_scores = (uint32_t)L.off_scores;
+  g.off_mask = (uint32_t)L.off_mask;
+
+  size_t frame_bytes = 0;  // tight device copy of one frame pair (host-resident input)
+  for (uint32_t c = 0; c < np; ++c) {
+    const size_t pw = c ? (s->width >> s->xdec) : s->width, ph = c ? (s->height >> s->ydec) : s->height;
+    frame_bytes += ((pw * s->bytes_per_sample + 15) & ~size_t(15)) * ph;
+    frame_bytes += ((pw * d->bytes_per_sample + 15) & ~size_t(15)) * ph;
+  }
+  for (Slot &sl : slots) {
+    HIP_TRY(hipHostMalloc((void **)&sl.h_planes, sizeof(FramePlanes) * batch, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&sl.d_planes, sizeof(FramePlanes) * batch));
+    HIP_TRY(hipMalloc((void **)&sl.d_records, L.size * batch));
+    HIP_TRY(hipHostMalloc((void **)&sl.h_records, L.size * batch, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&sl.d_flags, (size_t)g.nblocks * batch));
+    sl.stage_bytes_per_frame = frame_bytes;
+    HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
+  }
+  geometry_set = true;
+  return G1S_OK;
+}
+
+static bool same_shape(const g1s_frame_t &a, const g1s_frame_t &b) {
+  return a.width == b.width && a.height == b.height && a.xdec == b.xdec && a.ydec == b.ydec &&
+         a.nplanes == b.nplanes;
+}
+
+int g1s_diff::append(const g1s_frame_t *s, const g1s_frame_t *d) {
+  if (!s || !d) return fail(G1S_ERR_INVALID, "null frame");
+  if (!same_shape(*s, *d))
+    return fail(G1S_ERR_DIM_MISMATCH, "Source and denoised frame dimensions do not match");
+  if ((s->bytes_per_sample != 1 && s->bytes_per_sample != 2) ||
+      (d->bytes_per_sample != 1 && d->bytes_per_sample != 2) || (s->nplanes != 1 && s->nplanes != 3) ||
+      s->width < 1 || s->height < 1 || s->xdec > 1 || s->ydec > 1)
+    return fail(G1S_ERR_INVALID, "unsupported frame format");
+  if ((s->bytes_per_sample == 1) != (src_bd == 8) || (d->bytes_per_sample == 1) != (den_bd == 8))
+    return fail(G1S_ERR_INVALID, "bytes_per_sample does not match the bit depth given to g1s_diff_new");
+  if (!geometry_set) {
+    const int rc = set_geometry(s, d);
+    if (rc) return rc;
+  } else if (!same_shape(shape, *s) || shape.bytes_per_sample != s->bytes_per_sample) {
+    return fail(G1S_ERR_DIM_MISMATCH, "frame geometry changed mid-stream");
+  }
+  Slot &sl = slots[cur];
+  FramePlanes &fp = sl.h_planes[sl.count];
+  std::memset(&fp, 0, sizeof(fp));
+  const uint32_t np = (uint32_t)geom.nplanes;
+  const bool any_host = !s->on_device || !d->on_device;
+  if (any_host && !sl.d_stage)
+    HIP_TRY(hipMalloc((void **)&sl.d_stage, sl.stage_bytes_per_frame * batch));
+  uint8_t *stage = any_host ? sl.d_stage + sl.stage_bytes_per_frame * sl.count : nullptr;
+  for (int side = 0; side < 2; ++side) {
+    const g1s_frame_t *f = side ? d : s;
+    for (uint32_t c = 0; c < np; ++c) {
+      const size_t pw = c ? (f->width >> f->xdec) : f->width, ph = c ? (f->height >> f->ydec) : f->height;
+      const uint8_t *ptr;
+      uint32_t stride;
+      if (f->on_device) {
+        ptr = (const uint8_t *)f->data[c];
+        stride = (uint32_t)f->stride_bytes[c];
+      } else {
+        const size_t row = (pw * f->bytes_per_sample + 15) & ~size_t(15);
+        // the `&Frame` borrow ends when this call returns: copy now
+        HIP_TRY(hipMemcpy2D(stage, row, f->data[c], f->stride_bytes[c], pw * f->bytes_per_sample, ph,
+                            hipMemcpyHostToDevice));
+        ptr = stage;
+        stride = (uint32_t)row;
+        stage += row * ph;
+      }
+      if (side) {
+        fp.den[c] = ptr;
+        fp.den_stride[c] = stride;
+      } else {
+        fp.src[c] = ptr;
+        fp.src_stride[c] = stride;
+      }
+    }
+  }
+  sl.count++;
+  if (sl.count == batch) return submit(cur);
+  return G1S_OK;
+}
+
+int g1s_diff::submit(int si) {
+  Slot &sl = slots[si];
+  if (sl.count == 0) return G1S_OK;
+  const uint32_t B = sl.count;
+  Geom g = geom;
+  int fast = 1;
+  for (uint32_t i = 0; i < B; ++i) {
+    if (((uintptr_t)sl.h_planes[i].src[0] & 15) || (sl.h_planes[i].src_stride[0] & 15)) fast = 0;
+  }
+  g.fast_rows = fast;
+  HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(sl.d_records, 0, L.size * B, stream));
+  sl.timed = timing;
+  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], stream));
+  {
+    dim3 grid((g.nblocks + 63) / 64, B);
+    if (g.src_bps == 1)
+      hipLaunchKernelGGL(k1_flat_features<1>, grid, dim3(64), 0, stream, sl.d_planes, g, fc, d_lut, sl.d_records, sl.d_flags);
+    else
+      hipLaunchKernelGGL(k1_flat_features<2>, grid, dim3(64), 0, stream, sl.d_planes, g, fc, d_lut, sl.d_records, sl.d_flags);
+  }
+  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], stream));
+  hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(256), 0, stream, g, sl.d_records, sl.d_flags);
+  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], stream));
+  {
+    const int chunks = std::min(kK3Chunks, g.nblocks);
+    hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, sl.d_planes, g, sl.d_records);
+  }
+  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[3], stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(sl.done, stream));
+  in_flight.push_back(si);
+  stats.launches_flat_features++;
+  stats.launches_flat_select++;
+  stats.launches_ar_accumulate++;
+  // move to the other slot; if it is still in flight, fold it first
+  const int other = si ^ 1;
+  while (!in_flight.empty() && in_flight.front() == other) {
+    const int rc = drain_one();
+    if (rc && deferred == G1S_OK) deferred = rc;
+  }
+  cur = other;
+  return G1S_OK;
+}
+
+int g1s_diff::drain_one() {
+  if (in_flight.empty()) return G1S_OK;
+  const int si = in_flight.front();
+  in_flight.pop_front();
+  Slot &sl = slots[si];
+  HIP_TRY(hipEventSynchronize(sl.done));
+  if (sl.timed) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
+    stats.ms_flat_features += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
+    stats.ms_flat_select += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
+    stats.ms_ar_accumulate += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
+    stats.ms_total_gpu += ms;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = G1S_OK;
+  for (uint32_t i = 0; i < sl.count; ++i) {
+    uint8_t *rec = sl.h_records + L.size * i;
+    RecHeader h{};
+    h.magic = kRecMagic;
+    h.lag = lag;
+    h.width = shape.width;
+    h.height = shape.height;
+    h.xdec = shape.xdec;
+    h.ydec = shape.ydec;
+    h.nplanes = (uint32_t)geom.nplanes;
+    h.nbw = (uint32_t)geom.nbw;
+    h.nbh = (uint32_t)geom.nbh;
+    h.n = n;
+    h.size_bytes = L.size;
+    const uint8_t *mask = rec + L.off_mask;
+    uint32_t nflat = 0;
+    for (uint32_t b = 0; b < L.nblocks; ++b) nflat += mask[b] != 0;
+    h.status = nflat;
+    std::memcpy(rec, &h, sizeof(h));
+    // mirror the symmetric AR sums so consumers see full matrices
+    for (int c = 0; c < geom.nplanes; ++c) {
+      int64_t *S = reinterpret_cast<int64_t *>(rec + L.off_ar[c]);
+      const int nc = (int)n + (c > 0);
+      for (int a = 0; a < nc; ++a)
+        for (int b = a + 1; b < nc; ++b) S[b * nc + a] = S[a * nc + b];
+    }
+    stats.frames++;
+    stats.blocks += L.nblocks;
+    stats.flat_blocks += nflat;
+    if (records_only) {
+      records_out.insert(records_out.end(), rec, rec + L.size);
+      records_out_frames++;
+    } else if (sticky == G1S_OK) {
+      rc = fold->push(rec, L.size);
+      if (rc) {
+        err = fold->error();
+        sticky = rc;
+      }
+    }
+  }
+  if (sl.count) last_record.assign(sl.h_records + L.size * (sl.count - 1), sl.h_records + L.size * sl.count);
+  sl.count = 0;
+  stats.ms_host_fold += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
+int g1s_diff::drain_all() {
+  int rc = G1S_OK;
+  while (!in_flight.empty()) {
+    const int r = drain_one();
+    if (r && rc == G1S_OK) rc = r;
+  }
+  return rc;
+}
+
+void g1s_diff::release() {
+  if (stream) (void)hipStreamSynchronize(stream);
+  for (Slot &sl : slots) {
+    if (sl.h_planes) (void)hipHostFree(sl.h_planes);
+    if (sl.d_planes) (void)hipFree(sl.d_planes);
+    if (sl.d_records) (void)hipFree(sl.d_records);
+    if (sl.h_records) (void)hipHostFree(sl.h_records);
+    if (sl.d_flags) (void)hipFree(sl.d_flags);
+    if (sl.d_stage) (void)hipFree(sl.d_stage);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    for (auto &e : sl.ev)
+      if (e) (void)hipEventDestroy(e);
+    sl = Slot{};
+  }
+  if (d_lut) (void)hipFree(d_lut);
+  d_lut = nullptr;
+  if (stream) (void)hipStreamDestroy(stream);
+  stream = nullptr;
+  delete fold;
+  fold = nullptr;
+}
+
+// =============================================================== C ABI =====
+extern "C" {
+
+const char *g1s_last_global_error(void) { return g_global_error.c_str(); }
+
+g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_depth,
+                         uint32_t denoised_bit_depth, const g1s_opts_t *opts) {
+  g_global_error.clear();
+  if (fps_num <= 0 || fps_den <= 0) {
+    g_global_error = "frame rate must be positive";
+    return nullptr;
+  }
+  // src/main.rs:515-517: "Bit depths not between 8-16 are not currently supported"
+  if (source_bit_depth < 8 || source_bit_depth > 16 || denoised_bit_depth < 8 || denoised_bit_depth > 16) {
+    g_global_error = "Bit depths not between 8-16 are not currently supported";
+    return nullptr;
+  }
+  uint32_t lag = 3, batch = kDefaultBatch;
+  bool luma_only = false, records_only = false;
+  int device = -1;
+  if (opts) {
+    if (opts->struct_size != sizeof(g1s_opts_t)) {
+      g_global_error = "g1s_opts_t.struct_size mismatch";
+      return nullptr;
+    }
+    if (opts->ar_coeff_lag) lag = opts->ar_coeff_lag;
+    if (opts->batch_frames) batch = opts->batch_frames;
+    luma_only = opts->luma_only != 0;
+    records_only = opts->records_only != 0;
+    device = opts->device;
+  }
+  if (lag < 1 || lag > 3) {
+    g_global_error = "ar_coeff_lag must be 1..3";
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_global_error = "no HIP device available: the diff estimator has no CPU fallback";
+    return nullptr;
+  }
+  if (device >= 0) {
+    if (hipSetDevice(device) != hipSuccess) {
+      g_global_error = "hipSetDevice failed";
+      return nullptr;
+    }
+  } else if (hipGetDevice(&device) != hipSuccess) {
+    g_global_error = "hipGetDevice failed";
+    return nullptr;
+  }
+  g1s_diff *g = new g1s_diff();
+  g->fps_num = fps_num;
+  g->fps_den = fps_den;
+  g->src_bd = source_bit_depth;
+  g->den_bd = denoised_bit_depth;
+  g->lag = lag;
+  g->n = num_coeffs(lag);
+  g->luma_only = luma_only;
+  g->records_only = records_only;
+  g->batch = batch;
+  g->device = device;
+  make_flat_consts(g->fc);
+  double lut[256];
+  for (int i = 0; i < 256; ++i) lut[i] = ((double)i) / 255.0;  // block normalisation, on the host
+  if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void **)&g->d_lut, sizeof(lut)) != hipSuccess ||
+      hipMemcpy(g->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
+    g_global_error = std::string("HIP initialisation failed: ") + hipGetErrorString(hipGetLastError());
+    g->release();
+    delete g;
+    return nullptr;
+  }
+  if (!records_only) g->fold = new NoiseFold(fps_num, fps_den, lag);
+  return g;
+}
+
+static int take_deferred(g1s_diff *g) {
+  const int rc = g->deferred;
+  g->deferred = G1S_OK;
+  return rc;
+}
+
+int g1s_diff_frame(g1s_diff_t *g, const g1s_frame_t *source, const g1s_frame_t *denoised) {
+  if (!g) return G1S_ERR_INVALID;
+  if (g->finished) return g->fail(G1S_ERR_STATE, "generator already finished");
+  if (g->sticky) return g->sticky;
+  if (g->deferred) return take_deferred(g);
+  (void)hipSetDevice(g->device);
+  const int rc = g->append(source, denoised);
+  if (rc) return rc;
+  return take_deferred(g);
+}
+
+int g1s_diff_frames(g1s_diff_t *g, const g1s_frame_t *source, const g1s_frame_t *denoised, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const int rc = g1s_diff_frame(g, source + i, denoised + i);
+    if (rc) return rc;
+  }
+  return G1S_OK;
+}
+
+int g1s_diff_sync(g1s_diff_t *g) {
+  if (!g) return G1S_ERR_INVALID;
+  (void)hipSetDevice(g->device);
+  if (g->geometry_set) {
+    int rc = g->submit(g->cur);
+    if (rc) return rc;
+    rc = g->drain_all();
+    if (rc && g->deferred == G1S_OK) g->deferred = rc;
+  }
+  if (g->sticky) return g->sticky;
+  return take_deferred(g);
+}
+
+int g1s_diff_finish(g1s_diff_t *g, g1s_segment_t *out, size_t cap, size_t *n_out) {
+  if (!g) return G1S_ERR_INVALID;
+  if (g->finished) return g->fail(G1S_ERR_STATE, "generator already finished");
+  if (g->records_only) return g->fail(G1S_ERR_STATE, "records_only generator: use g1s_diff_take_records + g1s_fold_*");
+  const int rc = g1s_diff_sync(g);
+  if (rc) return rc;
+  g->finished = true;
+  std::vector<g1s_segment_t> segs;
+  g->fold->finish(segs);
+  if (n_out) *n_out = segs.size();
+  if (segs.size() > cap) return g->fail(G1S_ERR_CAPACITY, "segment buffer too small");
+  std::memcpy(out, segs.data(), sizeof(g1s_segment_t) * segs.size());
+  return G1S_OK;
+}
+
+void g1s_diff_free(g1s_diff_t *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  g->release();
+  delete g;
+}
+
+const char *g1s_diff_last_error(const g1s_diff_t *g) { return g ? g->err.c_str() : ""; }
+
+size_t g1s_record_size(uint32_t width, uint32_t height, uint32_t xdec, uint32_t ydec, uint32_t nplanes,
+                       uint32_t lag) {
+  (void)xdec;
+  (void)ydec;
+  return make_layout(width, height, nplanes, lag).size;
+}
+
+int g1s_record_init(void *rec, size_t cap_bytes, uint32_t width, uint32_t height, uint32_t xdec,
+                    uint32_t ydec, uint32_t nplanes, uint32_t lag) {
+  if (!rec || lag < 1 || lag > 3 || (nplanes != 1 && nplanes != 3)) return G1S_ERR_INVALID;
+  const RecLayout L = make_layout(width, height, nplanes, lag);
+  if (L.size > cap_bytes) return G1S_ERR_CAPACITY;
+  std::memset(rec, 0, L.size);
+  RecHeader h{};
+  h.magic = kRecMagic;
+  h.lag = lag;
+  h.width = width;
+  h.height = height;
+  h.xdec = xdec;
+  h.ydec = ydec;
+  h.nplanes = nplanes;
+  h.nbw = (width + kBlock - 1) / kBlock;
+  h.nbh = (height + kBlock - 1) / kBlock;
+  h.n = num_coeffs(lag);
+  h.size_bytes = L.size;
+  std::memcpy(rec, &h, sizeof(h));
+  return G1S_OK;
+}
+
+int g1s_diff_take_records(g1s_diff_t *g, void *buf, size_t cap_bytes, size_t *n_frames) {
+  if (!g) return G1S_ERR_INVALID;
+  if (!g->records_only) return g->fail(G1S_ERR_STATE, "not a records_only generator");
+  const int rc = g1s_diff_sync(g);
+  if (rc) return rc;
+  if (n_frames) *n_frames = g->records_out_frames;
+  if (g->records_out.size() > cap_bytes) return g->fail(G1S_ERR_CAPACITY, "record buffer too small");
+  if (!g->records_out.empty()) std::memcpy(buf, g->records_out.data(), g->records_out.size());
+  g->records_out.clear();
+  g->records_out_frames = 0;
+  return G1S_OK;
+}
+
+struct g1s_fold {
+  NoiseFold fold;
+  std::string err;
+  bool finished = false;
+  g1s_fold(int64_t a, int64_t b, uint32_t lag) : fold(a, b, lag) {}
+};
+
+g1s_fold_t *g1s_fold_new(int64_t fps_num, int64_t fps_den, uint32_t lag) {
+  if (fps_num <= 0 || fps_den <= 0 || lag < 1 || lag > 3) return nullptr;
+  return new g1s_fold(fps_num, fps_den, lag);
+}
+int g1s_fold_push(g1s_fold_t *f, const void *record, size_t size_bytes) {
+  if (!f || !record) return G1S_ERR_INVALID;
+  if (f->finished) return G1S_ERR_STATE;
+  const int rc = f->fold.push((const uint8_t *)record, size_bytes);
+  if (rc) f->err = f->fold.error();
+  return rc;
+}
+int g1s_fold_finish(g1s_fold_t *f, g1s_segment_t *out, size_t cap, size_t *n_out) {
+  if (!f) return G1S_ERR_INVALID;
+  if (f->finished) return G1S_ERR_STATE;
+  f->finished = true;
+  std::vector<g1s_segment_t> segs;
+  f->fold.finish(segs);
+  if (n_out) *n_out = segs.size();
+  if (segs.size() > cap) {
+    f->err = "segment buffer too small";
+    return G1S_ERR_CAPACITY;
+  }
+  std::memcpy(out, segs.data(), sizeof(g1s_segment_t) * segs.size());
+  return G1S_OK;
+}
+void g1s_fold_free(g1s_fold_t *f) { delete f; }
+const char *g1s_fold_last_error(const g1s_fold_t *f) { return f ? f->err.c_str() : ""; }
+
+long g1s_format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap) {
+  return format_tbl(segs, n, buf, cap);
+}
+int g1s_write_tbl(const char *path, const g1s_segment_t *segs, size_t n) {
+  std::vector<char> buf(1024 + 2048 * n);
+  const long k = format_tbl(segs, n, buf.data(), buf.size());
+  if (k < 0) return (int)k;
+  FILE *f = fopen(path, "wb");
+  if (!f) return G1S_ERR_INVALID;
+  const size_t w = fwrite(buf.data(), 1, (size_t)k, f);
+  const int c = fclose(f);
+  return (w == (size_t)k && c == 0) ? G1S_OK : G1S_ERR_INVALID;
+}
+
+int g1s_diff_get_stats(const g1s_diff_t *g, g1s_stats_t *out) {
+  if (!g || !out) return G1S_ERR_INVALID;
+  *out = g->stats;
+  return G1S_OK;
+}
+int g1s_diff_set_timing(g1s_diff_t *g, int enable) {
+  if (!g) return G1S_ERR_INVALID;
+  g->timing = enable != 0;
+  return G1S_OK;
+}
+
+int g1s_diff_last_record(const g1s_diff_t *g, void *buf, size_t cap_bytes) {
+  if (!g || !buf) return G1S_ERR_INVALID;
+  if (g->last_record.empty()) return G1S_ERR_STATE;
+  if (g->last_record.size() > cap_bytes) return G1S_ERR_CAPACITY;
+  std::memcpy(buf, g->last_record.data(), g->last_record.size());
+  return G1S_OK;
+}
+
+static bool rec_layout(const void *rec, RecHeader &h, RecLayout &L) {
+  if (!rec) return false;
+  std::memcpy(&h, rec, sizeof(h));
+  if (h.magic != kRecMagic) return false;
+  L = make_layout(h.width, h.height, h.nplanes, h.lag);
+  return L.size == h.size_bytes;
+}
+int g1s_record_geometry(const void *rec, uint32_t *nbw, uint32_t *nbh, uint32_t *nplanes, uint32_t *lag) {
+  RecHeader h;
+  RecLayout L;
+  if (!rec_layout(rec, h, L)) return G1S_ERR_INVALID;
+  if (nbw) *nbw = h.nbw;
+  if (nbh) *nbh = h.nbh;
+  if (nplanes) *nplanes = h.nplanes;
+  if (lag) *lag = h.lag;
+  return G1S_OK;
+}
+const uint8_t *g1s_record_flat_mask(const void *rec) {
+  RecHeader h;
+  RecLayout L;
+  if (!rec_layout(rec, h, L)) return nullptr;
+  return (const uint8_t *)rec + L.off_mask;
+}
+const float *g1s_record_scores(const void *rec) {
+  RecHeader h;
+  RecLayout L;
+  if (!rec_layout(rec, h, L)) return nullptr;
+  return reinterpret_cast<const float *>((const uint8_t *)rec + L.off_scores);
+}
+int g1s_record_ar_sums(const void *rec, uint32_t c, const int64_t **S, const int64_t **Sb, int64_t *nobs) {
+  RecHeader h;
+  RecLayout L;
+  if (!rec_layout(rec, h, L) || c >= h.nplanes) return G1S_ERR_INVALID;
+  const int nc = (int)h.n + (c > 0);
+  const int64_t *p = reinterpret_cast<const int64_t *>((const uint8_t *)rec + L.off_ar[c]);
+  if (S) *S = p;
+  if (Sb) *Sb = p + (size_t)nc * nc;
+  if (nobs) *nobs = p[(size_t)nc * nc + nc];
+  return nc;
+}
+int g1s_record_block_stats(const void *rec, uint32_t c, const uint32_t **luma_sum, const int32_t **sum_d,
+                           const uint32_t **sum_d2) {
+  RecHeader h;
+  RecLayout L;
+  if (!rec_layout(rec, h, L) || c >= h.nplanes) return G1S_ERR_INVALID;
+  const uint8_t *r = (const uint8_t *)rec;
+  if (luma_sum) *luma_sum = reinterpret_cast<const uint32_t *>(r + L.off_luma_sum);
+  if (sum_d) *sum_d = reinterpret_cast<const int32_t *>(r + L.off_sum_d[c]);
+  if (sum_d2) *sum_d2 = reinterpret_cast<const uint32_t *>(r + L.off_sum_d2[c]);
+  return (int)L.nblocks;
+}
+
+}  // extern "C"

@@ -1,0 +1,550 @@
+// fold.cpp -- ordered host fold of per-frame integer records (see fold.h).
+//
+// Follows av1_grain::DiffGenerator / NoiseModel (crate av1-grain 0.4.2, a port
+// of libaom aom_dsp/noise_model.c) as it is driven from the reference at
+// src/main.rs:420-427, :442, :524.  Must be compiled with -ffp-contract=off:
+// the f64 operation order below is part of the contract.
+#include "fold.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace g1s {
+
+namespace {
+constexpr double kTiny = 1.0e-16;        // TINY_NEAR_ZERO
+constexpr double kNorm2 = 255.0 * 255.0;  // BLOCK_NORMALIZATION^2
+constexpr uint16_t kDefaultGrainSeed = 10956;  // av1_grain::DEFAULT_GRAIN_SEED (src/parser/frame.rs:3)
+inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+}  // namespace
+
+// ---------------------------------------------------------------- solver ---
+bool gauss_solve(int n, double *A, double *b, double *x) {
+  // forward elimination with the reference's "bubble the larger magnitude up
+  // one row at a time" pivoting
+  for (int k = 0; k < n - 1; ++k) {
+    for (int i = n - 1; i > k; --i) {
+      double *lo = A + (i - 1) * n, *hi = A + i * n;
+      if (std::fabs(lo[k]) < std::fabs(hi[k])) {
+        for (int j = 0; j < n; ++j) std::swap(lo[j], hi[j]);
+        std::swap(b[i], b[i - 1]);
+      }
+    }
+    const double *pivot = A + k * n;
+    for (int i = k; i < n - 1; ++i) {
+      if (std::fabs(pivot[k]) < kTiny) return false;
+      double *row = A + (i + 1) * n;
+      const double c = row[k] / pivot[k];
+      for (int j = 0; j < n; ++j) row[j] -= c * pivot[j];
+      b[i + 1] -= c * b[k];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const double *row = A + i * n;
+    if (std::fabs(row[i]) < kTiny) return false;
+    double c = 0;
+    for (int j = i + 1; j <= n - 1; ++j) c += row[j] * x[j];
+    x[i] = (b[i] - c) / row[i];
+  }
+  return true;
+}
+
+void LinearSystem::resize(int n_) {
+  n = n_;
+  A.assign(size_t(n) * n, 0.0);
+  b.assign(n, 0.0);
+  x.assign(n, 0.0);
+}
+void LinearSystem::clear() {
+  std::fill(A.begin(), A.end(), 0.0);
+  std::fill(b.begin(), b.end(), 0.0);
+  std::fill(x.begin(), x.end(), 0.0);
+}
+void LinearSystem::add(const LinearSystem &o) {
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) A[i * n + j] += o.A[i * n + j];
+    b[i] += o.b[i];
+  }
+}
+void LinearSystem::assign(const LinearSystem &o) {
+  A = o.A;
+  b = o.b;
+  x = o.x;
+}
+bool LinearSystem::solve() {
+  double At[kMaxN * kMaxN], bt[kMaxN];
+  std::memcpy(At, A.data(), sizeof(double) * n * n);
+  std::memcpy(bt, b.data(), sizeof(double) * n);
+  return gauss_solve(n, At, bt, x.data());
+}
+
+// ------------------------------------------------------- strength solver ---
+StrengthSolver::StrengthSolver() { eq.resize(kNumBins); }
+void StrengthSolver::clear() {
+  eq.clear();
+  num_equations = 0;
+  total = 0.0;
+}
+void StrengthSolver::add(const StrengthSolver &o) {
+  eq.add(o.eq);
+  num_equations += o.num_equations;
+  total += o.total;
+}
+double StrengthSolver::bin_index(double value) {
+  const double val = clampd(value, 0.0, 255.0);
+  return (kNumBins - 1) * val / 255.0;
+}
+double StrengthSolver::value_at(double x) const {
+  const double bin = bin_index(x);
+  const int i0 = (int)std::floor(bin);
+  const int i1 = std::min(kNumBins - 1, i0 + 1);
+  const double a = bin - i0;
+  return (1.0 - a) * eq.x[i0] + a * eq.x[i1];
+}
+void StrengthSolver::add_measurement(double block_mean, double noise_std) {
+  const double bin = bin_index(block_mean);
+  const int i0 = (int)std::floor(bin);
+  const int i1 = std::min(kNumBins - 1, i0 + 1);
+  const double a = bin - i0;
+  const int n = kNumBins;
+  eq.A[i0 * n + i0] += (1.0 - a) * (1.0 - a);
+  eq.A[i1 * n + i0] += a * (1.0 - a);
+  eq.A[i1 * n + i1] += a * a;
+  eq.A[i0 * n + i1] += a * (1.0 - a);
+  eq.b[i0] += (1.0 - a) * noise_std;
+  eq.b[i1] += a * noise_std;
+  total += noise_std;
+  num_equations++;
+}
+bool StrengthSolver::solve() {
+  // Regularised solve on a copy of A; b keeps the mean/8192 term (the
+  // reference does not restore it either).
+  const int n = kNumBins;
+  const double alpha = 2.0 * (double)num_equations / n;
+  double At[kNumBins * kNumBins], bt[kNumBins];
+  std::memcpy(At, eq.A.data(), sizeof(At));
+  for (int i = 0; i < n; ++i) {
+    const int lo = std::max(0, i - 1), hi = std::min(n - 1, i + 1);
+    At[i * n + lo] -= alpha;
+    At[i * n + i] += 2 * alpha;
+    At[i * n + hi] -= alpha;
+  }
+  const double mean = total / num_equations;
+  for (int i = 0; i < n; ++i) {
+    At[i * n + i] += 1.0 / 8192.;
+    eq.b[i] += mean / 8192.;
+  }
+  std::memcpy(bt, eq.b.data(), sizeof(bt));
+  return gauss_solve(n, At, bt, eq.x.data());
+}
+double StrengthSolver::center(int i) { return ((double)i) / (kNumBins - 1) * 255.0; }
+
+void StrengthSolver::fit_piecewise(int max_points, std::vector<double> &px,
+                                   std::vector<double> &py) const {
+  const double tolerance = 255.0 * 0.00625 / 255.0;
+  const double dxbin = 255. / kNumBins;
+  px.resize(kNumBins);
+  py.resize(kNumBins);
+  for (int i = 0; i < kNumBins; ++i) {
+    px[i] = center(i);
+    py[i] = eq.x[i];
+  }
+  std::vector<double> residual(kNumBins, 0.0);
+  auto update = [&](int start, int end) {
+    const int np = (int)px.size();
+    for (int i = std::max(start, 1); i < std::min(end, np - 1); ++i) {
+      const int lower = std::max(0, (int)std::floor(bin_index(px[i - 1])));
+      const int upper = std::min(kNumBins - 1, (int)std::ceil(bin_index(px[i + 1])));
+      double r = 0;
+      for (int j = lower; j <= upper; ++j) {
+        const double x = center(j);
+        if (x < px[i - 1]) continue;
+        if (x >= px[i + 1]) continue;
+        const double y = eq.x[j];
+        const double a = (x - px[i - 1]) / (px[i + 1] - px[i - 1]);
+        const double estimate_y = py[i - 1] * (1.0 - a) + py[i + 1] * a;
+        r += std::fabs(y - estimate_y);
+      }
+      residual[i] = r * dxbin;
+    }
+  };
+  update(0, kNumBins);
+  while (px.size() > 2) {
+    int min_index = 1;
+    for (int j = 1; j < (int)px.size() - 1; ++j)
+      if (residual[j] < residual[min_index]) min_index = j;
+    const double dx = px[min_index + 1] - px[min_index - 1];
+    const double avg_residual = residual[min_index] / dx;
+    if ((int)px.size() <= max_points && avg_residual > tolerance) break;
+    px.erase(px.begin() + min_index);
+    py.erase(py.begin() + min_index);
+    residual.erase(residual.begin() + min_index);
+    update(min_index - 1, min_index + 1);
+  }
+}
+
+// ------------------------------------------------------------ noise fold ---
+NoiseFold::NoiseFold(int64_t fps_num, int64_t fps_den, uint32_t lag)
+    : fps_num_(fps_num), fps_den_(fps_den), lag_(lag), n_((int)num_coeffs(lag)) {
+  for (int c = 0; c < 3; ++c) {
+    latest_[c].ar.resize(n_ + (c > 0));
+    combined_[c].ar.resize(n_ + (c > 0));
+  }
+}
+
+bool NoiseFold::ar_solve(PlaneState &s, bool is_chroma) {
+  const bool ok = s.ar.solve();
+  s.ar_gain = 1.0;
+  if (!ok) return false;
+  // mean of the diagonal = variance of the correlated noise
+  const int n = s.ar.n;
+  const int m = n - (is_chroma ? 1 : 0);
+  double var = 0;
+  for (int i = 0; i < m; ++i) var += s.ar.A[i * n + i] / s.num_observations;
+  var /= m;
+  // E(y^2) = <b - A(:,end) x(end), x>
+  double sum_covar = 0;
+  for (int i = 0; i < m; ++i) {
+    double bi = s.ar.b[i];
+    if (is_chroma) bi -= s.ar.A[i * n + (n - 1)] * s.ar.x[n - 1];
+    sum_covar += (bi * s.ar.x[i]) / s.num_observations;
+  }
+  const double t = var - sum_covar;
+  const double noise_var = t > 1e-6 ? t : 1e-6;
+  const double q = var / noise_var;
+  const double g = std::sqrt(q > 1e-6 ? q : 1e-6);
+  s.ar_gain = 1 > g ? 1 : g;
+  return true;
+}
+
+bool NoiseFold::is_different() const {
+  const LinearSystem &l = latest_[0].ar, &c = combined_[0].ar;
+  double dot = 0, l2 = 0, c2 = 0;
+  for (int i = 0; i < c.n; ++i) {
+    l2 += l.x[i] * l.x[i];
+    c2 += c.x[i] * c.x[i];
+    dot += l.x[i] * c.x[i];
+  }
+  const double corr = dot / (std::sqrt(l2) * std::sqrt(c2));
+  if (corr < 0.9) return true;
+  const double dx = 1.0 / kNumBins;
+  const LinearSystem &ls = latest_[0].strength.eq, &cs = combined_[0].strength.eq;
+  double diff = 0, total_weight = 0;
+  for (int j = 0; j < ls.n; ++j) {
+    double weight = 0;
+    for (int i = 0; i < ls.n; ++i) weight += ls.A[i * ls.n + j];
+    weight = std::sqrt(weight);
+    diff += weight * std::fabs(ls.x[j] - cs.x[j]);
+    total_weight += weight;
+  }
+  return diff * dx / total_weight > 0.005;
+}
+
+void NoiseFold::save_latest() {
+  for (int c = 0; c < 3; ++c) {
+    combined_[c].ar.assign(latest_[c].ar);
+    combined_[c].strength.eq.assign(latest_[c].strength.eq);
+    combined_[c].strength.num_equations = latest_[c].strength.num_equations;
+    // (strength.total is deliberately NOT copied: reference quirk)
+    combined_[c].num_observations = latest_[c].num_observations;
+    combined_[c].ar_gain = latest_[c].ar_gain;
+  }
+}
+
+static void set_error(std::string &dst, const char *fmt, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  dst = buf;
+}
+
+int NoiseFold::push(const uint8_t *rec, size_t size) {
+  if (size < sizeof(RecHeader)) {
+    set_error(err_, "record too small");
+    return G1S_ERR_INVALID;
+  }
+  RecHeader h;
+  std::memcpy(&h, rec, sizeof(h));
+  if (h.magic != kRecMagic || h.lag != lag_ || h.size_bytes > size) {
+    set_error(err_, "bad record header (magic/lag/size)");
+    return G1S_ERR_INVALID;
+  }
+  const RecLayout L = make_layout(h.width, h.height, h.nplanes, h.lag);
+  if (L.size != h.size_bytes) {
+    set_error(err_, "record layout mismatch");
+    return G1S_ERR_INVALID;
+  }
+  const int nbw = (int)h.nbw, nbh = (int)h.nbh;
+  const uint8_t *mask = rec + L.off_mask;
+  const uint32_t *luma_sum = reinterpret_cast<const uint32_t *>(rec + L.off_luma_sum);
+  const int w = (int)h.width, hh = (int)h.height;
+
+  for (int c = 0; c < 3; ++c) {
+    latest_[c].ar.clear();
+    latest_[c].num_observations = 0;
+    latest_[c].strength.clear();
+  }
+  int num_flat = 0;
+  for (int i = 0; i < nbw * nbh; ++i) num_flat += mask[i] != 0;
+  if (num_flat <= 1) {
+    set_error(err_, "Not enough flat blocks to update noise estimate");
+    return G1S_ERR_NOT_ENOUGH_FLAT;
+  }
+
+  bool y_model_different = false;
+  for (int c = 0; c < (int)h.nplanes; ++c) {
+    const bool is_chroma = c != 0;
+    const int sx = is_chroma ? (int)h.xdec : 0, sy = is_chroma ? (int)h.ydec : 0;
+    PlaneState &lat = latest_[c];
+    const int nc = lat.ar.n;
+    // ---- exact integer sums -> f64 normal equations (one rounding each) ----
+    {
+      const int64_t *S = reinterpret_cast<const int64_t *>(rec + L.off_ar[c]);
+      const int64_t *Sb = S + size_t(nc) * nc;
+      const double ns = (double)((1 << sx) * (1 << sy));
+      for (int i = 0; i < nc; ++i) {
+        for (int j = 0; j < nc; ++j) {
+          double den = kNorm2;
+          if (is_chroma && i == nc - 1) den *= ns;
+          if (is_chroma && j == nc - 1) den *= ns;
+          // the device fills the upper triangle; the matrix is symmetric
+          const int64_t s = i <= j ? S[i * nc + j] : S[j * nc + i];
+          lat.ar.A[i * nc + j] = (double)s / den;
+        }
+        double den = kNorm2;
+        if (is_chroma && i == nc - 1) den *= ns;
+        lat.ar.b[i] = (double)Sb[i] / den;
+      }
+      lat.num_observations = Sb[nc];
+    }
+    if (!ar_solve(lat, is_chroma)) {
+      if (is_chroma) {
+        // fallback: zero AR coefficients, keep only the luma correlation
+        std::fill(lat.ar.x.begin(), lat.ar.x.end(), 0.0);
+        const int last = nc - 1;
+        if (std::fabs(lat.ar.A[last * nc + last]) > 1e-6)
+          lat.ar.x[last] = lat.ar.b[last] / lat.ar.A[last * nc + last];
+      } else {
+        set_error(err_, "Solving latest noise equation system failed %d!", c);
+        return G1S_ERR_SOLVE;
+      }
+    }
+    // ---- noise strength vs. intensity measurements, block raster order ----
+    {
+      const int32_t *sum_d = reinterpret_cast<const int32_t *>(rec + L.off_sum_d[c]);
+      const uint32_t *sum_d2 = reinterpret_cast<const uint32_t *>(rec + L.off_sum_d2[c]);
+      const int bw = kBlock >> sx, bh = kBlock >> sy;
+      const double luma_gain = latest_[0].ar_gain;
+      const double noise_gain = lat.ar_gain;
+      const double corr = is_chroma ? lat.ar.x[n_] : 0;
+      for (int by = 0; by < nbh; ++by) {
+        for (int bx = 0; bx < nbw; ++bx) {
+          const int bi = by * nbw + bx;
+          if (!mask[bi]) continue;
+          const int sh = std::min((hh >> sy) - by * bh, bh);
+          const int sw = std::min((w >> sx) - bx * bw, bw);
+          if (sw * sh > kBlock) {
+            const int lw = std::min(w - bx * kBlock, kBlock), lh = std::min(hh - by * kBlock, kBlock);
+            const double block_mean = (double)luma_sum[bi] / (lw * lh);
+            double noise_mean = (double)sum_d[bi];
+            const double noise_sq = (double)sum_d2[bi];
+            noise_mean /= (sw * sh);
+            const double noise_var = noise_sq / (sw * sh) - noise_mean * noise_mean;
+            const double luma_strength =
+                is_chroma ? luma_gain * latest_[0].strength.value_at(block_mean) : 0;
+            const double cl = corr * luma_strength;
+            const double t0 = noise_var / 16, t1 = noise_var - cl * cl;
+            const double uncorr_std = std::sqrt(t0 > t1 ? t0 : t1);
+            lat.strength.add_measurement(block_mean, uncorr_std / noise_gain);
+          }
+        }
+      }
+    }
+    if (!lat.strength.solve()) {
+      set_error(err_, "Solving latest noise strength failed!");
+      return G1S_ERR_SOLVE;
+    }
+    if (c == 0 && combined_[0].strength.num_equations > 0 && is_different()) y_model_different = true;
+    if (y_model_different) continue;
+
+    PlaneState &com = combined_[c];
+    com.num_observations += lat.num_observations;
+    com.ar.add(lat.ar);
+    if (!ar_solve(com, is_chroma)) {
+      if (is_chroma) {
+        std::fill(com.ar.x.begin(), com.ar.x.end(), 0.0);
+        const int last = nc - 1;
+        if (std::fabs(com.ar.A[last * nc + last]) > 1e-6)
+          com.ar.x[last] = com.ar.b[last] / com.ar.A[last * nc + last];
+      } else {
+        set_error(err_, "Solving combined noise equation system failed %d!", c);
+        return G1S_ERR_SOLVE;
+      }
+    }
+    com.strength.add(lat.strength);
+    if (!com.strength.solve()) {
+      set_error(err_, "Solving combined noise strength failed!");
+      return G1S_ERR_SOLVE;
+    }
+  }
+
+  if (y_model_different) {
+    const uint64_t cur = frame_count_ * 10000000ULL * (uint64_t)fps_den_ / (uint64_t)fps_num_;
+    table_.push_back(grain_parameters(prev_timestamp_, cur));
+    save_latest();
+    prev_timestamp_ = cur;
+  }
+  frame_count_ += 1;
+  return G1S_OK;
+}
+
+void NoiseFold::finish(std::vector<g1s_segment_t> &out) {
+  table_.push_back(grain_parameters(prev_timestamp_, (uint64_t)INT64_MAX));
+  out = table_;
+}
+
+g1s_segment_t NoiseFold::grain_parameters(uint64_t start_ts, uint64_t end_ts) const {
+  g1s_segment_t g;
+  std::memset(&g, 0, sizeof(g));
+  g.random_seed = start_ts == 0 ? kDefaultGrainSeed : 0;
+  g.start_time = start_ts;
+  g.end_time = end_ts;
+  g.ar_coeff_lag = (uint8_t)lag_;
+
+  std::vector<double> px[3], py[3];
+  combined_[0].strength.fit_piecewise(G1S_NUM_Y_POINTS, px[0], py[0]);
+  combined_[1].strength.fit_piecewise(G1S_NUM_UV_POINTS, px[1], py[1]);
+  combined_[2].strength.fit_piecewise(G1S_NUM_UV_POINTS, px[2], py[2]);
+  double max_scaling_value = 1e-4;
+  for (int c = 0; c < 3; ++c) {
+    for (size_t i = 0; i < px[c].size(); ++i) {
+      px[c][i] = std::min(255.0, px[c][i]);
+      py[c][i] = std::min(255.0, py[c][i]);
+      if (py[c][i] > max_scaling_value) max_scaling_value = py[c][i];
+    }
+  }
+  const int log2v = clampi((int)std::floor(std::log2(max_scaling_value) + 1), 2, 5);
+  g.scaling_shift = (uint8_t)(5 + (8 - log2v));
+  const double scale_factor = 1 << (8 - log2v);
+  g.num_y_points = (uint8_t)px[0].size();
+  g.num_cb_points = (uint8_t)px[1].size();
+  g.num_cr_points = (uint8_t)px[2].size();
+  uint8_t(*dst[3])[2] = {g.scaling_points_y, g.scaling_points_cb, g.scaling_points_cr};
+  for (int c = 0; c < 3; ++c) {
+    for (size_t i = 0; i < px[c].size(); ++i) {
+      dst[c][i][0] = (uint8_t)clampi((int)(px[c][i] + 0.5), 0, 255);
+      dst[c][i][1] = (uint8_t)clampi((int)(scale_factor * py[c][i] + 0.5), 0, 255);
+    }
+  }
+
+  const int n_coeff = n_;
+  double max_coeff = 1e-4, min_coeff = -1e-4;
+  double y_corr[2] = {0, 0};
+  double avg_luma_strength = 0;
+  for (int c = 0; c < 3; ++c) {
+    const LinearSystem &eq = combined_[c].ar;
+    for (int i = 0; i < n_coeff; ++i) {
+      if (eq.x[i] > max_coeff) max_coeff = eq.x[i];
+      if (eq.x[i] < min_coeff) min_coeff = eq.x[i];
+    }
+    const LinearSystem &se = combined_[c].strength.eq;
+    double average_strength = 0, total_weight = 0;
+    for (int i = 0; i < se.n; ++i) {
+      double wgt = 0;
+      for (int j = 0; j < se.n; ++j) wgt += se.A[i * se.n + j];
+      wgt = std::sqrt(wgt);
+      average_strength += se.x[i] * wgt;
+      total_weight += wgt;
+    }
+    if (total_weight == 0)
+      average_strength = 1;
+    else
+      average_strength /= total_weight;
+    if (c == 0) {
+      avg_luma_strength = average_strength;
+    } else {
+      y_corr[c - 1] = avg_luma_strength * eq.x[n_coeff] / average_strength;
+      if (y_corr[c - 1] > max_coeff) max_coeff = y_corr[c - 1];
+      if (y_corr[c - 1] < min_coeff) min_coeff = y_corr[c - 1];
+    }
+  }
+  {
+    const double a = 1 + std::floor(std::log2(max_coeff));
+    const double b = std::ceil(std::log2(-min_coeff));
+    g.ar_coeff_shift = (uint8_t)clampi(7 - (int)(a > b ? a : b), 6, 9);
+  }
+  const double scale_ar = 1 << g.ar_coeff_shift;
+  int8_t *ar[3] = {g.ar_coeffs_y, g.ar_coeffs_cb, g.ar_coeffs_cr};
+  for (int c = 0; c < 3; ++c) {
+    const LinearSystem &eq = combined_[c].ar;
+    for (int i = 0; i < n_coeff; ++i)
+      ar[c][i] = (int8_t)clampi((int)std::round(scale_ar * eq.x[i]), -128, 127);
+    if (c > 0) ar[c][n_coeff] = (int8_t)clampi((int)std::round(scale_ar * y_corr[c - 1]), -128, 127);
+  }
+  g.num_y_coeffs = (uint8_t)n_coeff;
+  g.num_uv_coeffs = (uint8_t)(n_coeff + 1);
+  g.cb_mult = 128;
+  g.cb_luma_mult = 192;
+  g.cb_offset = 256;
+  g.cr_mult = 128;
+  g.cr_luma_mult = 192;
+  g.cr_offset = 256;
+  g.chroma_scaling_from_luma = 0;
+  g.grain_scale_shift = 0;
+  g.overlap_flag = 1;
+  return g;
+}
+
+// ---------------------------------------------------------------- .tbl ----
+long format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap) {
+  std::string s = "filmgrn1\n";
+  char line[512];
+  for (size_t k = 0; k < n; ++k) {
+    const g1s_segment_t &g = segs[k];
+    snprintf(line, sizeof(line), "E %llu %llu 1 %u 1\n", (unsigned long long)g.start_time,
+             (unsigned long long)g.end_time, (unsigned)g.random_seed);
+    s += line;
+    snprintf(line, sizeof(line), "\tp %u %u %u %u %u %u %u %u %u %u %u %u\n", g.ar_coeff_lag,
+             g.ar_coeff_shift, g.grain_scale_shift, g.scaling_shift, g.chroma_scaling_from_luma,
+             g.overlap_flag, g.cb_mult, g.cb_luma_mult, g.cb_offset, g.cr_mult, g.cr_luma_mult,
+             g.cr_offset);
+    s += line;
+    auto points = [&](const char *tag, const uint8_t(*p)[2], int np) {
+      s += tag;
+      for (int i = 0; i < np; ++i) {
+        snprintf(line, sizeof(line), " %u %u", p[i][0], p[i][1]);
+        s += line;
+      }
+      s += "\n";
+    };
+    // "\tsY {n} " keeps its trailing space before the points (src/main.rs:659)
+    snprintf(line, sizeof(line), "\tsY %u ", g.num_y_points);
+    points(line, g.scaling_points_y, g.num_y_points);
+    snprintf(line, sizeof(line), "\tsCb %u", g.num_cb_points);
+    points(line, g.scaling_points_cb, g.num_cb_points);
+    snprintf(line, sizeof(line), "\tsCr %u", g.num_cr_points);
+    points(line, g.scaling_points_cr, g.num_cr_points);
+    auto coeffs = [&](const char *tag, const int8_t *c, int nc) {
+      s += tag;
+      for (int i = 0; i < nc; ++i) {
+        snprintf(line, sizeof(line), " %d", c[i]);
+        s += line;
+      }
+      s += "\n";
+    };
+    coeffs("\tcY", g.ar_coeffs_y, g.num_y_coeffs);
+    coeffs("\tcCb", g.ar_coeffs_cb, g.num_uv_coeffs);
+    coeffs("\tcCr", g.ar_coeffs_cr, g.num_uv_coeffs);
+  }
+  if (s.size() > cap) return G1S_ERR_CAPACITY;
+  std::memcpy(buf, s.data(), s.size());
+  return (long)s.size();
+}
+
+}  // namespace g1s

@@ -1,0 +1,85 @@
+// fold.h -- the ORDERED part of DiffGenerator, on the host.
+//
+// The HIP kernels turn each frame pair into a record of exact integers
+// (record.h).  What remains of av1_grain::DiffGenerator::diff_frame /
+// ::finish (reference call sites src/main.rs:442 and :524) is sequential in
+// frame order and tiny (24/25-dim AR solves, 20-bin strength solves, the
+// is-the-noise-different test, quantisation): that is this class.  It is the
+// product's own implementation; the test oracle under oracle/ is separate.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/g1s_diff.h"
+#include "record.h"
+
+namespace g1s {
+
+constexpr int kNumBins = 20;
+
+// Dense square system A x = b with the elimination order of the reference
+// solver (libaom linsolve == av1-grain solver::util::linsolve).
+struct LinearSystem {
+  int n = 0;
+  std::vector<double> A, b, x;
+  void resize(int n_);
+  void clear();
+  void add(const LinearSystem &o);
+  void assign(const LinearSystem &o);
+  bool solve();  // works on copies of A and b; writes x
+};
+
+bool gauss_solve(int n, double *A, double *b, double *x);
+
+struct StrengthSolver {
+  LinearSystem eq;
+  int num_equations = 0;
+  double total = 0.0;
+  StrengthSolver();
+  void clear();
+  void add(const StrengthSolver &o);
+  static double bin_index(double value);
+  double value_at(double x) const;
+  void add_measurement(double block_mean, double noise_std);
+  bool solve();
+  static double center(int i);
+  // piecewise-linear simplification -> (x, y) points
+  void fit_piecewise(int max_points, std::vector<double> &px, std::vector<double> &py) const;
+};
+
+struct PlaneState {
+  LinearSystem ar;
+  StrengthSolver strength;
+  int64_t num_observations = 0;
+  double ar_gain = 1.0;
+};
+
+class NoiseFold {
+ public:
+  NoiseFold(int64_t fps_num, int64_t fps_den, uint32_t lag);
+  // Consumes one record (frame order!).  Returns G1S_OK or an error code;
+  // message in error().
+  int push(const uint8_t *rec, size_t size);
+  void finish(std::vector<g1s_segment_t> &out);
+  const std::string &error() const { return err_; }
+  uint64_t frames() const { return frame_count_; }
+
+ private:
+  bool ar_solve(PlaneState &s, bool is_chroma);
+  bool is_different() const;
+  void save_latest();
+  g1s_segment_t grain_parameters(uint64_t start_ts, uint64_t end_ts) const;
+
+  int64_t fps_num_, fps_den_;
+  uint32_t lag_;
+  int n_;
+  PlaneState latest_[3], combined_[3];
+  uint64_t frame_count_ = 0, prev_timestamp_ = 0;
+  std::vector<g1s_segment_t> table_;
+  std::string err_;
+};
+
+long format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap);
+
+}  // namespace g1s

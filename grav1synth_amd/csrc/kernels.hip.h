@@ -1,0 +1,429 @@
+// kernels.hip.h -- gfx950 device code of the `diff` estimator.
+//
+//   K1 flat_features : per 32x32 luma block, the plane-fit residual + gradient
+//                      covariance features of FlatBlockFinder::run
+//                      (av1-grain diff/solver.rs == libaom
+//                      aom_flat_block_finder_run), one lane per block, f64 in
+//                      the reference's summation order (decision-exact).
+//   K2 flat_select   : per frame, the k-th order statistic of the f32 scores
+//                      (index nblocks*90/100 of the ascending order) by radix
+//                      select, then the 0/1/255 mask.
+//   K3 ar_accumulate : per plane, exact integer AR normal-equation sums
+//                      (add_block_observations) + per-block noise statistics
+//                      (get_block_mean / get_noise_var) over the flat blocks.
+//
+// Reference call site of all of it: differ.diff_frame(...) src/main.rs:442.
+// Compile with -ffp-contract=off: K1 must not contract mul+add into FMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "record.h"
+
+namespace g1s {
+
+struct FramePlanes {
+  const uint8_t *src[3];
+  const uint8_t *den[3];
+  uint32_t src_stride[3];
+  uint32_t den_stride[3];
+};
+
+struct Geom {
+  int W, H, xdec, ydec, nplanes;
+  int nbw, nbh, nblocks;
+  int src_bps, den_bps, src_shift, den_shift;
+  int lag, n;
+  int fast_rows;  // all luma source rows 16-byte aligned (base and stride)
+  // record layout (bytes from the start of a frame's record)
+  uint32_t rec_size;
+  uint32_t off_ar[3], off_luma_sum, off_sum_d[3], off_sum_d2[3], off_scores, off_mask;
+};
+
+struct FlatConsts {
+  double ata_inv[9];  // (A^T A)^-1 of the 1024x3 plane-fit design matrix
+};
+
+// ----------------------------------------------------------------------------
+// sample access: u8, or u16 narrowed by the truncating shift of
+// av1-grain util.rs frame_into_u8 (`(v >> (bd - 8)) as u8`)
+// ----------------------------------------------------------------------------
+template <int BPS>
+__device__ __forceinline__ int load_px(const uint8_t *base, uint32_t stride, int shift, int x, int y) {
+  if (BPS == 1) return base[(size_t)y * stride + x];
+  const uint16_t v = reinterpret_cast<const uint16_t *>(base + (size_t)y * stride)[x];
+  return (int)(uint8_t)(v >> shift);
+}
+__device__ __forceinline__ int load_px_rt(const uint8_t *base, uint32_t stride, int bps, int shift, int x, int y) {
+  return bps == 1 ? load_px<1>(base, stride, shift, x, y) : load_px<2>(base, stride, shift, x, y);
+}
+
+// 32 consecutive samples of one row -> 32 bytes packed in 8 dwords.
+template <int BPS>
+__device__ __forceinline__ void load_row32(const uint8_t *base, uint32_t stride, int shift, int ox, int y,
+                                           int W, bool fast, uint32_t (&pk)[8]) {
+  if (fast) {
+    if (BPS == 1) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(base + (size_t)y * stride + ox);
+      const uint4 a = p[0], b = p[1];
+      pk[0] = a.x; pk[1] = a.y; pk[2] = a.z; pk[3] = a.w;
+      pk[4] = b.x; pk[5] = b.y; pk[6] = b.z; pk[7] = b.w;
+    } else {
+      const uint4 *p = reinterpret_cast<const uint4 *>(base + (size_t)y * stride + 2 * (size_t)ox);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 a = p[q];
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t lo = w[2 * h], hi = w[2 * h + 1];
+          pk[2 * q + h] = (((lo & 0xffffu) >> shift) & 0xffu) | ((((lo >> 16) >> shift) & 0xffu) << 8) |
+                          ((((hi & 0xffffu) >> shift) & 0xffu) << 16) | ((((hi >> 16) >> shift) & 0xffu) << 24);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = min(ox + 4 * q + k, W - 1);
+        v |= (uint32_t)load_px<BPS>(base, stride, shift, x, y) << (8 * k);
+      }
+      pk[q] = v;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// K1: flat-block features.  One lane per 32x32 block; every f64 sum runs in the
+// reference's order (k = 0..1023 raster for the plane fit, (yi, xi) raster over
+// the 30x30 interior for the gradient sums), so the four threshold decisions
+// and the f32 score are those of the scalar CPU algorithm.
+// grid = (ceil(nblocks/64), batch), block = 64.
+// ----------------------------------------------------------------------------
+template <int BPS>
+__global__ __launch_bounds__(64) void k1_flat_features(const FramePlanes *__restrict__ frames, Geom g,
+                                                       FlatConsts fc, const double *__restrict__ lut_g,
+                                                       uint8_t *__restrict__ records,
+                                                       uint8_t *__restrict__ flags) {
+  __shared__ double lut[256];
+  for (int i = threadIdx.x; i < 256; i += 64) lut[i] = lut_g[i];
+  __syncthreads();
+  const int frame = blockIdx.y;
+  const int blk = blockIdx.x * 64 + threadIdx.x;
+  if (blk >= g.nblocks) return;
+  const FramePlanes fp = frames[frame];
+  const uint8_t *base = fp.src[0];
+  const uint32_t stride = fp.src_stride[0];
+  const int shift = g.src_shift;
+  const int bx = blk % g.nbw, by = blk / g.nbw;
+  const int ox = bx * kBlock, oy = by * kBlock;
+  const bool fast = g.fast_rows && (ox + kBlock <= g.W);
+
+  // ---- pass 1: t = block(1x1024) * A(1024x3), sequential sums from 0.0 ----
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+  for (int yi = 0; yi < kBlock; ++yi) {
+    const int y = min(oy + yi, g.H - 1);
+    uint32_t pk[8];
+    load_row32<BPS>(base, stride, shift, ox, y, g.W, fast, pk);
+    const double yd = (double)(yi - 16) * 0.0625;
+#pragma unroll
+    for (int xi = 0; xi < kBlock; ++xi) {
+      const double v = lut[(pk[xi >> 2] >> (8 * (xi & 3))) & 0xffu];
+      const double xd = (double)(xi - 16) * 0.0625;
+      t0 += v * yd;
+      t1 += v * xd;
+      t2 += v;  // v * 1.0
+    }
+  }
+  // coef = AtA_inv(3x3) * t, each a sequential sum from 0.0
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+  c0 += fc.ata_inv[0] * t0; c0 += fc.ata_inv[1] * t1; c0 += fc.ata_inv[2] * t2;
+  c1 += fc.ata_inv[3] * t0; c1 += fc.ata_inv[4] * t1; c1 += fc.ata_inv[5] * t2;
+  c2 += fc.ata_inv[6] * t0; c2 += fc.ata_inv[7] * t1; c2 += fc.ata_inv[8] * t2;
+
+  // ---- pass 2: residual rows + gradient covariance over the interior ----
+  // residual(yi, xi) = block - (((0 + yd*c0) + xd*c1) + 1*c2)
+  double ra[kBlock], rb[kBlock];
+  auto resid_row = [&](int yi, double (&out)[kBlock]) {
+    const int y = min(oy + yi, g.H - 1);
+    uint32_t pk[8];
+    load_row32<BPS>(base, stride, shift, ox, y, g.W, fast, pk);
+    const double yc = 0.0 + ((double)(yi - 16) * 0.0625) * c0;
+#pragma unroll
+    for (int xi = 0; xi < kBlock; ++xi) {
+      const double xd = (double)(xi - 16) * 0.0625;
+      const double fit = (yc + xd * c1) + c2;
+      out[xi] = lut[(pk[xi >> 2] >> (8 * (xi & 3))) & 0xffu] - fit;
+    }
+  };
+  double Gxx = 0.0, Gxy = 0.0, Gyy = 0.0, var = 0.0, mean = 0.0;
+  // `up` holds row yi-1 and is overwritten in place by row yi+1 as we go
+  auto grad_row = [&](int yi, double (&up)[kBlock], const double (&cur)[kBlock]) {
+    const int y = min(oy + yi + 1, g.H - 1);
+    uint32_t pk[8];
+    load_row32<BPS>(base, stride, shift, ox, y, g.W, fast, pk);
+    const double yc = 0.0 + ((double)(yi + 1 - 16) * 0.0625) * c0;
+#pragma unroll
+    for (int xi = 0; xi < kBlock; ++xi) {
+      const double xd = (double)(xi - 16) * 0.0625;
+      const double fit = (yc + xd * c1) + c2;
+      const double nv = lut[(pk[xi >> 2] >> (8 * (xi & 3))) & 0xffu] - fit;
+      if (xi >= 1 && xi <= kBlock - 2) {
+        const double gx = (cur[xi + 1] - cur[xi - 1]) * 0.5;
+        const double gy = (nv - up[xi]) * 0.5;
+        Gxx += gx * gx;
+        Gxy += gx * gy;
+        Gyy += gy * gy;
+        mean += cur[xi];
+        var += cur[xi] * cur[xi];
+      }
+      up[xi] = nv;
+    }
+  };
+  resid_row(0, ra);
+  resid_row(1, rb);
+  for (int yi = 1; yi < kBlock - 1; yi += 2) {
+    grad_row(yi, ra, rb);      // ra: row yi-1 -> row yi+1
+    grad_row(yi + 1, rb, ra);  // rb: row yi   -> row yi+2
+  }
+
+  const double nf = (double)((kBlock - 2) * (kBlock - 2));
+  mean /= nf;
+  Gxx /= nf;
+  Gxy /= nf;
+  Gyy /= nf;
+  var = var / nf - mean * mean;
+  const double trace = Gxx + Gyy;
+  const double det = Gxx * Gyy - Gxy * Gxy;
+  double disc = trace * trace - 4.0 * det;
+  if (!(disc > 0.0)) disc = 0.0;
+  const double sq = sqrt(disc);
+  const double e1 = (trace + sq) / 2.0;
+  const double e2 = (trace - sq) / 2.0;
+  const double norm = e1;
+  const double ratio = e1 / (e2 > 1e-6 ? e2 : 1e-6);
+  const double kTrace = 0.15 / 1024.0, kRatio = 1.25, kNorm = 0.08 / 1024.0, kVar = 0.005 / 1024.0;
+  const bool is_flat = (trace < kTrace) && (ratio < kRatio) && (norm < kNorm) && (var > kVar);
+  double sw = -6682.0 * var + -0.2056 * ratio + 13087.0 * trace + -12434.0 * norm + 2.5694;
+  sw = sw < -25.0 ? -25.0 : (sw > 100.0 ? 100.0 : sw);
+  const float score = (float)(1.0 / (1.0 + exp(-sw)));
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  reinterpret_cast<float *>(rec + g.off_scores)[blk] = var > kVar ? score : 0.0f;
+  flags[(size_t)frame * g.nblocks + blk] = is_flat ? 255 : 0;
+}
+
+// ----------------------------------------------------------------------------
+// K2: per frame, threshold = scores_sorted_ascending[nblocks*90/100]; every
+// block with score >= threshold gets `|= 1` (union with the 4-threshold flag).
+// All scores are >= +0.0f, so their bit patterns order like the floats.
+// grid = (batch), block = 256.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
+                                                      const uint8_t *__restrict__ flags) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_prefix, s_rank;
+  const int frame = blockIdx.x;
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  const uint32_t *sc = reinterpret_cast<const uint32_t *>(rec + g.off_scores);
+  const int nb = g.nblocks;
+  uint32_t prefix = 0, prefix_mask = 0;
+  uint32_t rank = (uint32_t)(nb * 90 / 100);  // 0-based rank in ascending order
+  for (int pass = 3; pass >= 0; --pass) {
+    for (int i = threadIdx.x; i < 256; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int sh = 8 * pass;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+      const uint32_t v = sc[i];
+      if ((v & prefix_mask) == prefix) atomicAdd(&hist[(v >> sh) & 0xffu], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t r = rank, b = 0;
+      for (; b < 256; ++b) {
+        if (r < hist[b]) break;
+        r -= hist[b];
+      }
+      s_prefix = prefix | (b << sh);
+      s_rank = r;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    rank = s_rank;
+    prefix_mask |= 0xffu << sh;
+    __syncthreads();
+  }
+  const uint32_t thr = prefix;  // bit pattern of the threshold score
+  uint8_t *mask = rec + g.off_mask;
+  const uint8_t *fl = flags + (size_t)frame * nb;
+  for (int i = threadIdx.x; i < nb; i += 256) mask[i] = fl[i] | (sc[i] >= thr ? 1 : 0);
+}
+
+// ----------------------------------------------------------------------------
+// K3 (generic): exact integer AR sums + block statistics, any lag 1..3.
+// One workgroup walks a strided subset of the frame's blocks; for each flat
+// block it stages the residual tile d = src8 - den8 (+halo `lag` left/right/up)
+// in LDS as int32, and every thread owns up to two (i, j) products of the
+// (n+1)-vector [d(p+c_0) .. d(p+c_{n-1}), (luma residual sum for chroma), d(p)].
+// Per-block partials are int32 (|product| <= 1020^2, <= 1024 samples), folded
+// into int64 per thread, and added to the record with one atomic per product.
+// grid = (chunks, nplanes, batch), block = 256.
+// ----------------------------------------------------------------------------
+constexpr int kK3Threads = 256;
+constexpr int kMaxTile = (kBlock + 6) * (kBlock + 3);  // d tile, lag 3
+constexpr int kMaxPairs = 350;                         // 25*26/2 + 25
+
+__device__ __forceinline__ int block_reduce_sum(int v, int *scratch) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FramePlanes *__restrict__ frames, Geom g,
+                                                            uint8_t *__restrict__ records) {
+  __shared__ int tile[kMaxTile + kBlock * kBlock];  // d tile, then luma-sum tile
+  __shared__ int red[4];
+  const int c = blockIdx.y;
+  const int frame = blockIdx.z;
+  const FramePlanes fp = frames[frame];
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  const uint8_t *mask = rec + g.off_mask;
+  const int lag = g.lag, n = g.n;
+  const int nc = n + (c > 0);
+  const int sx = c ? g.xdec : 0, sy = c ? g.ydec : 0;
+  const int pw = g.W >> sx, ph = g.H >> sy;
+  const int bw = kBlock >> sx, bh = kBlock >> sy;
+  const int TW = bw + 2 * lag, TH = bh + lag;
+  const int ltile0 = TW * TH;
+  const int ntri = nc * (nc + 1) / 2;
+  const int npairs = ntri + nc;
+
+  // operand k of the (nc+1)-vector -> (base offset, row stride) in `tile`
+  auto operand = [&](int k, int &base, int &stride) {
+    if (k < n) {  // causal neighbour k: rows -lag..0, cols -lag..lag (row 0: -lag..-1)
+      const int side = 2 * lag + 1;
+      const int cy = k / side - lag, cx = k % side - lag;
+      base = (lag + cy) * TW + (lag + cx);
+      stride = TW;
+    } else if (k < nc) {  // chroma: co-located luma residual sum
+      base = ltile0;
+      stride = bw;
+    } else {  // the sample itself
+      base = lag * TW + lag;
+      stride = TW;
+    }
+  };
+  int pa[2], sa[2], pb[2], sb[2], out_idx[2];
+  bool have[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int p = threadIdx.x + s * kK3Threads;
+    have[s] = p < npairs;
+    int i = 0, j = 0;
+    if (p < ntri) {
+      int rem = p;
+      i = 0;
+      while (rem >= nc - i) {
+        rem -= nc - i;
+        ++i;
+      }
+      j = i + rem;
+      out_idx[s] = i * nc + j;
+    } else {
+      i = p - ntri;
+      j = nc;  // target
+      out_idx[s] = nc * nc + i;
+    }
+    operand(have[s] ? i : 0, pa[s], sa[s]);
+    operand(have[s] ? j : 0, pb[s], sb[s]);
+  }
+  long long acc64[2] = {0, 0};
+  long long nobs = 0;
+
+  const uint8_t *sp = fp.src[c], *dp = fp.den[c];
+  const uint32_t sst = fp.src_stride[c], dst = fp.den_stride[c];
+
+  for (int blk = blockIdx.x; blk < g.nblocks; blk += gridDim.x) {
+    if (!mask[blk]) continue;
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const int x_o = bx * bw, y_o = by * bh;
+    // ---- stage the residual tile ----
+    int s_d = 0, s_d2 = 0, s_l = 0;
+    for (int idx = threadIdx.x; idx < TW * TH; idx += kK3Threads) {
+      const int tx = idx % TW, ty = idx / TW;
+      const int X = x_o - lag + tx, Y = y_o - lag + ty;
+      int d = 0;
+      if (X >= 0 && X < pw && Y >= 0 && Y < ph) {
+        const int s = load_px_rt(sp, sst, g.src_bps, g.src_shift, X, Y);
+        d = s - load_px_rt(dp, dst, g.den_bps, g.den_shift, X, Y);
+        if (tx >= lag && tx < lag + bw && ty >= lag) {  // block proper (clipped by the plane)
+          s_d += d;
+          s_d2 += d * d;
+          if (c == 0) s_l += s;
+        }
+      }
+      tile[idx] = d;
+    }
+    if (c > 0) {
+      for (int idx = threadIdx.x; idx < bw * bh; idx += kK3Threads) {
+        const int x = idx % bw, y = idx / bw;
+        const int X = x_o + x, Y = y_o + y;
+        int L = 0;
+        if (X < pw && Y < ph) {
+          for (int dy = 0; dy < (1 << sy); ++dy)
+            for (int dx = 0; dx < (1 << sx); ++dx) {
+              const int lx = (X << sx) + dx, ly = (Y << sy) + dy;
+              L += load_px_rt(fp.src[0], fp.src_stride[0], g.src_bps, g.src_shift, lx, ly) -
+                   load_px_rt(fp.den[0], fp.den_stride[0], g.den_bps, g.den_shift, lx, ly);
+            }
+        }
+        tile[ltile0 + idx] = L;
+      }
+    }
+    // ---- block statistics (get_block_mean / get_noise_var as exact sums) ----
+    {
+      const int td = block_reduce_sum(s_d, red);
+      const int td2 = block_reduce_sum(s_d2, red);
+      const int tl = c == 0 ? block_reduce_sum(s_l, red) : 0;
+      if (threadIdx.x == 0) {
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[c])[blk] = td;
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[c])[blk] = (uint32_t)td2;
+        if (c == 0) reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)tl;
+      }
+    }
+    __syncthreads();
+    // ---- observation window of this block (add_block_observations) ----
+    const int y_start = (by > 0 && mask[(by - 1) * g.nbw + bx]) ? 0 : lag;
+    const int x_start = (bx > 0 && mask[by * g.nbw + bx - 1]) ? 0 : lag;
+    const int y_end = min(ph - y_o, bh);
+    const int x_end = min(pw - x_o - lag, (bx + 1 < g.nbw && mask[by * g.nbw + bx + 1]) ? bw : (bw - lag));
+    if (x_end > x_start && y_end > y_start) {
+      nobs += (long long)(x_end - x_start) * (y_end - y_start);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (!have[s]) continue;
+        int acc = 0;
+        for (int y = y_start; y < y_end; ++y) {
+          const int *ra = tile + pa[s] + y * sa[s];
+          const int *rb = tile + pb[s] + y * sb[s];
+          for (int x = x_start; x < x_end; ++x) acc += ra[x] * rb[x];
+        }
+        acc64[s] += acc;
+      }
+    }
+    __syncthreads();
+  }
+  unsigned long long *ar = reinterpret_cast<unsigned long long *>(rec + g.off_ar[c]);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    if (have[s] && acc64[s] != 0) atomicAdd(&ar[out_idx[s]], (unsigned long long)acc64[s]);
+  if (threadIdx.x == 0 && nobs != 0) atomicAdd(&ar[nc * nc + nc], (unsigned long long)nobs);
+}
+
+}  // namespace g1s

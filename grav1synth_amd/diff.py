@@ -1,0 +1,368 @@
+"""Host-side mirror of `av1_grain::DiffGenerator` over the C-ABI.
+
+Same three methods, argument meaning and error behaviour as the object the
+reference drives at src/main.rs:420-427 (`new`), :442 (`diff_frame`, errors
+propagate) and :524 (`finish`, consumes the generator), plus the `.tbl` writer
+of src/main.rs:525-529,631-696.  All pixel work happens in the HIP kernels of
+libg1s_diff.so; this module only marshals pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from fractions import Fraction
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import G1SError, G1SFrame, G1SOpts, G1SSegment, G1SStats
+
+try:  # torch is plumbing (device memory); numpy host frames work without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+DEFAULT_GRAIN_SEED = 10956  # av1_grain::DEFAULT_GRAIN_SEED (src/parser/frame.rs:3)
+
+
+@dataclass
+class GrainTableSegment:
+    """Field-for-field mirror of av1_grain::GrainTableSegment as read by
+    src/parser/grain.rs:108-133."""
+
+    random_seed: int
+    start_time: int
+    end_time: int
+    scaling_points_y: List[Tuple[int, int]]
+    scaling_points_cb: List[Tuple[int, int]]
+    scaling_points_cr: List[Tuple[int, int]]
+    scaling_shift: int
+    ar_coeff_lag: int
+    ar_coeffs_y: List[int]
+    ar_coeffs_cb: List[int]
+    ar_coeffs_cr: List[int]
+    ar_coeff_shift: int
+    cb_mult: int
+    cb_luma_mult: int
+    cb_offset: int
+    cr_mult: int
+    cr_luma_mult: int
+    cr_offset: int
+    chroma_scaling_from_luma: bool
+    grain_scale_shift: int
+    overlap_flag: bool
+
+    @staticmethod
+    def from_c(s: G1SSegment) -> "GrainTableSegment":
+        return GrainTableSegment(
+            random_seed=s.random_seed,
+            start_time=s.start_time,
+            end_time=s.end_time,
+            scaling_points_y=[(s.scaling_points_y[i][0], s.scaling_points_y[i][1]) for i in range(s.num_y_points)],
+            scaling_points_cb=[(s.scaling_points_cb[i][0], s.scaling_points_cb[i][1]) for i in range(s.num_cb_points)],
+            scaling_points_cr=[(s.scaling_points_cr[i][0], s.scaling_points_cr[i][1]) for i in range(s.num_cr_points)],
+            scaling_shift=s.scaling_shift,
+            ar_coeff_lag=s.ar_coeff_lag,
+            ar_coeffs_y=[s.ar_coeffs_y[i] for i in range(s.num_y_coeffs)],
+            ar_coeffs_cb=[s.ar_coeffs_cb[i] for i in range(s.num_uv_coeffs)],
+            ar_coeffs_cr=[s.ar_coeffs_cr[i] for i in range(s.num_uv_coeffs)],
+            ar_coeff_shift=s.ar_coeff_shift,
+            cb_mult=s.cb_mult,
+            cb_luma_mult=s.cb_luma_mult,
+            cb_offset=s.cb_offset,
+            cr_mult=s.cr_mult,
+            cr_luma_mult=s.cr_luma_mult,
+            cr_offset=s.cr_offset,
+            chroma_scaling_from_luma=bool(s.chroma_scaling_from_luma),
+            grain_scale_shift=s.grain_scale_shift,
+            overlap_flag=bool(s.overlap_flag),
+        )
+
+    def to_c(self) -> G1SSegment:
+        s = G1SSegment()
+        s.start_time, s.end_time, s.random_seed = self.start_time, self.end_time, self.random_seed
+        s.num_y_points, s.num_cb_points, s.num_cr_points = (
+            len(self.scaling_points_y), len(self.scaling_points_cb), len(self.scaling_points_cr))
+        for dst, src in ((s.scaling_points_y, self.scaling_points_y), (s.scaling_points_cb, self.scaling_points_cb),
+                         (s.scaling_points_cr, self.scaling_points_cr)):
+            for i, (x, y) in enumerate(src):
+                dst[i][0], dst[i][1] = x, y
+        s.scaling_shift, s.ar_coeff_lag = self.scaling_shift, self.ar_coeff_lag
+        s.num_y_coeffs, s.num_uv_coeffs = len(self.ar_coeffs_y), len(self.ar_coeffs_cb)
+        for i, v in enumerate(self.ar_coeffs_y):
+            s.ar_coeffs_y[i] = v
+        for i, v in enumerate(self.ar_coeffs_cb):
+            s.ar_coeffs_cb[i] = v
+        for i, v in enumerate(self.ar_coeffs_cr):
+            s.ar_coeffs_cr[i] = v
+        s.ar_coeff_shift = self.ar_coeff_shift
+        s.cb_mult, s.cb_luma_mult, s.cb_offset = self.cb_mult, self.cb_luma_mult, self.cb_offset
+        s.cr_mult, s.cr_luma_mult, s.cr_offset = self.cr_mult, self.cr_luma_mult, self.cr_offset
+        s.chroma_scaling_from_luma = int(self.chroma_scaling_from_luma)
+        s.grain_scale_shift = self.grain_scale_shift
+        s.overlap_flag = int(self.overlap_flag)
+        return s
+
+
+Plane = Union[np.ndarray, "torch.Tensor"]
+
+
+@dataclass
+class Frame:
+    """A decoded frame: 1 or 3 planes (Y, U, V), u8 or u16 samples, like the
+    `v_frame::Frame<T>` built at src/reader.rs:183-209.  Planes may be numpy
+    arrays (host) or torch tensors (host or HIP device)."""
+
+    planes: Sequence[Plane]
+    xdec: int = 1
+    ydec: int = 1
+
+    def to_c(self, keep: list) -> G1SFrame:
+        f = G1SFrame()
+        p0 = self.planes[0]
+        f.height, f.width = int(p0.shape[0]), int(p0.shape[1])
+        f.xdec, f.ydec = self.xdec, self.ydec
+        f.nplanes = len(self.planes)
+        on_dev = None
+        for i, p in enumerate(self.planes):
+            if torch is not None and isinstance(p, torch.Tensor):
+                if p.stride(1) != 1:
+                    raise ValueError("plane rows must be contiguous")
+                isz = p.element_size()
+                f.data[i] = p.data_ptr()
+                f.stride_bytes[i] = p.stride(0) * isz
+                dev = p.is_cuda
+            else:
+                p = np.asarray(p)
+                if p.strides[1] != p.dtype.itemsize:
+                    raise ValueError("plane rows must be contiguous")
+                isz = p.dtype.itemsize
+                f.data[i] = p.ctypes.data
+                f.stride_bytes[i] = p.strides[0]
+                dev = False
+            if on_dev is None:
+                on_dev = dev
+            elif on_dev != dev:
+                raise ValueError("all planes of a frame must live on the same side (host or device)")
+            f.bytes_per_sample = isz
+            keep.append(p)
+        f.on_device = int(bool(on_dev))
+        return f
+
+
+def _as_frame(x, xdec, ydec) -> Frame:
+    return x if isinstance(x, Frame) else Frame(list(x), xdec, ydec)
+
+
+class DiffGenerator:
+    """`av1_grain::DiffGenerator` on an MI355X.
+
+    >>> differ = DiffGenerator(Fraction(24000, 1001), 10, 10)
+    >>> differ.diff_frame(source_frame, denoised_frame)   # per frame pair, in order
+    >>> segments = differ.finish()                        # consumes the generator
+    """
+
+    def __init__(self, fps, source_bit_depth: int, denoised_bit_depth: int, *, ar_coeff_lag: int = 3,
+                 luma_only: bool = False, device: int = -1, batch_frames: int = 0, records_only: bool = False):
+        self._L = _lib.lib()
+        fr = Fraction(fps)
+        opts = G1SOpts()
+        opts.struct_size = C.sizeof(G1SOpts)
+        opts.device = device
+        opts.ar_coeff_lag = ar_coeff_lag
+        opts.luma_only = int(luma_only)
+        opts.batch_frames = batch_frames
+        opts.records_only = int(records_only)
+        self._h = self._L.g1s_diff_new(fr.numerator, fr.denominator, source_bit_depth, denoised_bit_depth,
+                                       C.byref(opts))
+        if not self._h:
+            raise G1SError(-5, self._L.g1s_last_global_error().decode())
+        self._keep: list = []
+        self._finished = False
+        self.records_only = records_only
+        self.fps = fr
+        self.ar_coeff_lag = ar_coeff_lag
+
+    # -- DiffGenerator::diff_frame (src/main.rs:442) ------------------------------------
+    def diff_frame(self, source, denoised, xdec: int = 1, ydec: int = 1, sync_torch: bool = True) -> None:
+        s = _as_frame(source, xdec, ydec)
+        d = _as_frame(denoised, xdec, ydec)
+        keep: list = []
+        fs, fd = s.to_c(keep), d.to_c(keep)
+        if (fs.on_device or fd.on_device):
+            if sync_torch:
+                torch.cuda.current_stream().synchronize()  # producer (torch) -> consumer (engine stream)
+            self._keep.extend(keep)  # device planes must outlive the queued kernels
+        self._check(self._L.g1s_diff_frame(self._h, C.byref(fs), C.byref(fd)))
+
+    def sync(self) -> None:
+        self._check(self._L.g1s_diff_sync(self._h))
+        self._keep.clear()
+
+    # -- DiffGenerator::finish (src/main.rs:524) ----------------------------------------
+    def finish(self) -> List[GrainTableSegment]:
+        arr = (G1SSegment * 1024)()
+        n = C.c_size_t()
+        self._check(self._L.g1s_diff_finish(self._h, arr, 1024, C.byref(n)))
+        self._finished = True
+        self._keep.clear()
+        return [GrainTableSegment.from_c(arr[i]) for i in range(n.value)]
+
+    # -- frame-shard mode -----------------------------------------------------------------
+    def take_records(self, width: int, height: int, nplanes: int, max_frames: int) -> Tuple[np.ndarray, int]:
+        rs = self._L.g1s_record_size(width, height, 0, 0, nplanes, self.ar_coeff_lag)
+        buf = np.zeros(rs * max(max_frames, 1), dtype=np.uint8)
+        n = C.c_size_t()
+        self._check(self._L.g1s_diff_take_records(self._h, buf.ctypes.data, buf.size, C.byref(n)))
+        self._keep.clear()
+        return buf[: rs * n.value].reshape(n.value, rs), n.value
+
+    # -- measurement / parity hooks ------------------------------------------------------
+    def set_timing(self, enable: bool) -> None:
+        self._L.g1s_diff_set_timing(self._h, int(enable))
+
+    def stats(self) -> G1SStats:
+        st = G1SStats()
+        self._L.g1s_diff_get_stats(self._h, C.byref(st))
+        return st
+
+    def last_record(self) -> "Record":
+        buf = np.zeros(64 << 20, dtype=np.uint8)
+        self._check(self._L.g1s_diff_last_record(self._h, buf.ctypes.data, buf.size))
+        return Record(buf)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.g1s_diff_free(self._h)
+            self._h = None
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise G1SError(rc, self._L.g1s_diff_last_error(self._h).decode())
+
+
+class Record:
+    """Read-only view of one per-frame integer record."""
+
+    def __init__(self, buf: np.ndarray):
+        self._L = _lib.lib()
+        self.buf = buf
+        nbw, nbh, npl, lag = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = self._L.g1s_record_geometry(buf.ctypes.data, C.byref(nbw), C.byref(nbh), C.byref(npl), C.byref(lag))
+        if rc != 0:
+            raise G1SError(rc, "bad record")
+        self.nbw, self.nbh, self.nplanes, self.lag = nbw.value, nbh.value, npl.value, lag.value
+
+    @staticmethod
+    def blank(width: int, height: int, xdec: int, ydec: int, nplanes: int, lag: int) -> "Record":
+        L = _lib.lib()
+        size = L.g1s_record_size(width, height, xdec, ydec, nplanes, lag)
+        buf = np.zeros(size, dtype=np.uint8)
+        rc = L.g1s_record_init(buf.ctypes.data, buf.size, width, height, xdec, ydec, nplanes, lag)
+        if rc != 0:
+            raise G1SError(rc, "g1s_record_init")
+        return Record(buf)
+
+    def views(self, c: int):
+        """Writable numpy views (mask, scores, S, Sb+nobs, luma_sum, sum_d, sum_d2)
+        into the record buffer -- used to assemble records in tests."""
+        d = self.buf.ctypes.data
+        nb = self.nbw * self.nbh
+        S, Sb, nobs = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_int64()
+        n = self._L.g1s_record_ar_sums(d, c, C.byref(S), C.byref(Sb), C.byref(nobs))
+        ls, sd, sd2 = C.POINTER(C.c_uint32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_uint32)()
+        self._L.g1s_record_block_stats(d, c, C.byref(ls), C.byref(sd), C.byref(sd2))
+        return dict(
+            mask=np.ctypeslib.as_array(self._L.g1s_record_flat_mask(d), shape=(nb,)),
+            scores=np.ctypeslib.as_array(self._L.g1s_record_scores(d), shape=(nb,)),
+            S=np.ctypeslib.as_array(S, shape=(n, n)),
+            Sb_nobs=np.ctypeslib.as_array(Sb, shape=(n + 1,)),
+            luma_sum=np.ctypeslib.as_array(ls, shape=(nb,)),
+            sum_d=np.ctypeslib.as_array(sd, shape=(nb,)),
+            sum_d2=np.ctypeslib.as_array(sd2, shape=(nb,)),
+        )
+
+    def flat_mask(self) -> np.ndarray:
+        p = self._L.g1s_record_flat_mask(self.buf.ctypes.data)
+        return np.ctypeslib.as_array(p, shape=(self.nbh, self.nbw)).copy()
+
+    def scores(self) -> np.ndarray:
+        p = self._L.g1s_record_scores(self.buf.ctypes.data)
+        return np.ctypeslib.as_array(p, shape=(self.nbh, self.nbw)).copy()
+
+    def ar_sums(self, c: int):
+        S, Sb, nobs = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_int64()
+        n = self._L.g1s_record_ar_sums(self.buf.ctypes.data, c, C.byref(S), C.byref(Sb), C.byref(nobs))
+        if n < 0:
+            raise G1SError(n, "bad plane")
+        return (np.ctypeslib.as_array(S, shape=(n, n)).copy(), np.ctypeslib.as_array(Sb, shape=(n,)).copy(),
+                nobs.value)
+
+    def block_stats(self, c: int):
+        ls, sd, sd2 = C.POINTER(C.c_uint32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_uint32)()
+        nb = self._L.g1s_record_block_stats(self.buf.ctypes.data, c, C.byref(ls), C.byref(sd), C.byref(sd2))
+        if nb < 0:
+            raise G1SError(nb, "bad plane")
+        return (np.ctypeslib.as_array(ls, shape=(nb,)).copy(), np.ctypeslib.as_array(sd, shape=(nb,)).copy(),
+                np.ctypeslib.as_array(sd2, shape=(nb,)).copy())
+
+
+class RecordFold:
+    """The ordered fold over records (host only): what runs after the RCCL
+    exchange in frame-shard mode, and inside DiffGenerator on a single GPU."""
+
+    def __init__(self, fps, ar_coeff_lag: int = 3):
+        self._L = _lib.lib()
+        fr = Fraction(fps)
+        self._h = self._L.g1s_fold_new(fr.numerator, fr.denominator, ar_coeff_lag)
+        if not self._h:
+            raise G1SError(-1, "g1s_fold_new failed")
+
+    def push(self, record: np.ndarray) -> None:
+        record = np.ascontiguousarray(record, dtype=np.uint8)
+        rc = self._L.g1s_fold_push(self._h, record.ctypes.data, record.size)
+        if rc != 0:
+            raise G1SError(rc, self._L.g1s_fold_last_error(self._h).decode())
+
+    def finish(self) -> List[GrainTableSegment]:
+        arr = (G1SSegment * 1024)()
+        n = C.c_size_t()
+        rc = self._L.g1s_fold_finish(self._h, arr, 1024, C.byref(n))
+        if rc != 0:
+            raise G1SError(rc, self._L.g1s_fold_last_error(self._h).decode())
+        return [GrainTableSegment.from_c(arr[i]) for i in range(n.value)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.g1s_fold_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_tbl(segments: Sequence[GrainTableSegment]) -> bytes:
+    """`filmgrn1` text exactly as src/main.rs:525-529,631-696 writes it."""
+    L = _lib.lib()
+    arr = (G1SSegment * max(len(segments), 1))(*[s.to_c() for s in segments])
+    buf = C.create_string_buffer(1024 + 2048 * len(segments))
+    n = L.g1s_format_tbl(arr, len(segments), buf, len(buf))
+    if n < 0:
+        raise G1SError(n, "g1s_format_tbl")
+    return buf.raw[:n]
+
+
+def write_tbl(path: str, segments: Sequence[GrainTableSegment]) -> None:
+    with open(path, "wb") as f:
+        f.write(format_tbl(segments))

@@ -1,0 +1,181 @@
+/*
+ * g1s_diff.h -- C-ABI of the MI355X-native `diff` film-grain estimator.
+ *
+ * Drop-in boundary: the three-method object API of av1_grain::DiffGenerator as
+ * grav1synth uses it (paths relative to the reference tree):
+ *     DiffGenerator::new(fps, source_bd, denoised_bd)   src/main.rs:420-427
+ *     differ.diff_frame(&source_frame, &denoised_frame) src/main.rs:442,462,482,502
+ *     differ.finish() -> Vec<GrainTableSegment>         src/main.rs:524
+ * and the `.tbl` writer fed from it (src/main.rs:525-529, 631-696).  A Rust
+ * `grav1synth` binds these symbols with an `extern "C"` block.
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * All pixel work runs as HIP kernels for gfx950; the library fails loudly
+ * (G1S_ERR_NO_DEVICE) when no HIP device is usable -- there is no CPU fallback.
+ */
+#ifndef G1S_DIFF_H
+#define G1S_DIFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G1S_ABI_VERSION 1
+
+/* av1_grain::{NUM_Y_POINTS, NUM_UV_POINTS, NUM_Y_COEFFS, NUM_UV_COEFFS}
+ * (imported at src/parser/grain.rs:2; capacities at :27-31 and :46-50). */
+#define G1S_NUM_Y_POINTS 14
+#define G1S_NUM_UV_POINTS 10
+#define G1S_NUM_Y_COEFFS 24
+#define G1S_NUM_UV_COEFFS 25
+
+enum {
+  G1S_OK = 0,
+  G1S_ERR_INVALID = -1,       /* bad argument / unsupported format */
+  G1S_ERR_DIM_MISMATCH = -2,  /* source and denoised frame geometry differ */
+  G1S_ERR_NOT_ENOUGH_FLAT = -3, /* "Not enough flat blocks to update noise estimate" */
+  G1S_ERR_SOLVE = -4,         /* luma AR / strength equation system is singular */
+  G1S_ERR_NO_DEVICE = -5,     /* no usable HIP device or kernel image */
+  G1S_ERR_HIP = -6,           /* a HIP runtime call failed (see last_error) */
+  G1S_ERR_STATE = -7,         /* call not legal in this state (e.g. after finish) */
+  G1S_ERR_CAPACITY = -8       /* output buffer too small */
+};
+
+/* One decoded frame == v_frame::Frame<T> as produced by
+ * BitstreamReader::decode_frame (src/reader.rs:172-212): planar Y,U,V; u8 for
+ * 8-bit, native-endian u16 for 9..16-bit (src/reader.rs:51-67); chroma planes
+ * decimated by (xdec, ydec) (src/reader.rs:69-85). */
+typedef struct {
+  uint32_t width, height;   /* luma plane size in samples */
+  uint8_t bytes_per_sample; /* 1 or 2 */
+  uint8_t xdec, ydec;       /* chroma subsampling log2: 4:2:0=(1,1) 4:2:2=(1,0) 4:4:4=(0,0) */
+  uint8_t nplanes;          /* 1 (monochrome) or 3 */
+  const void *data[3];
+  size_t stride_bytes[3];
+  int32_t on_device;        /* 0: host memory, copied before the call returns (the
+                               `&Frame` borrow of src/main.rs:442).
+                               1: device (HIP) memory of this process; must stay
+                               valid and unmodified until g1s_diff_sync()/finish */
+} g1s_frame_t;
+
+/* POD mirror of av1_grain::GrainTableSegment, field for field as consumed by
+ * `impl From<av1_grain::GrainTableSegment>` at src/parser/grain.rs:108-133 and
+ * src/main.rs:705-713. */
+typedef struct {
+  uint64_t start_time, end_time;
+  uint16_t random_seed;
+  uint8_t num_y_points, num_cb_points, num_cr_points;
+  uint8_t scaling_points_y[G1S_NUM_Y_POINTS][2];
+  uint8_t scaling_points_cb[G1S_NUM_UV_POINTS][2];
+  uint8_t scaling_points_cr[G1S_NUM_UV_POINTS][2];
+  uint8_t scaling_shift;
+  uint8_t ar_coeff_lag;
+  uint8_t num_y_coeffs, num_uv_coeffs; /* 2*lag*(lag+1) and that + 1 (src/parser/grain.rs:40-44) */
+  int8_t ar_coeffs_y[G1S_NUM_Y_COEFFS];
+  int8_t ar_coeffs_cb[G1S_NUM_UV_COEFFS];
+  int8_t ar_coeffs_cr[G1S_NUM_UV_COEFFS];
+  uint8_t ar_coeff_shift;
+  uint8_t cb_mult, cb_luma_mult;
+  uint16_t cb_offset;
+  uint8_t cr_mult, cr_luma_mult;
+  uint16_t cr_offset;
+  uint8_t chroma_scaling_from_luma;
+  uint8_t grain_scale_shift;
+  uint8_t overlap_flag;
+} g1s_segment_t;
+
+/* Options; NULL == reference behaviour (lag 3, chroma estimated when present). */
+typedef struct {
+  uint32_t struct_size;   /* sizeof(g1s_opts_t), for forward compatibility */
+  int32_t device;         /* HIP device ordinal; -1 = current device */
+  uint32_t ar_coeff_lag;  /* 1..3; 0 = default (3, the reference's NOISE_MODEL_LAG) */
+  uint32_t luma_only;     /* 1 = skip chroma planes (extension; reference: 0) */
+  uint32_t batch_frames;  /* frames per kernel batch; 0 = default */
+  uint32_t records_only;  /* 1 = frame-shard mode: emit per-frame records, do not
+                             fold (the ordered fold runs after the exchange, see
+                             g1s_fold_*).  0 = fold locally (single GPU). */
+} g1s_opts_t;
+
+typedef struct g1s_diff g1s_diff_t;
+
+/* DiffGenerator::new (src/main.rs:420-427).  Returns NULL on failure; the
+ * reason is then available from g1s_last_global_error(). */
+g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_depth,
+                         uint32_t denoised_bit_depth, const g1s_opts_t *opts);
+const char *g1s_last_global_error(void);
+
+/* DiffGenerator::diff_frame (src/main.rs:442).  Frames are consumed in call
+ * order.  Work is queued and may still be running when the call returns;
+ * errors of queued frames (not enough flat blocks, singular system) surface on
+ * a later diff_frame / sync / finish call, exactly once. */
+int g1s_diff_frame(g1s_diff_t *, const g1s_frame_t *source, const g1s_frame_t *denoised);
+/* n frame pairs in one call (same semantics as n diff_frame calls). */
+int g1s_diff_frames(g1s_diff_t *, const g1s_frame_t *source, const g1s_frame_t *denoised, size_t n);
+/* Drain all queued work (kernels + ordered fold). */
+int g1s_diff_sync(g1s_diff_t *);
+/* DiffGenerator::finish (src/main.rs:524).  Consumes the generator: afterwards
+ * only g1s_diff_free / g1s_diff_last_error / g1s_diff_get_stats are legal. */
+int g1s_diff_finish(g1s_diff_t *, g1s_segment_t *out, size_t cap, size_t *n_out);
+void g1s_diff_free(g1s_diff_t *);
+/* anyhow::Error text of the last failure ("" if none). */
+const char *g1s_diff_last_error(const g1s_diff_t *);
+
+/* ---- frame-shard mode (multi-GPU): records out, ordered fold after exchange ---- */
+/* Size in bytes of one per-frame record for this geometry (all exact integers:
+ * AR normal-equation sums, per-block noise statistics, flat mask). */
+size_t g1s_record_size(uint32_t width, uint32_t height, uint32_t xdec, uint32_t ydec,
+                       uint32_t nplanes, uint32_t lag);
+/* Zero a record buffer of g1s_record_size() bytes and write its header. */
+int g1s_record_init(void *rec, size_t cap_bytes, uint32_t width, uint32_t height, uint32_t xdec,
+                    uint32_t ydec, uint32_t nplanes, uint32_t lag);
+/* Copies the records of all frames queued so far (frame order) into buf and
+ * clears the internal list.  records_only generators only. */
+int g1s_diff_take_records(g1s_diff_t *, void *buf, size_t cap_bytes, size_t *n_frames);
+
+typedef struct g1s_fold g1s_fold_t;
+/* The sequential part of DiffGenerator (noise-model update, segmentation,
+ * quantisation) over records, in frame order.  Pure host code. */
+g1s_fold_t *g1s_fold_new(int64_t fps_num, int64_t fps_den, uint32_t lag);
+int g1s_fold_push(g1s_fold_t *, const void *record, size_t size_bytes);
+int g1s_fold_finish(g1s_fold_t *, g1s_segment_t *out, size_t cap, size_t *n_out);
+void g1s_fold_free(g1s_fold_t *);
+const char *g1s_fold_last_error(const g1s_fold_t *);
+
+/* ---- `.tbl` text, byte for byte what src/main.rs:525-529,631-696 writes ---- */
+/* Returns the number of bytes written (no NUL), or G1S_ERR_CAPACITY. */
+long g1s_format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap);
+int g1s_write_tbl(const char *path, const g1s_segment_t *segs, size_t n);
+
+/* ---- measurement hooks (bench.py) ---- */
+typedef struct {
+  uint64_t frames;            /* frame pairs processed by the kernels */
+  uint64_t blocks, flat_blocks;
+  /* HIP-event time per kernel family, summed over launches, milliseconds */
+  double ms_flat_features, ms_flat_select, ms_ar_accumulate, ms_total_gpu;
+  uint64_t launches_flat_features, launches_flat_select, launches_ar_accumulate;
+  double ms_host_fold;        /* wall time spent in the ordered host fold */
+} g1s_stats_t;
+int g1s_diff_get_stats(const g1s_diff_t *, g1s_stats_t *out);
+/* Enable per-kernel HIP-event timing (off by default: events serialise batches). */
+int g1s_diff_set_timing(g1s_diff_t *, int enable);
+
+/* ---- introspection of the most recently *completed* frame (parity tests) ---- */
+/* Copies the frame's record (layout: g1s_record_* accessors below). */
+int g1s_diff_last_record(const g1s_diff_t *, void *buf, size_t cap_bytes);
+/* Record field accessors (so that bindings need not know the layout). */
+int g1s_record_geometry(const void *rec, uint32_t *nbw, uint32_t *nbh, uint32_t *nplanes, uint32_t *lag);
+const uint8_t *g1s_record_flat_mask(const void *rec);
+const float *g1s_record_scores(const void *rec);
+/* n x n sums S[i*n+j] and Sb[i] of plane c (chroma regressor n-1 pre-scaled by
+ * ns = (1<<xdec)*(1<<ydec)); returns n. */
+int g1s_record_ar_sums(const void *rec, uint32_t c, const int64_t **S, const int64_t **Sb, int64_t *nobs);
+int g1s_record_block_stats(const void *rec, uint32_t c, const uint32_t **luma_sum,
+                           const int32_t **sum_d, const uint32_t **sum_d2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G1S_DIFF_H */

@@ -662,7 +662,8 @@ static void add_noise_std_observations(noise_model *m, int c, const double *coef
         const double corr = c > 0 ? coeffs[num_coords] : 0;
         /* don't allow fully correlated noise (hence the max) */
         const double t0 = noise_var / 16;
-        const double t1 = noise_var - pow(corr * luma_strength, 2);
+        const double cl = corr * luma_strength; /* Rust powi(2) == x*x */
+        const double t1 = noise_var - cl * cl;
         const double uncorr_std = sqrt(t0 > t1 ? t0 : t1);
         /* undo the gain of the IIR filter */
         const double adjusted_strength = uncorr_std / noise_gain;
