@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- `diff` throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (flat-block finder, AR accumulation,
+block statistics, ordered fold) over one batch of synthetic frame pairs that
+are already resident in HBM.  Workload at any N: 3840x2160 10-bit 4:2:0,
+ar_coeff_lag 3, chroma (BASELINE.json configs[2], the one the metric is quoted
+on); each rank owns its own `--frames` frame pairs per step (weak scaling,
+frame sharding), exchanges the per-frame integer records with ONE RCCL
+all-gather per step, and rank 0 runs the ordered fold over all N*frames records.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from fractions import Fraction
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (W, H, bit_depth, xdec, ydec, lag, chroma, bytes per luma pixel)
+    "4k10": (3840, 2160, 10, 1, 1, 3, True, 6),
+    "1080p8_lag2_luma": (1920, 1080, 8, 1, 1, 2, False, 2),
+    "1080p8": (1920, 1080, 8, 1, 1, 3, True, 3),
+    "8k10_444": (7680, 4320, 10, 0, 0, 3, True, 12),
+}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=16, help="frame pairs per rank per step")
+    ap.add_argument("--batch", type=int, default=8, help="frames per kernel launch group")
+    ap.add_argument("--workload", default="4k10", choices=sorted(WORKLOADS))
+    ap.add_argument("--flat", action="store_true", help="all-flat stress variant (no textured region)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the diff path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from grav1synth_amd.diff import DiffGenerator, format_tbl
+    from grav1synth_amd.dist import ShardedDiff
+    from grav1synth_amd.synth import SynthSpec, make_pair
+
+    W, H, bd, xdec, ydec, lag, chroma, bpp = WORKLOADS[args.workload]
+    spec = SynthSpec(W, H, bd, xdec, ydec, textured=not args.flat)
+    F = args.frames
+    fps = Fraction(24, 1)
+
+    # ---- synthetic frame pairs, resident in HBM before any timed region ----
+    frames = []
+    for k in range(F):
+        s, d = make_pair(spec, rank * F + k, device=dev)
+        if not chroma:
+            s, d = s[:1], d[:1]
+        frames.append((s, d))
+    torch.cuda.synchronize()
+
+    stats_total = None
+    last_tbl = None
+
+    def one_step(timing: bool):
+        nonlocal stats_total, last_tbl
+        sd = ShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=local_rank,
+                         batch_frames=args.batch, group=dist if world > 1 else None)
+        sd.generator.set_timing(timing)
+        for s, d in frames:
+            sd.diff_frame(s, d, xdec, ydec, sync_torch=False)
+        segs = sd.finish()  # exchange + ordered fold (rank 0 holds the table)
+        st = sd.generator.stats()
+        if segs is not None:
+            last_tbl = format_tbl(segs)
+        sd.close()
+        return st
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel HIP-event timing, in separate (untimed) steps: events between
+    # kernels serialise nothing here but we keep them out of the headline number ----
+    st = one_step(True)
+    kernels = {
+        "k1_flat_features": (st.ms_flat_features, st.launches_flat_features),
+        "k2_flat_select": (st.ms_flat_select, st.launches_flat_select),
+        "k3_ar_accumulate": (st.ms_ar_accumulate, st.launches_ar_accumulate),
+    }
+    dom = max(kernels, key=lambda k: kernels[k][0])
+    dom_ms, dom_launches = kernels[dom]
+    frames_per_launch = F / max(dom_launches, 1)
+    alg_bytes_per_launch = bpp * W * H * frames_per_launch
+    avg_launch_ms = dom_ms / max(dom_launches, 1)
+    achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as f:
+                traffic = json.load(f).get(args.workload, {}).get(dom)
+        except Exception:
+            traffic = None
+
+    total_px = float(W) * H * F * args.steps * world
+    value = total_px / elapsed / 1e6
+    out = {
+        "metric": "diff Mpixels/s (luma pixels of frame pairs fully processed: flat-block finder + AR accumulation + block stats + ordered fold)",
+        "value": value,
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8/i32/i64 exact-integer accumulation + f64 flat-block features",
+        "data": "synthetic (deterministic integer generator, grav1synth_amd/synth.py), device-resident",
+        "config": {
+            "workload": f"diff {W}x{H} {bd}-bit {'4:2:0' if (xdec, ydec) == (1, 1) else '4:4:4' if (xdec, ydec) == (0, 0) else '4:2:2'}, ar_coeff_lag={lag}, {'chroma' if chroma else 'luma-only'} ({args.workload}{', all-flat' if args.flat else ''})",
+            "frames_per_rank_per_step": F,
+            "batch_frames": args.batch,
+            "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
+            "parallelism": f"frame-shard x{world}, one RCCL all-gather of integer records per step" if world > 1 else "single GPU",
+        },
+        "hbm_roofline_frac_whole_job": (value * bpp * 1e6 / 1e9) / (HBM_PEAK_GBS * world),
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dom,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "avg_launch_ms": avg_launch_ms,
+            "alg_bytes_per_launch": alg_bytes_per_launch,
+            "all_kernels_ms_per_frame": {k: v[0] / F for k, v in kernels.items()},
+            "host_fold_ms_per_frame": st.ms_host_fold / F,
+        },
+    }
+
+    # ---- CPU baseline: the oracle (a port, scalar f64, 1 thread) on a bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from tests.oracle_binding import OracleDiff
+
+        n_cpu = max(1, args.cpu_frames)
+        o = OracleDiff(fps.numerator, fps.denominator, bd, bd, lag, chroma)
+        host = []
+        for k in range(n_cpu):
+            s, d = frames[k]
+            host.append(([p.cpu().numpy() for p in s], [p.cpu().numpy() for p in d]))
+        t0 = time.perf_counter()
+        for s, d in host:
+            o.diff_frame(s, d, xdec, ydec)
+        o.finish()
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": W * H * n_cpu / cpu_s / 1e6,
+            "unit": "Mpixels/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{n_cpu} frame pair(s) of the same workload through oracle/liborc_diff.so (scalar f64, reference operation order), {cpu_s:.1f} s",
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

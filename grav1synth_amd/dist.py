@@ -1,0 +1,104 @@
+"""Frame-shard mode: one process per GPU, one exchange, one ordered fold.
+
+The reference's `diff` loop is strictly serial (src/main.rs:432-521), but
+everything pixel-sized in it is per-frame independent.  Rank r runs the HIP
+kernels over its contiguous chunk of frames and keeps only the per-frame
+integer records; ONE all-gather (RCCL over xGMI with the "nccl" backend, gloo
+in the CPU tests) moves them to every rank, and rank 0 replays the sequential
+noise-model update over the records in global frame order.  Records are exact
+integers, so the result does not depend on the number of ranks.
+"""
+from __future__ import annotations
+
+from fractions import Fraction
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .diff import DiffGenerator, GrainTableSegment, RecordFold
+
+
+def gather_records(records: np.ndarray, dist, device: Optional[torch.device] = None) -> List[np.ndarray]:
+    """All-gather each rank's [n_r, record_size] uint8 records.  Returns the
+    per-rank arrays in rank order (on every rank).  One collective for the
+    payload (+ one tiny one for the frame counts)."""
+    world = dist.get_world_size()
+    backend = dist.get_backend()
+    dev = device if (backend == "nccl" and device is not None) else torch.device("cpu")
+    n_local = int(records.shape[0])
+    rs = int(records.shape[1]) if records.ndim == 2 else 0
+    meta = torch.tensor([n_local, rs], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    counts = [int(m[0].item()) for m in metas]
+    rs = max(int(m[1].item()) for m in metas)
+    nmax = max(counts)
+    pad = torch.zeros((nmax, rs), dtype=torch.uint8)
+    if n_local:
+        pad[:n_local] = torch.from_numpy(np.ascontiguousarray(records))
+    pad = pad.to(dev)
+    if backend == "nccl":  # RCCL: one flat all-gather over xGMI
+        out = torch.empty((world, nmax, rs), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, pad)
+        host = out.cpu().numpy()
+    else:  # gloo (CPU tests)
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        host = torch.stack(parts).numpy()
+    return [host[r, : counts[r]] for r in range(world)]
+
+
+def fold_records(per_rank: List[np.ndarray], fps, ar_coeff_lag: int = 3) -> List[GrainTableSegment]:
+    """The ordered fold over all records, rank-major == global frame order for
+    contiguous frame chunks."""
+    fold = RecordFold(fps, ar_coeff_lag)
+    for recs in per_rank:
+        for i in range(recs.shape[0]):
+            fold.push(recs[i])
+    segs = fold.finish()
+    fold.close()
+    return segs
+
+
+class ShardedDiff:
+    """DiffGenerator over a frame shard.  With `group=None` it is the plain
+    single-GPU generator; with a torch.distributed module/group, each rank feeds
+    ITS frames (rank r's frames precede rank r+1's in the video) and `finish()`
+    returns the segments on rank 0 (None elsewhere)."""
+
+    def __init__(self, fps, source_bit_depth: int, denoised_bit_depth: int, *, ar_coeff_lag: int = 3,
+                 luma_only: bool = False, device: int = -1, batch_frames: int = 0, group=None):
+        self.dist = group
+        self.fps = Fraction(fps)
+        self.lag = ar_coeff_lag
+        self.device = device
+        self.generator = DiffGenerator(fps, source_bit_depth, denoised_bit_depth, ar_coeff_lag=ar_coeff_lag,
+                                       luma_only=luma_only, device=device, batch_frames=batch_frames,
+                                       records_only=group is not None)
+        self._shape = None
+        self._nframes = 0
+        self._luma_only = luma_only
+
+    def diff_frame(self, source, denoised, xdec: int = 1, ydec: int = 1, sync_torch: bool = True) -> None:
+        if self._shape is None:
+            p0 = source[0] if not hasattr(source, "planes") else source.planes[0]
+            npl = 1 if self._luma_only else (len(source) if not hasattr(source, "planes") else len(source.planes))
+            self._shape = (int(p0.shape[1]), int(p0.shape[0]), npl)
+        self.generator.diff_frame(source, denoised, xdec, ydec, sync_torch=sync_torch)
+        self._nframes += 1
+
+    def finish(self) -> Optional[List[GrainTableSegment]]:
+        if self.dist is None:
+            return self.generator.finish()
+        w, h, npl = self._shape if self._shape else (32, 32, 1)
+        recs, n = self.generator.take_records(w, h, npl, self._nframes)
+        dev = torch.device("cuda", self.device if self.device >= 0 else torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
+        per_rank = gather_records(recs, self.dist, dev)
+        if self.dist.get_rank() != 0:
+            return None
+        return fold_records(per_rank, self.fps, self.lag)
+
+    def close(self) -> None:
+        self.generator.close()

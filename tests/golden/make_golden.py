@@ -1,0 +1,44 @@
+"""Generates tests/golden/oracle_*.tbl with the CPU oracle on seeded synthetic
+frames.  These pin the ORACLE against regressions (and the GPU path against the
+oracle); they do NOT pin the oracle against the reference: the reference has
+no `diff` vectors and its arithmetic (crate av1-grain 0.4.2) cannot be built
+here.  reference-example-table.tbl is the reference's own data
+file tests/example-table.tbl (format anchor for the writer/parser)."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from fractions import Fraction  # noqa: E402
+
+from grav1synth_amd.synth import SynthSpec  # noqa: E402
+from tests.helpers import oracle_run  # noqa: E402
+
+GOLDEN = {
+    "oracle_320x192_8b_420_lag3.tbl": dict(spec=SynthSpec(320, 192, 8), frames=3, lag=3, chroma=True),
+    "oracle_320x200_10b_420_lag3.tbl": dict(spec=SynthSpec(320, 200, 10), frames=2, lag=3, chroma=True),
+    "oracle_256x160_10b_444_lag3.tbl": dict(spec=SynthSpec(256, 160, 10, xdec=0, ydec=0), frames=2, lag=3, chroma=True),
+    "oracle_320x192_8b_lag2_luma.tbl": dict(spec=SynthSpec(320, 192, 8), frames=2, lag=2, chroma=False),
+    "oracle_scenecut_30000_1001.tbl": dict(spec=SynthSpec(320, 192, 8), frames=6, lag=3, chroma=True, cut=3),
+}
+
+
+def generate(name):
+    g = GOLDEN[name]
+    spec = g["spec"]
+    specs = None
+    fps = Fraction(24, 1)
+    if "cut" in g:
+        b = SynthSpec(spec.width, spec.height, spec.bit_depth, gain_scale=3)
+        specs = [spec if k < g["cut"] else b for k in range(g["frames"])]
+        fps = Fraction(30000, 1001)
+    tbl, _ = oracle_run(spec, range(g["frames"]), g["lag"], g["chroma"], fps=fps, specs_per_frame=specs)
+    return tbl
+
+
+if __name__ == "__main__":
+    for name in GOLDEN:
+        with open(os.path.join(HERE, name), "wb") as f:
+            f.write(generate(name))
+        print("wrote", name)
