@@ -18,6 +18,7 @@
 #include "../../include/g1s_diff.h"
 #include "fold.h"
 #include "kernels.hip.h"
+#include "k3_fast.hip.h"
 #include "record.h"
 
 using namespace g1s;
@@ -45,6 +46,8 @@ struct Slot {
   uint8_t *d_records = nullptr;
   uint8_t *h_records = nullptr;  // pinned
   uint8_t *d_flags = nullptr;
+  int32_t *d_partials = nullptr;   // k3_fast chunk partials
+  uint8_t *d_defer = nullptr;      // [batch][nblocks] + [batch] u32 flags behind it
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
   hipEvent_t done = nullptr;
@@ -69,6 +72,8 @@ struct g1s_diff {
   RecLayout L{};
   FlatConsts fc{};
   double *d_lut = nullptr;
+  int fast_chunks = 0;
+  size_t defer_bytes = 0;
   Slot slots[2];
   int cur = 0;
   std::deque<int> in_flight;
@@ -163,6 +168,13 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     HIP_TRY(hipMalloc((void **)&sl.d_records, L.size * batch));
     HIP_TRY(hipHostMalloc((void **)&sl.h_records, L.size * batch, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&sl.d_flags, (size_t)g.nblocks * batch));
+    if (lag == kFastLag) {
+      fast_chunks = (g.nblocks + kMaxBlocksPerWG - 1) / kMaxBlocksPerWG;
+      if (fast_chunks < 64) fast_chunks = std::min(64, g.nblocks);
+      HIP_TRY(hipMalloc((void **)&sl.d_partials, sizeof(int32_t) * (size_t)batch * 3 * fast_chunks * kPartStride));
+      defer_bytes = (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15)) + sizeof(uint32_t) * batch;
+      HIP_TRY(hipMalloc((void **)&sl.d_defer, defer_bytes));
+    }
     sl.stage_bytes_per_frame = frame_bytes;
     HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
@@ -256,9 +268,26 @@ int g1s_diff::submit(int si) {
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], stream));
   hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(256), 0, stream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], stream));
-  {
+  if ((int)lag == kFastLag) {
+    // lag 3: dot4 kernel per plane kind, chunk reducer, then the generic kernel
+    // for the (rare) blocks whose residual does not fit int8
+    FastParams fpm;
+    fpm.nchunks = fast_chunks;
+    fpm.partials = sl.d_partials;
+    fpm.defer = sl.d_defer;
+    fpm.defer_any = reinterpret_cast<uint32_t *>(sl.d_defer + (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15)));
+    HIP_TRY(hipMemsetAsync(sl.d_defer, 0, defer_bytes, stream));
+    hipLaunchKernelGGL(k3_fast<false>, dim3(fast_chunks, 1, B), dim3(kFastThreads), 0, stream, sl.d_planes, g, fpm, sl.d_records);
+    if (g.nplanes == 3)
+      hipLaunchKernelGGL(k3_fast<true>, dim3(fast_chunks, 1, B), dim3(kFastThreads), 0, stream, sl.d_planes, g, fpm, sl.d_records);
+    hipLaunchKernelGGL(k3_fast_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, fpm, sl.d_records);
     const int chunks = std::min(kK3Chunks, g.nblocks);
-    hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, sl.d_planes, g, sl.d_records);
+    hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, sl.d_planes, g, sl.d_records,
+                       (const uint8_t *)fpm.defer, (const uint32_t *)fpm.defer_any);
+  } else {
+    const int chunks = std::min(kK3Chunks, g.nblocks);
+    hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, sl.d_planes, g, sl.d_records,
+                       (const uint8_t *)nullptr, (const uint32_t *)nullptr);
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[3], stream));
   HIP_TRY(hipGetLastError());
@@ -360,6 +389,8 @@ void g1s_diff::release() {
     if (sl.d_records) (void)hipFree(sl.d_records);
     if (sl.h_records) (void)hipHostFree(sl.h_records);
     if (sl.d_flags) (void)hipFree(sl.d_flags);
+    if (sl.d_partials) (void)hipFree(sl.d_partials);
+    if (sl.d_defer) (void)hipFree(sl.d_defer);
     if (sl.d_stage) (void)hipFree(sl.d_stage);
     if (sl.done) (void)hipEventDestroy(sl.done);
     for (auto &e : sl.ev)

@@ -285,12 +285,19 @@ __device__ __forceinline__ int block_reduce_sum(int v, int *scratch) {
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
+// `only` (optional): per-frame block lists [batch][2][nblocks] (luma, chroma); when given, only the
+// blocks marked there are processed (the blocks the lag-3 fast kernel deferred
+// because |d| > 127), and frames with only_any[frame] == 0 exit at once.
 __global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FramePlanes *__restrict__ frames, Geom g,
-                                                            uint8_t *__restrict__ records) {
+                                                            uint8_t *__restrict__ records,
+                                                            const uint8_t *__restrict__ only,
+                                                            const uint32_t *__restrict__ only_any) {
   __shared__ int tile[kMaxTile + kBlock * kBlock];  // d tile, then luma-sum tile
   __shared__ int red[4];
   const int c = blockIdx.y;
   const int frame = blockIdx.z;
+  if (only_any && only_any[frame] == 0) return;
+  const uint8_t *only_f = only ? only + ((size_t)frame * 2 + (c > 0 ? 1 : 0)) * g.nblocks : nullptr;
   const FramePlanes fp = frames[frame];
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
@@ -351,6 +358,7 @@ __global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FramePlanes *_
 
   for (int blk = blockIdx.x; blk < g.nblocks; blk += gridDim.x) {
     if (!mask[blk]) continue;
+    if (only_f && !only_f[blk]) continue;
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int x_o = bx * bw, y_o = by * bh;
     // ---- stage the residual tile ----

@@ -158,3 +158,36 @@ def test_errors_match_reference_behaviour():
     with pytest.raises(G1SError) as e:
         g2.diff_frame(s, d)
     assert e.value.code == -7
+
+
+@pytest.mark.parametrize("bd,xdec,ydec", [(8, 1, 1), (10, 0, 0)])
+def test_large_residuals_take_the_deferred_path(bd, xdec, ydec):
+    """|src - den| > 127 does not fit the int8 dot4 path: those blocks must be
+    handled by the generic kernel with identical integer sums."""
+    spec = SynthSpec(320, 192, bd, xdec=xdec, ydec=ydec)
+    up = bd - 8
+    o_args = (24, 1, bd, bd, 3, True)
+    from tests.oracle_binding import OracleDiff, format_tbl as ofmt
+
+    o = OracleDiff(*o_args)
+    g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=2)
+    rng = np.random.default_rng(7)
+    for k in range(2):
+        s, d = np_pair(spec, k)
+        d = [p.copy() for p in d]
+        # damage the DENOISED side only (the flat-block finder looks at the source)
+        for c in range(3):
+            h, w = d[c].shape
+            for _ in range(12):
+                y, x = int(rng.integers(0, h)), int(rng.integers(0, w * 2 // 3))
+                d[c][y, x] = 0 if s[c][y, x] > (140 << up) else (255 << up)
+        o.diff_frame(s, d, xdec, ydec)
+        g.diff_frame([torch.from_numpy(p).cuda() for p in s], [torch.from_numpy(p).cuda() for p in d], xdec, ydec)
+        if k == 1:
+            g.sync()
+            r = g.last_record()
+            for c in range(3):
+                S, Sb, n = o.ar_sums(c)
+                S2, Sb2, n2 = r.ar_sums(c)
+                assert n == n2 and np.array_equal(S, S2) and np.array_equal(Sb, Sb2), f"plane {c}"
+    assert format_tbl(g.finish()) == ofmt(o.finish())
