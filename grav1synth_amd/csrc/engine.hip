@@ -254,6 +254,14 @@ int g1s_diff::submit(int si) {
     if (((uintptr_t)sl.h_planes[i].src[0] & 15) || (sl.h_planes[i].src_stride[0] & 15)) fast = 0;
   }
   g.fast_rows = fast;
+  int vec_mask = 0x3f;
+  for (uint32_t i = 0; i < B; ++i) {
+    for (int c = 0; c < g.nplanes; ++c) {
+      if (((uintptr_t)sl.h_planes[i].src[c] & 15) || (sl.h_planes[i].src_stride[c] & 15)) vec_mask &= ~(1 << c);
+      if (((uintptr_t)sl.h_planes[i].den[c] & 15) || (sl.h_planes[i].den_stride[c] & 15)) vec_mask &= ~(8 << c);
+    }
+  }
+  g.vec_mask = vec_mask;
   HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(sl.d_records, 0, L.size * B, stream));
   sl.timed = timing;
@@ -268,7 +276,8 @@ int g1s_diff::submit(int si) {
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], stream));
   hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(256), 0, stream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], stream));
-  if ((int)lag == kFastLag) {
+  const bool fast_ok = (int)lag == kFastLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
+  if (fast_ok) {
     // lag 3: dot4 kernel per plane kind, chunk reducer, then the generic kernel
     // for the (rare) blocks whose residual does not fit int8
     FastParams fpm;
@@ -277,9 +286,16 @@ int g1s_diff::submit(int si) {
     fpm.defer = sl.d_defer;
     fpm.defer_any = reinterpret_cast<uint32_t *>(sl.d_defer + (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15)));
     HIP_TRY(hipMemsetAsync(sl.d_defer, 0, defer_bytes, stream));
-    hipLaunchKernelGGL(k3_fast<false>, dim3(fast_chunks, 1, B), dim3(kFastThreads), 0, stream, sl.d_planes, g, fpm, sl.d_records);
-    if (g.nplanes == 3)
-      hipLaunchKernelGGL(k3_fast<true>, dim3(fast_chunks, 1, B), dim3(kFastThreads), 0, stream, sl.d_planes, g, fpm, sl.d_records);
+    hipLaunchKernelGGL(k3_fast<0>, dim3(fast_chunks, 1, B), dim3(kFastThreads), 0, stream, sl.d_planes, g, fpm, sl.d_records);
+    if (g.nplanes == 3) {
+      const dim3 cg(fast_chunks, 1, B), cb(kFastThreads);
+      if (g.xdec == 1 && g.ydec == 1)
+        hipLaunchKernelGGL(k3_fast<1>, cg, cb, 0, stream, sl.d_planes, g, fpm, sl.d_records);
+      else if (g.xdec == 1)
+        hipLaunchKernelGGL(k3_fast<2>, cg, cb, 0, stream, sl.d_planes, g, fpm, sl.d_records);
+      else
+        hipLaunchKernelGGL(k3_fast<3>, cg, cb, 0, stream, sl.d_planes, g, fpm, sl.d_records);
+    }
     hipLaunchKernelGGL(k3_fast_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, fpm, sl.d_records);
     const int chunks = std::min(kK3Chunks, g.nblocks);
     hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, sl.d_planes, g, sl.d_records,

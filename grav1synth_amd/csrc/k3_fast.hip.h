@@ -15,6 +15,10 @@
 //    workgroup = 4 waves = {half 0, half 1} x {2 row halves} for luma, or
 //    {Cb, Cr} x {half 0, half 1} for chroma (both planes share the L tile);
 //  * the window of a block is a per-lane byte mask on the LEFT operand only;
+//  * HBM -> LDS staging is software-pipelined: while the waves multiply block k,
+//    the 8-sample (16-byte for u16) vector loads of the next flat block are
+//    already in flight into registers; they are narrowed (>> (bd-8)), subtracted
+//    and written with ds_write_b64 after the barrier;
 //  * per-lane int32 accumulators live across all blocks of the workgroup's chunk
 //    (<= 128 blocks, so int32 cannot overflow), are reduced across the wave once
 //    at the end and stored as int32 partials; k3_fast_reduce adds the chunks
@@ -46,14 +50,13 @@ __host__ __device__ constexpr bool in_half(int half, int i) {
 
 // Partial layout per (frame, kind, chunk): kind 0 = luma, 1 = Cb, 2 = Cr.
 //   [half0 accumulators][half1 accumulators][nobs]
-constexpr int kPartLuma = 2 * kHalfPairs + 1;
 constexpr int kPartChroma = 2 * kHalfPairsChroma + 1;
 constexpr int kPartStride = kPartChroma;  // ints per (frame, kind, chunk) slot
 
 struct FastParams {
   int nchunks;
-  int32_t *partials;  // [batch][3][nchunks][kPartStride]
-  uint8_t *defer;     // [batch][2][nblocks] (luma, chroma) 1 = block left to the generic kernel
+  int32_t *partials;    // [batch][3][nchunks][kPartStride]
+  uint8_t *defer;       // [batch][2][nblocks] (luma, chroma) 1 = block left to the generic kernel
   uint32_t *defer_any;  // [batch] nonzero if the frame has deferred blocks
 };
 
@@ -65,6 +68,19 @@ __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// all accumulators at once: 6 butterfly stages, each with N independent shuffles in flight
+template <int N>
+__device__ __forceinline__ void wave_sum_all(int (&a)[N]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = __shfl_xor(a[i], o, 64);
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] += t[i];
+  }
 }
 
 // One group step: all products of this wave's half.  V[k]: operand k (k = (cy+3)*7 + cx+3),
@@ -102,17 +118,100 @@ __device__ __forceinline__ void accumulate_half(int (&acc)[CHROMA ? kHalfPairsCh
   }
 }
 
-// LDS tile geometry: sample (x, y) of the block (x in -3..bw+2, y in -3..bh-1)
-// lives at byte (y + 3) * pitch + 4 + x, so that group g (x = 4g) starts on a
-// dword boundary and dword index of x=4g is g + 1.
-template <bool CHROMA>
+// ---- 8 consecutive samples of a row -----------------------------------------
+struct Px8 {
+  uint4 raw;  // u16: 8 samples; u8: .x,.y hold 8 samples
+  int state;  // 0 = all zero (outside the plane), 1 = raw is valid, 2 = edge segment: per-sample loads later
+};
+__device__ __forceinline__ Px8 fetch8(const uint8_t *base, uint32_t stride, int bps, bool vec_ok, int X0, int Y,
+                                      int pw, int ph) {
+  Px8 r;
+  r.raw = make_uint4(0, 0, 0, 0);
+  r.state = 0;
+  if (Y < 0 || Y >= ph || X0 + 8 <= 0 || X0 >= pw) return r;
+  if (X0 >= 0 && X0 + 8 <= pw && vec_ok) {
+    gptr_u8 p = as_global(base) + (size_t)Y * stride + (size_t)X0 * bps;
+    if (bps == 2) {
+      r.raw = gload4((gptr_u4)p);
+    } else {
+      const uint2 v = gload2((gptr_u2)p);
+      r.raw.x = v.x;
+      r.raw.y = v.y;
+    }
+    r.state = 1;
+  } else {
+    r.state = 2;
+  }
+  return r;
+}
+// narrow to 8-bit samples (frame_into_u8: truncating shift); v[k] for k = 0..7
+__device__ __forceinline__ void unpack8(const Px8 &p, const uint8_t *base, uint32_t stride, int bps, int shift,
+                                        int X0, int Y, int pw, int (&v)[8]) {
+  if (p.state == 1) {
+    if (bps == 2) {
+      const uint32_t w[4] = {p.raw.x, p.raw.y, p.raw.z, p.raw.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] = (int)(((w[k] & 0xffffu) >> shift) & 0xffu);
+        v[2 * k + 1] = (int)(((w[k] >> 16) >> shift) & 0xffu);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = (int)((p.raw.x >> (8 * k)) & 0xffu);
+        v[4 + k] = (int)((p.raw.y >> (8 * k)) & 0xffu);
+      }
+    }
+  } else if (p.state == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int X = X0 + k;
+      v[k] = (X >= 0 && X < pw) ? load_px_rt(base, stride, bps, shift, X, Y) : 0;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0;
+  }
+}
+
+// KIND: 0 = luma; 1 = chroma 4:2:0; 2 = chroma 4:2:2; 3 = chroma 4:4:4.
+template <int KIND>
+struct FastShape {
+  static constexpr bool kChroma = KIND != 0;
+  static constexpr int SX = (KIND == 1 || KIND == 2) ? 1 : 0;
+  static constexpr int SY = (KIND == 1) ? 1 : 0;
+  static constexpr int BW = kBlock >> SX, BH = kBlock >> SY;
+  static constexpr int G = BW / 4;              // groups per block row
+  static constexpr int ROWS_PER_STEP = 64 / G;  // 8 or 16
+  static constexpr int STEPS = BH / ROWS_PER_STEP;
+  static constexpr int PITCH_DW = 32 + G;  // conflict-free for the (group, row) lane map
+  static constexpr int PITCH = PITCH_DW * 4;
+  static constexpr int TH = BH + 3;
+  static constexpr int SEGS = (BW + 16) / 8;  // 8-sample segments per tile row: x = -8 .. BW+7
+  static constexpr int NPL = kChroma ? 2 : 1;
+  static constexpr int NTILE = TH * SEGS * NPL;
+  static constexpr int LCH = 8 >> SX;  // chroma samples per L item (8 luma samples wide)
+  static constexpr int LSEGS = BW / LCH;
+  static constexpr int NL = kChroma ? BH * LSEGS : 0;
+  static constexpr int LROWS = 1 << SY;
+  static constexpr int NITEMS = NTILE + NL;
+  static constexpr int MAXIT = (NITEMS + kFastThreads - 1) / kFastThreads;
+  static constexpr int SLOT = kChroma ? LROWS : 1;  // Px8 pairs per item slot
+  static constexpr int TILE_BYTES = TH * PITCH;
+  static constexpr int LTILE_BYTES = BH * PITCH;
+  static constexpr int LDS_BYTES = NPL * TILE_BYTES + (kChroma ? 2 * LTILE_BYTES : 0);
+  static constexpr int NACC = kChroma ? kHalfPairsChroma : kHalfPairs;
+};
+
+// LDS tile geometry: sample (x, y) of the block (x in -8..BW+7, y in -3..BH-1)
+// lives at byte (y + 3) * PITCH + 8 + x: group g (x = 4g) is dword g + 2.
+template <int KIND>
 __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__restrict__ frames, Geom g,
                                                            FastParams fpm, uint8_t *__restrict__ records) {
-  constexpr int NACC = CHROMA ? kHalfPairsChroma : kHalfPairs;
-  constexpr int kMaxPitchDw = 40;
-  constexpr int kTileBytes = (kBlock + 3) * kMaxPitchDw * 4;
-  // chroma: tile 0 = Cb, tile 1 = Cr, then La, Lb (offset-0 only: no halo)
-  __shared__ __attribute__((aligned(16))) uint8_t lds[CHROMA ? (2 * kTileBytes + 2 * kBlock * kMaxPitchDw * 4) : kTileBytes];
+  using S = FastShape<KIND>;
+  constexpr bool CHROMA = S::kChroma;
+  constexpr int NACC = S::NACC;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[S::LDS_BYTES];
   __shared__ int s_flag[2];
   __shared__ int s_stat[2][4][4];  // double-buffered by iteration parity
 
@@ -122,82 +221,157 @@ __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-
-  const int sx = CHROMA ? g.xdec : 0, sy = CHROMA ? g.ydec : 0;
-  const int pw = g.W >> sx, ph = g.H >> sy;
-  const int bw = kBlock >> sx, bh = kBlock >> sy;
-  const int G = bw >> 2;            // groups per block row (8 or 4)
-  const int rows_per_step = 64 / G;  // 8 or 16
-  const int steps_per_block = bh / rows_per_step;
-  const int pitch_dw = 32 + G;  // conflict-free for the (group, row) lane map
-  const int pitch = pitch_dw * 4;
-  const int TW = bw + 6, TH = bh + 3;
-  const int lag = kFastLag;
+  const int pw = g.W >> S::SX, ph = g.H >> S::SY;
+  constexpr int bw = S::BW, bh = S::BH, lag = kFastLag;
 
   // wave roles
-  const int half = CHROMA ? (wave & 1) : (wave & 1);
+  const int half = wave & 1;
   const int plane_sel = CHROMA ? (wave >> 1) : 0;  // 0 = Cb, 1 = Cr
   const int row_half = CHROMA ? 0 : (wave >> 1);
-  const int my_steps = CHROMA ? steps_per_block : steps_per_block / 2;
-  const int lg = lane % G, lr = lane / G;
+  constexpr int my_steps = CHROMA ? S::STEPS : S::STEPS / 2;
+  const int lg = lane % S::G, lr = lane / S::G;
 
   int acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0;
   int nobs = 0;
   if (tid < 2) s_flag[tid] = 0;
+
+  // ---- staging items of this thread (fixed for the whole kernel) ----
+  // item < NTILE: (plane pl, tile row ty, segment sg); else: L item (chroma row, segment)
+  Px8 ps[S::MAXIT][S::SLOT], pd[S::MAXIT][S::SLOT];
+  auto item_fetch = [&](int blk) {
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const int x_o = bx * bw, y_o = by * bh;
+#pragma unroll
+    for (int k = 0; k < S::MAXIT; ++k) {
+      const int it = tid + k * kFastThreads;
+      if (it < S::NTILE) {
+        const int pl = it / (S::TH * S::SEGS);
+        const int r = it - pl * (S::TH * S::SEGS);
+        const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
+        const int c = CHROMA ? 1 + pl : 0;
+        const int X0 = x_o - 8 + 8 * sg, Y = y_o - lag + ty;
+        ps[k][0] = fetch8(fp.src[c], fp.src_stride[c], g.src_bps, (g.vec_mask >> c) & 1, X0, Y, pw, ph);
+        pd[k][0] = fetch8(fp.den[c], fp.den_stride[c], g.den_bps, (g.vec_mask >> (3 + c)) & 1, X0, Y, pw, ph);
+      } else if (CHROMA && it < S::NITEMS) {
+        const int r = it - S::NTILE;
+        const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
+        const int X0 = (x_o + sg * S::LCH) << S::SX;  // luma coordinates
+#pragma unroll
+        for (int q = 0; q < S::LROWS; ++q) {
+          const int Y = ((y_o + y) << S::SY) + q;
+          ps[k][q] = fetch8(fp.src[0], fp.src_stride[0], g.src_bps, g.vec_mask & 1, X0, Y, g.W, g.H);
+          pd[k][q] = fetch8(fp.den[0], fp.den_stride[0], g.den_bps, (g.vec_mask >> 3) & 1, X0, Y, g.W, g.H);
+        }
+      }
+    }
+  };
+  // narrow, subtract, range-check and write the staged block into LDS
+  auto item_store = [&](int blk, int &lsum) -> bool {
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const int x_o = bx * bw, y_o = by * bh;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < S::MAXIT; ++k) {
+      const int it = tid + k * kFastThreads;
+      if (it < S::NTILE) {
+        const int pl = it / (S::TH * S::SEGS);
+        const int r = it - pl * (S::TH * S::SEGS);
+        const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
+        const int c = CHROMA ? 1 + pl : 0;
+        const int X0 = x_o - 8 + 8 * sg, Y = y_o - lag + ty;
+        int sv[8], dv[8];
+        unpack8(ps[k][0], fp.src[c], fp.src_stride[c], g.src_bps, g.src_shift, X0, Y, pw, sv);
+        unpack8(pd[k][0], fp.den[c], fp.den_stride[c], g.den_bps, g.den_shift, X0, Y, pw, dv);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int d = sv[q] - dv[q];
+          bad |= (d > 127) | (d < -127);
+          const uint32_t b = (uint32_t)d & 0xffu;
+          if (q < 4) lo |= b << (8 * q); else hi |= b << (8 * (q - 4));
+        }
+        if (!CHROMA && sg >= 1 && sg <= 4 && ty >= lag) {  // block proper -> luma sum of the source
+#pragma unroll
+          for (int q = 0; q < 8; ++q) lsum += sv[q];
+        }
+        *reinterpret_cast<uint2 *>(lds + pl * S::TILE_BYTES + ty * S::PITCH + 8 * sg) = make_uint2(lo, hi);
+      } else if (CHROMA && it < S::NITEMS) {
+        const int r = it - S::NTILE;
+        const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
+        const int X0 = (x_o + sg * S::LCH) << S::SX;
+        int L[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) L[q] = 0;
+#pragma unroll
+        for (int q = 0; q < S::LROWS; ++q) {
+          const int Y = ((y_o + y) << S::SY) + q;
+          int sv[8], dv[8];
+          unpack8(ps[k][q], fp.src[0], fp.src_stride[0], g.src_bps, g.src_shift, X0, Y, g.W, sv);
+          unpack8(pd[k][q], fp.den[0], fp.den_stride[0], g.den_bps, g.den_shift, X0, Y, g.W, dv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int d = sv[e] - dv[e];
+            bad |= (d > 127) | (d < -127);
+            L[e >> S::SX] += d;
+          }
+        }
+        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+        for (int e = 0; e < S::LCH; ++e) {
+          const uint32_t av = (uint32_t)(L[e] >> 2) & 0xffu, bv = (uint32_t)(L[e] & 3);
+          if (e < 4) {
+            a0 |= av << (8 * e);
+            b0 |= bv << (8 * e);
+          } else {
+            a1 |= av << (8 * (e - 4));
+            b1 |= bv << (8 * (e - 4));
+          }
+        }
+        uint8_t *ta = lds + S::NPL * S::TILE_BYTES + y * S::PITCH + sg * S::LCH;
+        uint8_t *tb = ta + S::LTILE_BYTES;
+        if (S::LCH == 8) {
+          *reinterpret_cast<uint2 *>(ta) = make_uint2(a0, a1);
+          *reinterpret_cast<uint2 *>(tb) = make_uint2(b0, b1);
+        } else {
+          *reinterpret_cast<uint32_t *>(ta) = a0;
+          *reinterpret_cast<uint32_t *>(tb) = b0;
+        }
+      }
+    }
+    return bad;
+  };
+
+  auto next_flat = [&](int blk) {
+    while (blk < g.nblocks && !mask[blk]) blk += fpm.nchunks;
+    return blk;
+  };
+
+  int cur = next_flat(chunk);
+  if (cur < g.nblocks) item_fetch(cur);
   __syncthreads();
 
   int iter = 0;
-  for (int blk = chunk; blk < g.nblocks; blk += fpm.nchunks) {
-    if (!mask[blk]) continue;
+  while (cur < g.nblocks) {
+    const int blk = cur;
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int x_o = bx * bw, y_o = by * bh;
     const int fl = iter & 1;
     ++iter;
 
-    // ------------------------------ stage the tile(s) ------------------------------
+    // ---------------- staged registers -> LDS ----------------
     int lsum = 0;
-    bool bad = false;
-    const int nplanes_here = CHROMA ? 2 : 1;
-    for (int pl = 0; pl < nplanes_here; ++pl) {
-      const int c = CHROMA ? 1 + pl : 0;
-      const uint8_t *sp = fp.src[c], *dp = fp.den[c];
-      const uint32_t sst = fp.src_stride[c], dst = fp.den_stride[c];
-      uint8_t *tile = lds + pl * kTileBytes;
-      for (int idx = tid; idx < TW * TH; idx += kFastThreads) {
-        const int ty = idx / TW, tx = idx - ty * TW;
-        const int X = x_o - lag + tx, Y = y_o - lag + ty;
-        int d = 0;
-        if (X >= 0 && X < pw && Y >= 0 && Y < ph) {
-          const int s = load_px_rt(sp, sst, g.src_bps, g.src_shift, X, Y);
-          d = s - load_px_rt(dp, dst, g.den_bps, g.den_shift, X, Y);
-          if (!CHROMA && tx >= lag && tx < lag + bw && ty >= lag) lsum += s;
-        }
-        if (d > 127 || d < -127) bad = true;
-        tile[ty * pitch + 1 + tx] = (uint8_t)(int8_t)d;  // x = tx - 3 -> byte 4 + x
-      }
-    }
-    if (CHROMA) {
-      uint8_t *ta = lds + 2 * kTileBytes, *tb = ta + kBlock * kMaxPitchDw * 4;
-      for (int idx = tid; idx < bw * bh; idx += kFastThreads) {
-        const int y = idx / bw, x = idx - y * bw;
-        const int X = x_o + x, Y = y_o + y;
-        int L = 0;
-        if (X < pw && Y < ph) {
-          for (int dy = 0; dy < (1 << sy); ++dy)
-            for (int dx = 0; dx < (1 << sx); ++dx) {
-              const int lx = (X << sx) + dx, ly = (Y << sy) + dy;
-              const int dd = load_px_rt(fp.src[0], fp.src_stride[0], g.src_bps, g.src_shift, lx, ly) -
-                             load_px_rt(fp.den[0], fp.den_stride[0], g.den_bps, g.den_shift, lx, ly);
-              if (dd > 127 || dd < -127) bad = true;
-              L += dd;
-            }
-        }
-        ta[y * pitch + x] = (uint8_t)(int8_t)(L >> 2);
-        tb[y * pitch + x] = (uint8_t)(L & 3);
-      }
-    }
+    const bool bad = item_store(blk, lsum);
+    // window of this block + the next flat block: every mask byte is read BEFORE the
+    // prefetch is issued (vmcnt retires in order: a later load waited on would drain it)
+    const int y_start = (by > 0 && mask[(by - 1) * g.nbw + bx]) ? 0 : lag;
+    const int x_start = (bx > 0 && mask[by * g.nbw + bx - 1]) ? 0 : lag;
+    const int y_end = min(ph - y_o, bh);
+    const int x_end = min(pw - x_o - lag, (bx + 1 < g.nbw && mask[by * g.nbw + bx + 1]) ? bw : (bw - lag));
+    cur = next_flat(blk + fpm.nchunks);
+    // ---------------- prefetch the next flat block: in flight during the products below ----------------
+    if (cur < g.nblocks) item_fetch(cur);
     if (bad) s_flag[fl] = 1;
     if (!CHROMA) {
       lsum = wave_sum(lsum);
@@ -215,20 +389,15 @@ __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__
       continue;
     }
 
-    // ------------------------------ window of this block ------------------------------
-    const int y_start = (by > 0 && mask[(by - 1) * g.nbw + bx]) ? 0 : lag;
-    const int x_start = (bx > 0 && mask[by * g.nbw + bx - 1]) ? 0 : lag;
-    const int y_end = min(ph - y_o, bh);
-    const int x_end = min(pw - x_o - lag, (bx + 1 < g.nbw && mask[by * g.nbw + bx + 1]) ? bw : (bw - lag));
     if (tid == 0 && x_end > x_start && y_end > y_start) nobs += (x_end - x_start) * (y_end - y_start);
 
     // ------------------------------ products ------------------------------
-    const uint8_t *tile = lds + (CHROMA ? plane_sel * kTileBytes : 0);
+    const uint32_t *t32 = reinterpret_cast<const uint32_t *>(lds + (CHROMA ? plane_sel * S::TILE_BYTES : 0));
     int sd = 0, sd2 = 0;
+#pragma unroll 1
     for (int s = 0; s < my_steps; ++s) {
-      const int row = (row_half * my_steps + s) * rows_per_step + lr;  // sample row in the block
-      // window byte mask of this group
-      uint32_t wm = 0;
+      const int row = (row_half * my_steps + s) * S::ROWS_PER_STEP + lr;  // sample row in the block
+      uint32_t wm = 0;  // window byte mask of this group
       if (row >= y_start && row < y_end) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -236,12 +405,10 @@ __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__
           if (x >= x_start && x < x_end) wm |= 0xffu << (8 * k);
         }
       }
-      // operand rows: tile row (row + cy + 3), dwords lg .. lg+2
       uint32_t V[kFastN];
-      const uint32_t *t32 = reinterpret_cast<const uint32_t *>(tile);
 #pragma unroll
       for (int cy = -3; cy <= -1; ++cy) {
-        const uint32_t *rp = t32 + (row + cy + 3) * pitch_dw + lg;
+        const uint32_t *rp = t32 + (row + cy + 3) * S::PITCH_DW + lg + 1;
         const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
         const int k0 = (cy + 3) * 7;
         V[k0 + 0] = alignbyte(d1, d0, 1);  // cx = -3
@@ -254,7 +421,7 @@ __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__
       }
       uint32_t VY;
       {
-        const uint32_t *rp = t32 + (row + 3) * pitch_dw + lg;
+        const uint32_t *rp = t32 + (row + 3) * S::PITCH_DW + lg + 1;
         const uint32_t d0 = rp[0], d1 = rp[1];
         V[21] = alignbyte(d1, d0, 1);
         V[22] = alignbyte(d1, d0, 2);
@@ -263,10 +430,9 @@ __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__
       }
       uint32_t La = 0, Lb = 0;
       if (CHROMA) {
-        const uint32_t *ta = reinterpret_cast<const uint32_t *>(lds + 2 * kTileBytes);
-        const uint32_t *tb = ta + kBlock * kMaxPitchDw;
-        La = ta[row * pitch_dw + lg];
-        Lb = tb[row * pitch_dw + lg];
+        const uint32_t *ta = reinterpret_cast<const uint32_t *>(lds + S::NPL * S::TILE_BYTES);
+        La = ta[row * S::PITCH_DW + lg];
+        Lb = ta[S::LTILE_BYTES / 4 + row * S::PITCH_DW + lg];
       }
       if (half == 0) {
         accumulate_half<0, CHROMA>(acc, V, VY, La, Lb, wm);
@@ -287,13 +453,12 @@ __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__
     }
     __syncthreads();
     if (tid == 0) {
+      const int(*st)[4] = s_stat[fl];
       if (!CHROMA) {
-        const int(*st)[4] = s_stat[fl];
         reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = st[0][0] + st[2][0];
         reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)(st[0][1] + st[2][1]);
         reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)(st[0][3] + st[1][3] + st[2][3] + st[3][3]);
       } else {
-        const int(*st)[4] = s_stat[fl];
         reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = st[0][0];
         reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)st[0][1];
         reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = st[2][0];
@@ -305,18 +470,28 @@ __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__
   }
 
   // ------------------------------ wave reduction + partial store ------------------------------
-  const int kinds = 3;
-  (void)kinds;
-  if (!CHROMA) {
-    // luma: two waves (row halves) hold the same half -> both add into the slot via LDS
-    __syncthreads();
-    int *red = reinterpret_cast<int *>(lds);  // tiles are dead now
+  __syncthreads();
+  int *red = reinterpret_cast<int *>(lds);  // tiles are dead now
+  static_assert(4 * NACC * 4 <= S::LDS_BYTES, "reduction scratch must fit in the tile LDS");
+  // reduce in chunks of 27 accumulators: 27 independent ds_bpermute per stage
+  {
+    constexpr int CH = 27;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-      const int v = wave_sum(acc[i]);
-      if (lane == 0) red[wave * NACC + i] = v;
+    for (int b0 = 0; b0 < NACC; b0 += CH) {
+      int tmp[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) tmp[i] = (b0 + i < NACC) ? acc[b0 + i] : 0;
+      wave_sum_all<CH>(tmp);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if (b0 + i < NACC) red[wave * NACC + b0 + i] = tmp[i];
+      }
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (!CHROMA) {
+    // two waves (row halves) hold the same half
     int32_t *out = fpm.partials + (((size_t)frame * 3 + 0) * fpm.nchunks + chunk) * kPartStride;
     for (int i = tid; i < 2 * NACC; i += kFastThreads) {
       const int h = i / NACC, k = i - h * NACC;
@@ -324,14 +499,6 @@ __global__ __launch_bounds__(kFastThreads, 2) void k3_fast(const FramePlanes *__
     }
     if (tid == 0) out[2 * NACC] = nobs;
   } else {
-    __syncthreads();
-    int *red = reinterpret_cast<int *>(lds);
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-      const int v = wave_sum(acc[i]);
-      if (lane == 0) red[wave * NACC + i] = v;
-    }
-    __syncthreads();
     for (int pl = 0; pl < 2; ++pl) {
       int32_t *out = fpm.partials + (((size_t)frame * 3 + 1 + pl) * fpm.nchunks + chunk) * kPartStride;
       for (int i = tid; i < 2 * NACC; i += kFastThreads) out[i] = red[pl * 2 * NACC + i];
@@ -361,8 +528,6 @@ __global__ __launch_bounds__(256) void k3_fast_reduce(Geom g, FastParams fpm, ui
   }
   __syncthreads();
   // scatter accumulator slots to (i, j); one thread per left operand
-  const int ns_scale = 1;  // L is stored pre-scaled by ns already (it is the SUM of luma residuals)
-  (void)ns_scale;
   if (threadIdx.x < kFastN) {
     const int i = threadIdx.x;
     const int h = in_half(0, i) ? 0 : 1;

@@ -35,6 +35,7 @@ struct Geom {
   int src_bps, den_bps, src_shift, den_shift;
   int lag, n;
   int fast_rows;  // all luma source rows 16-byte aligned (base and stride)
+  int vec_mask;   // bit c: src plane c rows 16-byte aligned in every frame of the batch; bit 3+c: den plane c
   // record layout (bytes from the start of a frame's record)
   uint32_t rec_size;
   uint32_t off_ar[3], off_luma_sum, off_sum_d[3], off_sum_d2[3], off_scores, off_mask;
@@ -48,10 +49,31 @@ struct FlatConsts {
 // sample access: u8, or u16 narrowed by the truncating shift of
 // av1-grain util.rs frame_into_u8 (`(v >> (bd - 8)) as u8`)
 // ----------------------------------------------------------------------------
+// Plane pointers come out of the frame table in memory, so the compiler would
+// treat them as generic (flat) addresses; flat loads also tick lgkmcnt and would
+// serialise against LDS traffic.  They are HBM pointers: say so.
+#define G1S_GLOBAL __attribute__((address_space(1)))
+typedef const G1S_GLOBAL uint8_t *gptr_u8;
+typedef const G1S_GLOBAL uint16_t *gptr_u16;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const G1S_GLOBAL u32x2 *gptr_u2;
+typedef const G1S_GLOBAL u32x4 *gptr_u4;
+__device__ __forceinline__ gptr_u8 as_global(const uint8_t *p) { return (gptr_u8)(uintptr_t)p; }
+__device__ __forceinline__ uint4 gload4(gptr_u4 p) {
+  const u32x4 v = *p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 gload2(gptr_u2 p) {
+  const u32x2 v = *p;
+  return make_uint2(v.x, v.y);
+}
+
 template <int BPS>
 __device__ __forceinline__ int load_px(const uint8_t *base, uint32_t stride, int shift, int x, int y) {
-  if (BPS == 1) return base[(size_t)y * stride + x];
-  const uint16_t v = reinterpret_cast<const uint16_t *>(base + (size_t)y * stride)[x];
+  gptr_u8 row = as_global(base) + (size_t)y * stride;
+  if (BPS == 1) return row[x];
+  const uint16_t v = ((gptr_u16)row)[x];
   return (int)(uint8_t)(v >> shift);
 }
 __device__ __forceinline__ int load_px_rt(const uint8_t *base, uint32_t stride, int bps, int shift, int x, int y) {
@@ -64,15 +86,15 @@ __device__ __forceinline__ void load_row32(const uint8_t *base, uint32_t stride,
                                            int W, bool fast, uint32_t (&pk)[8]) {
   if (fast) {
     if (BPS == 1) {
-      const uint4 *p = reinterpret_cast<const uint4 *>(base + (size_t)y * stride + ox);
-      const uint4 a = p[0], b = p[1];
+      gptr_u4 p = (gptr_u4)(as_global(base) + (size_t)y * stride + ox);
+      const uint4 a = gload4(p), b = gload4(p + 1);
       pk[0] = a.x; pk[1] = a.y; pk[2] = a.z; pk[3] = a.w;
       pk[4] = b.x; pk[5] = b.y; pk[6] = b.z; pk[7] = b.w;
     } else {
-      const uint4 *p = reinterpret_cast<const uint4 *>(base + (size_t)y * stride + 2 * (size_t)ox);
+      gptr_u4 p = (gptr_u4)(as_global(base) + (size_t)y * stride + 2 * (size_t)ox);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint4 a = p[q];
+        const uint4 a = gload4(p + q);
         const uint32_t w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {

@@ -1,0 +1,120 @@
+"""CPU suite, part 2: the product's host logic without a GPU -- the C-ABI
+library loads and exports every declared symbol, the ordered fold equals the
+oracle, the .tbl writer/parser agree with the reference's format sample."""
+import ctypes as C
+import os
+import re
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from grav1synth_amd import _lib
+from grav1synth_amd.diff import GrainTableSegment, Record, RecordFold, format_tbl
+from grav1synth_amd.synth import SynthSpec
+from grav1synth_amd.tbl import TblError, parse_tbl
+from tests.helpers import oracle_run, record_from_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "g1s_diff.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(g1s_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/g1s_diff.h but not exported"
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, f"binding/header mismatch: {declared ^ bound}"
+    _lib.lib()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from grav1synth_amd.diff import DiffGenerator
+
+    with pytest.raises(_lib.G1SError) as e:
+        DiffGenerator(Fraction(24, 1), 8, 8)
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The shipped package must never import, link or call anything under oracle/."""
+    banned = ("liborc_diff", "oracle_binding", "diff_oracle", "orc_diff", "orc_format", "OracleDiff")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "grav1synth_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for b in banned:
+                    assert b not in txt, f"{f} references {b}"
+
+
+CASES = [
+    (SynthSpec(320, 192, 8), 3, True, 3),
+    (SynthSpec(320, 200, 10, xdec=1, ydec=0), 3, True, 2),
+    (SynthSpec(256, 160, 8, xdec=0, ydec=0), 2, True, 2),
+    (SynthSpec(256, 160, 8), 2, False, 2),
+    (SynthSpec(256, 160, 12), 1, True, 2),
+]
+
+
+@pytest.mark.parametrize("spec,lag,chroma,nframes", CASES)
+def test_fold_over_exact_integer_records_equals_oracle(spec, lag, chroma, nframes):
+    """The product converts exact integer sums to f64 once, the reference sums
+    rounded f64 terms: the emitted table must still be byte-identical."""
+    fold = RecordFold(Fraction(24, 1), lag)
+    npl = 3 if chroma else 1
+    tbl, _ = oracle_run(spec, range(nframes), lag, chroma,
+                        collect=lambda o, k: fold.push(record_from_oracle(o, spec, lag, npl).buf))
+    assert format_tbl(fold.finish()) == tbl
+
+
+def test_fold_segmentation_matches_oracle():
+    a = SynthSpec(320, 192, 8)
+    b = SynthSpec(320, 192, 8, gain_scale=3)
+    specs = [a, a, a, b, b, b]
+    fps = Fraction(30000, 1001)
+    fold = RecordFold(fps, 3)
+    tbl, segs = oracle_run(a, range(6), fps=fps, specs_per_frame=specs,
+                           collect=lambda o, k: fold.push(record_from_oracle(o, a, 3, 3).buf))
+    out = fold.finish()
+    assert len(out) == len(segs) >= 2
+    assert format_tbl(out) == tbl
+
+
+def test_fold_rejects_bad_records():
+    fold = RecordFold(Fraction(24, 1), 3)
+    with pytest.raises(_lib.G1SError):
+        fold.push(np.zeros(16, np.uint8))
+    r = Record.blank(64, 64, 1, 1, 3, 2)  # lag mismatch
+    with pytest.raises(_lib.G1SError):
+        fold.push(r.buf)
+    r = Record.blank(64, 64, 1, 1, 3, 3)  # no flat blocks
+    with pytest.raises(_lib.G1SError) as e:
+        fold.push(r.buf)
+    assert e.value.code == -3 and "Not enough flat blocks" in e.value.message
+
+
+def test_tbl_writer_reproduces_the_reference_sample_byte_for_byte():
+    """tests/golden/reference-example-table.tbl is the reference's own data file
+    (tests/example-table.tbl): parse -> write must give the same bytes, incl. the
+    double space after `sY 14` (src/main.rs:659) and empty `cY` (lag 0)."""
+    raw = open(os.path.join(ROOT, "tests", "golden", "reference-example-table.tbl"), "rb").read()
+    segs = parse_tbl(raw)
+    assert len(segs) == 1 and segs[0].ar_coeff_lag == 0 and segs[0].random_seed == 7391
+    assert len(segs[0].scaling_points_y) == 14 and segs[0].ar_coeffs_cb == [0]
+    assert format_tbl(segs) == raw
+
+
+def test_tbl_round_trip_of_diff_output_and_parser_errors():
+    tbl, _ = oracle_run(SynthSpec(192, 128, 8), range(1))
+    assert format_tbl(parse_tbl(tbl)) == tbl
+    with pytest.raises(TblError):
+        parse_tbl(b"filmgrn2\n")
+    with pytest.raises(TblError):
+        parse_tbl(tbl.replace(b"\tcY", b"\tcY 1"))  # coefficient count no longer 2*lag*(lag+1)

@@ -1,0 +1,74 @@
+// valu_rate.hip -- instruction-throughput microbenchmark for the candidate
+// inner-loop instructions of the AR accumulation kernel (gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef short short2_ __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+typedef float float2_ __attribute__((ext_vector_type(2)));
+
+#define NACC 32
+#define ITERS 2048
+
+template <int OP>
+__global__ __launch_bounds__(256) void rate(int *out, int a0, int b0) {
+  int acc[NACC];
+  float facc[NACC];
+  int a = a0 + threadIdx.x, b = b0 ^ threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) { acc[i] = i; facc[i] = (float)i; }
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      if (OP == 0) acc[i] = __builtin_amdgcn_sdot4(a, b + i, acc[i], false);
+      if (OP == 1) acc[i] = __builtin_amdgcn_udot4(a, b + i, acc[i], false);
+      if (OP == 2) { short2_ x = __builtin_bit_cast(short2_, a), y = __builtin_bit_cast(short2_, b + i); acc[i] = __builtin_amdgcn_sdot2(x, y, acc[i], false); }
+      if (OP == 3) acc[i] = ((a << 8) >> 8) * (((b + i) << 8) >> 8) + acc[i];  // 24-bit operands -> v_mad_i32_i24
+      if (OP == 4) acc[i] = a * (b + i) + acc[i];                      // 32-bit mul + add
+      if (OP == 5) facc[i] = __builtin_fmaf((float)a, facc[i], (float)b);
+      if (OP == 6) { half2_ x = __builtin_bit_cast(half2_, a), y = __builtin_bit_cast(half2_, b + i); facc[i] = __builtin_amdgcn_fdot2(x, y, facc[i], false); }
+      if (OP == 7) acc[i] = __builtin_amdgcn_alignbyte(a, acc[i], 1);
+      if (OP == 8) acc[i] = (acc[i] & a) + b;
+      if (OP == 9) acc[i] = __builtin_amdgcn_sdot8(a, b + i, acc[i], false);
+    }
+    a += it;
+  }
+  int s = 0;
+  for (int i = 0; i < NACC; ++i) s += acc[i] + (int)facc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int OP>
+void run(const char *name, int macs_per_instr) {
+  int *d;
+  const int blocks = 256 * 8;
+  hipMalloc(&d, blocks * 256 * sizeof(int));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  rate<OP><<<blocks, 256>>>(d, 3, 5);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  rate<OP><<<blocks, 256>>>(d, 3, 5);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double instr = (double)blocks * 256 * ITERS * NACC;   // lane-instructions
+  const double gips = instr / (ms * 1e-3) / 1e12;
+  // 256 CU * 4 SIMD * 32 lanes * 2.4 GHz = 78.6 T lane-instr/s at 1 per lane per clk
+  printf("%-22s %8.3f ms  %7.2f T lane-instr/s  (%.2f of 78.6)  %7.1f T MAC/s\n", name, ms, gips, gips / 78.6, gips * macs_per_instr);
+  hipFree(d);
+}
+int main() {
+  run<0>("v_dot4c_i32_i8", 4);
+  run<1>("v_dot4_u32_u8", 4);
+  run<2>("v_dot2c_i32_i16", 2);
+  run<3>("v_mad_i32_i24", 1);
+  run<4>("v_mul_lo_u32+add", 1);
+  run<5>("v_fma_f32", 1);
+  run<6>("v_dot2_f32_f16", 2);
+  run<7>("v_alignbyte_b32", 0);
+  run<8>("v_and+v_add", 0);
+  run<9>("v_dot8_i32_i4", 8);
+  return 0;
+}
