@@ -10,9 +10,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/g1s_diff.h"
@@ -40,6 +44,83 @@ constexpr int kK3Chunks = 48;
     }                                                                                      \
   } while (0)
 
+// Minimal persistent worker pool: the per-frame half of the fold (AR solve,
+// block measurements, strength solve) is independent across frames.
+class Pool {
+ public:
+  explicit Pool(unsigned n) {
+    for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  // runs fn(i) for i in [0, n); the caller participates
+  void parallel_for(int n, const std::function<void(int)> &fn) {
+    if (n <= 0) return;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      n_ = n;
+      next_.store(0);
+      done_ = 0;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [this] { return done_ == n_; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_) break;
+      (*fn_)(i);
+      std::lock_guard<std::mutex> lk(m_);
+      if (++done_ == n_) cv_done_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+        if (stop_) return;
+        seen = epoch_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, cv_done_;
+  const std::function<void(int)> *fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, done_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+
+// One pool per process (creating 30 threads per generator would dominate short jobs).
+Pool *shared_pool() {
+  static Pool *p = [] {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("G1S_FOLD_THREADS")) hw = (unsigned)atoi(e);
+    if (hw > 32) hw = 32;
+    return hw > 1 ? new Pool(hw - 1) : nullptr;  // the calling thread participates
+  }();
+  return p;
+}
+std::mutex g_pool_mutex;  // parallel_for is not re-entrant: one fold batch at a time
+
 struct Slot {
   FramePlanes *h_planes = nullptr;  // pinned
   FramePlanes *d_planes = nullptr;
@@ -55,6 +136,24 @@ struct Slot {
   uint32_t count = 0;
   bool timed = false;
 };
+
+// Process-wide cache of slot buffers: pinned-host and device allocations cost
+// hundreds of microseconds each; consecutive generators of the same geometry
+// (one per video, or one per bench step) reuse them.
+struct SlotKey {
+  int device;
+  size_t planes, records, flags, partials, defer, stage;
+  bool operator==(const SlotKey &o) const {
+    return device == o.device && planes == o.planes && records == o.records && flags == o.flags &&
+           partials == o.partials && defer == o.defer && stage == o.stage;
+  }
+};
+struct CachedSlot {
+  SlotKey key;
+  Slot slot;
+};
+std::mutex g_cache_mutex;
+std::vector<CachedSlot> g_slot_cache;
 
 }  // namespace
 
@@ -74,10 +173,13 @@ struct g1s_diff {
   double *d_lut = nullptr;
   int fast_chunks = 0;
   size_t defer_bytes = 0;
+  SlotKey slot_key{};
   Slot slots[2];
   int cur = 0;
   std::deque<int> in_flight;
   NoiseFold *fold = nullptr;
+  Pool *pool = nullptr;
+  std::vector<FrameLatest> latest;  // one per frame of a batch, reused
   std::vector<uint8_t> records_out;
   size_t records_out_frames = 0;
   std::vector<uint8_t> last_record;
@@ -162,20 +264,38 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     frame_bytes += ((pw * s->bytes_per_sample + 15) & ~size_t(15)) * ph;
     frame_bytes += ((pw * d->bytes_per_sample + 15) & ~size_t(15)) * ph;
   }
+  size_t partial_bytes = 0;
+  if (lag == kFastLag) {
+    fast_chunks = (g.nblocks + kMaxBlocksPerWG - 1) / kMaxBlocksPerWG;
+    if (fast_chunks < 64) fast_chunks = std::min(64, g.nblocks);
+    partial_bytes = sizeof(int32_t) * (size_t)batch * 3 * fast_chunks * kPartStride;
+    defer_bytes = (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15)) + sizeof(uint32_t) * batch;
+  }
+  slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
+                     partial_bytes, defer_bytes, frame_bytes * batch};
   for (Slot &sl : slots) {
-    HIP_TRY(hipHostMalloc((void **)&sl.h_planes, sizeof(FramePlanes) * batch, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&sl.d_planes, sizeof(FramePlanes) * batch));
-    HIP_TRY(hipMalloc((void **)&sl.d_records, L.size * batch));
-    HIP_TRY(hipHostMalloc((void **)&sl.h_records, L.size * batch, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&sl.d_flags, (size_t)g.nblocks * batch));
-    if (lag == kFastLag) {
-      fast_chunks = (g.nblocks + kMaxBlocksPerWG - 1) / kMaxBlocksPerWG;
-      if (fast_chunks < 64) fast_chunks = std::min(64, g.nblocks);
-      HIP_TRY(hipMalloc((void **)&sl.d_partials, sizeof(int32_t) * (size_t)batch * 3 * fast_chunks * kPartStride));
-      defer_bytes = (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15)) + sizeof(uint32_t) * batch;
-      HIP_TRY(hipMalloc((void **)&sl.d_defer, defer_bytes));
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mutex);
+      for (size_t i = 0; i < g_slot_cache.size(); ++i) {
+        if (g_slot_cache[i].key == slot_key) {
+          sl = g_slot_cache[i].slot;
+          g_slot_cache.erase(g_slot_cache.begin() + i);
+          break;
+        }
+      }
     }
     sl.stage_bytes_per_frame = frame_bytes;
+    sl.count = 0;
+    if (sl.h_planes) continue;  // reused
+    HIP_TRY(hipHostMalloc((void **)&sl.h_planes, slot_key.planes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&sl.d_planes, slot_key.planes));
+    HIP_TRY(hipMalloc((void **)&sl.d_records, slot_key.records));
+    HIP_TRY(hipHostMalloc((void **)&sl.h_records, slot_key.records, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&sl.d_flags, slot_key.flags));
+    if (partial_bytes) {
+      HIP_TRY(hipMalloc((void **)&sl.d_partials, partial_bytes));
+      HIP_TRY(hipMalloc((void **)&sl.d_defer, defer_bytes));
+    }
     HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
   }
@@ -342,7 +462,10 @@ int g1s_diff::drain_one() {
   }
   const auto t0 = std::chrono::steady_clock::now();
   int rc = G1S_OK;
-  for (uint32_t i = 0; i < sl.count; ++i) {
+  if (latest.size() < sl.count) latest.resize(sl.count);
+  std::vector<uint32_t> nflat_v(sl.count, 0);
+  // ---- per-frame half, concurrent: header, symmetric mirror, latest noise state ----
+  auto per_frame = [&](int i) {
     uint8_t *rec = sl.h_records + L.size * i;
     RecHeader h{};
     h.magic = kRecMagic;
@@ -360,6 +483,7 @@ int g1s_diff::drain_one() {
     uint32_t nflat = 0;
     for (uint32_t b = 0; b < L.nblocks; ++b) nflat += mask[b] != 0;
     h.status = nflat;
+    nflat_v[i] = nflat;
     std::memcpy(rec, &h, sizeof(h));
     // mirror the symmetric AR sums so consumers see full matrices
     for (int c = 0; c < geom.nplanes; ++c) {
@@ -368,14 +492,25 @@ int g1s_diff::drain_one() {
       for (int a = 0; a < nc; ++a)
         for (int b = a + 1; b < nc; ++b) S[b * nc + a] = S[a * nc + b];
     }
+    if (!records_only) compute_latest(rec, L.size, lag, latest[i]);
+  };
+  if (pool && sl.count > 1) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    pool->parallel_for((int)sl.count, per_frame);
+  } else {
+    for (uint32_t i = 0; i < sl.count; ++i) per_frame((int)i);
+  }
+  // ---- ordered half, serial ----
+  for (uint32_t i = 0; i < sl.count; ++i) {
+    uint8_t *rec = sl.h_records + L.size * i;
     stats.frames++;
     stats.blocks += L.nblocks;
-    stats.flat_blocks += nflat;
+    stats.flat_blocks += nflat_v[i];
     if (records_only) {
       records_out.insert(records_out.end(), rec, rec + L.size);
       records_out_frames++;
     } else if (sticky == G1S_OK) {
-      rc = fold->push(rec, L.size);
+      rc = fold->push_latest(latest[i]);
       if (rc) {
         err = fold->error();
         sticky = rc;
@@ -400,6 +535,15 @@ int g1s_diff::drain_all() {
 void g1s_diff::release() {
   if (stream) (void)hipStreamSynchronize(stream);
   for (Slot &sl : slots) {
+    if (sl.h_planes && geometry_set) {  // park the buffers for the next generator of this geometry
+      std::lock_guard<std::mutex> lk(g_cache_mutex);
+      if (g_slot_cache.size() < 8) {
+        sl.count = 0;
+        g_slot_cache.push_back(CachedSlot{slot_key, sl});
+        sl = Slot{};
+        continue;
+      }
+    }
     if (sl.h_planes) (void)hipHostFree(sl.h_planes);
     if (sl.d_planes) (void)hipFree(sl.d_planes);
     if (sl.d_records) (void)hipFree(sl.d_records);
@@ -419,6 +563,7 @@ void g1s_diff::release() {
   stream = nullptr;
   delete fold;
   fold = nullptr;
+  pool = nullptr;  // shared
 }
 
 // =============================================================== C ABI =====
@@ -492,7 +637,10 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
     delete g;
     return nullptr;
   }
-  if (!records_only) g->fold = new NoiseFold(fps_num, fps_den, lag);
+  if (!records_only) {
+    g->fold = new NoiseFold(fps_num, fps_den, lag);
+    g->pool = shared_pool();
+  }
   return g;
 }
 
@@ -602,9 +750,12 @@ int g1s_diff_take_records(g1s_diff_t *g, void *buf, size_t cap_bytes, size_t *n_
 
 struct g1s_fold {
   NoiseFold fold;
+  uint32_t lag;
   std::string err;
   bool finished = false;
-  g1s_fold(int64_t a, int64_t b, uint32_t lag) : fold(a, b, lag) {}
+  Pool *pool = nullptr;
+  std::vector<FrameLatest> latest;
+  g1s_fold(int64_t a, int64_t b, uint32_t lag_) : fold(a, b, lag_), lag(lag_) {}
 };
 
 g1s_fold_t *g1s_fold_new(int64_t fps_num, int64_t fps_den, uint32_t lag) {
@@ -617,6 +768,31 @@ int g1s_fold_push(g1s_fold_t *f, const void *record, size_t size_bytes) {
   const int rc = f->fold.push((const uint8_t *)record, size_bytes);
   if (rc) f->err = f->fold.error();
   return rc;
+}
+int g1s_fold_push_many(g1s_fold_t *f, const void *records, size_t stride_bytes, size_t n) {
+  if (!f || (!records && n)) return G1S_ERR_INVALID;
+  if (f->finished) return G1S_ERR_STATE;
+  if (!f->pool) f->pool = shared_pool();
+  const uint8_t *base = (const uint8_t *)records;
+  const size_t chunk = 64;
+  for (size_t o = 0; o < n; o += chunk) {
+    const size_t m = std::min(chunk, n - o);
+    if (f->latest.size() < m) f->latest.resize(m);
+    auto one = [&](int i) { compute_latest(base + (o + i) * stride_bytes, stride_bytes, f->lag, f->latest[i]); };
+    if (f->pool && m > 1) {
+      std::lock_guard<std::mutex> lk(g_pool_mutex);
+      f->pool->parallel_for((int)m, one);
+    } else
+      for (size_t i = 0; i < m; ++i) one((int)i);
+    for (size_t i = 0; i < m; ++i) {
+      const int rc = f->fold.push_latest(f->latest[i]);
+      if (rc) {
+        f->err = f->fold.error();
+        return rc;
+      }
+    }
+  }
+  return G1S_OK;
 }
 int g1s_fold_finish(g1s_fold_t *f, g1s_segment_t *out, size_t cap, size_t *n_out) {
   if (!f) return G1S_ERR_INVALID;

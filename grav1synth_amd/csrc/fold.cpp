@@ -120,9 +120,12 @@ void StrengthSolver::add_measurement(double block_mean, double noise_std) {
   total += noise_std;
   num_equations++;
 }
-bool StrengthSolver::solve() {
-  // Regularised solve on a copy of A; b keeps the mean/8192 term (the
-  // reference does not restore it either).
+void StrengthSolver::apply_regularisation_to_b() {
+  const double mean = total / num_equations;
+  for (int i = 0; i < kNumBins; ++i) eq.b[i] += mean / 8192.;
+}
+bool StrengthSolver::solve_x_only() {
+  // Regularised system on a copy of A (A itself is restored by the reference too)
   const int n = kNumBins;
   const double alpha = 2.0 * (double)num_equations / n;
   double At[kNumBins * kNumBins], bt[kNumBins];
@@ -133,13 +136,14 @@ bool StrengthSolver::solve() {
     At[i * n + i] += 2 * alpha;
     At[i * n + hi] -= alpha;
   }
-  const double mean = total / num_equations;
-  for (int i = 0; i < n; ++i) {
-    At[i * n + i] += 1.0 / 8192.;
-    eq.b[i] += mean / 8192.;
-  }
+  for (int i = 0; i < n; ++i) At[i * n + i] += 1.0 / 8192.;
   std::memcpy(bt, eq.b.data(), sizeof(bt));
   return gauss_solve(n, At, bt, eq.x.data());
+}
+bool StrengthSolver::solve() {
+  // b keeps the mean/8192 term (the reference does not restore it either)
+  apply_regularisation_to_b();
+  return solve_x_only();
 }
 double StrengthSolver::center(int i) { return ((double)i) / (kNumBins - 1) * 255.0; }
 
@@ -196,7 +200,7 @@ NoiseFold::NoiseFold(int64_t fps_num, int64_t fps_den, uint32_t lag)
   }
 }
 
-bool NoiseFold::ar_solve(PlaneState &s, bool is_chroma) {
+bool ar_solve(PlaneState &s, bool is_chroma) {
   const bool ok = s.ar.solve();
   s.ar_gain = 1.0;
   if (!ok) return false;
@@ -219,6 +223,13 @@ bool NoiseFold::ar_solve(PlaneState &s, bool is_chroma) {
   const double g = std::sqrt(q > 1e-6 ? q : 1e-6);
   s.ar_gain = 1 > g ? 1 : g;
   return true;
+}
+
+void chroma_fallback(PlaneState &s) {
+  // zero AR coefficients, keep only the luma correlation
+  const int nc = s.ar.n, last = nc - 1;
+  std::fill(s.ar.x.begin(), s.ar.x.end(), 0.0);
+  if (std::fabs(s.ar.A[last * nc + last]) > 1e-6) s.ar.x[last] = s.ar.b[last] / s.ar.A[last * nc + last];
 }
 
 bool NoiseFold::is_different() const {
@@ -245,6 +256,7 @@ bool NoiseFold::is_different() const {
 }
 
 void NoiseFold::save_latest() {
+  chroma_dirty_ = false;  // combined := latest, whose x is solved
   for (int c = 0; c < 3; ++c) {
     combined_[c].ar.assign(latest_[c].ar);
     combined_[c].strength.eq.assign(latest_[c].strength.eq);
@@ -264,44 +276,44 @@ static void set_error(std::string &dst, const char *fmt, ...) {
   dst = buf;
 }
 
-int NoiseFold::push(const uint8_t *rec, size_t size) {
-  if (size < sizeof(RecHeader)) {
-    set_error(err_, "record too small");
-    return G1S_ERR_INVALID;
-  }
+int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &out) {
+  out.status = G1S_OK;
+  out.err.clear();
+  auto fail = [&](int code, const char *fmt, int arg = 0) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), fmt, arg);
+    out.err = buf;
+    out.status = code;
+    return code;
+  };
+  if (size < sizeof(RecHeader)) return fail(G1S_ERR_INVALID, "record too small");
   RecHeader h;
   std::memcpy(&h, rec, sizeof(h));
-  if (h.magic != kRecMagic || h.lag != lag_ || h.size_bytes > size) {
-    set_error(err_, "bad record header (magic/lag/size)");
-    return G1S_ERR_INVALID;
-  }
+  if (h.magic != kRecMagic || h.lag != lag || h.size_bytes > size)
+    return fail(G1S_ERR_INVALID, "bad record header (magic/lag/size)");
   const RecLayout L = make_layout(h.width, h.height, h.nplanes, h.lag);
-  if (L.size != h.size_bytes) {
-    set_error(err_, "record layout mismatch");
-    return G1S_ERR_INVALID;
-  }
+  if (L.size != h.size_bytes) return fail(G1S_ERR_INVALID, "record layout mismatch");
   const int nbw = (int)h.nbw, nbh = (int)h.nbh;
   const uint8_t *mask = rec + L.off_mask;
   const uint32_t *luma_sum = reinterpret_cast<const uint32_t *>(rec + L.off_luma_sum);
   const int w = (int)h.width, hh = (int)h.height;
-
+  const int n = (int)num_coeffs(lag);
+  out.nplanes = h.nplanes;
   for (int c = 0; c < 3; ++c) {
-    latest_[c].ar.clear();
-    latest_[c].num_observations = 0;
-    latest_[c].strength.clear();
+    if (out.st[c].ar.n != n + (c > 0)) out.st[c].ar.resize(n + (c > 0));
+    out.st[c].ar.clear();
+    out.st[c].num_observations = 0;
+    out.st[c].ar_gain = 1.0;
+    out.st[c].strength.clear();
   }
   int num_flat = 0;
   for (int i = 0; i < nbw * nbh; ++i) num_flat += mask[i] != 0;
-  if (num_flat <= 1) {
-    set_error(err_, "Not enough flat blocks to update noise estimate");
-    return G1S_ERR_NOT_ENOUGH_FLAT;
-  }
+  if (num_flat <= 1) return fail(G1S_ERR_NOT_ENOUGH_FLAT, "Not enough flat blocks to update noise estimate");
 
-  bool y_model_different = false;
   for (int c = 0; c < (int)h.nplanes; ++c) {
     const bool is_chroma = c != 0;
     const int sx = is_chroma ? (int)h.xdec : 0, sy = is_chroma ? (int)h.ydec : 0;
-    PlaneState &lat = latest_[c];
+    PlaneState &lat = out.st[c];
     const int nc = lat.ar.n;
     // ---- exact integer sums -> f64 normal equations (one rounding each) ----
     {
@@ -324,25 +336,19 @@ int NoiseFold::push(const uint8_t *rec, size_t size) {
       lat.num_observations = Sb[nc];
     }
     if (!ar_solve(lat, is_chroma)) {
-      if (is_chroma) {
-        // fallback: zero AR coefficients, keep only the luma correlation
-        std::fill(lat.ar.x.begin(), lat.ar.x.end(), 0.0);
-        const int last = nc - 1;
-        if (std::fabs(lat.ar.A[last * nc + last]) > 1e-6)
-          lat.ar.x[last] = lat.ar.b[last] / lat.ar.A[last * nc + last];
-      } else {
-        set_error(err_, "Solving latest noise equation system failed %d!", c);
-        return G1S_ERR_SOLVE;
-      }
+      if (is_chroma)
+        chroma_fallback(lat);
+      else
+        return fail(G1S_ERR_SOLVE, "Solving latest noise equation system failed %d!", c);
     }
     // ---- noise strength vs. intensity measurements, block raster order ----
     {
       const int32_t *sum_d = reinterpret_cast<const int32_t *>(rec + L.off_sum_d[c]);
       const uint32_t *sum_d2 = reinterpret_cast<const uint32_t *>(rec + L.off_sum_d2[c]);
       const int bw = kBlock >> sx, bh = kBlock >> sy;
-      const double luma_gain = latest_[0].ar_gain;
+      const double luma_gain = out.st[0].ar_gain;
       const double noise_gain = lat.ar_gain;
-      const double corr = is_chroma ? lat.ar.x[n_] : 0;
+      const double corr = is_chroma ? lat.ar.x[n] : 0;
       for (int by = 0; by < nbh; ++by) {
         for (int bx = 0; bx < nbw; ++bx) {
           const int bi = by * nbw + bx;
@@ -356,8 +362,7 @@ int NoiseFold::push(const uint8_t *rec, size_t size) {
             const double noise_sq = (double)sum_d2[bi];
             noise_mean /= (sw * sh);
             const double noise_var = noise_sq / (sw * sh) - noise_mean * noise_mean;
-            const double luma_strength =
-                is_chroma ? luma_gain * latest_[0].strength.value_at(block_mean) : 0;
+            const double luma_strength = is_chroma ? luma_gain * out.st[0].strength.value_at(block_mean) : 0;
             const double cl = corr * luma_strength;
             const double t0 = noise_var / 16, t1 = noise_var - cl * cl;
             const double uncorr_std = std::sqrt(t0 > t1 ? t0 : t1);
@@ -366,34 +371,60 @@ int NoiseFold::push(const uint8_t *rec, size_t size) {
         }
       }
     }
-    if (!lat.strength.solve()) {
-      set_error(err_, "Solving latest noise strength failed!");
-      return G1S_ERR_SOLVE;
-    }
+    if (!lat.strength.solve()) return fail(G1S_ERR_SOLVE, "Solving latest noise strength failed!");
+  }
+  return G1S_OK;
+}
+
+int NoiseFold::push(const uint8_t *rec, size_t size) {
+  FrameLatest fl;
+  compute_latest(rec, size, lag_, fl);
+  return push_latest(fl);
+}
+
+// The combined chroma state is only read at segment boundaries: between them
+// the per-frame AR solve is skipped and the strength solve is reduced to its
+// side effect on b; this brings x up to date for the current (A, b).
+void NoiseFold::finalize_chroma() const {
+  if (!chroma_dirty_) return;
+  for (int c = 1; c < 3; ++c) {
+    PlaneState &com = combined_[c];
+    if (!ar_solve(com, true)) chroma_fallback(com);
+    com.strength.solve_x_only();
+  }
+  chroma_dirty_ = false;
+}
+
+int NoiseFold::push_latest(FrameLatest &fl) {
+  if (fl.status != G1S_OK) {
+    err_ = fl.err;
+    return fl.status;
+  }
+  for (int c = 0; c < 3; ++c) std::swap(latest_[c], fl.st[c]);
+  bool y_model_different = false;
+  for (int c = 0; c < (int)fl.nplanes; ++c) {
+    const bool is_chroma = c != 0;
+    PlaneState &lat = latest_[c];
     if (c == 0 && combined_[0].strength.num_equations > 0 && is_different()) y_model_different = true;
     if (y_model_different) continue;
-
     PlaneState &com = combined_[c];
     com.num_observations += lat.num_observations;
     com.ar.add(lat.ar);
-    if (!ar_solve(com, is_chroma)) {
-      if (is_chroma) {
-        std::fill(com.ar.x.begin(), com.ar.x.end(), 0.0);
-        const int last = nc - 1;
-        if (std::fabs(com.ar.A[last * nc + last]) > 1e-6)
-          com.ar.x[last] = com.ar.b[last] / com.ar.A[last * nc + last];
-      } else {
+    com.strength.add(lat.strength);
+    if (!is_chroma) {
+      if (!ar_solve(com, false)) {
         set_error(err_, "Solving combined noise equation system failed %d!", c);
         return G1S_ERR_SOLVE;
       }
-    }
-    com.strength.add(lat.strength);
-    if (!com.strength.solve()) {
-      set_error(err_, "Solving combined noise strength failed!");
-      return G1S_ERR_SOLVE;
+      if (!com.strength.solve()) {
+        set_error(err_, "Solving combined noise strength failed!");
+        return G1S_ERR_SOLVE;
+      }
+    } else {
+      com.strength.apply_regularisation_to_b();
+      chroma_dirty_ = true;
     }
   }
-
   if (y_model_different) {
     const uint64_t cur = frame_count_ * 10000000ULL * (uint64_t)fps_den_ / (uint64_t)fps_num_;
     table_.push_back(grain_parameters(prev_timestamp_, cur));
@@ -410,6 +441,7 @@ void NoiseFold::finish(std::vector<g1s_segment_t> &out) {
 }
 
 g1s_segment_t NoiseFold::grain_parameters(uint64_t start_ts, uint64_t end_ts) const {
+  finalize_chroma();
   g1s_segment_t g;
   std::memset(&g, 0, sizeof(g));
   g.random_seed = start_ts == 0 ? kDefaultGrainSeed : 0;

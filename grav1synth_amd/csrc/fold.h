@@ -31,6 +31,9 @@ struct LinearSystem {
 };
 
 bool gauss_solve(int n, double *A, double *b, double *x);
+struct PlaneState;
+bool ar_solve(PlaneState &s, bool is_chroma);
+void chroma_fallback(PlaneState &s);
 
 struct StrengthSolver {
   LinearSystem eq;
@@ -43,6 +46,12 @@ struct StrengthSolver {
   double value_at(double x) const;
   void add_measurement(double block_mean, double noise_std);
   bool solve();
+  // The two halves of solve(): the reference's solve() both perturbs b
+  // (b += mean/8192, never undone) and computes x.  When x is not needed yet
+  // (combined chroma state between segment boundaries) only the perturbation is
+  // applied per frame and x is computed later from the same (A, b).
+  void apply_regularisation_to_b();
+  bool solve_x_only();
   static double center(int i);
   // piecewise-linear simplification -> (x, y) points
   void fit_piecewise(int max_points, std::vector<double> &px, std::vector<double> &py) const;
@@ -55,26 +64,41 @@ struct PlaneState {
   double ar_gain = 1.0;
 };
 
+// Per-frame ("latest") noise state: depends on that frame's record only, so it
+// can be computed for many frames concurrently.
+struct FrameLatest {
+  PlaneState st[3];
+  uint32_t nplanes = 0;
+  int status = 0;  // G1S_OK or error code
+  std::string err;
+};
+// Thread-safe: record -> latest state (AR solve, measurements, strength solve).
+int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &out);
+
 class NoiseFold {
  public:
   NoiseFold(int64_t fps_num, int64_t fps_den, uint32_t lag);
   // Consumes one record (frame order!).  Returns G1S_OK or an error code;
   // message in error().
   int push(const uint8_t *rec, size_t size);
+  // The sequential half: merge one frame's latest state (frame order!).
+  int push_latest(FrameLatest &fl);
   void finish(std::vector<g1s_segment_t> &out);
   const std::string &error() const { return err_; }
   uint64_t frames() const { return frame_count_; }
 
  private:
-  bool ar_solve(PlaneState &s, bool is_chroma);
   bool is_different() const;
+  void finalize_chroma() const;
   void save_latest();
   g1s_segment_t grain_parameters(uint64_t start_ts, uint64_t end_ts) const;
 
   int64_t fps_num_, fps_den_;
   uint32_t lag_;
   int n_;
-  PlaneState latest_[3], combined_[3];
+  PlaneState latest_[3];
+  mutable PlaneState combined_[3];
+  mutable bool chroma_dirty_ = false;  // combined chroma x not yet solved for the current (A, b)
   uint64_t frame_count_ = 0, prev_timestamp_ = 0;
   std::vector<g1s_segment_t> table_;
   std::string err_;

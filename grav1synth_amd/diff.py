@@ -332,6 +332,15 @@ class RecordFold:
         if rc != 0:
             raise G1SError(rc, self._L.g1s_fold_last_error(self._h).decode())
 
+    def push_many(self, records: np.ndarray) -> None:
+        """records: [n, record_size] uint8, frame order."""
+        records = np.ascontiguousarray(records, dtype=np.uint8)
+        if records.shape[0] == 0:
+            return
+        rc = self._L.g1s_fold_push_many(self._h, records.ctypes.data, records.shape[1], records.shape[0])
+        if rc != 0:
+            raise G1SError(rc, self._L.g1s_fold_last_error(self._h).decode())
+
     def finish(self) -> List[GrainTableSegment]:
         arr = (G1SSegment * 1024)()
         n = C.c_size_t()

@@ -54,8 +54,7 @@ def fold_records(per_rank: List[np.ndarray], fps, ar_coeff_lag: int = 3) -> List
     contiguous frame chunks."""
     fold = RecordFold(fps, ar_coeff_lag)
     for recs in per_rank:
-        for i in range(recs.shape[0]):
-            fold.push(recs[i])
+        fold.push_many(recs)
     segs = fold.finish()
     fold.close()
     return segs

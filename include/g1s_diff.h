@@ -140,6 +140,9 @@ typedef struct g1s_fold g1s_fold_t;
  * quantisation) over records, in frame order.  Pure host code. */
 g1s_fold_t *g1s_fold_new(int64_t fps_num, int64_t fps_den, uint32_t lag);
 int g1s_fold_push(g1s_fold_t *, const void *record, size_t size_bytes);
+/* n records, stride_bytes apart, in frame order: the per-frame half runs on a
+ * host thread pool, the ordered half serially.  Same result as n pushes. */
+int g1s_fold_push_many(g1s_fold_t *, const void *records, size_t stride_bytes, size_t n);
 int g1s_fold_finish(g1s_fold_t *, g1s_segment_t *out, size_t cap, size_t *n_out);
 void g1s_fold_free(g1s_fold_t *);
 const char *g1s_fold_last_error(const g1s_fold_t *);
