@@ -22,7 +22,7 @@
 #include "../../include/g1s_diff.h"
 #include "fold.h"
 #include "kernels.hip.h"
-#include "k3_fast.hip.h"
+#include "k3q.hip.h"
 #include "record.h"
 
 using namespace g1s;
@@ -127,8 +127,8 @@ struct Slot {
   uint8_t *d_records = nullptr;
   uint8_t *h_records = nullptr;  // pinned
   uint8_t *d_flags = nullptr;
-  int32_t *d_partials = nullptr;   // k3_fast chunk partials
-  uint8_t *d_defer = nullptr;      // [batch][nblocks] + [batch] u32 flags behind it
+  int32_t *d_partials = nullptr;   // k3_interior chunk partials
+  uint8_t *d_defer = nullptr;      // area classes [batch][2][nblocks] + todo list [batch][2][nblocks]
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
   hipEvent_t done = nullptr;
@@ -265,11 +265,11 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     frame_bytes += ((pw * d->bytes_per_sample + 15) & ~size_t(15)) * ph;
   }
   size_t partial_bytes = 0;
-  if (lag == kFastLag) {
-    fast_chunks = (g.nblocks + kMaxBlocksPerWG - 1) / kMaxBlocksPerWG;
+  if (lag == kQLag) {
+    fast_chunks = (g.nblocks + kMaxAreasPerWG - 1) / kMaxAreasPerWG;
     if (fast_chunks < 64) fast_chunks = std::min(64, g.nblocks);
-    partial_bytes = sizeof(int32_t) * (size_t)batch * 3 * fast_chunks * kPartStride;
-    defer_bytes = (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15)) + sizeof(uint32_t) * batch;
+    partial_bytes = sizeof(int32_t) * (size_t)batch * 3 * fast_chunks * kQPart;
+    defer_bytes = 2 * (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15));
   }
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
                      partial_bytes, defer_bytes, frame_bytes * batch};
@@ -396,30 +396,32 @@ int g1s_diff::submit(int si) {
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], stream));
   hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(256), 0, stream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], stream));
-  const bool fast_ok = (int)lag == kFastLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
+  const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   if (fast_ok) {
-    // lag 3: dot4 kernel per plane kind, chunk reducer, then the generic kernel
-    // for the (rare) blocks whose residual does not fit int8
-    FastParams fpm;
-    fpm.nchunks = fast_chunks;
-    fpm.partials = sl.d_partials;
-    fpm.defer = sl.d_defer;
-    fpm.defer_any = reinterpret_cast<uint32_t *>(sl.d_defer + (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15)));
-    HIP_TRY(hipMemsetAsync(sl.d_defer, 0, defer_bytes, stream));
-    hipLaunchKernelGGL(k3_fast<0>, dim3(fast_chunks, 1, B), dim3(kFastThreads), 0, stream, sl.d_planes, g, fpm, sl.d_records);
+    // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
+    // then the generic int32 kernel on mixed / deferred areas
+    QParams qp;
+    qp.nchunks = fast_chunks;
+    qp.partials = sl.d_partials;
+    qp.cls = sl.d_defer;
+    qp.todo = sl.d_defer + (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15));
+    const int kinds = g.nplanes == 3 ? 2 : 1;
+    hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + 255) / 256, kinds, B), dim3(256), 0, stream, g,
+                       (const uint8_t *)sl.d_records, qp);
+    hipLaunchKernelGGL(k3_interior<0>, dim3(fast_chunks, 1, B), dim3(QShape<0>::THREADS), 0, stream, sl.d_planes, g, qp,
+                       sl.d_records);
     if (g.nplanes == 3) {
-      const dim3 cg(fast_chunks, 1, B), cb(kFastThreads);
+      const dim3 cg(fast_chunks, 1, B);
       if (g.xdec == 1 && g.ydec == 1)
-        hipLaunchKernelGGL(k3_fast<1>, cg, cb, 0, stream, sl.d_planes, g, fpm, sl.d_records);
+        hipLaunchKernelGGL(k3_interior<1>, cg, dim3(QShape<1>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records);
       else if (g.xdec == 1)
-        hipLaunchKernelGGL(k3_fast<2>, cg, cb, 0, stream, sl.d_planes, g, fpm, sl.d_records);
+        hipLaunchKernelGGL(k3_interior<2>, cg, dim3(QShape<2>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records);
       else
-        hipLaunchKernelGGL(k3_fast<3>, cg, cb, 0, stream, sl.d_planes, g, fpm, sl.d_records);
+        hipLaunchKernelGGL(k3_interior<3>, cg, dim3(QShape<3>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records);
     }
-    hipLaunchKernelGGL(k3_fast_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, fpm, sl.d_records);
-    const int chunks = std::min(kK3Chunks, g.nblocks);
-    hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, sl.d_planes, g, sl.d_records,
-                       (const uint8_t *)fpm.defer, (const uint32_t *)fpm.defer_any);
+    hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, qp, sl.d_records);
+    const int chunks = std::min(256, g.nblocks);
+    hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, B), dim3(256), 0, stream, sl.d_planes, g, qp, sl.d_records);
   } else {
     const int chunks = std::min(kK3Chunks, g.nblocks);
     hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, sl.d_planes, g, sl.d_records,

@@ -1,0 +1,743 @@
+// k3q.hip.h -- K3 for lag 3 by the autocorrelation structure of the normal equations.
+//
+// add_block_observations (av1-grain diff/solver.rs == libaom noise_model.c) sums, over
+// window samples p (w(p) = 1), the outer product of [d(p+c_0)..d(p+c_23), (L(p)), d(p)],
+// d = src8 - den8, L = co-located luma residual sum.  Substituting q = p + c_i,
+//     A[i][j] = sum_q w(q - c_i) * d(q) * d(q + c_j - c_i)          (i <= j)
+//     b[i]    = sum_q w(q - c_i) * d(q) * d(q - c_i)
+// and the sum over q is partitioned by the 32x32 block AREA that contains q.  For an
+// area where every needed w(q - c_i) is 1 ("interior": the block, its left/right/lower
+// neighbours are flat with full windows) the 324 products collapse onto 46 lag sums
+//     G(delta) = sum_q d(q) d(q + delta),   delta = (0..6, 0) or (-6..6, 1..3),
+// an area where every needed w is 0 contributes nothing, and only "mixed" areas (along
+// the boundary of flat regions) need the 324 masked products.  All integers, exact, and
+// independent of how areas are distributed over workgroups.
+// The chroma cross terms sum_p w(p) L(p) d(p+c_i), sum w L^2, sum w L d stay p-centric
+// under the block's own window (a separate, consistent partition).
+//
+//   k3_classify        : per (frame, kind, block area): EXT / INT / MIX from the window rule
+//   k3_interior<KIND>  : INT areas, 46 (+53 chroma) v_dot4c_i32_i8 per 4-sample group
+//   k3q_generic        : MIX areas and areas whose |d| > 127 (deferred), plain int32
+//   k3q_reduce         : chunk partials -> record int64 S/Sb/nobs
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hip.h"
+
+namespace g1s {
+
+constexpr int kQLag = 3;
+constexpr int kQN = 24;
+constexpr int kNumLags = 46;              // distinct c_j - c_i (incl. 0) and -c_i
+constexpr int kNumLTerms = 24 * 2 + 5;    // (i,La),(i,Lb), LaLa, LaLb, LbLb, La*y, Lb*y
+constexpr int kQThreads = 256;
+constexpr int kMaxAreasPerWG = 128;       // int32 accumulators stay exact (see below)
+enum : uint8_t { kClsExt = 0, kClsInt = 1, kClsMix = 2 };
+
+// lag index: dy = 0: dx 0..6 -> 0..6 ; dy = 1..3: dx -6..6 -> 7 + (dy-1)*13 + (dx+6)
+__host__ __device__ constexpr int lag_index(int dx, int dy) { return dy == 0 ? dx : 7 + (dy - 1) * 13 + (dx + 6); }
+__host__ __device__ constexpr int coord_x(int k) { return k % 7 - 3; }
+__host__ __device__ constexpr int coord_y(int k) { return k / 7 - 3; }
+
+// partial layout per (frame, plane, chunk): [46 lag sums][53 L terms][nobs]
+constexpr int kQPart = kNumLags + kNumLTerms + 1;
+
+struct QParams {
+  int nchunks;
+  int32_t *partials;    // [batch][3][nchunks][kQPart]
+  uint8_t *cls;         // [batch][2][nblocks]  (luma, chroma) area class
+  uint8_t *todo;        // [batch][2][nblocks]  1 = area left to k3q_generic (MIX or deferred)
+};
+
+__device__ __forceinline__ int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, int sh) {
+  return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wave_sum_all(int (&a)[N]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = __shfl_xor(a[i], o, 64);
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] += t[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// window of a block (libaom add_block_observations), in samples of its plane
+// ---------------------------------------------------------------------------------
+struct Win {
+  int flat, xs, xe, ys, ye;
+};
+__device__ __forceinline__ Win block_window(const uint8_t *mask, int nbw, int nbh, int bx, int by, int bw, int bh,
+                                            int pw, int ph) {
+  Win w{0, 0, 0, 0, 0};
+  if (bx < 0 || by < 0 || bx >= nbw || by >= nbh) return w;
+  if (!mask[by * nbw + bx]) return w;
+  w.flat = 1;
+  w.ys = (by > 0 && mask[(by - 1) * nbw + bx]) ? 0 : kQLag;
+  w.xs = (bx > 0 && mask[by * nbw + bx - 1]) ? 0 : kQLag;
+  w.ye = min(ph - by * bh, bh);
+  w.xe = min(pw - bx * bw - kQLag, (bx + 1 < nbw && mask[by * nbw + bx + 1]) ? bw : (bw - kQLag));
+  if (w.xe <= w.xs || w.ye <= w.ys) w.flat = 0;  // empty window
+  return w;
+}
+// w at plane sample (X, Y)
+__device__ __forceinline__ int window_at(const uint8_t *mask, int nbw, int nbh, int bw, int bh, int pw, int ph, int X,
+                                         int Y) {
+  if (X < 0 || Y < 0 || X >= pw || Y >= ph) return 0;
+  const int bx = X / bw, by = Y / bh;
+  const Win w = block_window(mask, nbw, nbh, bx, by, bw, bh, pw, ph);
+  const int lx = X - bx * bw, ly = Y - by * bh;
+  return w.flat && lx >= w.xs && lx < w.xe && ly >= w.ys && ly < w.ye;
+}
+
+// ---------------------------------------------------------------------------------
+// k3_classify: one thread per block area and plane kind.
+// needed area of w for the area of block (bx, by): rows by*bh .. by*bh+bh+2,
+// cols bx*bw-3 .. bx*bw+bw+2   (q - c_i: up to 3 below, 3 left/right)
+// grid = (ceil(nblocks/256), kinds, batch)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k3_classify(Geom g, const uint8_t *__restrict__ records, QParams qp) {
+  const int blk = blockIdx.x * 256 + threadIdx.x;
+  const int kind = blockIdx.y, frame = blockIdx.z;
+  if (blk >= g.nblocks) return;
+  const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
+  const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
+  const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
+  const int bx = blk % g.nbw, by = blk / g.nbw;
+  const int AX0 = bx * bw - kQLag, AX1 = bx * bw + bw + kQLag, AY0 = by * bh, AY1 = by * bh + bh + kQLag;
+  bool all1 = !(AX0 < 0 || AX1 > pw || AY1 > ph);
+  bool any1 = false;
+  for (int dby = 0; dby <= 1; ++dby) {
+    for (int dbx = -1; dbx <= 1; ++dbx) {
+      const int Bx = bx + dbx, By = by + dby;
+      const int rx0 = max(AX0, Bx * bw), rx1 = min(AX1, Bx * bw + bw);
+      const int ry0 = max(AY0, By * bh), ry1 = min(AY1, By * bh + bh);
+      if (rx0 >= rx1 || ry0 >= ry1) continue;
+      const Win w = block_window(mask, g.nbw, g.nbh, Bx, By, bw, bh, pw, ph);
+      if (!w.flat) {
+        all1 = false;
+        continue;
+      }
+      const int ax0 = rx0 - Bx * bw, ax1 = rx1 - Bx * bw, ay0 = ry0 - By * bh, ay1 = ry1 - By * bh;
+      if (max(ax0, w.xs) < min(ax1, w.xe) && max(ay0, w.ys) < min(ay1, w.ye)) any1 = true;
+      if (!(w.xs <= ax0 && ax1 <= w.xe && w.ys <= ay0 && ay1 <= w.ye)) all1 = false;
+    }
+  }
+  const uint8_t c = all1 ? kClsInt : (any1 ? kClsMix : kClsExt);
+  const size_t o = ((size_t)frame * 2 + kind) * g.nblocks + blk;
+  qp.cls[o] = c;
+  // MIX areas go to the generic kernel; a flat block whose own area is EXT still needs its
+  // block statistics (and has no window samples): generic handles it too.
+  qp.todo[o] = (c == kClsMix || (c == kClsExt && mask[blk])) ? 1 : 0;
+}
+
+// ---- 8 consecutive samples of a row (vector global load, narrowed later) ----
+struct Px8 {
+  uint4 raw;  // u16: 8 samples; u8: .x,.y hold 8 samples
+  int state;  // 0 = zero (outside the plane), 1 = raw valid, 2 = edge segment: per-sample loads later
+};
+__device__ __forceinline__ Px8 fetch8(const uint8_t *base, uint32_t stride, int bps, bool vec_ok, int X0, int Y,
+                                      int pw, int ph) {
+  Px8 r;
+  r.raw = make_uint4(0, 0, 0, 0);
+  r.state = 0;
+  if (Y < 0 || Y >= ph || X0 + 8 <= 0 || X0 >= pw) return r;
+  if (X0 >= 0 && X0 + 8 <= pw && vec_ok) {
+    gptr_u8 p = as_global(base) + (size_t)Y * stride + (size_t)X0 * bps;
+    if (bps == 2) {
+      r.raw = gload4((gptr_u4)p);
+    } else {
+      const uint2 v = gload2((gptr_u2)p);
+      r.raw.x = v.x;
+      r.raw.y = v.y;
+    }
+    r.state = 1;
+  } else {
+    r.state = 2;
+  }
+  return r;
+}
+__device__ __forceinline__ void unpack8(const Px8 &p, const uint8_t *base, uint32_t stride, int bps, int shift,
+                                        int X0, int Y, int pw, int (&v)[8]) {
+  if (p.state == 1) {
+    if (bps == 2) {
+      const uint32_t w[4] = {p.raw.x, p.raw.y, p.raw.z, p.raw.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] = (int)(((w[k] & 0xffffu) >> shift) & 0xffu);
+        v[2 * k + 1] = (int)(((w[k] >> 16) >> shift) & 0xffu);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = (int)((p.raw.x >> (8 * k)) & 0xffu);
+        v[4 + k] = (int)((p.raw.y >> (8 * k)) & 0xffu);
+      }
+    }
+  } else if (p.state == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int X = X0 + k;
+      v[k] = (X >= 0 && X < pw) ? load_px_rt(base, stride, bps, shift, X, Y) : 0;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0;
+  }
+}
+
+// KIND: 0 = luma; 1 = chroma 4:2:0; 2 = chroma 4:2:2; 3 = chroma 4:4:4.
+template <int KIND>
+struct QShape {
+  static constexpr bool kChroma = KIND != 0;
+  static constexpr int SX = (KIND == 1 || KIND == 2) ? 1 : 0;
+  static constexpr int SY = (KIND == 1) ? 1 : 0;
+  static constexpr int BW = kBlock >> SX, BH = kBlock >> SY;
+  static constexpr int G = BW / 4;              // 4-sample groups per row
+  static constexpr int ROWS_PER_STEP = 64 / G;  // rows covered by one wave step
+  static constexpr int NS = BH / ROWS_PER_STEP; // wave steps per plane area
+  static constexpr int NPL = kChroma ? 2 : 1;
+  static constexpr int WAVES = (NPL * NS) < 4 ? (NPL * NS) : 4;
+  static constexpr int THREADS = WAVES * 64;
+  static constexpr int STEPS_PER_WAVE = NPL * NS / WAVES;
+  static constexpr int PITCH_DW = 32 + G;  // conflict-free for the (group, row) lane map
+  static constexpr int PITCH = PITCH_DW * 4;
+  static constexpr int UP = kChroma ? kQLag : 0;  // rows above the area (chroma L terms are p-centric)
+  static constexpr int TH = BH + kQLag + UP;      // tile rows: -UP .. BH+2
+  static constexpr int SEGS = (BW + 16) / 8;      // 8-sample segments per tile row: x = -8 .. BW+7
+  static constexpr int NTILE = TH * SEGS * NPL;
+  static constexpr int LCH = 8 >> SX;  // chroma samples per L item (8 luma samples wide)
+  static constexpr int LSEGS = BW / LCH;
+  static constexpr int NL = kChroma ? BH * LSEGS : 0;
+  static constexpr int LROWS = 1 << SY;
+  static constexpr int NITEMS = NTILE + NL;
+  static constexpr int MAXIT = (NITEMS + THREADS - 1) / THREADS;
+  static constexpr int SLOT = kChroma ? LROWS : 1;
+  static constexpr int TILE_BYTES = TH * PITCH;
+  static constexpr int LTILE_BYTES = BH * PITCH;
+  static constexpr int LDS_BYTES = NPL * TILE_BYTES + (kChroma ? 2 * LTILE_BYTES : 0);
+  static constexpr int NACC = kNumLags + (kChroma ? kNumLTerms : 0);
+};
+
+// ---------------------------------------------------------------------------------
+// k3_interior<KIND>: INT areas.  LDS tile: sample (x, y), x in -8..BW+7, y in -UP..BH+2,
+// at byte (y + UP) * PITCH + 8 + x; group g (x = 4g) is dword g + 2.
+// grid = (nchunks, 1, batch), block = QShape::THREADS.
+// int32 safety: per group step |sum| <= 4*127^2 = 64516; a lane sees <= 128 areas *
+// STEPS_PER_WAVE(<=2) steps; the 64-lane reduction multiplies by 64: < 2^31.
+// ---------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const FramePlanes *__restrict__ frames, Geom g,
+                                                                     QParams qp, uint8_t *__restrict__ records) {
+  using S = QShape<KIND>;
+  constexpr bool CHROMA = S::kChroma;
+  constexpr int NACC = S::NACC, NT = S::THREADS;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[S::LDS_BYTES];
+  __shared__ int s_flag[2];
+  __shared__ int s_stat[2][4][4];
+
+  const int frame = blockIdx.z, chunk = blockIdx.x;
+  const FramePlanes fp = frames[frame];
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  const uint8_t *cls = qp.cls + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
+  uint8_t *todo = qp.todo + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int pw = g.W >> S::SX, ph = g.H >> S::SY;
+  constexpr int bw = S::BW, bh = S::BH;
+  const int lg = lane % S::G, lr = lane / S::G;
+
+  int acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0;
+  int nareas = 0;
+  if (tid < 2) s_flag[tid] = 0;
+
+  Px8 ps[S::MAXIT][S::SLOT], pd[S::MAXIT][S::SLOT];
+  auto item_fetch = [&](int blk) {
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const int x_o = bx * bw, y_o = by * bh;
+#pragma unroll
+    for (int k = 0; k < S::MAXIT; ++k) {
+      const int it = tid + k * NT;
+      if (it < S::NTILE) {
+        const int pl = it / (S::TH * S::SEGS);
+        const int r = it - pl * (S::TH * S::SEGS);
+        const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
+        const int c = CHROMA ? 1 + pl : 0;
+        const int X0 = x_o - 8 + 8 * sg, Y = y_o - S::UP + ty;
+        ps[k][0] = fetch8(fp.src[c], fp.src_stride[c], g.src_bps, (g.vec_mask >> c) & 1, X0, Y, pw, ph);
+        pd[k][0] = fetch8(fp.den[c], fp.den_stride[c], g.den_bps, (g.vec_mask >> (3 + c)) & 1, X0, Y, pw, ph);
+      } else if (CHROMA && it < S::NITEMS) {
+        const int r = it - S::NTILE;
+        const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
+        const int X0 = (x_o + sg * S::LCH) << S::SX;  // luma coordinates
+#pragma unroll
+        for (int q = 0; q < S::LROWS; ++q) {
+          const int Y = ((y_o + y) << S::SY) + q;
+          ps[k][q] = fetch8(fp.src[0], fp.src_stride[0], g.src_bps, g.vec_mask & 1, X0, Y, g.W, g.H);
+          pd[k][q] = fetch8(fp.den[0], fp.den_stride[0], g.den_bps, (g.vec_mask >> 3) & 1, X0, Y, g.W, g.H);
+        }
+      }
+    }
+  };
+  auto item_store = [&](int blk, int &lsum) -> bool {
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const int x_o = bx * bw, y_o = by * bh;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < S::MAXIT; ++k) {
+      const int it = tid + k * NT;
+      if (it < S::NTILE) {
+        const int pl = it / (S::TH * S::SEGS);
+        const int r = it - pl * (S::TH * S::SEGS);
+        const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
+        const int c = CHROMA ? 1 + pl : 0;
+        const int X0 = x_o - 8 + 8 * sg, Y = y_o - S::UP + ty;
+        int sv[8], dv[8];
+        unpack8(ps[k][0], fp.src[c], fp.src_stride[c], g.src_bps, g.src_shift, X0, Y, pw, sv);
+        unpack8(pd[k][0], fp.den[c], fp.den_stride[c], g.den_bps, g.den_shift, X0, Y, pw, dv);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int d = sv[q] - dv[q];
+          bad |= (d > 127) | (d < -127);
+          const uint32_t b = (uint32_t)d & 0xffu;
+          if (q < 4) lo |= b << (8 * q); else hi |= b << (8 * (q - 4));
+        }
+        if (!CHROMA && sg >= 1 && sg <= 4 && ty < bh) {  // block proper -> luma sum of the source
+#pragma unroll
+          for (int q = 0; q < 8; ++q) lsum += sv[q];
+        }
+        *reinterpret_cast<uint2 *>(lds + pl * S::TILE_BYTES + ty * S::PITCH + 8 * sg) = make_uint2(lo, hi);
+      } else if (CHROMA && it < S::NITEMS) {
+        const int r = it - S::NTILE;
+        const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
+        const int X0 = (x_o + sg * S::LCH) << S::SX;
+        int L[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) L[q] = 0;
+#pragma unroll
+        for (int q = 0; q < S::LROWS; ++q) {
+          const int Y = ((y_o + y) << S::SY) + q;
+          int sv[8], dv[8];
+          unpack8(ps[k][q], fp.src[0], fp.src_stride[0], g.src_bps, g.src_shift, X0, Y, g.W, sv);
+          unpack8(pd[k][q], fp.den[0], fp.den_stride[0], g.den_bps, g.den_shift, X0, Y, g.W, dv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int d = sv[e] - dv[e];
+            bad |= (d > 127) | (d < -127);
+            L[e >> S::SX] += d;
+          }
+        }
+        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+        for (int e = 0; e < S::LCH; ++e) {
+          const uint32_t av = (uint32_t)(L[e] >> 2) & 0xffu, bv = (uint32_t)(L[e] & 3);
+          if (e < 4) {
+            a0 |= av << (8 * e);
+            b0 |= bv << (8 * e);
+          } else {
+            a1 |= av << (8 * (e - 4));
+            b1 |= bv << (8 * (e - 4));
+          }
+        }
+        uint8_t *ta = lds + S::NPL * S::TILE_BYTES + y * S::PITCH + sg * S::LCH;
+        uint8_t *tb = ta + S::LTILE_BYTES;
+        if (S::LCH == 8) {
+          *reinterpret_cast<uint2 *>(ta) = make_uint2(a0, a1);
+          *reinterpret_cast<uint2 *>(tb) = make_uint2(b0, b1);
+        } else {
+          *reinterpret_cast<uint32_t *>(ta) = a0;
+          *reinterpret_cast<uint32_t *>(tb) = b0;
+        }
+      }
+    }
+    return bad;
+  };
+  auto next_area = [&](int blk) {
+    while (blk < g.nblocks && cls[blk] != kClsInt) blk += qp.nchunks;
+    return blk;
+  };
+
+  int cur = next_area(chunk);
+  if (cur < g.nblocks) item_fetch(cur);
+  __syncthreads();
+
+  int iter = 0;
+  while (cur < g.nblocks) {
+    const int blk = cur;
+    const int fl = iter & 1;
+    ++iter;
+    int lsum = 0;
+    const bool bad = item_store(blk, lsum);
+    cur = next_area(blk + qp.nchunks);     // class bytes are read BEFORE the prefetch is issued
+    if (cur < g.nblocks) item_fetch(cur);  // in flight during the products below
+    if (bad) s_flag[fl] = 1;
+    if (!CHROMA) {
+      lsum = wave_sum(lsum);
+      if (lane == 0) s_stat[fl][wave][3] = lsum;
+    }
+    __syncthreads();
+    const bool deferred = s_flag[fl] != 0;
+    if (tid == 0) s_flag[fl ^ 1] = 0;
+    if (deferred) {
+      if (tid == 0) todo[blk] = 1;  // the generic kernel redoes this area in int32
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0) ++nareas;
+
+    int sd = 0, sd2 = 0;
+#pragma unroll 1
+    for (int s = 0; s < S::STEPS_PER_WAVE; ++s) {
+      const int widx = wave * S::STEPS_PER_WAVE + s;
+      const int pl = widx / S::NS, step = widx - pl * S::NS;
+      const int row = step * S::ROWS_PER_STEP + lr;  // sample row of the area
+      const uint32_t *t32 = reinterpret_cast<const uint32_t *>(lds + pl * S::TILE_BYTES) + (row + S::UP) * S::PITCH_DW + lg;
+      // row 0 of delta: dwords g+2 .. g+4
+      const uint32_t c0 = t32[2], c1 = t32[3], c2 = t32[4];
+      const uint32_t D0 = c0;
+      acc[0] = sdot4((int)D0, (int)D0, acc[0]);
+      acc[1] = sdot4((int)D0, (int)alignbyte(c1, c0, 1), acc[1]);
+      acc[2] = sdot4((int)D0, (int)alignbyte(c1, c0, 2), acc[2]);
+      acc[3] = sdot4((int)D0, (int)alignbyte(c1, c0, 3), acc[3]);
+      acc[4] = sdot4((int)D0, (int)c1, acc[4]);
+      acc[5] = sdot4((int)D0, (int)alignbyte(c2, c1, 1), acc[5]);
+      acc[6] = sdot4((int)D0, (int)alignbyte(c2, c1, 2), acc[6]);
+#pragma unroll
+      for (int dy = 1; dy <= 3; ++dy) {
+        const uint32_t *rp = t32 + dy * S::PITCH_DW;
+        const uint32_t e0 = rp[0], e1 = rp[1], e2 = rp[2], e3 = rp[3], e4 = rp[4];
+        const int b = 7 + (dy - 1) * 13;
+        acc[b + 0] = sdot4((int)D0, (int)alignbyte(e1, e0, 2), acc[b + 0]);   // dx = -6
+        acc[b + 1] = sdot4((int)D0, (int)alignbyte(e1, e0, 3), acc[b + 1]);   // -5
+        acc[b + 2] = sdot4((int)D0, (int)e1, acc[b + 2]);                     // -4
+        acc[b + 3] = sdot4((int)D0, (int)alignbyte(e2, e1, 1), acc[b + 3]);   // -3
+        acc[b + 4] = sdot4((int)D0, (int)alignbyte(e2, e1, 2), acc[b + 4]);   // -2
+        acc[b + 5] = sdot4((int)D0, (int)alignbyte(e2, e1, 3), acc[b + 5]);   // -1
+        acc[b + 6] = sdot4((int)D0, (int)e2, acc[b + 6]);                     // 0
+        acc[b + 7] = sdot4((int)D0, (int)alignbyte(e3, e2, 1), acc[b + 7]);   // +1
+        acc[b + 8] = sdot4((int)D0, (int)alignbyte(e3, e2, 2), acc[b + 8]);   // +2
+        acc[b + 9] = sdot4((int)D0, (int)alignbyte(e3, e2, 3), acc[b + 9]);   // +3
+        acc[b + 10] = sdot4((int)D0, (int)e3, acc[b + 10]);                   // +4
+        acc[b + 11] = sdot4((int)D0, (int)alignbyte(e4, e3, 1), acc[b + 11]); // +5
+        acc[b + 12] = sdot4((int)D0, (int)alignbyte(e4, e3, 2), acc[b + 12]); // +6
+      }
+      sd = sdot4((int)D0, 0x01010101, sd);
+      sd2 = sdot4((int)D0, (int)D0, sd2);
+      if (CHROMA) {
+        // p-centric L terms (interior: the block's own window is the whole area)
+        const uint32_t *ta = reinterpret_cast<const uint32_t *>(lds + S::NPL * S::TILE_BYTES);
+        const uint32_t La = ta[row * S::PITCH_DW + lg];
+        const uint32_t Lb = ta[S::LTILE_BYTES / 4 + row * S::PITCH_DW + lg];
+        int *al = acc + kNumLags;
+#pragma unroll
+        for (int cy = -3; cy <= 0; ++cy) {
+          const uint32_t *rp = t32 + cy * S::PITCH_DW;
+          const uint32_t u1 = rp[1], u2 = rp[2], u3 = rp[3];
+          const int k0 = (cy + 3) * 7;
+          const uint32_t v0 = alignbyte(u2, u1, 1), v1 = alignbyte(u2, u1, 2), v2 = alignbyte(u2, u1, 3);
+          al[2 * (k0 + 0)] = sdot4((int)La, (int)v0, al[2 * (k0 + 0)]);
+          al[2 * (k0 + 0) + 1] = sdot4((int)Lb, (int)v0, al[2 * (k0 + 0) + 1]);
+          al[2 * (k0 + 1)] = sdot4((int)La, (int)v1, al[2 * (k0 + 1)]);
+          al[2 * (k0 + 1) + 1] = sdot4((int)Lb, (int)v1, al[2 * (k0 + 1) + 1]);
+          al[2 * (k0 + 2)] = sdot4((int)La, (int)v2, al[2 * (k0 + 2)]);
+          al[2 * (k0 + 2) + 1] = sdot4((int)Lb, (int)v2, al[2 * (k0 + 2) + 1]);
+          if (cy < 0) {
+            const uint32_t v3 = u2, v4 = alignbyte(u3, u2, 1), v5 = alignbyte(u3, u2, 2), v6 = alignbyte(u3, u2, 3);
+            al[2 * (k0 + 3)] = sdot4((int)La, (int)v3, al[2 * (k0 + 3)]);
+            al[2 * (k0 + 3) + 1] = sdot4((int)Lb, (int)v3, al[2 * (k0 + 3) + 1]);
+            al[2 * (k0 + 4)] = sdot4((int)La, (int)v4, al[2 * (k0 + 4)]);
+            al[2 * (k0 + 4) + 1] = sdot4((int)Lb, (int)v4, al[2 * (k0 + 4) + 1]);
+            al[2 * (k0 + 5)] = sdot4((int)La, (int)v5, al[2 * (k0 + 5)]);
+            al[2 * (k0 + 5) + 1] = sdot4((int)Lb, (int)v5, al[2 * (k0 + 5) + 1]);
+            al[2 * (k0 + 6)] = sdot4((int)La, (int)v6, al[2 * (k0 + 6)]);
+            al[2 * (k0 + 6) + 1] = sdot4((int)Lb, (int)v6, al[2 * (k0 + 6) + 1]);
+          }
+        }
+        al[48] = sdot4((int)La, (int)La, al[48]);
+        al[49] = sdot4((int)La, (int)Lb, al[49]);
+        al[50] = sdot4((int)Lb, (int)Lb, al[50]);
+        al[51] = sdot4((int)La, (int)D0, al[51]);
+        al[52] = sdot4((int)Lb, (int)D0, al[52]);
+      }
+    }
+    // block statistics of the area's own block (every INT area is a flat block)
+    sd = wave_sum(sd);
+    sd2 = wave_sum(sd2);
+    if (lane == 0) {
+      s_stat[fl][wave][0] = sd;
+      s_stat[fl][wave][1] = sd2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int(*st)[4] = s_stat[fl];
+      if (!CHROMA) {
+        int a = 0, b = 0, l = 0;
+        for (int w = 0; w < S::WAVES; ++w) {
+          a += st[w][0];
+          b += st[w][1];
+          l += st[w][3];
+        }
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = a;
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)b;
+        reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)l;
+      } else {
+        int a[2] = {0, 0}, b[2] = {0, 0};
+        for (int w = 0; w < S::WAVES; ++w) {
+          const int pl = (w * S::STEPS_PER_WAVE) / S::NS;  // a wave's steps stay within one plane
+          a[pl] += st[w][0];
+          b[pl] += st[w][1];
+        }
+        for (int pl = 0; pl < 2; ++pl) {
+          reinterpret_cast<int32_t *>(rec + g.off_sum_d[1 + pl])[blk] = a[pl];
+          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1 + pl])[blk] = (uint32_t)b[pl];
+        }
+      }
+    }
+  }
+
+  // ---- wave reduction + partial store: waves of the same plane add up ----
+  __syncthreads();
+  int *red = reinterpret_cast<int *>(lds);
+  static_assert(4 * (kNumLags + kNumLTerms) * 4 <= S::LDS_BYTES, "reduction scratch must fit");
+  {
+    constexpr int CH = 23;
+#pragma unroll
+    for (int b0 = 0; b0 < NACC; b0 += CH) {
+      int tmp[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) tmp[i] = (b0 + i < NACC) ? acc[b0 + i] : 0;
+      wave_sum_all<CH>(tmp);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if (b0 + i < NACC) red[wave * NACC + b0 + i] = tmp[i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int pl = 0; pl < S::NPL; ++pl) {
+    int32_t *out = qp.partials + (((size_t)frame * 3 + (CHROMA ? 1 + pl : 0)) * qp.nchunks + chunk) * kQPart;
+    for (int i = tid; i < NACC; i += NT) {
+      int v = 0;
+      for (int w = 0; w < S::WAVES; ++w)
+        if ((w * S::STEPS_PER_WAVE) / S::NS == pl) v += red[w * NACC + i];
+      out[i] = v;
+    }
+    if (!CHROMA)
+      for (int i = NACC + tid; i < kNumLags + kNumLTerms; i += NT) out[i] = 0;
+    if (tid == 0) out[kNumLags + kNumLTerms] = nareas;  // nobs = nareas * BW * BH (reducer)
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k3q_generic: areas marked in `todo` (MIX, EXT-but-flat, deferred INT), plain int32.
+// One workgroup per area iteration; thread t owns up to two of the 350 products.
+//   product (i, j):  sum_q W(q - c_i) d(q) d(q + c_j - c_i)
+//   product (i, y):  sum_q W(q - c_i) d(q) d(q - c_i)
+//   product (i, L):  sum_p w(p) L(p) d(p + c_i);  (L,L), (L,y) likewise      [chroma]
+// Adds straight into the record with int64 atomics (few areas), writes the block stats.
+// grid = (chunks, nplanes, batch), block = 256.
+// ---------------------------------------------------------------------------------
+constexpr int kGW = kBlock + 12, kGH = kBlock + 6;  // d tile: cols -6..37, rows -3..34
+__global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict__ frames, Geom g, QParams qp,
+                                                   uint8_t *__restrict__ records) {
+  __shared__ int dt[kGH * kGW];       // d(q), x in -6..bw+5, y in -3..bh+2
+  __shared__ uint8_t wt[kGH * kGW];   // w at the same positions
+  __shared__ int lt[kBlock * kBlock];  // L(p) on the block proper
+  __shared__ int red[4];
+  const int c = blockIdx.y, frame = blockIdx.z;
+  const int kind = c > 0 ? 1 : 0;
+  const uint8_t *todo = qp.todo + ((size_t)frame * 2 + kind) * g.nblocks;
+  const FramePlanes fp = frames[frame];
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  const uint8_t *mask = rec + g.off_mask;
+  const int sx = c ? g.xdec : 0, sy = c ? g.ydec : 0;
+  const int pw = g.W >> sx, ph = g.H >> sy, bw = kBlock >> sx, bh = kBlock >> sy;
+  const int TW = bw + 12, TH = bh + 6;
+  const int nc = kQN + (c > 0);
+  const int ntri = nc * (nc + 1) / 2, npairs = ntri + nc;
+  // product descriptors
+  int kindp[2], oa[2], ob[2], om[2], out_idx[2];
+  bool have[2];
+  auto tile_off = [&](int dx, int dy) { return (dy + 3) * TW + (dx + 6); };
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int p = threadIdx.x + s * 256;
+    have[s] = p < npairs;
+    int i = 0, j = 0;
+    if (p < ntri) {
+      int rem = p;
+      while (rem >= nc - i) {
+        rem -= nc - i;
+        ++i;
+      }
+      j = i + rem;
+      out_idx[s] = i * nc + j;
+    } else {
+      i = p - ntri;
+      j = nc;  // y
+      out_idx[s] = nc * nc + i;
+    }
+    if (!have[s]) i = j = 0;
+    const bool iL = (c > 0 && i == kQN), jL = (c > 0 && j == kQN), jY = (j == nc);
+    if (!iL && !jL) {
+      // q-centric: d(q) * d(q + delta), mask W(q - c_i)
+      kindp[s] = 0;
+      const int cxi = coord_x(i), cyi = coord_y(i);
+      const int dx = (jY ? 0 : coord_x(j)) - cxi, dy = (jY ? 0 : coord_y(j)) - cyi;
+      oa[s] = tile_off(0, 0);
+      ob[s] = tile_off(dx, dy);
+      om[s] = tile_off(-cxi, -cyi);
+    } else if (!iL && jL) {
+      kindp[s] = 1;  // p-centric: L(p) * d(p + c_i), mask w(p)
+      oa[s] = tile_off(coord_x(i), coord_y(i));
+      ob[s] = 0;
+      om[s] = tile_off(0, 0);
+    } else if (iL && jL) {
+      kindp[s] = 2;  // L(p)^2
+      oa[s] = ob[s] = 0;
+      om[s] = tile_off(0, 0);
+    } else {
+      kindp[s] = 3;  // L(p) * d(p)
+      oa[s] = tile_off(0, 0);
+      ob[s] = 0;
+      om[s] = tile_off(0, 0);
+    }
+  }
+  unsigned long long *ar = reinterpret_cast<unsigned long long *>(rec + g.off_ar[c]);
+  const uint8_t *sp = fp.src[c], *dp = fp.den[c];
+  const uint32_t sst = fp.src_stride[c], dst = fp.den_stride[c];
+
+  for (int blk = blockIdx.x; blk < g.nblocks; blk += gridDim.x) {
+    if (!todo[blk]) continue;
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const int x_o = bx * bw, y_o = by * bh;
+    int s_d = 0, s_d2 = 0, s_l = 0, s_n = 0;
+    for (int idx = threadIdx.x; idx < TW * TH; idx += 256) {
+      const int ty = idx / TW, tx = idx - ty * TW;
+      const int X = x_o - 6 + tx, Y = y_o - 3 + ty;
+      int d = 0, wv = 0;
+      if (X >= 0 && X < pw && Y >= 0 && Y < ph) {
+        const int s = load_px_rt(sp, sst, g.src_bps, g.src_shift, X, Y);
+        d = s - load_px_rt(dp, dst, g.den_bps, g.den_shift, X, Y);
+        wv = window_at(mask, g.nbw, g.nbh, bw, bh, pw, ph, X, Y);
+        if (tx >= 6 && tx < 6 + bw && ty >= 3 && ty < 3 + bh) {  // block proper
+          s_d += d;
+          s_d2 += d * d;
+          s_n += wv;
+          if (c == 0) s_l += s;
+        }
+      }
+      dt[idx] = d;
+      wt[idx] = (uint8_t)wv;
+    }
+    if (c > 0) {
+      for (int idx = threadIdx.x; idx < bw * bh; idx += 256) {
+        const int y = idx / bw, x = idx - y * bw;
+        const int X = x_o + x, Y = y_o + y;
+        int L = 0;
+        if (X < pw && Y < ph) {
+          for (int dy = 0; dy < (1 << sy); ++dy)
+            for (int dx = 0; dx < (1 << sx); ++dx) {
+              const int lx = (X << sx) + dx, ly = (Y << sy) + dy;
+              L += load_px_rt(fp.src[0], fp.src_stride[0], g.src_bps, g.src_shift, lx, ly) -
+                   load_px_rt(fp.den[0], fp.den_stride[0], g.den_bps, g.den_shift, lx, ly);
+            }
+        }
+        lt[idx] = L;
+      }
+    }
+    {
+      const int td = block_reduce_sum(s_d, red);
+      const int td2 = block_reduce_sum(s_d2, red);
+      const int tn = block_reduce_sum(s_n, red);
+      const int tl = c == 0 ? block_reduce_sum(s_l, red) : 0;
+      if (threadIdx.x == 0) {
+        if (mask[blk]) {
+          reinterpret_cast<int32_t *>(rec + g.off_sum_d[c])[blk] = td;
+          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[c])[blk] = (uint32_t)td2;
+          if (c == 0) reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)tl;
+        }
+        if (tn) atomicAdd(&ar[nc * nc + nc], (unsigned long long)tn);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (!have[s]) continue;
+      int acc = 0;
+      for (int y = 0; y < bh; ++y) {
+        const int ro = y * TW;
+        if (kindp[s] == 0) {
+          for (int x = 0; x < bw; ++x)
+            if (wt[om[s] + ro + x]) acc += dt[oa[s] + ro + x] * dt[ob[s] + ro + x];
+        } else if (kindp[s] == 1) {
+          for (int x = 0; x < bw; ++x)
+            if (wt[om[s] + ro + x]) acc += lt[y * bw + x] * dt[oa[s] + ro + x];
+        } else if (kindp[s] == 2) {
+          for (int x = 0; x < bw; ++x)
+            if (wt[om[s] + ro + x]) acc += lt[y * bw + x] * lt[y * bw + x];
+        } else {
+          for (int x = 0; x < bw; ++x)
+            if (wt[om[s] + ro + x]) acc += lt[y * bw + x] * dt[oa[s] + ro + x];
+        }
+      }
+      if (acc != 0) atomicAdd(&ar[out_idx[s]], (unsigned long long)(long long)acc);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k3q_reduce: chunk partials of the interior kernel -> record (upper triangle).
+//   S[i][j] += G(c_j - c_i);  Sb[i] += G(-c_i);  chroma: S[i][L] += 4 Xa_i + Xb_i, ...
+// grid = (nplanes, batch), block = 256.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *__restrict__ records) {
+  const int c = blockIdx.x, frame = blockIdx.y;
+  const bool chroma = c > 0;
+  const int nc = kQN + (chroma ? 1 : 0);
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
+  const int32_t *base = qp.partials + ((size_t)frame * 3 + c) * qp.nchunks * kQPart;
+  __shared__ long long tot[kQPart];
+  for (int e = threadIdx.x; e < kQPart; e += 256) {
+    long long s = 0;
+    for (int ch = 0; ch < qp.nchunks; ++ch) s += base[(size_t)ch * kQPart + e];
+    tot[e] = s;
+  }
+  __syncthreads();
+  const int sx = chroma ? g.xdec : 0, sy = chroma ? g.ydec : 0;
+  for (int p = threadIdx.x; p < kQN * kQN; p += 256) {
+    const int i = p / kQN, j = p % kQN;
+    if (j < i) continue;
+    const int dx = coord_x(j) - coord_x(i), dy = coord_y(j) - coord_y(i);
+    ar[i * nc + j] += tot[lag_index(dx, dy)];
+  }
+  if (threadIdx.x < kQN) {
+    const int i = threadIdx.x;
+    ar[nc * nc + i] += tot[lag_index(-coord_x(i), -coord_y(i))];  // Sb[i]
+    if (chroma) ar[i * nc + kQN] += 4 * tot[kNumLags + 2 * i] + tot[kNumLags + 2 * i + 1];
+  }
+  if (chroma && threadIdx.x == 32) {
+    const long long *t = tot + kNumLags + 48;
+    ar[kQN * nc + kQN] += 16 * t[0] + 8 * t[1] + t[2];
+    ar[nc * nc + kQN] += 4 * t[3] + t[4];
+  }
+  if (threadIdx.x == 64)
+    ar[nc * nc + nc] += tot[kNumLags + kNumLTerms] * (long long)((kBlock >> sx) * (kBlock >> sy));
+}
+
+}  // namespace g1s
