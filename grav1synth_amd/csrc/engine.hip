@@ -127,7 +127,7 @@ struct Slot {
   uint8_t *d_records = nullptr;
   uint8_t *h_records = nullptr;  // pinned
   uint8_t *d_flags = nullptr;
-  int32_t *d_partials = nullptr;   // k3_interior chunk partials
+  int32_t *d_partials = nullptr;   // k3_interior chunk partials, then k3_mixed chunk partials
   uint8_t *d_defer = nullptr;      // area classes [batch][2][nblocks] + todo list [batch][2][nblocks]
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
@@ -171,7 +171,7 @@ struct g1s_diff {
   RecLayout L{};
   FlatConsts fc{};
   double *d_lut = nullptr;
-  int fast_chunks = 0;
+  int fast_chunks = 0, mix_chunks = 0;
   size_t defer_bytes = 0;
   SlotKey slot_key{};
   Slot slots[2];
@@ -266,10 +266,14 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   }
   size_t partial_bytes = 0;
   if (lag == kQLag) {
-    fast_chunks = (g.nblocks + kMaxAreasPerWG - 1) / kMaxAreasPerWG;
-    if (fast_chunks < 64) fast_chunks = std::min(64, g.nblocks);
-    partial_bytes = sizeof(int32_t) * (size_t)batch * 3 * fast_chunks * kQPart;
-    defer_bytes = 2 * (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15));
+    // interior: ~24 areas per workgroup (many small workgroups hide the staging latency);
+    // mixed: fewer, larger workgroups (189 accumulators to reduce at the end), <= 128 areas each
+    fast_chunks = std::max(1, std::min(g.nblocks, std::max(64, (g.nblocks + 23) / 24)));
+    mix_chunks = std::max(1, std::min(g.nblocks, std::max(64, (g.nblocks + 63) / 64)));
+    partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart);
+    const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
+    // [cls][todo][lists u32 x4 per frame][counts]
+    defer_bytes = 2 * cls_bytes + sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 6);
   }
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
                      partial_bytes, defer_bytes, frame_bytes * batch};
@@ -402,25 +406,46 @@ int g1s_diff::submit(int si) {
     // then the generic int32 kernel on mixed / deferred areas
     QParams qp;
     qp.nchunks = fast_chunks;
-    qp.partials = sl.d_partials;
+    qp.nchunks_mix = mix_chunks;
+    static const bool force_generic = getenv("G1S_MIXED_GENERIC") != nullptr;  // debugging aid
+    qp.mixed_fast = force_generic ? 0 : 1;
+    qp.lagacc = reinterpret_cast<long long *>(sl.d_partials);
+    qp.paracc = qp.lagacc + (size_t)batch * 3 * kQPart;
+    HIP_TRY(hipMemsetAsync(sl.d_partials, 0, sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart), stream));
+    const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
     qp.cls = sl.d_defer;
-    qp.todo = sl.d_defer + (((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15));
+    qp.todo = sl.d_defer + cls_bytes;
+    qp.lists = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes);
+    qp.counts = qp.lists + (size_t)batch * 6 * g.nblocks;
+    HIP_TRY(hipMemsetAsync(qp.counts, 0, sizeof(uint32_t) * (size_t)batch * 6, stream));
     const int kinds = g.nplanes == 3 ? 2 : 1;
     hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + 255) / 256, kinds, B), dim3(256), 0, stream, g,
                        (const uint8_t *)sl.d_records, qp);
-    hipLaunchKernelGGL(k3_interior<0>, dim3(fast_chunks, 1, B), dim3(QShape<0>::THREADS), 0, stream, sl.d_planes, g, qp,
-                       sl.d_records);
-    if (g.nplanes == 3) {
-      const dim3 cg(fast_chunks, 1, B);
-      if (g.xdec == 1 && g.ydec == 1)
-        hipLaunchKernelGGL(k3_interior<1>, cg, dim3(QShape<1>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records);
-      else if (g.xdec == 1)
-        hipLaunchKernelGGL(k3_interior<2>, cg, dim3(QShape<2>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records);
-      else
-        hipLaunchKernelGGL(k3_interior<3>, cg, dim3(QShape<3>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records);
+    const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
+    auto launch_lag = [&](bool mixed) {
+      const dim3 gr(mixed ? mix_chunks : fast_chunks, 1, B);
+#define G1S_LAG(K)                                                                                              \
+  if (mixed)                                                                                                    \
+    hipLaunchKernelGGL((k3_lag<K, true>), gr, dim3(QShape<K>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records); \
+  else                                                                                                          \
+    hipLaunchKernelGGL((k3_lag<K, false>), gr, dim3(QShape<K>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records);
+      G1S_LAG(0)
+      if (ck == 1) { G1S_LAG(1) }
+      else if (ck == 2) { G1S_LAG(2) }
+      else if (ck == 3) { G1S_LAG(3) }
+#undef G1S_LAG
+    };
+    launch_lag(false);
+    if (qp.mixed_fast) {
+      launch_lag(true);
+      const dim3 pg(mix_chunks, 1, B), pb(256);
+      hipLaunchKernelGGL(k3_partial<0>, pg, pb, 0, stream, sl.d_planes, g, qp, sl.d_records);
+      if (ck == 1) hipLaunchKernelGGL(k3_partial<1>, pg, pb, 0, stream, sl.d_planes, g, qp, sl.d_records);
+      else if (ck == 2) hipLaunchKernelGGL(k3_partial<2>, pg, pb, 0, stream, sl.d_planes, g, qp, sl.d_records);
+      else if (ck == 3) hipLaunchKernelGGL(k3_partial<3>, pg, pb, 0, stream, sl.d_planes, g, qp, sl.d_records);
     }
     hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, qp, sl.d_records);
-    const int chunks = std::min(256, g.nblocks);
+    const int chunks = std::min(64, g.nblocks);
     hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, B), dim3(256), 0, stream, sl.d_planes, g, qp, sl.d_records);
   } else {
     const int chunks = std::min(kK3Chunks, g.nblocks);

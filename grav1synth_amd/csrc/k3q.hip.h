@@ -5,20 +5,24 @@
 // d = src8 - den8, L = co-located luma residual sum.  Substituting q = p + c_i,
 //     A[i][j] = sum_q w(q - c_i) * d(q) * d(q + c_j - c_i)          (i <= j)
 //     b[i]    = sum_q w(q - c_i) * d(q) * d(q - c_i)
-// and the sum over q is partitioned by the 32x32 block AREA that contains q.  For an
-// area where every needed w(q - c_i) is 1 ("interior": the block, its left/right/lower
-// neighbours are flat with full windows) the 324 products collapse onto 46 lag sums
-//     G(delta) = sum_q d(q) d(q + delta),   delta = (0..6, 0) or (-6..6, 1..3),
-// an area where every needed w is 0 contributes nothing, and only "mixed" areas (along
-// the boundary of flat regions) need the 324 masked products.  All integers, exact, and
-// independent of how areas are distributed over workgroups.
+// and the sum over q is partitioned by the 32x32 block AREA that contains q, and inside
+// an area by 4-sample GROUP.  A group is
+//     FULL    if every w(q - c_i) it needs is 1: its 324 products collapse onto 46 lag
+//             sums G(delta) = sum d(q) d(q + delta), delta = (0..6,0) or (-6..6,1..3);
+//     EMPTY   if every such w is 0: contributes nothing;
+//     PARTIAL otherwise: the 324 masked products are needed.
+// An area is INT if all its groups are full (the block, its left/right/lower neighbours
+// are flat with full windows), EXT if all are empty, else MIX.  All integers, exact, and
+// independent of how areas / groups are distributed over workgroups.
 // The chroma cross terms sum_p w(p) L(p) d(p+c_i), sum w L^2, sum w L d stay p-centric
 // under the block's own window (a separate, consistent partition).
 //
-//   k3_classify        : per (frame, kind, block area): EXT / INT / MIX from the window rule
-//   k3_interior<KIND>  : INT areas, 46 (+53 chroma) v_dot4c_i32_i8 per 4-sample group
-//   k3q_generic        : MIX areas and areas whose |d| > 127 (deferred), plain int32
-//   k3q_reduce         : chunk partials -> record int64 S/Sb/nobs
+//   k3_classify          per (frame, kind, area): class + compacted INT / MIX lists
+//   k3_lag<KIND, false>  INT areas: 46 (+53 chroma) v_dot4c_i32_i8 per group
+//   k3_lag<KIND, true>   MIX areas: the same for their FULL groups (+ L terms, statistics)
+//   k3_partial<KIND>     MIX areas: PARTIAL groups, compacted per area, 324 masked products
+//   k3q_generic          deferred areas (|d| > 127) and oddballs, plain int32
+//   k3q_reduce           all chunk partials -> record int64 S / Sb / nobs
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,10 +33,9 @@ namespace g1s {
 
 constexpr int kQLag = 3;
 constexpr int kQN = 24;
-constexpr int kNumLags = 46;              // distinct c_j - c_i (incl. 0) and -c_i
-constexpr int kNumLTerms = 24 * 2 + 5;    // (i,La),(i,Lb), LaLa, LaLb, LbLb, La*y, Lb*y
-constexpr int kQThreads = 256;
-constexpr int kMaxAreasPerWG = 128;       // int32 accumulators stay exact (see below)
+constexpr int kNumLags = 46;            // distinct c_j - c_i (incl. 0) and -c_i
+constexpr int kNumLTerms = 24 * 2 + 5;  // (i,La),(i,Lb), LaLa, LaLb, LbLb, La*y, Lb*y
+constexpr int kMaxAreasPerWG = 128;     // int32 accumulators stay exact
 enum : uint8_t { kClsExt = 0, kClsInt = 1, kClsMix = 2 };
 
 // lag index: dy = 0: dx 0..6 -> 0..6 ; dy = 1..3: dx -6..6 -> 7 + (dy-1)*13 + (dx+6)
@@ -40,14 +43,26 @@ __host__ __device__ constexpr int lag_index(int dx, int dy) { return dy == 0 ? d
 __host__ __device__ constexpr int coord_x(int k) { return k % 7 - 3; }
 __host__ __device__ constexpr int coord_y(int k) { return k / 7 - 3; }
 
-// partial layout per (frame, plane, chunk): [46 lag sums][53 L terms][nobs]
+// lag-kernel partial per (frame, plane, chunk): [46 lag sums][53 L terms][nobs term]
 constexpr int kQPart = kNumLags + kNumLTerms + 1;
+// partial-group kernel: two halves of 162 products, split by anchor
+constexpr int kPHalf = 162;
+constexpr int kPPart = 2 * kPHalf;
+// anchors of half 0: {0,3,4,7,8,11,12,15,16,19,20,23}: 25+22+21+18+17+14+13+10+9+6+5+2 = 162
+__host__ __device__ constexpr bool p_in_half(int half, int i) {
+  return (((i & 3) == 0 || (i & 3) == 3) ? 0 : 1) == half;
+}
 
 struct QParams {
-  int nchunks;
-  int32_t *partials;    // [batch][3][nchunks][kQPart]
-  uint8_t *cls;         // [batch][2][nblocks]  (luma, chroma) area class
-  uint8_t *todo;        // [batch][2][nblocks]  1 = area left to k3q_generic (MIX or deferred)
+  int nchunks;       // workgroups per frame of k3_lag<.., false>
+  int nchunks_mix;   // workgroups per frame of k3_lag<.., true> and k3_partial
+  int mixed_fast;    // 1: MIX areas by k3_lag<true> + k3_partial; 0: by k3q_generic (debug)
+  long long *lagacc;   // [batch][3][kQPart]  int64 sums of all lag-kernel workgroups (zeroed per batch)
+  long long *paracc;   // [batch][3][kPPart]  int64 sums of all k3_partial workgroups (zeroed per batch)
+  uint8_t *cls;        // [batch][2][nblocks]  area class per kind (luma, chroma)
+  uint8_t *todo;       // [batch][2][nblocks]  1 = area left to k3q_generic
+  uint32_t *lists;     // [batch][2 kinds][3 (INT, MIX, GENERIC)][nblocks] compacted area indices
+  uint32_t *counts;    // [batch][2][3] list lengths (zeroed before k3_classify)
 };
 
 __device__ __forceinline__ int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
@@ -90,7 +105,6 @@ __device__ __forceinline__ Win block_window(const uint8_t *mask, int nbw, int nb
   if (w.xe <= w.xs || w.ye <= w.ys) w.flat = 0;  // empty window
   return w;
 }
-// w at plane sample (X, Y)
 __device__ __forceinline__ int window_at(const uint8_t *mask, int nbw, int nbh, int bw, int bh, int pw, int ph, int X,
                                          int Y) {
   if (X < 0 || Y < 0 || X >= pw || Y >= ph) return 0;
@@ -101,44 +115,59 @@ __device__ __forceinline__ int window_at(const uint8_t *mask, int nbw, int nbh, 
 }
 
 // ---------------------------------------------------------------------------------
-// k3_classify: one thread per block area and plane kind.
-// needed area of w for the area of block (bx, by): rows by*bh .. by*bh+bh+2,
-// cols bx*bw-3 .. bx*bw+bw+2   (q - c_i: up to 3 below, 3 left/right)
-// grid = (ceil(nblocks/256), kinds, batch)
+// k3_classify: one thread per block area and plane kind.  The area of block (bx, by)
+// needs w on rows by*bh .. by*bh+bh+2, cols bx*bw-3 .. bx*bw+bw+2.
+// grid = (ceil(nblocks/256), kinds, batch), block = 256.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k3_classify(Geom g, const uint8_t *__restrict__ records, QParams qp) {
   const int blk = blockIdx.x * 256 + threadIdx.x;
   const int kind = blockIdx.y, frame = blockIdx.z;
-  if (blk >= g.nblocks) return;
   const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
-  const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
-  const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
-  const int bx = blk % g.nbw, by = blk / g.nbw;
-  const int AX0 = bx * bw - kQLag, AX1 = bx * bw + bw + kQLag, AY0 = by * bh, AY1 = by * bh + bh + kQLag;
-  bool all1 = !(AX0 < 0 || AX1 > pw || AY1 > ph);
-  bool any1 = false;
-  for (int dby = 0; dby <= 1; ++dby) {
-    for (int dbx = -1; dbx <= 1; ++dbx) {
-      const int Bx = bx + dbx, By = by + dby;
-      const int rx0 = max(AX0, Bx * bw), rx1 = min(AX1, Bx * bw + bw);
-      const int ry0 = max(AY0, By * bh), ry1 = min(AY1, By * bh + bh);
-      if (rx0 >= rx1 || ry0 >= ry1) continue;
-      const Win w = block_window(mask, g.nbw, g.nbh, Bx, By, bw, bh, pw, ph);
-      if (!w.flat) {
-        all1 = false;
-        continue;
+  uint8_t c = kClsExt;
+  if (blk < g.nblocks) {
+    const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
+    const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const int AX0 = bx * bw - kQLag, AX1 = bx * bw + bw + kQLag, AY0 = by * bh, AY1 = by * bh + bh + kQLag;
+    bool all1 = !(AX0 < 0 || AX1 > pw || AY1 > ph);
+    bool any1 = false;
+    for (int dby = 0; dby <= 1; ++dby) {
+      for (int dbx = -1; dbx <= 1; ++dbx) {
+        const int Bx = bx + dbx, By = by + dby;
+        const int rx0 = max(AX0, Bx * bw), rx1 = min(AX1, Bx * bw + bw);
+        const int ry0 = max(AY0, By * bh), ry1 = min(AY1, By * bh + bh);
+        if (rx0 >= rx1 || ry0 >= ry1) continue;
+        const Win w = block_window(mask, g.nbw, g.nbh, Bx, By, bw, bh, pw, ph);
+        if (!w.flat) {
+          all1 = false;
+          continue;
+        }
+        const int ax0 = rx0 - Bx * bw, ax1 = rx1 - Bx * bw, ay0 = ry0 - By * bh, ay1 = ry1 - By * bh;
+        if (max(ax0, w.xs) < min(ax1, w.xe) && max(ay0, w.ys) < min(ay1, w.ye)) any1 = true;
+        if (!(w.xs <= ax0 && ax1 <= w.xe && w.ys <= ay0 && ay1 <= w.ye)) all1 = false;
       }
-      const int ax0 = rx0 - Bx * bw, ax1 = rx1 - Bx * bw, ay0 = ry0 - By * bh, ay1 = ry1 - By * bh;
-      if (max(ax0, w.xs) < min(ax1, w.xe) && max(ay0, w.ys) < min(ay1, w.ye)) any1 = true;
-      if (!(w.xs <= ax0 && ax1 <= w.xe && w.ys <= ay0 && ay1 <= w.ye)) all1 = false;
     }
+    c = all1 ? kClsInt : (any1 ? kClsMix : kClsExt);
+    const size_t o = ((size_t)frame * 2 + kind) * g.nblocks + blk;
+    qp.cls[o] = c;
+    // deferred-to-generic: MIX when the fast mixed path is off; a flat block whose own area
+    // is EXT still needs its block statistics
+    qp.todo[o] = ((c == kClsMix && !qp.mixed_fast) || (c == kClsExt && mask[blk])) ? 1 : 0;
   }
-  const uint8_t c = all1 ? kClsInt : (any1 ? kClsMix : kClsExt);
-  const size_t o = ((size_t)frame * 2 + kind) * g.nblocks + blk;
-  qp.cls[o] = c;
-  // MIX areas go to the generic kernel; a flat block whose own area is EXT still needs its
-  // block statistics (and has no window samples): generic handles it too.
-  qp.todo[o] = (c == kClsMix || (c == kClsExt && mask[blk])) ? 1 : 0;
+  // compacted lists, one atomic per wave and class (any order: the sums are exact integers)
+  const int lane = threadIdx.x & 63;
+  const bool gen = blk < g.nblocks && qp.todo[((size_t)frame * 2 + kind) * g.nblocks + blk] != 0;
+  for (int which = 0; which < 3; ++which) {
+    const bool mine = blk < g.nblocks &&
+                      (which == 0 ? c == kClsInt : (which == 1 ? (c == kClsMix && qp.mixed_fast) : gen));
+    const unsigned long long b = __ballot(mine);
+    if (b == 0) continue;
+    const size_t lo = ((size_t)frame * 2 + kind) * 3 + which;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&qp.counts[lo], (uint32_t)__popcll(b));
+    base = __shfl(base, 0, 64);
+    if (mine) qp.lists[lo * g.nblocks + base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)blk;
+  }
 }
 
 // ---- 8 consecutive samples of a row (vector global load, narrowed later) ----
@@ -203,9 +232,10 @@ struct QShape {
   static constexpr int SX = (KIND == 1 || KIND == 2) ? 1 : 0;
   static constexpr int SY = (KIND == 1) ? 1 : 0;
   static constexpr int BW = kBlock >> SX, BH = kBlock >> SY;
-  static constexpr int G = BW / 4;              // 4-sample groups per row
-  static constexpr int ROWS_PER_STEP = 64 / G;  // rows covered by one wave step
-  static constexpr int NS = BH / ROWS_PER_STEP; // wave steps per plane area
+  static constexpr int G = BW / 4;               // 4-sample groups per row
+  static constexpr int NG = G * BH;              // groups per plane area
+  static constexpr int ROWS_PER_STEP = 64 / G;   // rows covered by one wave step
+  static constexpr int NS = BH / ROWS_PER_STEP;  // wave steps per plane area
   static constexpr int NPL = kChroma ? 2 : 1;
   static constexpr int WAVES = (NPL * NS) < 4 ? (NPL * NS) : 4;
   static constexpr int THREADS = WAVES * 64;
@@ -221,53 +251,35 @@ struct QShape {
   static constexpr int NL = kChroma ? BH * LSEGS : 0;
   static constexpr int LROWS = 1 << SY;
   static constexpr int NITEMS = NTILE + NL;
-  static constexpr int MAXIT = (NITEMS + THREADS - 1) / THREADS;
   static constexpr int SLOT = kChroma ? LROWS : 1;
   static constexpr int TILE_BYTES = TH * PITCH;
   static constexpr int LTILE_BYTES = BH * PITCH;
-  static constexpr int LDS_BYTES = NPL * TILE_BYTES + (kChroma ? 2 * LTILE_BYTES : 0);
+  static constexpr int DATA_BYTES = NPL * TILE_BYTES + (kChroma ? 2 * LTILE_BYTES : 0);
+  static constexpr int WTILE_BYTES = (BH + kQLag) * PITCH;  // rows 0..BH+2
   static constexpr int NACC = kNumLags + (kChroma ? kNumLTerms : 0);
 };
 
 // ---------------------------------------------------------------------------------
-// k3_interior<KIND>: INT areas.  LDS tile: sample (x, y), x in -8..BW+7, y in -UP..BH+2,
-// at byte (y + UP) * PITCH + 8 + x; group g (x = 4g) is dword g + 2.
-// grid = (nchunks, 1, batch), block = QShape::THREADS.
-// int32 safety: per group step |sum| <= 4*127^2 = 64516; a lane sees <= 128 areas *
-// STEPS_PER_WAVE(<=2) steps; the 64-lane reduction multiplies by 64: < 2^31.
+// Stager: HBM -> registers (prefetch, vector loads) -> LDS tiles of one area.
+// LDS layout: plane tile pl at lds + pl*TILE_BYTES, sample (x, y) (x in -8..BW+7,
+// y in -UP..BH+2) at byte (y + UP) * PITCH + 8 + x, so group g (x = 4g) is dword g + 2;
+// then La, Lb tiles (block proper, byte y*PITCH + x); then (WTILE) the window-indicator
+// tile, rows 0..BH+2, same column layout, bytes 0xFF / 0x00.
 // ---------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const FramePlanes *__restrict__ frames, Geom g,
-                                                                     QParams qp, uint8_t *__restrict__ records) {
+template <int KIND, int NT, bool WTILE, bool LTERMS>
+struct Stager {
   using S = QShape<KIND>;
-  constexpr bool CHROMA = S::kChroma;
-  constexpr int NACC = S::NACC, NT = S::THREADS;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[S::LDS_BYTES];
-  __shared__ int s_flag[2];
-  __shared__ int s_stat[2][4][4];
+  static constexpr int NITEMS = S::NTILE + (LTERMS ? S::NL : 0);
+  static constexpr int MAXIT = (NITEMS + NT - 1) / NT;
+  Px8 ps[MAXIT][S::SLOT], pd[MAXIT][S::SLOT];
 
-  const int frame = blockIdx.z, chunk = blockIdx.x;
-  const FramePlanes fp = frames[frame];
-  uint8_t *rec = records + (size_t)frame * g.rec_size;
-  const uint8_t *cls = qp.cls + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
-  uint8_t *todo = qp.todo + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int pw = g.W >> S::SX, ph = g.H >> S::SY;
-  constexpr int bw = S::BW, bh = S::BH;
-  const int lg = lane % S::G, lr = lane / S::G;
-
-  int acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) acc[i] = 0;
-  int nareas = 0;
-  if (tid < 2) s_flag[tid] = 0;
-
-  Px8 ps[S::MAXIT][S::SLOT], pd[S::MAXIT][S::SLOT];
-  auto item_fetch = [&](int blk) {
+  __device__ __forceinline__ void fetch(const FramePlanes &fp, const Geom &g, int tid, int blk) {
+    constexpr bool CHROMA = S::kChroma;
+    const int pw = g.W >> S::SX, ph = g.H >> S::SY;
     const int bx = blk % g.nbw, by = blk / g.nbw;
-    const int x_o = bx * bw, y_o = by * bh;
+    const int x_o = bx * S::BW, y_o = by * S::BH;
 #pragma unroll
-    for (int k = 0; k < S::MAXIT; ++k) {
+    for (int k = 0; k < MAXIT; ++k) {
       const int it = tid + k * NT;
       if (it < S::NTILE) {
         const int pl = it / (S::TH * S::SEGS);
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
         const int X0 = x_o - 8 + 8 * sg, Y = y_o - S::UP + ty;
         ps[k][0] = fetch8(fp.src[c], fp.src_stride[c], g.src_bps, (g.vec_mask >> c) & 1, X0, Y, pw, ph);
         pd[k][0] = fetch8(fp.den[c], fp.den_stride[c], g.den_bps, (g.vec_mask >> (3 + c)) & 1, X0, Y, pw, ph);
-      } else if (CHROMA && it < S::NITEMS) {
+      } else if (LTERMS && it < NITEMS) {
         const int r = it - S::NTILE;
         const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
         const int X0 = (x_o + sg * S::LCH) << S::SX;  // luma coordinates
@@ -289,13 +301,19 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
         }
       }
     }
-  };
-  auto item_store = [&](int blk, int &lsum) -> bool {
+  }
+
+  // narrow, subtract, range-check, write LDS.  Returns true if some |d| > 127.
+  __device__ __forceinline__ bool store(const FramePlanes &fp, const Geom &g, int tid, int blk, uint8_t *lds,
+                                        const int (*s_win)[5], int &lsum) {
+    constexpr bool CHROMA = S::kChroma;
+    constexpr int bw = S::BW, bh = S::BH;
+    const int pw = g.W >> S::SX;
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int x_o = bx * bw, y_o = by * bh;
     bool bad = false;
 #pragma unroll
-    for (int k = 0; k < S::MAXIT; ++k) {
+    for (int k = 0; k < MAXIT; ++k) {
       const int it = tid + k * NT;
       if (it < S::NTILE) {
         const int pl = it / (S::TH * S::SEGS);
@@ -319,7 +337,22 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
           for (int q = 0; q < 8; ++q) lsum += sv[q];
         }
         *reinterpret_cast<uint2 *>(lds + pl * S::TILE_BYTES + ty * S::PITCH + 8 * sg) = make_uint2(lo, hi);
-      } else if (CHROMA && it < S::NITEMS) {
+        if (WTILE && pl == 0 && ty >= S::UP) {  // window indicator of rows 0..BH+2
+          const int y = ty - S::UP;
+          const int dby = y >= bh ? 1 : 0, ly = y - dby * bh;
+          uint32_t wlo = 0, whi = 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int x = -8 + 8 * sg + q;
+            const int dbx = x < 0 ? -1 : (x >= bw ? 1 : 0), lx = x - dbx * bw;
+            const int *wn = s_win[dby * 3 + dbx + 1];
+            const bool in = wn[0] && lx >= wn[1] && lx < wn[2] && ly >= wn[3] && ly < wn[4];
+            const uint32_t b = in ? 0xffu : 0u;
+            if (q < 4) wlo |= b << (8 * q); else whi |= b << (8 * (q - 4));
+          }
+          *reinterpret_cast<uint2 *>(lds + S::DATA_BYTES + y * S::PITCH + 8 * sg) = make_uint2(wlo, whi);
+        }
+      } else if (LTERMS && it < NITEMS) {
         const int r = it - S::NTILE;
         const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
         const int X0 = (x_o + sg * S::LCH) << S::SX;
@@ -363,39 +396,120 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
       }
     }
     return bad;
-  };
-  auto next_area = [&](int blk) {
-    while (blk < g.nblocks && cls[blk] != kClsInt) blk += qp.nchunks;
-    return blk;
-  };
+  }
+};
 
-  int cur = next_area(chunk);
-  if (cur < g.nblocks) item_fetch(cur);
+// windows of the six blocks an area can see -> s_win (threads 0..5)
+template <int KIND>
+__device__ __forceinline__ void load_windows(const uint8_t *mask, const Geom &g, int tid, int blk, int (*s_win)[5]) {
+  using S = QShape<KIND>;
+  if (tid < 6) {
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const Win w = block_window(mask, g.nbw, g.nbh, bx + (tid % 3) - 1, by + tid / 3, S::BW, S::BH, g.W >> S::SX,
+                               g.H >> S::SY);
+    s_win[tid][0] = w.flat;
+    s_win[tid][1] = w.xs;
+    s_win[tid][2] = w.xe;
+    s_win[tid][3] = w.ys;
+    s_win[tid][4] = w.ye;
+  }
+}
+
+// Group classification from the w tile: w32 points at dword (row*PITCH_DW + g) of the w
+// tile; the group's own samples are dword +2.  FULL / EMPTY are decided on the bytes
+// x-3 .. x+6 of rows 0..3 (a superset of what the 24 masks read; both kernels use this
+// same predicate, so the partition into full / partial / empty groups is consistent).
+template <int PITCH_DW>
+__device__ __forceinline__ void group_state(const uint32_t *w32, bool &full, bool &empty) {
+  uint32_t all_and = 0xffffffffu, all_or = 0;
+#pragma unroll
+  for (int dy = 0; dy <= 3; ++dy) {
+    const uint32_t *rp = w32 + dy * PITCH_DW;
+    const uint32_t q1 = rp[1], q2 = rp[2], q3 = rp[3];
+    all_and &= (q1 | 0x000000ffu) & q2 & (q3 | 0xff000000u);
+    all_or |= (q1 & 0xffffff00u) | q2 | (q3 & 0x00ffffffu);
+  }
+  full = all_and == 0xffffffffu;
+  empty = all_or == 0;
+}
+
+// ---------------------------------------------------------------------------------
+// k3_lag<KIND, MIXED>: 46 lag sums (+53 chroma L terms) per group.
+//   MIXED = false: the INT list (every group full, own window = whole block)
+//   MIXED = true : the MIX list; only FULL groups enter the lag sums; L terms, nobs and
+//                  block statistics use the block's own window / flat flag.
+// grid = (nchunks or nchunks_mix, 1, batch), block = QShape::THREADS.
+// int32 safety: per step |sum| <= 4*127^2; <= 128 areas * STEPS_PER_WAVE(<=2); x64 lanes < 2^31.
+// ---------------------------------------------------------------------------------
+template <int KIND, bool MIXED>
+__global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(const FramePlanes *__restrict__ frames, Geom g,
+                                                                QParams qp, uint8_t *__restrict__ records) {
+  using S = QShape<KIND>;
+  constexpr bool CHROMA = S::kChroma;
+  constexpr int NACC = S::NACC, NT = S::THREADS;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[S::DATA_BYTES + (MIXED ? S::WTILE_BYTES : 0)];
+  __shared__ int s_flag[2];
+  __shared__ int s_stat[2][4][4];
+  __shared__ int s_win[6][5];
+
+  const int frame = blockIdx.z, chunk = blockIdx.x;
+  const int stride = MIXED ? qp.nchunks_mix : qp.nchunks;
+  const FramePlanes fp = frames[frame];
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  const uint8_t *mask = rec + g.off_mask;
+  const size_t lsel = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + (MIXED ? 1 : 0);
+  const uint32_t *list = qp.lists + lsel * g.nblocks;
+  const int nlist = (int)qp.counts[lsel];
+  uint8_t *todo = qp.todo + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lg = lane % S::G, lr = lane / S::G;
+
+  int acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0;
+  int nobs = 0;  // INT: number of areas (x BW*BH in the reducer); MIX: window samples
+  if (tid < 2) s_flag[tid] = 0;
+
+  Stager<KIND, NT, MIXED, CHROMA> st;
+  int li = chunk;
+  int cur = li < nlist ? (int)list[li] : -1;
+  if (cur >= 0) {
+    if (MIXED) load_windows<KIND>(mask, g, tid, cur, s_win);
+    st.fetch(fp, g, tid, cur);
+  }
   __syncthreads();
 
   int iter = 0;
-  while (cur < g.nblocks) {
+  while (cur >= 0) {
     const int blk = cur;
     const int fl = iter & 1;
     ++iter;
     int lsum = 0;
-    const bool bad = item_store(blk, lsum);
-    cur = next_area(blk + qp.nchunks);     // class bytes are read BEFORE the prefetch is issued
-    if (cur < g.nblocks) item_fetch(cur);  // in flight during the products below
+    const bool bad = st.store(fp, g, tid, blk, lds, s_win, lsum);
+    li += stride;
+    cur = li < nlist ? (int)list[li] : -1;  // list entry read BEFORE the prefetch is issued
     if (bad) s_flag[fl] = 1;
     if (!CHROMA) {
       lsum = wave_sum(lsum);
       if (lane == 0) s_stat[fl][wave][3] = lsum;
     }
-    __syncthreads();
+    __syncthreads();  // tiles complete; s_win free again
+    if (cur >= 0) {
+      if (MIXED) load_windows<KIND>(mask, g, tid, cur, s_win);  // mask bytes first (vmcnt retires in order)
+      st.fetch(fp, g, tid, cur);                                 // in flight during the products below
+    }
     const bool deferred = s_flag[fl] != 0;
     if (tid == 0) s_flag[fl ^ 1] = 0;
     if (deferred) {
-      if (tid == 0) todo[blk] = 1;  // the generic kernel redoes this area in int32
+      if (tid == 0) {  // the generic kernel redoes this area in int32
+        todo[blk] = 1;
+        const size_t lg3 = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + 2;
+        qp.lists[lg3 * g.nblocks + atomicAdd(&qp.counts[lg3], 1u)] = (uint32_t)blk;
+      }
       __syncthreads();
       continue;
     }
-    if (tid == 0) ++nareas;
+    if (!MIXED && tid == 0) ++nobs;
 
     int sd = 0, sd2 = 0;
 #pragma unroll 1
@@ -404,10 +518,17 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
       const int pl = widx / S::NS, step = widx - pl * S::NS;
       const int row = step * S::ROWS_PER_STEP + lr;  // sample row of the area
       const uint32_t *t32 = reinterpret_cast<const uint32_t *>(lds + pl * S::TILE_BYTES) + (row + S::UP) * S::PITCH_DW + lg;
-      // row 0 of delta: dwords g+2 .. g+4
       const uint32_t c0 = t32[2], c1 = t32[3], c2 = t32[4];
-      const uint32_t D0 = c0;
-      acc[0] = sdot4((int)D0, (int)D0, acc[0]);
+      uint32_t D0 = c0, Wc = 0xffffffffu;
+      if (MIXED) {
+        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(lds + S::DATA_BYTES) + row * S::PITCH_DW + lg;
+        bool full, empty;
+        group_state<S::PITCH_DW>(w32, full, empty);
+        Wc = w32[2];
+        if (!full) D0 = 0;  // partial groups belong to k3_partial, empty ones to nobody
+        if (pl == 0) nobs = sdot4((int)(Wc & 0x01010101u), 0x01010101, nobs);
+      }
+      acc[0] = sdot4((int)D0, (int)c0, acc[0]);
       acc[1] = sdot4((int)D0, (int)alignbyte(c1, c0, 1), acc[1]);
       acc[2] = sdot4((int)D0, (int)alignbyte(c1, c0, 2), acc[2]);
       acc[3] = sdot4((int)D0, (int)alignbyte(c1, c0, 3), acc[3]);
@@ -419,60 +540,53 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
         const uint32_t *rp = t32 + dy * S::PITCH_DW;
         const uint32_t e0 = rp[0], e1 = rp[1], e2 = rp[2], e3 = rp[3], e4 = rp[4];
         const int b = 7 + (dy - 1) * 13;
-        acc[b + 0] = sdot4((int)D0, (int)alignbyte(e1, e0, 2), acc[b + 0]);   // dx = -6
-        acc[b + 1] = sdot4((int)D0, (int)alignbyte(e1, e0, 3), acc[b + 1]);   // -5
-        acc[b + 2] = sdot4((int)D0, (int)e1, acc[b + 2]);                     // -4
-        acc[b + 3] = sdot4((int)D0, (int)alignbyte(e2, e1, 1), acc[b + 3]);   // -3
-        acc[b + 4] = sdot4((int)D0, (int)alignbyte(e2, e1, 2), acc[b + 4]);   // -2
-        acc[b + 5] = sdot4((int)D0, (int)alignbyte(e2, e1, 3), acc[b + 5]);   // -1
-        acc[b + 6] = sdot4((int)D0, (int)e2, acc[b + 6]);                     // 0
-        acc[b + 7] = sdot4((int)D0, (int)alignbyte(e3, e2, 1), acc[b + 7]);   // +1
-        acc[b + 8] = sdot4((int)D0, (int)alignbyte(e3, e2, 2), acc[b + 8]);   // +2
-        acc[b + 9] = sdot4((int)D0, (int)alignbyte(e3, e2, 3), acc[b + 9]);   // +3
-        acc[b + 10] = sdot4((int)D0, (int)e3, acc[b + 10]);                   // +4
-        acc[b + 11] = sdot4((int)D0, (int)alignbyte(e4, e3, 1), acc[b + 11]); // +5
-        acc[b + 12] = sdot4((int)D0, (int)alignbyte(e4, e3, 2), acc[b + 12]); // +6
+        acc[b + 0] = sdot4((int)D0, (int)alignbyte(e1, e0, 2), acc[b + 0]);    // dx = -6
+        acc[b + 1] = sdot4((int)D0, (int)alignbyte(e1, e0, 3), acc[b + 1]);    // -5
+        acc[b + 2] = sdot4((int)D0, (int)e1, acc[b + 2]);                      // -4
+        acc[b + 3] = sdot4((int)D0, (int)alignbyte(e2, e1, 1), acc[b + 3]);    // -3
+        acc[b + 4] = sdot4((int)D0, (int)alignbyte(e2, e1, 2), acc[b + 4]);    // -2
+        acc[b + 5] = sdot4((int)D0, (int)alignbyte(e2, e1, 3), acc[b + 5]);    // -1
+        acc[b + 6] = sdot4((int)D0, (int)e2, acc[b + 6]);                      // 0
+        acc[b + 7] = sdot4((int)D0, (int)alignbyte(e3, e2, 1), acc[b + 7]);    // +1
+        acc[b + 8] = sdot4((int)D0, (int)alignbyte(e3, e2, 2), acc[b + 8]);    // +2
+        acc[b + 9] = sdot4((int)D0, (int)alignbyte(e3, e2, 3), acc[b + 9]);    // +3
+        acc[b + 10] = sdot4((int)D0, (int)e3, acc[b + 10]);                    // +4
+        acc[b + 11] = sdot4((int)D0, (int)alignbyte(e4, e3, 1), acc[b + 11]);  // +5
+        acc[b + 12] = sdot4((int)D0, (int)alignbyte(e4, e3, 2), acc[b + 12]);  // +6
       }
-      sd = sdot4((int)D0, 0x01010101, sd);
-      sd2 = sdot4((int)D0, (int)D0, sd2);
+      sd = sdot4((int)c0, 0x01010101, sd);
+      sd2 = sdot4((int)c0, (int)c0, sd2);
       if (CHROMA) {
-        // p-centric L terms (interior: the block's own window is the whole area)
+        // p-centric L terms under the block's own window (Wc; all ones for INT areas)
         const uint32_t *ta = reinterpret_cast<const uint32_t *>(lds + S::NPL * S::TILE_BYTES);
-        const uint32_t La = ta[row * S::PITCH_DW + lg];
-        const uint32_t Lb = ta[S::LTILE_BYTES / 4 + row * S::PITCH_DW + lg];
+        const uint32_t Lar = ta[row * S::PITCH_DW + lg];
+        const uint32_t Lbr = ta[S::LTILE_BYTES / 4 + row * S::PITCH_DW + lg];
+        const uint32_t La = Lar & Wc, Lb = Lbr & Wc;
         int *al = acc + kNumLags;
 #pragma unroll
         for (int cy = -3; cy <= 0; ++cy) {
           const uint32_t *rp = t32 + cy * S::PITCH_DW;
           const uint32_t u1 = rp[1], u2 = rp[2], u3 = rp[3];
-          const int k0 = (cy + 3) * 7;
-          const uint32_t v0 = alignbyte(u2, u1, 1), v1 = alignbyte(u2, u1, 2), v2 = alignbyte(u2, u1, 3);
-          al[2 * (k0 + 0)] = sdot4((int)La, (int)v0, al[2 * (k0 + 0)]);
-          al[2 * (k0 + 0) + 1] = sdot4((int)Lb, (int)v0, al[2 * (k0 + 0) + 1]);
-          al[2 * (k0 + 1)] = sdot4((int)La, (int)v1, al[2 * (k0 + 1)]);
-          al[2 * (k0 + 1) + 1] = sdot4((int)Lb, (int)v1, al[2 * (k0 + 1) + 1]);
-          al[2 * (k0 + 2)] = sdot4((int)La, (int)v2, al[2 * (k0 + 2)]);
-          al[2 * (k0 + 2) + 1] = sdot4((int)Lb, (int)v2, al[2 * (k0 + 2) + 1]);
-          if (cy < 0) {
-            const uint32_t v3 = u2, v4 = alignbyte(u3, u2, 1), v5 = alignbyte(u3, u2, 2), v6 = alignbyte(u3, u2, 3);
-            al[2 * (k0 + 3)] = sdot4((int)La, (int)v3, al[2 * (k0 + 3)]);
-            al[2 * (k0 + 3) + 1] = sdot4((int)Lb, (int)v3, al[2 * (k0 + 3) + 1]);
-            al[2 * (k0 + 4)] = sdot4((int)La, (int)v4, al[2 * (k0 + 4)]);
-            al[2 * (k0 + 4) + 1] = sdot4((int)Lb, (int)v4, al[2 * (k0 + 4) + 1]);
-            al[2 * (k0 + 5)] = sdot4((int)La, (int)v5, al[2 * (k0 + 5)]);
-            al[2 * (k0 + 5) + 1] = sdot4((int)Lb, (int)v5, al[2 * (k0 + 5) + 1]);
-            al[2 * (k0 + 6)] = sdot4((int)La, (int)v6, al[2 * (k0 + 6)]);
-            al[2 * (k0 + 6) + 1] = sdot4((int)Lb, (int)v6, al[2 * (k0 + 6) + 1]);
+#pragma unroll
+          for (int cx = -3; cx <= 3; ++cx) {
+            if (cy == 0 && cx >= 0) continue;
+            const int k = (cy + 3) * 7 + (cx + 3);
+            uint32_t v;
+            if (cx < 0) v = alignbyte(u2, u1, 4 + cx);
+            else if (cx == 0) v = u2;
+            else v = alignbyte(u3, u2, cx);
+            al[2 * k] = sdot4((int)La, (int)v, al[2 * k]);
+            al[2 * k + 1] = sdot4((int)Lb, (int)v, al[2 * k + 1]);
           }
         }
-        al[48] = sdot4((int)La, (int)La, al[48]);
-        al[49] = sdot4((int)La, (int)Lb, al[49]);
-        al[50] = sdot4((int)Lb, (int)Lb, al[50]);
-        al[51] = sdot4((int)La, (int)D0, al[51]);
-        al[52] = sdot4((int)Lb, (int)D0, al[52]);
+        al[48] = sdot4((int)La, (int)Lar, al[48]);
+        al[49] = sdot4((int)La, (int)Lbr, al[49]);
+        al[50] = sdot4((int)Lb, (int)Lbr, al[50]);
+        al[51] = sdot4((int)La, (int)c0, al[51]);
+        al[52] = sdot4((int)Lb, (int)c0, al[52]);
       }
     }
-    // block statistics of the area's own block (every INT area is a flat block)
+    // block statistics (only meaningful / stored for flat blocks)
     sd = wave_sum(sd);
     sd2 = wave_sum(sd2);
     if (lane == 0) {
@@ -480,25 +594,20 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
       s_stat[fl][wave][1] = sd2;
     }
     __syncthreads();
-    if (tid == 0) {
-      const int(*st)[4] = s_stat[fl];
+    if (tid == 0 && (!MIXED || mask[blk])) {
+      const int(*sp)[4] = s_stat[fl];
+      int a[2] = {0, 0}, b[2] = {0, 0}, l = 0;
+      for (int w = 0; w < S::WAVES; ++w) {
+        const int pl = (w * S::STEPS_PER_WAVE) / S::NS;  // a wave's steps stay within one plane
+        a[pl] += sp[w][0];
+        b[pl] += sp[w][1];
+        l += sp[w][3];
+      }
       if (!CHROMA) {
-        int a = 0, b = 0, l = 0;
-        for (int w = 0; w < S::WAVES; ++w) {
-          a += st[w][0];
-          b += st[w][1];
-          l += st[w][3];
-        }
-        reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = a;
-        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)b;
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = a[0];
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)b[0];
         reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)l;
       } else {
-        int a[2] = {0, 0}, b[2] = {0, 0};
-        for (int w = 0; w < S::WAVES; ++w) {
-          const int pl = (w * S::STEPS_PER_WAVE) / S::NS;  // a wave's steps stay within one plane
-          a[pl] += st[w][0];
-          b[pl] += st[w][1];
-        }
         for (int pl = 0; pl < 2; ++pl) {
           reinterpret_cast<int32_t *>(rec + g.off_sum_d[1 + pl])[blk] = a[pl];
           reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1 + pl])[blk] = (uint32_t)b[pl];
@@ -510,7 +619,7 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
   // ---- wave reduction + partial store: waves of the same plane add up ----
   __syncthreads();
   int *red = reinterpret_cast<int *>(lds);
-  static_assert(4 * (kNumLags + kNumLTerms) * 4 <= S::LDS_BYTES, "reduction scratch must fit");
+  static_assert(4 * (kQPart + 1) * 4 <= S::DATA_BYTES, "reduction scratch must fit");
   {
     constexpr int CH = 23;
 #pragma unroll
@@ -522,44 +631,259 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_interior(const Frame
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
-          if (b0 + i < NACC) red[wave * NACC + b0 + i] = tmp[i];
+          if (b0 + i < NACC) red[wave * (kQPart + 1) + b0 + i] = tmp[i];
+      }
+    }
+    if (MIXED) nobs = wave_sum(nobs);
+    if (lane == 0) red[wave * (kQPart + 1) + kQPart] = nobs;
+  }
+  __syncthreads();
+  for (int pl = 0; pl < S::NPL; ++pl) {
+    unsigned long long *out =
+        reinterpret_cast<unsigned long long *>(qp.lagacc) + ((size_t)frame * 3 + (CHROMA ? 1 + pl : 0)) * kQPart;
+    for (int i = tid; i < NACC; i += NT) {
+      int v = 0;
+      for (int w = 0; w < S::WAVES; ++w)
+        if ((w * S::STEPS_PER_WAVE) / S::NS == pl) v += red[w * (kQPart + 1) + i];
+      if (v != 0) atomicAdd(&out[i], (unsigned long long)(long long)v);
+    }
+    if (tid == 0) {
+      long long v = 0;
+      if (MIXED) {
+        for (int w = 0; w < S::WAVES; ++w)
+          if ((w * S::STEPS_PER_WAVE) / S::NS == 0) v += red[w * (kQPart + 1) + kQPart];  // counted on plane 0
+      } else {
+        v = (long long)red[kQPart] * S::BW * S::BH;  // thread 0 counted the areas
+      }
+      if (v != 0) atomicAdd(&out[kQPart - 1], (unsigned long long)v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k3_partial<KIND>: PARTIAL groups of MIX areas, compacted per area, 324 masked products
+//     acc(i, j) += dot4(D(q) & W(q - c_i), D(q + c_j - c_i)),  acc(i, y) likewise.
+// A wave owns one (plane, half) combo; waves sharing a combo interleave list steps.
+// grid = (nchunks_mix, 1, batch), block = 256.
+// ---------------------------------------------------------------------------------
+template <int HALF, int PITCH_DW>
+__device__ __forceinline__ void partial_products(int (&acc)[kPHalf], const uint32_t (&D)[kNumLags],
+                                                 const uint32_t *w32) {
+  // window dwords of rows 0..3: q1 = x-4.., q2 = x.., q3 = x+4..
+  uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+  for (int dy = 0; dy <= 3; ++dy) {
+    const uint32_t *rp = w32 + dy * PITCH_DW;
+    q1[dy] = rp[1];
+    q2[dy] = rp[2];
+    q3[dy] = rp[3];
+  }
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < kQN; ++i) {
+    if (!p_in_half(HALF, i)) continue;
+    const int dx = -coord_x(i), dy = -coord_y(i);  // W(q - c_i)
+    uint32_t wi;
+    if (dx < 0) wi = alignbyte(q2[dy], q1[dy], 4 + dx);
+    else if (dx == 0) wi = q2[dy];
+    else wi = alignbyte(q3[dy], q2[dy], dx);
+    const uint32_t md = D[0] & wi;
+#pragma unroll
+    for (int j = i; j < kQN; ++j) {
+      acc[idx] = sdot4((int)md, (int)D[lag_index(coord_x(j) - coord_x(i), coord_y(j) - coord_y(i))], acc[idx]);
+      ++idx;
+    }
+    acc[idx] = sdot4((int)md, (int)D[lag_index(dx, dy)], acc[idx]);
+    ++idx;
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void k3_partial(const FramePlanes *__restrict__ frames, Geom g, QParams qp,
+                                                     uint8_t *__restrict__ records) {
+  using S = QShape<KIND>;
+  constexpr bool CHROMA = S::kChroma;
+  constexpr int NT = 256;
+  constexpr int NC = S::NPL * 2;   // (plane, half) combos
+  constexpr int WPC = 4 / NC;      // waves per combo
+  __shared__ __attribute__((aligned(16))) uint8_t lds[S::DATA_BYTES + S::WTILE_BYTES];
+  __shared__ int s_flag[2];
+  __shared__ int s_win[6][5];
+  __shared__ uint16_t s_plist[S::NG];
+  __shared__ int s_wcount[4];
+
+  const int frame = blockIdx.z, chunk = blockIdx.x;
+  const FramePlanes fp = frames[frame];
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  const uint8_t *mask = rec + g.off_mask;
+  const size_t lsel = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + 1;
+  const uint32_t *list = qp.lists + lsel * g.nblocks;
+  const int nlist = (int)qp.counts[lsel];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int combo = wave % NC, sub = wave / NC;
+  const int my_pl = combo >> 1, my_half = combo & 1;
+
+  int acc[kPHalf];
+#pragma unroll
+  for (int i = 0; i < kPHalf; ++i) acc[i] = 0;
+  if (tid < 2) s_flag[tid] = 0;
+
+  // areas that k3_lag<.., true> (which ran before on this stream) deferred to the generic
+  // kernel are skipped here too: one decision, taken once
+  const uint8_t *todo = qp.todo + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
+  auto next_area = [&](int &pos) {
+    while (pos < nlist) {
+      const int b = (int)list[pos];
+      if (!todo[b]) return b;
+      pos += qp.nchunks_mix;
+    }
+    return -1;
+  };
+  Stager<KIND, NT, true, false> st;
+  int li = chunk;
+  int cur = next_area(li);
+  if (cur >= 0) {
+    load_windows<KIND>(mask, g, tid, cur, s_win);
+    st.fetch(fp, g, tid, cur);
+  }
+  __syncthreads();
+
+  while (cur >= 0) {
+    const int blk = cur;
+    int lsum = 0;
+    (void)st.store(fp, g, tid, blk, lds, s_win, lsum);
+    li += qp.nchunks_mix;
+    cur = next_area(li);
+    __syncthreads();
+    if (cur >= 0) {
+      load_windows<KIND>(mask, g, tid, cur, s_win);
+      st.fetch(fp, g, tid, cur);
+    }
+    // ---- compact the partial groups of this area ----
+    const uint32_t *w32b = reinterpret_cast<const uint32_t *>(lds + S::DATA_BYTES);
+    bool part = false;
+    if (tid < S::NG) {
+      const int gr = tid / S::G, gg = tid - gr * S::G;
+      bool full, empty;
+      group_state<S::PITCH_DW>(w32b + gr * S::PITCH_DW + gg, full, empty);
+      part = !full && !empty;
+    }
+    const unsigned long long bal = __ballot(part);
+    if (lane == 0) s_wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) off += s_wcount[w];
+      total += s_wcount[w];
+    }
+    if (part) s_plist[off + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    __syncthreads();
+
+    // ---- masked products over the compacted list ----
+    const uint32_t *t32b = reinterpret_cast<const uint32_t *>(lds + my_pl * S::TILE_BYTES);
+    const int nsteps = (total + 63) >> 6;
+#pragma unroll 1
+    for (int s = sub; s < nsteps; s += WPC) {
+      const int e = s * 64 + lane;
+      if (e < total) {
+        const int gi = s_plist[e];
+        const int row = gi / S::G, gg = gi - row * S::G;
+        const uint32_t *t32 = t32b + (row + S::UP) * S::PITCH_DW + gg;
+        uint32_t D[kNumLags];
+        {
+          const uint32_t c0 = t32[2], c1 = t32[3], c2 = t32[4];
+          D[0] = c0;
+          D[1] = alignbyte(c1, c0, 1);
+          D[2] = alignbyte(c1, c0, 2);
+          D[3] = alignbyte(c1, c0, 3);
+          D[4] = c1;
+          D[5] = alignbyte(c2, c1, 1);
+          D[6] = alignbyte(c2, c1, 2);
+#pragma unroll
+          for (int dy = 1; dy <= 3; ++dy) {
+            const uint32_t *rp = t32 + dy * S::PITCH_DW;
+            const uint32_t e0 = rp[0], e1 = rp[1], e2 = rp[2], e3 = rp[3], e4 = rp[4];
+            const int b = 7 + (dy - 1) * 13;
+            D[b + 0] = alignbyte(e1, e0, 2);
+            D[b + 1] = alignbyte(e1, e0, 3);
+            D[b + 2] = e1;
+            D[b + 3] = alignbyte(e2, e1, 1);
+            D[b + 4] = alignbyte(e2, e1, 2);
+            D[b + 5] = alignbyte(e2, e1, 3);
+            D[b + 6] = e2;
+            D[b + 7] = alignbyte(e3, e2, 1);
+            D[b + 8] = alignbyte(e3, e2, 2);
+            D[b + 9] = alignbyte(e3, e2, 3);
+            D[b + 10] = e3;
+            D[b + 11] = alignbyte(e4, e3, 1);
+            D[b + 12] = alignbyte(e4, e3, 2);
+          }
+        }
+        const uint32_t *w32 = w32b + row * S::PITCH_DW + gg;
+        if (my_half == 0)
+          partial_products<0, S::PITCH_DW>(acc, D, w32);
+        else
+          partial_products<1, S::PITCH_DW>(acc, D, w32);
+      }
+    }
+    __syncthreads();  // tiles and list are rewritten by the next iteration
+  }
+
+  // ---- wave reduction + partial store ----
+  __syncthreads();
+  int *red = reinterpret_cast<int *>(lds);
+  static_assert(4 * kPHalf * 4 <= S::DATA_BYTES, "reduction scratch must fit");
+  {
+    constexpr int CH = 27;
+#pragma unroll
+    for (int b0 = 0; b0 < kPHalf; b0 += CH) {
+      int tmp[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) tmp[i] = (b0 + i < kPHalf) ? acc[b0 + i] : 0;
+      wave_sum_all<CH>(tmp);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if (b0 + i < kPHalf) red[wave * kPHalf + b0 + i] = tmp[i];
       }
     }
   }
   __syncthreads();
   for (int pl = 0; pl < S::NPL; ++pl) {
-    int32_t *out = qp.partials + (((size_t)frame * 3 + (CHROMA ? 1 + pl : 0)) * qp.nchunks + chunk) * kQPart;
-    for (int i = tid; i < NACC; i += NT) {
+    unsigned long long *out =
+        reinterpret_cast<unsigned long long *>(qp.paracc) + ((size_t)frame * 3 + (CHROMA ? 1 + pl : 0)) * kPPart;
+    for (int i = tid; i < kPPart; i += NT) {
+      const int h = i / kPHalf, k = i - h * kPHalf;
       int v = 0;
-      for (int w = 0; w < S::WAVES; ++w)
-        if ((w * S::STEPS_PER_WAVE) / S::NS == pl) v += red[w * NACC + i];
-      out[i] = v;
+      for (int w = 0; w < 4; ++w)
+        if (w % NC == pl * 2 + h) v += red[w * kPHalf + k];
+      if (v != 0) atomicAdd(&out[i], (unsigned long long)(long long)v);
     }
-    if (!CHROMA)
-      for (int i = NACC + tid; i < kNumLags + kNumLTerms; i += NT) out[i] = 0;
-    if (tid == 0) out[kNumLags + kNumLTerms] = nareas;  // nobs = nareas * BW * BH (reducer)
   }
 }
 
 // ---------------------------------------------------------------------------------
-// k3q_generic: areas marked in `todo` (MIX, EXT-but-flat, deferred INT), plain int32.
-// One workgroup per area iteration; thread t owns up to two of the 350 products.
-//   product (i, j):  sum_q W(q - c_i) d(q) d(q + c_j - c_i)
-//   product (i, y):  sum_q W(q - c_i) d(q) d(q - c_i)
-//   product (i, L):  sum_p w(p) L(p) d(p + c_i);  (L,L), (L,y) likewise      [chroma]
+// k3q_generic: areas marked in `todo` (deferred because |d| > 127, EXT-but-flat, or MIX
+// when the fast mixed path is off), plain int32.  Thread t owns up to two of the 350
+// products:
+//   (i, j):  sum_q W(q - c_i) d(q) d(q + c_j - c_i)        (i, y): ... d(q - c_i)
+//   (i, L):  sum_p w(p) L(p) d(p + c_i);  (L,L), (L,y) likewise      [chroma]
 // Adds straight into the record with int64 atomics (few areas), writes the block stats.
 // grid = (chunks, nplanes, batch), block = 256.
 // ---------------------------------------------------------------------------------
 constexpr int kGW = kBlock + 12, kGH = kBlock + 6;  // d tile: cols -6..37, rows -3..34
 __global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict__ frames, Geom g, QParams qp,
                                                    uint8_t *__restrict__ records) {
-  __shared__ int dt[kGH * kGW];       // d(q), x in -6..bw+5, y in -3..bh+2
-  __shared__ uint8_t wt[kGH * kGW];   // w at the same positions
+  __shared__ int dt[kGH * kGW];        // d(q), x in -6..bw+5, y in -3..bh+2
+  __shared__ uint8_t wt[kGH * kGW];    // w at the same positions
   __shared__ int lt[kBlock * kBlock];  // L(p) on the block proper
   __shared__ int red[4];
   const int c = blockIdx.y, frame = blockIdx.z;
   const int kind = c > 0 ? 1 : 0;
-  const uint8_t *todo = qp.todo + ((size_t)frame * 2 + kind) * g.nblocks;
+  const size_t lsel = ((size_t)frame * 2 + kind) * 3 + 2;
+  const int nlist = (int)qp.counts[lsel];
+  if ((int)blockIdx.x >= nlist) return;  // the common case: nothing deferred
+  const uint32_t *list = qp.lists + lsel * g.nblocks;
   const FramePlanes fp = frames[frame];
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
@@ -568,7 +892,6 @@ __global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict
   const int TW = bw + 12, TH = bh + 6;
   const int nc = kQN + (c > 0);
   const int ntri = nc * (nc + 1) / 2, npairs = ntri + nc;
-  // product descriptors
   int kindp[2], oa[2], ob[2], om[2], out_idx[2];
   bool have[2];
   auto tile_off = [&](int dx, int dy) { return (dy + 3) * TW + (dx + 6); };
@@ -593,8 +916,7 @@ __global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict
     if (!have[s]) i = j = 0;
     const bool iL = (c > 0 && i == kQN), jL = (c > 0 && j == kQN), jY = (j == nc);
     if (!iL && !jL) {
-      // q-centric: d(q) * d(q + delta), mask W(q - c_i)
-      kindp[s] = 0;
+      kindp[s] = 0;  // q-centric: d(q) * d(q + delta), mask W(q - c_i)
       const int cxi = coord_x(i), cyi = coord_y(i);
       const int dx = (jY ? 0 : coord_x(j)) - cxi, dy = (jY ? 0 : coord_y(j)) - cyi;
       oa[s] = tile_off(0, 0);
@@ -620,8 +942,8 @@ __global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict
   const uint8_t *sp = fp.src[c], *dp = fp.den[c];
   const uint32_t sst = fp.src_stride[c], dst = fp.den_stride[c];
 
-  for (int blk = blockIdx.x; blk < g.nblocks; blk += gridDim.x) {
-    if (!todo[blk]) continue;
+  for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
+    const int blk = (int)list[li];
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int x_o = bx * bw, y_o = by * bh;
     int s_d = 0, s_d2 = 0, s_l = 0, s_n = 0;
@@ -701,9 +1023,10 @@ __global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict
 }
 
 // ---------------------------------------------------------------------------------
-// k3q_reduce: chunk partials of the interior kernel -> record (upper triangle).
+// k3q_reduce: every chunk partial of one (frame, plane) -> record (upper triangle).
 //   S[i][j] += G(c_j - c_i);  Sb[i] += G(-c_i);  chroma: S[i][L] += 4 Xa_i + Xb_i, ...
-// grid = (nplanes, batch), block = 256.
+//   + the 324 masked products of k3_partial.
+// grid = (nplanes, batch), block = 256: 4 lanes-groups of 64 split the chunk range.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *__restrict__ records) {
   const int c = blockIdx.x, frame = blockIdx.y;
@@ -711,33 +1034,34 @@ __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *_
   const int nc = kQN + (chroma ? 1 : 0);
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
-  const int32_t *base = qp.partials + ((size_t)frame * 3 + c) * qp.nchunks * kQPart;
-  __shared__ long long tot[kQPart];
-  for (int e = threadIdx.x; e < kQPart; e += 256) {
-    long long s = 0;
-    for (int ch = 0; ch < qp.nchunks; ++ch) s += base[(size_t)ch * kQPart + e];
-    tot[e] = s;
-  }
-  __syncthreads();
-  const int sx = chroma ? g.xdec : 0, sy = chroma ? g.ydec : 0;
+  const long long *lag = qp.lagacc + ((size_t)frame * 3 + c) * kQPart;
+  const long long *par = qp.paracc + ((size_t)frame * 3 + c) * kPPart;
   for (int p = threadIdx.x; p < kQN * kQN; p += 256) {
     const int i = p / kQN, j = p % kQN;
     if (j < i) continue;
-    const int dx = coord_x(j) - coord_x(i), dy = coord_y(j) - coord_y(i);
-    ar[i * nc + j] += tot[lag_index(dx, dy)];
+    ar[i * nc + j] += lag[lag_index(coord_x(j) - coord_x(i), coord_y(j) - coord_y(i))];
   }
+  __syncthreads();  // the same S entries get the masked products below
   if (threadIdx.x < kQN) {
     const int i = threadIdx.x;
-    ar[nc * nc + i] += tot[lag_index(-coord_x(i), -coord_y(i))];  // Sb[i]
-    if (chroma) ar[i * nc + kQN] += 4 * tot[kNumLags + 2 * i] + tot[kNumLags + 2 * i + 1];
+    ar[nc * nc + i] += lag[lag_index(-coord_x(i), -coord_y(i))];  // Sb[i]
+    if (chroma) ar[i * nc + kQN] += 4 * lag[kNumLags + 2 * i] + lag[kNumLags + 2 * i + 1];
+    // masked products of anchor i
+    const int h = p_in_half(0, i) ? 0 : 1;
+    int idx = 0;
+    for (int a = 0; a < i; ++a)
+      if (p_in_half(h, a)) idx += (kQN - a) + 1;
+    const long long *t = par + h * kPHalf + idx;
+    int k = 0;
+    for (int j = i; j < kQN; ++j) ar[i * nc + j] += t[k++];
+    ar[nc * nc + i] += t[k];
   }
   if (chroma && threadIdx.x == 32) {
-    const long long *t = tot + kNumLags + 48;
+    const long long *t = lag + kNumLags + 48;
     ar[kQN * nc + kQN] += 16 * t[0] + 8 * t[1] + t[2];
     ar[nc * nc + kQN] += 4 * t[3] + t[4];
   }
-  if (threadIdx.x == 64)
-    ar[nc * nc + nc] += tot[kNumLags + kNumLTerms] * (long long)((kBlock >> sx) * (kBlock >> sy));
+  if (threadIdx.x == 64) ar[nc * nc + nc] += lag[kQPart - 1];
 }
 
 }  // namespace g1s
