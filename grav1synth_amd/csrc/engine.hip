@@ -164,7 +164,11 @@ struct g1s_diff {
   bool luma_only, records_only;
   uint32_t batch;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // == slot_stream[0]
+  hipStream_t slot_stream[2] = {nullptr, nullptr};  // one stream per batch slot: consecutive batches overlap
+  hipStream_t aux[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // K3 kernels of one batch run side by side
+  hipEvent_t ev_fork[2] = {nullptr, nullptr};
+  hipEvent_t ev_join[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   bool geometry_set = false;
   g1s_frame_t shape{};  // geometry of the first frame
   Geom geom{};
@@ -268,12 +272,14 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   if (lag == kQLag) {
     // interior: ~24 areas per workgroup (many small workgroups hide the staging latency);
     // mixed: fewer, larger workgroups (189 accumulators to reduce at the end), <= 128 areas each
-    fast_chunks = std::max(1, std::min(g.nblocks, std::max(64, (g.nblocks + 23) / 24)));
-    mix_chunks = std::max(1, std::min(g.nblocks, std::max(64, (g.nblocks + 63) / 64)));
+    // (multiples of 8: the list slices are XCD-aware)
+    fast_chunks = (std::max(64, (g.nblocks + 23) / 24) + 7) & ~7;
+    mix_chunks = (std::max(64, (g.nblocks + 63) / 64) + 7) & ~7;
     partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart);
     const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
     // [cls][todo][lists u32 x4 per frame][counts]
-    defer_bytes = 2 * cls_bytes + sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 6);
+    defer_bytes = 2 * cls_bytes + sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 8) +
+                  (size_t)batch * 2 * g.nblocks * 32;  // + windows per area
   }
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
                      partial_bytes, defer_bytes, frame_bytes * batch};
@@ -386,6 +392,10 @@ int g1s_diff::submit(int si) {
     }
   }
   g.vec_mask = vec_mask;
+  static const bool slot_streams = getenv("G1S_SLOT_STREAMS") != nullptr;  // experiments: default one stream
+  static const bool k3_streams = getenv("G1S_K3_STREAMS") != nullptr;
+  hipStream_t stream = slot_stream[slot_streams ? si : 0];  // (shadows the member on purpose)
+  hipStream_t ax[3] = {k3_streams ? aux[si][0] : stream, k3_streams ? aux[si][1] : stream, k3_streams ? aux[si][2] : stream};
   HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(sl.d_records, 0, L.size * B, stream));
   sl.timed = timing;
@@ -417,32 +427,52 @@ int g1s_diff::submit(int si) {
     qp.todo = sl.d_defer + cls_bytes;
     qp.lists = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes);
     qp.counts = qp.lists + (size_t)batch * 6 * g.nblocks;
+    qp.winbuf = reinterpret_cast<uint8_t *>(qp.counts + (size_t)batch * 8);
     HIP_TRY(hipMemsetAsync(qp.counts, 0, sizeof(uint32_t) * (size_t)batch * 6, stream));
     const int kinds = g.nplanes == 3 ? 2 : 1;
     hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + 255) / 256, kinds, B), dim3(256), 0, stream, g,
                        (const uint8_t *)sl.d_records, qp);
     const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
-    auto launch_lag = [&](bool mixed) {
+    // fork: the six accumulation kernels are independent and latency-bound -> four streams
+    if (k3_streams) {
+      HIP_TRY(hipEventRecord(ev_fork[si], stream));
+      for (int a = 0; a < 3; ++a) HIP_TRY(hipStreamWaitEvent(aux[si][a], ev_fork[si], 0));
+    }
+    auto launch_lag = [&](int K, bool mixed, hipStream_t st) {
       const dim3 gr(mixed ? mix_chunks : fast_chunks, 1, B);
-#define G1S_LAG(K)                                                                                              \
-  if (mixed)                                                                                                    \
-    hipLaunchKernelGGL((k3_lag<K, true>), gr, dim3(QShape<K>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records); \
-  else                                                                                                          \
-    hipLaunchKernelGGL((k3_lag<K, false>), gr, dim3(QShape<K>::THREADS), 0, stream, sl.d_planes, g, qp, sl.d_records);
-      G1S_LAG(0)
-      if (ck == 1) { G1S_LAG(1) }
-      else if (ck == 2) { G1S_LAG(2) }
-      else if (ck == 3) { G1S_LAG(3) }
+#define G1S_LAG(KK)                                                                                              \
+  if (mixed)                                                                                                     \
+    hipLaunchKernelGGL((k3_lag<KK, true, kLagWaves>), gr, dim3(QShape<KK>::THREADS), 0, st, sl.d_planes, g, qp, sl.d_records); \
+  else                                                                                                           \
+    hipLaunchKernelGGL((k3_lag<KK, false, kLagWaves>), gr, dim3(QShape<KK>::THREADS), 0, st, sl.d_planes, g, qp, sl.d_records);
+      if (K == 0) { G1S_LAG(0) }
+      else if (K == 1) { G1S_LAG(1) }
+      else if (K == 2) { G1S_LAG(2) }
+      else { G1S_LAG(3) }
 #undef G1S_LAG
     };
-    launch_lag(false);
-    if (qp.mixed_fast) {
-      launch_lag(true);
+    auto launch_partial = [&](int K, hipStream_t st) {
       const dim3 pg(mix_chunks, 1, B), pb(256);
-      hipLaunchKernelGGL(k3_partial<0>, pg, pb, 0, stream, sl.d_planes, g, qp, sl.d_records);
-      if (ck == 1) hipLaunchKernelGGL(k3_partial<1>, pg, pb, 0, stream, sl.d_planes, g, qp, sl.d_records);
-      else if (ck == 2) hipLaunchKernelGGL(k3_partial<2>, pg, pb, 0, stream, sl.d_planes, g, qp, sl.d_records);
-      else if (ck == 3) hipLaunchKernelGGL(k3_partial<3>, pg, pb, 0, stream, sl.d_planes, g, qp, sl.d_records);
+      if (K == 0) hipLaunchKernelGGL(k3_partial<0>, pg, pb, 0, st, sl.d_planes, g, qp, sl.d_records);
+      else if (K == 1) hipLaunchKernelGGL(k3_partial<1>, pg, pb, 0, st, sl.d_planes, g, qp, sl.d_records);
+      else if (K == 2) hipLaunchKernelGGL(k3_partial<2>, pg, pb, 0, st, sl.d_planes, g, qp, sl.d_records);
+      else hipLaunchKernelGGL(k3_partial<3>, pg, pb, 0, st, sl.d_planes, g, qp, sl.d_records);
+    };
+    launch_lag(0, false, stream);
+    if (ck) launch_lag(ck, false, ax[0]);
+    if (qp.mixed_fast) {
+      launch_lag(0, true, ax[1]);
+      launch_partial(0, ax[1]);
+      if (ck) {
+        launch_lag(ck, true, ax[2]);
+        launch_partial(ck, ax[2]);
+      }
+    }
+    if (k3_streams) {
+      for (int a = 0; a < 3; ++a) {  // join
+        HIP_TRY(hipEventRecord(ev_join[si][a], aux[si][a]));
+        HIP_TRY(hipStreamWaitEvent(stream, ev_join[si][a], 0));
+      }
     }
     hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, qp, sl.d_records);
     const int chunks = std::min(64, g.nblocks);
@@ -560,7 +590,11 @@ int g1s_diff::drain_all() {
 }
 
 void g1s_diff::release() {
-  if (stream) (void)hipStreamSynchronize(stream);
+  for (int i = 0; i < 2; ++i) {
+    if (slot_stream[i]) (void)hipStreamSynchronize(slot_stream[i]);
+    for (int a = 0; a < 3; ++a)
+      if (aux[i][a]) (void)hipStreamSynchronize(aux[i][a]);
+  }
   for (Slot &sl : slots) {
     if (sl.h_planes && geometry_set) {  // park the buffers for the next generator of this geometry
       std::lock_guard<std::mutex> lk(g_cache_mutex);
@@ -586,7 +620,18 @@ void g1s_diff::release() {
   }
   if (d_lut) (void)hipFree(d_lut);
   d_lut = nullptr;
-  if (stream) (void)hipStreamDestroy(stream);
+  for (int i = 0; i < 2; ++i) {
+    if (slot_stream[i]) (void)hipStreamDestroy(slot_stream[i]);
+    slot_stream[i] = nullptr;
+    if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
+    ev_fork[i] = nullptr;
+    for (int a = 0; a < 3; ++a) {
+      if (aux[i][a]) (void)hipStreamDestroy(aux[i][a]);
+      aux[i][a] = nullptr;
+      if (ev_join[i][a]) (void)hipEventDestroy(ev_join[i][a]);
+      ev_join[i][a] = nullptr;
+    }
+  }
   stream = nullptr;
   delete fold;
   fold = nullptr;
@@ -656,7 +701,16 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   make_flat_consts(g->fc);
   double lut[256];
   for (int i = 0; i < 256; ++i) lut[i] = ((double)i) / 255.0;  // block normalisation, on the host
-  if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+  bool streams_ok = true;
+  for (int i = 0; i < 2 && streams_ok; ++i) {
+    streams_ok = hipStreamCreateWithFlags(&g->slot_stream[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&g->ev_fork[i], hipEventDisableTiming) == hipSuccess;
+    for (int a = 0; a < 3 && streams_ok; ++a)
+      streams_ok = hipStreamCreateWithFlags(&g->aux[i][a], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&g->ev_join[i][a], hipEventDisableTiming) == hipSuccess;
+  }
+  g->stream = g->slot_stream[0];
+  if (!streams_ok ||
       hipMalloc((void **)&g->d_lut, sizeof(lut)) != hipSuccess ||
       hipMemcpy(g->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
     g_global_error = std::string("HIP initialisation failed: ") + hipGetErrorString(hipGetLastError());

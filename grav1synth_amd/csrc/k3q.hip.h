@@ -63,16 +63,27 @@ struct QParams {
   uint8_t *todo;       // [batch][2][nblocks]  1 = area left to k3q_generic
   uint32_t *lists;     // [batch][2 kinds][3 (INT, MIX, GENERIC)][nblocks] compacted area indices
   uint32_t *counts;    // [batch][2][3] list lengths (zeroed before k3_classify)
+  uint8_t *winbuf;     // [batch][2][nblocks][32] windows of the 6 blocks an area sees (flat,xs,xe,ys,ye) x 6
 };
+constexpr uint32_t kEntryFlat = 0x80000000u;      // list entry = block index | (block is flat ? bit 31 : 0)
+constexpr uint32_t kEntryDeferred = 0x40000000u;  // set by k3_lag<.., true> on a MIX entry it deferred to k3q_generic
+constexpr uint32_t kEntryNone = 0xffffffffu;
+constexpr uint32_t kEntryIndex = 0x3fffffffu;
 
 __device__ __forceinline__ int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, int sh) {
   return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
+// full-wave integer sum, all in the VALU (DPP): quad swaps, half-row / row mirrors, then
+// the row broadcasts; the total lands in lane 63 and is read back as a scalar.
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 template <int N>
 __device__ __forceinline__ void wave_sum_all(int (&a)[N]) {
@@ -131,13 +142,22 @@ __global__ __launch_bounds__(256) void k3_classify(Geom g, const uint8_t *__rest
     const int AX0 = bx * bw - kQLag, AX1 = bx * bw + bw + kQLag, AY0 = by * bh, AY1 = by * bh + bh + kQLag;
     bool all1 = !(AX0 < 0 || AX1 > pw || AY1 > ph);
     bool any1 = false;
+    uint8_t *wb = qp.winbuf + (((size_t)frame * 2 + kind) * g.nblocks + blk) * 32;
     for (int dby = 0; dby <= 1; ++dby) {
       for (int dbx = -1; dbx <= 1; ++dbx) {
         const int Bx = bx + dbx, By = by + dby;
+        const Win w = block_window(mask, g.nbw, g.nbh, Bx, By, bw, bh, pw, ph);
+        {
+          uint8_t *o = wb + (dby * 3 + dbx + 1) * 5;
+          o[0] = (uint8_t)w.flat;
+          o[1] = (uint8_t)w.xs;
+          o[2] = (uint8_t)max(w.xe, 0);
+          o[3] = (uint8_t)w.ys;
+          o[4] = (uint8_t)max(w.ye, 0);
+        }
         const int rx0 = max(AX0, Bx * bw), rx1 = min(AX1, Bx * bw + bw);
         const int ry0 = max(AY0, By * bh), ry1 = min(AY1, By * bh + bh);
         if (rx0 >= rx1 || ry0 >= ry1) continue;
-        const Win w = block_window(mask, g.nbw, g.nbh, Bx, By, bw, bh, pw, ph);
         if (!w.flat) {
           all1 = false;
           continue;
@@ -166,8 +186,22 @@ __global__ __launch_bounds__(256) void k3_classify(Geom g, const uint8_t *__rest
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&qp.counts[lo], (uint32_t)__popcll(b));
     base = __shfl(base, 0, 64);
-    if (mine) qp.lists[lo * g.nblocks + base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)blk;
+    if (mine)
+      qp.lists[lo * g.nblocks + base + __popcll(b & ((1ull << lane) - 1ull))] =
+          (uint32_t)blk | (mask[blk] ? kEntryFlat : 0u);
   }
+}
+
+// XCD-aware contiguous slice of a list of n entries for workgroup b of N (N % 8 == 0):
+// block b runs on XCD b % 8 (observed, speed only), so XCD x gets the list range
+// [x*n/8, (x+1)*n/8) and its workgroups walk adjacent sub-slices: neighbouring areas
+// (which share halo lines) stay within one L2.
+__device__ __forceinline__ void list_slice(int b, int N, int n, int &begin, int &end) {
+  const int cpx = N >> 3;
+  const int w = (b & 7) * cpx + (b >> 3);
+  const int per = (n + N - 1) / N;
+  begin = min(n, w * per);
+  end = min(n, begin + per);
 }
 
 // ---- 8 consecutive samples of a row (vector global load, narrowed later) ----
@@ -304,8 +338,33 @@ struct Stager {
   }
 
   // narrow, subtract, range-check, write LDS.  Returns true if some |d| > 127.
+  // window-indicator tile (rows 0..BH+2 of the area) from the six windows in s_win
+  __device__ __forceinline__ void build_wtile(int tid, uint8_t *lds, const uint8_t *s_win) {
+    constexpr int bw = S::BW, bh = S::BH;
+    constexpr int NW = (bh + kQLag) * S::SEGS;
+#pragma unroll
+    for (int k = 0; k < (NW + NT - 1) / NT; ++k) {
+      const int it = tid + k * NT;
+      if (it < NW) {
+        const int y = it / S::SEGS, sg = it - y * S::SEGS;
+        const int dby = y >= bh ? 1 : 0, ly = y - dby * bh;
+        uint32_t wlo = 0, whi = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int x = -8 + 8 * sg + q;
+          const int dbx = x < 0 ? -1 : (x >= bw ? 1 : 0), lx = x - dbx * bw;
+          const uint8_t *wn = s_win + (dby * 3 + dbx + 1) * 5;
+          const bool in = wn[0] && lx >= wn[1] && lx < wn[2] && ly >= wn[3] && ly < wn[4];
+          const uint32_t b = in ? 0xffu : 0u;
+          if (q < 4) wlo |= b << (8 * q); else whi |= b << (8 * (q - 4));
+        }
+        *reinterpret_cast<uint2 *>(lds + S::DATA_BYTES + y * S::PITCH + 8 * sg) = make_uint2(wlo, whi);
+      }
+    }
+  }
+
   __device__ __forceinline__ bool store(const FramePlanes &fp, const Geom &g, int tid, int blk, uint8_t *lds,
-                                        const int (*s_win)[5], int &lsum) {
+                                        int &lsum) {
     constexpr bool CHROMA = S::kChroma;
     constexpr int bw = S::BW, bh = S::BH;
     const int pw = g.W >> S::SX;
@@ -337,21 +396,6 @@ struct Stager {
           for (int q = 0; q < 8; ++q) lsum += sv[q];
         }
         *reinterpret_cast<uint2 *>(lds + pl * S::TILE_BYTES + ty * S::PITCH + 8 * sg) = make_uint2(lo, hi);
-        if (WTILE && pl == 0 && ty >= S::UP) {  // window indicator of rows 0..BH+2
-          const int y = ty - S::UP;
-          const int dby = y >= bh ? 1 : 0, ly = y - dby * bh;
-          uint32_t wlo = 0, whi = 0;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int x = -8 + 8 * sg + q;
-            const int dbx = x < 0 ? -1 : (x >= bw ? 1 : 0), lx = x - dbx * bw;
-            const int *wn = s_win[dby * 3 + dbx + 1];
-            const bool in = wn[0] && lx >= wn[1] && lx < wn[2] && ly >= wn[3] && ly < wn[4];
-            const uint32_t b = in ? 0xffu : 0u;
-            if (q < 4) wlo |= b << (8 * q); else whi |= b << (8 * (q - 4));
-          }
-          *reinterpret_cast<uint2 *>(lds + S::DATA_BYTES + y * S::PITCH + 8 * sg) = make_uint2(wlo, whi);
-        }
       } else if (LTERMS && it < NITEMS) {
         const int r = it - S::NTILE;
         const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
@@ -399,22 +443,6 @@ struct Stager {
   }
 };
 
-// windows of the six blocks an area can see -> s_win (threads 0..5)
-template <int KIND>
-__device__ __forceinline__ void load_windows(const uint8_t *mask, const Geom &g, int tid, int blk, int (*s_win)[5]) {
-  using S = QShape<KIND>;
-  if (tid < 6) {
-    const int bx = blk % g.nbw, by = blk / g.nbw;
-    const Win w = block_window(mask, g.nbw, g.nbh, bx + (tid % 3) - 1, by + tid / 3, S::BW, S::BH, g.W >> S::SX,
-                               g.H >> S::SY);
-    s_win[tid][0] = w.flat;
-    s_win[tid][1] = w.xs;
-    s_win[tid][2] = w.xe;
-    s_win[tid][3] = w.ys;
-    s_win[tid][4] = w.ye;
-  }
-}
-
 // Group classification from the w tile: w32 points at dword (row*PITCH_DW + g) of the w
 // tile; the group's own samples are dword +2.  FULL / EMPTY are decided on the bytes
 // x-3 .. x+6 of rows 0..3 (a superset of what the 24 masks read; both kernels use this
@@ -441,16 +469,23 @@ __device__ __forceinline__ void group_state(const uint32_t *w32, bool &full, boo
 // grid = (nchunks or nchunks_mix, 1, batch), block = QShape::THREADS.
 // int32 safety: per step |sum| <= 4*127^2; <= 128 areas * STEPS_PER_WAVE(<=2); x64 lanes < 2^31.
 // ---------------------------------------------------------------------------------
-template <int KIND, bool MIXED>
-__global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(const FramePlanes *__restrict__ frames, Geom g,
-                                                                QParams qp, uint8_t *__restrict__ records) {
+// WV = waves per workgroup.  WV = 1 makes a wave autonomous: it stages and multiplies whole
+// areas alone, workgroup barriers degenerate, and a CU runs 8-12 independent area pipelines.
+constexpr int kLagWaves = 0;  // 0 = QShape<KIND>::WAVES (4 luma, 2 chroma 4:2:0); 1 was measured slower and is invalid for chroma
+template <int KIND, bool MIXED, int WV>
+__global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(const FramePlanes *__restrict__ frames,
+                                                                              Geom g, QParams qp,
+                                                                              uint8_t *__restrict__ records) {
   using S = QShape<KIND>;
   constexpr bool CHROMA = S::kChroma;
-  constexpr int NACC = S::NACC, NT = S::THREADS;
+  constexpr int WAVES = WV ? WV : S::WAVES;
+  constexpr int NACC = S::NACC, NT = 64 * WAVES;
+  constexpr int STEPS_PER_WAVE = S::NPL * S::NS / WAVES;
+  static_assert(S::NPL * S::NS % WAVES == 0 && WAVES % S::NPL == 0, "a wave owns the accumulators of ONE plane");
   __shared__ __attribute__((aligned(16))) uint8_t lds[S::DATA_BYTES + (MIXED ? S::WTILE_BYTES : 0)];
   __shared__ int s_flag[2];
   __shared__ int s_stat[2][4][4];
-  __shared__ int s_win[6][5];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[32];  // windows of the six blocks the current MIX area sees
 
   const int frame = blockIdx.z, chunk = blockIdx.x;
   const int stride = MIXED ? qp.nchunks_mix : qp.nchunks;
@@ -458,9 +493,10 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(const FramePlane
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
   const size_t lsel = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + (MIXED ? 1 : 0);
-  const uint32_t *list = qp.lists + lsel * g.nblocks;
+  uint32_t *list = qp.lists + lsel * g.nblocks;
   const int nlist = (int)qp.counts[lsel];
   uint8_t *todo = qp.todo + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
+  const uint8_t *winbase = qp.winbuf + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks * 32;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lg = lane % S::G, lr = lane / S::G;
 
@@ -470,33 +506,42 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(const FramePlane
   int nobs = 0;  // INT: number of areas (x BW*BH in the reducer); MIX: window samples
   if (tid < 2) s_flag[tid] = 0;
 
+  // Software pipeline over the list slice.  Per iteration k: the samples of area k were
+  // requested one iteration ago, the list entry of area k+1 two iterations ago; no load that
+  // is waited on is ever issued after the prefetch (vmcnt retires in order).
   Stager<KIND, NT, MIXED, CHROMA> st;
-  int li = chunk;
-  int cur = li < nlist ? (int)list[li] : -1;
-  if (cur >= 0) {
-    if (MIXED) load_windows<KIND>(mask, g, tid, cur, s_win);
-    st.fetch(fp, g, tid, cur);
+  int li, li_end;
+  list_slice(chunk, stride, nlist, li, li_end);
+  auto entry_at = [&](int pos) -> uint32_t { return pos < li_end ? list[pos] : kEntryNone; };
+  uint32_t e_cur = entry_at(li), e_nxt = entry_at(li + 1);
+  uint32_t wreg = 0;  // threads 0..7: one dword of the windows of the area being prefetched
+  if (e_cur != kEntryNone) {
+    const int b0 = (int)(e_cur & kEntryIndex);
+    if (MIXED && tid < 8) wreg = reinterpret_cast<const uint32_t *>(winbase + (size_t)b0 * 32)[tid];
+    st.fetch(fp, g, tid, b0);
   }
   __syncthreads();
 
   int iter = 0;
-  while (cur >= 0) {
-    const int blk = cur;
+  for (; e_cur != kEntryNone; e_cur = e_nxt, e_nxt = entry_at(li + 1)) {
+    const int blk = (int)(e_cur & kEntryIndex);
+    const bool isflat = (e_cur & kEntryFlat) != 0;
     const int fl = iter & 1;
     ++iter;
+    if (MIXED && tid < 8) reinterpret_cast<uint32_t *>(s_win)[tid] = wreg;
     int lsum = 0;
-    const bool bad = st.store(fp, g, tid, blk, lds, s_win, lsum);
-    li += stride;
-    cur = li < nlist ? (int)list[li] : -1;  // list entry read BEFORE the prefetch is issued
+    const bool bad = st.store(fp, g, tid, blk, lds, lsum);
     if (bad) s_flag[fl] = 1;
     if (!CHROMA) {
       lsum = wave_sum(lsum);
       if (lane == 0) s_stat[fl][wave][3] = lsum;
     }
-    __syncthreads();  // tiles complete; s_win free again
-    if (cur >= 0) {
-      if (MIXED) load_windows<KIND>(mask, g, tid, cur, s_win);  // mask bytes first (vmcnt retires in order)
-      st.fetch(fp, g, tid, cur);                                 // in flight during the products below
+    __syncthreads();  // d tiles + s_win complete
+    ++li;
+    if (e_nxt != kEntryNone) {  // prefetch area k+1 (in flight during the products below)
+      const int bn = (int)(e_nxt & kEntryIndex);
+      if (MIXED && tid < 8) wreg = reinterpret_cast<const uint32_t *>(winbase + (size_t)bn * 32)[tid];
+      st.fetch(fp, g, tid, bn);
     }
     const bool deferred = s_flag[fl] != 0;
     if (tid == 0) s_flag[fl ^ 1] = 0;
@@ -505,16 +550,21 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(const FramePlane
         todo[blk] = 1;
         const size_t lg3 = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + 2;
         qp.lists[lg3 * g.nblocks + atomicAdd(&qp.counts[lg3], 1u)] = (uint32_t)blk;
+        if (MIXED) list[li - 1] = e_cur | kEntryDeferred;  // k3_partial skips it as well
       }
       __syncthreads();
       continue;
+    }
+    if (MIXED) {
+      st.build_wtile(tid, lds, s_win);
+      __syncthreads();
     }
     if (!MIXED && tid == 0) ++nobs;
 
     int sd = 0, sd2 = 0;
 #pragma unroll 1
-    for (int s = 0; s < S::STEPS_PER_WAVE; ++s) {
-      const int widx = wave * S::STEPS_PER_WAVE + s;
+    for (int s = 0; s < STEPS_PER_WAVE; ++s) {
+      const int widx = wave * STEPS_PER_WAVE + s;
       const int pl = widx / S::NS, step = widx - pl * S::NS;
       const int row = step * S::ROWS_PER_STEP + lr;  // sample row of the area
       const uint32_t *t32 = reinterpret_cast<const uint32_t *>(lds + pl * S::TILE_BYTES) + (row + S::UP) * S::PITCH_DW + lg;
@@ -594,11 +644,11 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(const FramePlane
       s_stat[fl][wave][1] = sd2;
     }
     __syncthreads();
-    if (tid == 0 && (!MIXED || mask[blk])) {
+    if (tid == 0 && (!MIXED || isflat)) {
       const int(*sp)[4] = s_stat[fl];
       int a[2] = {0, 0}, b[2] = {0, 0}, l = 0;
-      for (int w = 0; w < S::WAVES; ++w) {
-        const int pl = (w * S::STEPS_PER_WAVE) / S::NS;  // a wave's steps stay within one plane
+      for (int w = 0; w < WAVES; ++w) {
+        const int pl = (w * STEPS_PER_WAVE) / S::NS;  // a wave's steps stay within one plane
         a[pl] += sp[w][0];
         b[pl] += sp[w][1];
         l += sp[w][3];
@@ -643,15 +693,15 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(const FramePlane
         reinterpret_cast<unsigned long long *>(qp.lagacc) + ((size_t)frame * 3 + (CHROMA ? 1 + pl : 0)) * kQPart;
     for (int i = tid; i < NACC; i += NT) {
       int v = 0;
-      for (int w = 0; w < S::WAVES; ++w)
-        if ((w * S::STEPS_PER_WAVE) / S::NS == pl) v += red[w * (kQPart + 1) + i];
+      for (int w = 0; w < WAVES; ++w)
+        if ((w * STEPS_PER_WAVE) / S::NS == pl) v += red[w * (kQPart + 1) + i];
       if (v != 0) atomicAdd(&out[i], (unsigned long long)(long long)v);
     }
     if (tid == 0) {
       long long v = 0;
       if (MIXED) {
-        for (int w = 0; w < S::WAVES; ++w)
-          if ((w * S::STEPS_PER_WAVE) / S::NS == 0) v += red[w * (kQPart + 1) + kQPart];  // counted on plane 0
+        for (int w = 0; w < WAVES; ++w)
+          if ((w * STEPS_PER_WAVE) / S::NS == 0) v += red[w * (kQPart + 1) + kQPart];  // counted on plane 0
       } else {
         v = (long long)red[kQPart] * S::BW * S::BH;  // thread 0 counted the areas
       }
@@ -707,18 +757,16 @@ __global__ __launch_bounds__(256, 2) void k3_partial(const FramePlanes *__restri
   constexpr int NC = S::NPL * 2;   // (plane, half) combos
   constexpr int WPC = 4 / NC;      // waves per combo
   __shared__ __attribute__((aligned(16))) uint8_t lds[S::DATA_BYTES + S::WTILE_BYTES];
-  __shared__ int s_flag[2];
-  __shared__ int s_win[6][5];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[32];
   __shared__ uint16_t s_plist[S::NG];
   __shared__ int s_wcount[4];
 
   const int frame = blockIdx.z, chunk = blockIdx.x;
   const FramePlanes fp = frames[frame];
-  uint8_t *rec = records + (size_t)frame * g.rec_size;
-  const uint8_t *mask = rec + g.off_mask;
   const size_t lsel = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + 1;
   const uint32_t *list = qp.lists + lsel * g.nblocks;
   const int nlist = (int)qp.counts[lsel];
+  const uint8_t *winbase = qp.winbuf + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks * 32;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int combo = wave % NC, sub = wave / NC;
   const int my_pl = combo >> 1, my_half = combo & 1;
@@ -726,39 +774,41 @@ __global__ __launch_bounds__(256, 2) void k3_partial(const FramePlanes *__restri
   int acc[kPHalf];
 #pragma unroll
   for (int i = 0; i < kPHalf; ++i) acc[i] = 0;
-  if (tid < 2) s_flag[tid] = 0;
 
-  // areas that k3_lag<.., true> (which ran before on this stream) deferred to the generic
-  // kernel are skipped here too: one decision, taken once
-  const uint8_t *todo = qp.todo + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
-  auto next_area = [&](int &pos) {
-    while (pos < nlist) {
-      const int b = (int)list[pos];
-      if (!todo[b]) return b;
-      pos += qp.nchunks_mix;
-    }
-    return -1;
-  };
+  // Same software pipeline as k3_lag.  Areas that k3_lag<.., true> (which ran before on this
+  // stream) deferred to the generic kernel carry kEntryDeferred and are skipped: one decision,
+  // taken once.
+  int li, li_end;
+  list_slice(chunk, qp.nchunks_mix, nlist, li, li_end);
+  auto entry_at = [&](int pos) -> uint32_t { return pos < li_end ? list[pos] : kEntryNone; };
   Stager<KIND, NT, true, false> st;
-  int li = chunk;
-  int cur = next_area(li);
-  if (cur >= 0) {
-    load_windows<KIND>(mask, g, tid, cur, s_win);
-    st.fetch(fp, g, tid, cur);
+  uint32_t e_cur = entry_at(li), e_nxt = entry_at(li + 1);
+  uint32_t wreg = 0;
+  if (e_cur != kEntryNone && !(e_cur & kEntryDeferred)) {
+    const int b0 = (int)(e_cur & kEntryIndex);
+    if (tid < 8) wreg = reinterpret_cast<const uint32_t *>(winbase + (size_t)b0 * 32)[tid];
+    st.fetch(fp, g, tid, b0);
   }
   __syncthreads();
 
-  while (cur >= 0) {
-    const int blk = cur;
-    int lsum = 0;
-    (void)st.store(fp, g, tid, blk, lds, s_win, lsum);
-    li += qp.nchunks_mix;
-    cur = next_area(li);
-    __syncthreads();
-    if (cur >= 0) {
-      load_windows<KIND>(mask, g, tid, cur, s_win);
-      st.fetch(fp, g, tid, cur);
+  for (; e_cur != kEntryNone; e_cur = e_nxt, e_nxt = entry_at(li + 1)) {
+    const int blk = (int)(e_cur & kEntryIndex);
+    const bool skip = (e_cur & kEntryDeferred) != 0;
+    if (!skip) {
+      if (tid < 8) reinterpret_cast<uint32_t *>(s_win)[tid] = wreg;
+      int lsum = 0;
+      (void)st.store(fp, g, tid, blk, lds, lsum);
     }
+    __syncthreads();
+    ++li;
+    if (e_nxt != kEntryNone && !(e_nxt & kEntryDeferred)) {
+      const int bn = (int)(e_nxt & kEntryIndex);
+      if (tid < 8) wreg = reinterpret_cast<const uint32_t *>(winbase + (size_t)bn * 32)[tid];
+      st.fetch(fp, g, tid, bn);
+    }
+    if (skip) continue;
+    st.build_wtile(tid, lds, s_win);
+    __syncthreads();
     // ---- compact the partial groups of this area ----
     const uint32_t *w32b = reinterpret_cast<const uint32_t *>(lds + S::DATA_BYTES);
     bool part = false;
