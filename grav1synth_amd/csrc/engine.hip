@@ -394,8 +394,9 @@ int g1s_diff::submit(int si) {
   g.vec_mask = vec_mask;
   static const bool slot_streams = getenv("G1S_SLOT_STREAMS") != nullptr;  // experiments: default one stream
   static const bool k3_streams = getenv("G1S_K3_STREAMS") != nullptr;
-  hipStream_t stream = slot_stream[slot_streams ? si : 0];  // (shadows the member on purpose)
-  hipStream_t ax[3] = {k3_streams ? aux[si][0] : stream, k3_streams ? aux[si][1] : stream, k3_streams ? aux[si][2] : stream};
+  hipStream_t stream = (slot_streams && slot_stream[si]) ? slot_stream[si] : slot_stream[0];  // (shadows the member)
+  const bool k3s = k3_streams && aux[si][0];
+  hipStream_t ax[3] = {k3s ? aux[si][0] : stream, k3s ? aux[si][1] : stream, k3s ? aux[si][2] : stream};
   HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(sl.d_records, 0, L.size * B, stream));
   sl.timed = timing;
@@ -434,7 +435,7 @@ int g1s_diff::submit(int si) {
                        (const uint8_t *)sl.d_records, qp);
     const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
     // fork: the six accumulation kernels are independent and latency-bound -> four streams
-    if (k3_streams) {
+    if (k3s) {
       HIP_TRY(hipEventRecord(ev_fork[si], stream));
       for (int a = 0; a < 3; ++a) HIP_TRY(hipStreamWaitEvent(aux[si][a], ev_fork[si], 0));
     }
@@ -468,7 +469,7 @@ int g1s_diff::submit(int si) {
         launch_partial(ck, ax[2]);
       }
     }
-    if (k3_streams) {
+    if (k3s) {
       for (int a = 0; a < 3; ++a) {  // join
         HIP_TRY(hipEventRecord(ev_join[si][a], aux[si][a]));
         HIP_TRY(hipStreamWaitEvent(stream, ev_join[si][a], 0));
@@ -618,8 +619,7 @@ void g1s_diff::release() {
       if (e) (void)hipEventDestroy(e);
     sl = Slot{};
   }
-  if (d_lut) (void)hipFree(d_lut);
-  d_lut = nullptr;
+  d_lut = nullptr;  // shared per device
   for (int i = 0; i < 2; ++i) {
     if (slot_stream[i]) (void)hipStreamDestroy(slot_stream[i]);
     slot_stream[i] = nullptr;
@@ -699,20 +699,37 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   g->batch = batch;
   g->device = device;
   make_flat_consts(g->fc);
-  double lut[256];
-  for (int i = 0; i < 256; ++i) lut[i] = ((double)i) / 255.0;  // block normalisation, on the host
-  bool streams_ok = true;
-  for (int i = 0; i < 2 && streams_ok; ++i) {
-    streams_ok = hipStreamCreateWithFlags(&g->slot_stream[i], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&g->ev_fork[i], hipEventDisableTiming) == hipSuccess;
+  // One stream by default; per-slot and per-kernel streams only for experiments
+  // (G1S_SLOT_STREAMS / G1S_K3_STREAMS): creating streams costs ~0.1-0.2 ms each.
+  const bool want_slot = getenv("G1S_SLOT_STREAMS") != nullptr, want_k3 = getenv("G1S_K3_STREAMS") != nullptr;
+  bool streams_ok = hipStreamCreateWithFlags(&g->slot_stream[0], hipStreamNonBlocking) == hipSuccess;
+  if (streams_ok && want_slot)
+    streams_ok = hipStreamCreateWithFlags(&g->slot_stream[1], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && streams_ok && want_k3; ++i) {
+    streams_ok = hipEventCreateWithFlags(&g->ev_fork[i], hipEventDisableTiming) == hipSuccess;
     for (int a = 0; a < 3 && streams_ok; ++a)
       streams_ok = hipStreamCreateWithFlags(&g->aux[i][a], hipStreamNonBlocking) == hipSuccess &&
                    hipEventCreateWithFlags(&g->ev_join[i][a], hipEventDisableTiming) == hipSuccess;
   }
   g->stream = g->slot_stream[0];
-  if (!streams_ok ||
-      hipMalloc((void **)&g->d_lut, sizeof(lut)) != hipSuccess ||
-      hipMemcpy(g->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
+  // the p/255 table is the same for every generator: one device copy per device, kept
+  {
+    static std::mutex lut_mutex;
+    static double *lut_dev[64] = {nullptr};
+    std::lock_guard<std::mutex> lk(lut_mutex);
+    const int di = device & 63;
+    if (!lut_dev[di]) {
+      double lut[256];
+      for (int i = 0; i < 256; ++i) lut[i] = ((double)i) / 255.0;  // block normalisation, on the host
+      if (hipMalloc((void **)&lut_dev[di], sizeof(lut)) != hipSuccess ||
+          hipMemcpy(lut_dev[di], lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
+        lut_dev[di] = nullptr;
+        streams_ok = false;
+      }
+    }
+    g->d_lut = lut_dev[di];
+  }
+  if (!streams_ok) {
     g_global_error = std::string("HIP initialisation failed: ") + hipGetErrorString(hipGetLastError());
     g->release();
     delete g;

@@ -196,6 +196,26 @@ class DiffGenerator:
             self._keep.extend(keep)  # device planes must outlive the queued kernels
         self._check(self._L.g1s_diff_frame(self._h, C.byref(fs), C.byref(fd)))
 
+    # -- many frame pairs in one FFI call (g1s_diff_frames) -------------------------------
+    @staticmethod
+    def prepare_frames(pairs, xdec: int = 1, ydec: int = 1) -> "PreparedFrames":
+        """Marshal (source, denoised) pairs once; the result can be fed to
+        `diff_prepared` of any generator of the same format, any number of times."""
+        keep: list = []
+        n = len(pairs)
+        src = (G1SFrame * n)()
+        den = (G1SFrame * n)()
+        for i, (s, d) in enumerate(pairs):
+            src[i] = _as_frame(s, xdec, ydec).to_c(keep)
+            den[i] = _as_frame(d, xdec, ydec).to_c(keep)
+        return PreparedFrames(src, den, n, keep)
+
+    def diff_prepared(self, prepared: "PreparedFrames", sync_torch: bool = True) -> None:
+        if sync_torch and torch is not None and torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        self._keep.append(prepared)
+        self._check(self._L.g1s_diff_frames(self._h, prepared.src, prepared.den, prepared.n))
+
     def sync(self) -> None:
         self._check(self._L.g1s_diff_sync(self._h))
         self._keep.clear()
@@ -247,6 +267,14 @@ class DiffGenerator:
     def _check(self, rc: int) -> None:
         if rc != 0:
             raise G1SError(rc, self._L.g1s_diff_last_error(self._h).decode())
+
+
+@dataclass
+class PreparedFrames:
+    src: object
+    den: object
+    n: int
+    keep: list
 
 
 class Record:

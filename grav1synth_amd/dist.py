@@ -87,6 +87,12 @@ class ShardedDiff:
         self.generator.diff_frame(source, denoised, xdec, ydec, sync_torch=sync_torch)
         self._nframes += 1
 
+    def diff_prepared(self, prepared, width: int, height: int, nplanes: int, sync_torch: bool = True) -> None:
+        if self._shape is None:
+            self._shape = (width, height, 1 if self._luma_only else nplanes)
+        self.generator.diff_prepared(prepared, sync_torch=sync_torch)
+        self._nframes += prepared.n
+
     def finish(self) -> Optional[List[GrainTableSegment]]:
         if self.dist is None:
             return self.generator.finish()
