@@ -259,6 +259,55 @@ __device__ __forceinline__ void unpack8(const Px8 &p, const uint8_t *base, uint3
   }
 }
 
+// ---- packed 16-bit staging arithmetic ---------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+// 8 samples -> 4 dwords of two u16 each, already narrowed to 8 bits (frame_into_u8:
+// `(v >> (bd - 8)) as u8`).  Edge segments (state 2) take the per-sample path.
+__device__ __forceinline__ void to16(const Px8 &p, const uint8_t *base, uint32_t stride, int bps, int shift, int X0,
+                                     int Y, int pw, uint32_t (&h)[4]) {
+  if (p.state == 1) {
+    if (bps == 2) {
+      const uint32_t w[4] = {p.raw.x, p.raw.y, p.raw.z, p.raw.w};
+      const u16x2 sh = {(unsigned short)shift, (unsigned short)shift};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        h[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, w[k]) >> sh) & 0x00ff00ffu;
+    } else {
+      h[0] = __builtin_amdgcn_perm(0u, p.raw.x, 0x0c010c00u);
+      h[1] = __builtin_amdgcn_perm(0u, p.raw.x, 0x0c030c02u);
+      h[2] = __builtin_amdgcn_perm(0u, p.raw.y, 0x0c010c00u);
+      h[3] = __builtin_amdgcn_perm(0u, p.raw.y, 0x0c030c02u);
+    }
+  } else if (p.state == 2) {
+    int v[8];
+    unpack8(p, base, stride, bps, shift, X0, Y, pw, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = (uint32_t)v[2 * k] | ((uint32_t)v[2 * k + 1] << 16);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = 0;
+  }
+}
+// running min / max of packed i16 -> any |d| > 127 ?
+__device__ __forceinline__ bool range_bad(uint32_t mx, uint32_t mn) {
+  const int mxa = max((int)(short)(mx & 0xffffu), (int)(short)(mx >> 16));
+  const int mna = min((int)(short)(mn & 0xffffu), (int)(short)(mn >> 16));
+  return mxa > 127 || mna < -127;
+}
+
 // KIND: 0 = luma; 1 = chroma 4:2:0; 2 = chroma 4:2:2; 3 = chroma 4:4:4.
 template <int KIND>
 struct QShape {
@@ -370,7 +419,7 @@ struct Stager {
     const int pw = g.W >> S::SX;
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int x_o = bx * bw, y_o = by * bh;
-    bool bad = false;
+    uint32_t mx = 0, mn = 0;  // packed running max / min of the residuals
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
       const int it = tid + k * NT;
@@ -380,66 +429,69 @@ struct Stager {
         const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
         const int c = CHROMA ? 1 + pl : 0;
         const int X0 = x_o - 8 + 8 * sg, Y = y_o - S::UP + ty;
-        int sv[8], dv[8];
-        unpack8(ps[k][0], fp.src[c], fp.src_stride[c], g.src_bps, g.src_shift, X0, Y, pw, sv);
-        unpack8(pd[k][0], fp.den[c], fp.den_stride[c], g.den_bps, g.den_shift, X0, Y, pw, dv);
-        uint32_t lo = 0, hi = 0;
+        uint32_t hs[4], hv[4], d[4];
+        to16(ps[k][0], fp.src[c], fp.src_stride[c], g.src_bps, g.src_shift, X0, Y, pw, hs);
+        to16(pd[k][0], fp.den[c], fp.den_stride[c], g.den_bps, g.den_shift, X0, Y, pw, hv);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int d = sv[q] - dv[q];
-          bad |= (d > 127) | (d < -127);
-          const uint32_t b = (uint32_t)d & 0xffu;
-          if (q < 4) lo |= b << (8 * q); else hi |= b << (8 * (q - 4));
+        for (int q = 0; q < 4; ++q) {
+          d[q] = pk_sub(hs[q], hv[q]);
+          mx = pk_max(mx, d[q]);
+          mn = pk_min(mn, d[q]);
         }
+        const uint32_t lo = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u);
+        const uint32_t hi = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u);
         if (!CHROMA && sg >= 1 && sg <= 4 && ty < bh) {  // block proper -> luma sum of the source
-#pragma unroll
-          for (int q = 0; q < 8; ++q) lsum += sv[q];
+          lsum = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(hs[1], hs[0], 0x06040200u), 0u, (uint32_t)lsum);
+          lsum = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(hs[3], hs[2], 0x06040200u), 0u, (uint32_t)lsum);
         }
         *reinterpret_cast<uint2 *>(lds + pl * S::TILE_BYTES + ty * S::PITCH + 8 * sg) = make_uint2(lo, hi);
       } else if (LTERMS && it < NITEMS) {
         const int r = it - S::NTILE;
         const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
         const int X0 = (x_o + sg * S::LCH) << S::SX;
-        int L[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) L[q] = 0;
+        uint32_t dsum[4] = {0, 0, 0, 0};  // packed i16 residuals, summed over the LROWS luma rows
 #pragma unroll
         for (int q = 0; q < S::LROWS; ++q) {
           const int Y = ((y_o + y) << S::SY) + q;
-          int sv[8], dv[8];
-          unpack8(ps[k][q], fp.src[0], fp.src_stride[0], g.src_bps, g.src_shift, X0, Y, g.W, sv);
-          unpack8(pd[k][q], fp.den[0], fp.den_stride[0], g.den_bps, g.den_shift, X0, Y, g.W, dv);
+          uint32_t hs[4], hv[4];
+          to16(ps[k][q], fp.src[0], fp.src_stride[0], g.src_bps, g.src_shift, X0, Y, g.W, hs);
+          to16(pd[k][q], fp.den[0], fp.den_stride[0], g.den_bps, g.den_shift, X0, Y, g.W, hv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int d = sv[e] - dv[e];
-            bad |= (d > 127) | (d < -127);
-            L[e >> S::SX] += d;
-          }
-        }
-        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-#pragma unroll
-        for (int e = 0; e < S::LCH; ++e) {
-          const uint32_t av = (uint32_t)(L[e] >> 2) & 0xffu, bv = (uint32_t)(L[e] & 3);
-          if (e < 4) {
-            a0 |= av << (8 * e);
-            b0 |= bv << (8 * e);
-          } else {
-            a1 |= av << (8 * (e - 4));
-            b1 |= bv << (8 * (e - 4));
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t d = pk_sub(hs[e], hv[e]);
+            mx = pk_max(mx, d);
+            mn = pk_min(mn, d);
+            dsum[e] = pk_add(dsum[e], d);
           }
         }
         uint8_t *ta = lds + S::NPL * S::TILE_BYTES + y * S::PITCH + sg * S::LCH;
         uint8_t *tb = ta + S::LTILE_BYTES;
-        if (S::LCH == 8) {
-          *reinterpret_cast<uint2 *>(ta) = make_uint2(a0, a1);
-          *reinterpret_cast<uint2 *>(tb) = make_uint2(b0, b1);
-        } else {
+        if (S::SX == 1) {
+          // L = horizontal pair sums: 4 chroma samples per item
+          uint32_t a0 = 0, b0 = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int L = (int)(short)(dsum[e] & 0xffffu) + (int)(short)(dsum[e] >> 16);
+            a0 |= ((uint32_t)(L >> 2) & 0xffu) << (8 * e);
+            b0 |= (uint32_t)(L & 3) << (8 * e);
+          }
           *reinterpret_cast<uint32_t *>(ta) = a0;
           *reinterpret_cast<uint32_t *>(tb) = b0;
+        } else {
+          // L = the (row-summed) luma residual itself: 8 chroma samples per item
+          uint32_t a[2] = {0, 0}, b[2] = {0, 0};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int L0 = (int)(short)(dsum[e] & 0xffffu), L1 = (int)(short)(dsum[e] >> 16);
+            a[e >> 1] |= (((uint32_t)(L0 >> 2) & 0xffu) | (((uint32_t)(L1 >> 2) & 0xffu) << 8)) << (16 * (e & 1));
+            b[e >> 1] |= ((uint32_t)(L0 & 3) | ((uint32_t)(L1 & 3) << 8)) << (16 * (e & 1));
+          }
+          *reinterpret_cast<uint2 *>(ta) = make_uint2(a[0], a[1]);
+          *reinterpret_cast<uint2 *>(tb) = make_uint2(b[0], b[1]);
         }
       }
     }
-    return bad;
+    return range_bad(mx, mn);
   }
 };
 
