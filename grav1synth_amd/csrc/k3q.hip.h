@@ -34,7 +34,7 @@ namespace g1s {
 constexpr int kQLag = 3;
 constexpr int kQN = 24;
 constexpr int kNumLags = 46;            // distinct c_j - c_i (incl. 0) and -c_i
-constexpr int kNumLTerms = 24 * 2 + 5;  // (i,La),(i,Lb), LaLa, LaLb, LbLb, La*y, Lb*y
+constexpr int kNumLTerms = 24 + 2;      // (i,L) for the 24 neighbours, L*L, L*y  (L as ONE int8: |L| <= 127 or the area is deferred)
 constexpr int kMaxAreasPerWG = 128;     // int32 accumulators stay exact
 enum : uint8_t { kClsExt = 0, kClsInt = 1, kClsMix = 2 };
 
@@ -206,23 +206,28 @@ __device__ __forceinline__ void list_slice(int b, int N, int n, int &begin, int 
 
 // ---- 8 consecutive samples of a row (vector global load, narrowed later) ----
 struct Px8 {
-  uint4 raw;  // u16: 8 samples; u8: .x,.y hold 8 samples
-  int state;  // 0 = zero (outside the plane), 1 = raw valid, 2 = edge segment: per-sample loads later
+  // plain scalars (not HIP's uint4 wrapper): arrays of this struct must stay in VGPRs
+  uint32_t x, y, z, w;  // u16: 8 samples; u8: x, y hold 8 samples
+  int state;            // 0 = zero (outside the plane), 1 = raw valid, 2 = edge segment: per-sample loads later
 };
 __device__ __forceinline__ Px8 fetch8(const uint8_t *base, uint32_t stride, int bps, bool vec_ok, int X0, int Y,
                                       int pw, int ph) {
   Px8 r;
-  r.raw = make_uint4(0, 0, 0, 0);
+  r.x = r.y = r.z = r.w = 0;
   r.state = 0;
   if (Y < 0 || Y >= ph || X0 + 8 <= 0 || X0 >= pw) return r;
   if (X0 >= 0 && X0 + 8 <= pw && vec_ok) {
     gptr_u8 p = as_global(base) + (size_t)Y * stride + (size_t)X0 * bps;
     if (bps == 2) {
-      r.raw = gload4((gptr_u4)p);
+      const u32x4 v = *(gptr_u4)p;
+      r.x = v.x;
+      r.y = v.y;
+      r.z = v.z;
+      r.w = v.w;
     } else {
-      const uint2 v = gload2((gptr_u2)p);
-      r.raw.x = v.x;
-      r.raw.y = v.y;
+      const u32x2 v = *(gptr_u2)p;
+      r.x = v.x;
+      r.y = v.y;
     }
     r.state = 1;
   } else {
@@ -234,7 +239,7 @@ __device__ __forceinline__ void unpack8(const Px8 &p, const uint8_t *base, uint3
                                         int X0, int Y, int pw, int (&v)[8]) {
   if (p.state == 1) {
     if (bps == 2) {
-      const uint32_t w[4] = {p.raw.x, p.raw.y, p.raw.z, p.raw.w};
+      const uint32_t w[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         v[2 * k] = (int)(((w[k] & 0xffffu) >> shift) & 0xffu);
@@ -243,8 +248,8 @@ __device__ __forceinline__ void unpack8(const Px8 &p, const uint8_t *base, uint3
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        v[k] = (int)((p.raw.x >> (8 * k)) & 0xffu);
-        v[4 + k] = (int)((p.raw.y >> (8 * k)) & 0xffu);
+        v[k] = (int)((p.x >> (8 * k)) & 0xffu);
+        v[4 + k] = (int)((p.y >> (8 * k)) & 0xffu);
       }
     }
   } else if (p.state == 2) {
@@ -280,16 +285,16 @@ __device__ __forceinline__ void to16(const Px8 &p, const uint8_t *base, uint32_t
                                      int Y, int pw, uint32_t (&h)[4]) {
   if (p.state == 1) {
     if (bps == 2) {
-      const uint32_t w[4] = {p.raw.x, p.raw.y, p.raw.z, p.raw.w};
+      const uint32_t w[4] = {p.x, p.y, p.z, p.w};
       const u16x2 sh = {(unsigned short)shift, (unsigned short)shift};
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         h[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, w[k]) >> sh) & 0x00ff00ffu;
     } else {
-      h[0] = __builtin_amdgcn_perm(0u, p.raw.x, 0x0c010c00u);
-      h[1] = __builtin_amdgcn_perm(0u, p.raw.x, 0x0c030c02u);
-      h[2] = __builtin_amdgcn_perm(0u, p.raw.y, 0x0c010c00u);
-      h[3] = __builtin_amdgcn_perm(0u, p.raw.y, 0x0c030c02u);
+      h[0] = __builtin_amdgcn_perm(0u, p.x, 0x0c010c00u);
+      h[1] = __builtin_amdgcn_perm(0u, p.x, 0x0c030c02u);
+      h[2] = __builtin_amdgcn_perm(0u, p.y, 0x0c010c00u);
+      h[3] = __builtin_amdgcn_perm(0u, p.y, 0x0c030c02u);
     }
   } else if (p.state == 2) {
     int v[8];
@@ -337,7 +342,7 @@ struct QShape {
   static constexpr int SLOT = kChroma ? LROWS : 1;
   static constexpr int TILE_BYTES = TH * PITCH;
   static constexpr int LTILE_BYTES = BH * PITCH;
-  static constexpr int DATA_BYTES = NPL * TILE_BYTES + (kChroma ? 2 * LTILE_BYTES : 0);
+  static constexpr int DATA_BYTES = NPL * TILE_BYTES + (kChroma ? LTILE_BYTES : 0);
   static constexpr int WTILE_BYTES = (BH + kQLag) * PITCH;  // rows 0..BH+2
   static constexpr int NACC = kNumLags + (kChroma ? kNumLTerms : 0);
 };
@@ -363,25 +368,36 @@ struct Stager {
     const int x_o = bx * S::BW, y_o = by * S::BH;
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
+      // ONE straight-line path per (k, q) slot, parameters chosen by selects: every slot is
+      // written exactly once with a static index, so ps / pd stay in VGPRs.
       const int it = tid + k * NT;
-      if (it < S::NTILE) {
-        const int pl = it / (S::TH * S::SEGS);
-        const int r = it - pl * (S::TH * S::SEGS);
-        const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
-        const int c = CHROMA ? 1 + pl : 0;
-        const int X0 = x_o - 8 + 8 * sg, Y = y_o - S::UP + ty;
-        ps[k][0] = fetch8(fp.src[c], fp.src_stride[c], g.src_bps, (g.vec_mask >> c) & 1, X0, Y, pw, ph);
-        pd[k][0] = fetch8(fp.den[c], fp.den_stride[c], g.den_bps, (g.vec_mask >> (3 + c)) & 1, X0, Y, pw, ph);
-      } else if (LTERMS && it < NITEMS) {
-        const int r = it - S::NTILE;
-        const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
-        const int X0 = (x_o + sg * S::LCH) << S::SX;  // luma coordinates
+      const bool tile = it < S::NTILE;
+      const bool lit = LTERMS && !tile && it < NITEMS;
+      const int pl = it / (S::TH * S::SEGS);
+      const int r = it - pl * (S::TH * S::SEGS);
+      const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
+      const int rl = it - S::NTILE;
+      const int yl = rl / S::LSEGS, sgl = rl - yl * S::LSEGS;
+      // (no runtime index into fp: that would push the frame table to scratch memory)
+      const uint8_t *spt = CHROMA ? (pl ? fp.src[2] : fp.src[1]) : fp.src[0];
+      const uint8_t *dpt = CHROMA ? (pl ? fp.den[2] : fp.den[1]) : fp.den[0];
+      const uint32_t sstt = CHROMA ? (pl ? fp.src_stride[2] : fp.src_stride[1]) : fp.src_stride[0];
+      const uint32_t dstt = CHROMA ? (pl ? fp.den_stride[2] : fp.den_stride[1]) : fp.den_stride[0];
+      const int vst = CHROMA ? (pl ? (g.vec_mask >> 2) : (g.vec_mask >> 1)) : g.vec_mask;
+      const int vdt = CHROMA ? (pl ? (g.vec_mask >> 5) : (g.vec_mask >> 4)) : (g.vec_mask >> 3);
+      const uint8_t *sp = tile ? spt : fp.src[0];
+      const uint8_t *dp = tile ? dpt : fp.den[0];
+      const uint32_t sst = tile ? sstt : fp.src_stride[0];
+      const uint32_t dst = tile ? dstt : fp.den_stride[0];
+      const bool vs = ((tile ? vst : g.vec_mask) & 1) != 0, vd = ((tile ? vdt : (g.vec_mask >> 3)) & 1) != 0;
+      const int X0 = tile ? (x_o - 8 + 8 * sg) : ((x_o + sgl * S::LCH) << S::SX);
+      const int Yb = tile ? (y_o - S::UP + ty) : ((y_o + yl) << S::SY);
+      const int pwq = tile ? pw : g.W, phq = tile ? ph : g.H;
 #pragma unroll
-        for (int q = 0; q < S::LROWS; ++q) {
-          const int Y = ((y_o + y) << S::SY) + q;
-          ps[k][q] = fetch8(fp.src[0], fp.src_stride[0], g.src_bps, g.vec_mask & 1, X0, Y, g.W, g.H);
-          pd[k][q] = fetch8(fp.den[0], fp.den_stride[0], g.den_bps, (g.vec_mask >> 3) & 1, X0, Y, g.W, g.H);
-        }
+      for (int q = 0; q < S::SLOT; ++q) {
+        const bool valid = tile ? (q == 0) : lit;
+        ps[k][q] = fetch8(sp, sst, g.src_bps, vs, valid ? X0 : -64, Yb + q, pwq, phq);  // X0 = -64: outside -> zero
+        pd[k][q] = fetch8(dp, dst, g.den_bps, vd, valid ? X0 : -64, Yb + q, pwq, phq);
       }
     }
   }
@@ -420,6 +436,7 @@ struct Stager {
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int x_o = bx * bw, y_o = by * bh;
     uint32_t mx = 0, mn = 0;  // packed running max / min of the residuals
+    bool lbad = false;        // the luma residual sum L does not fit int8
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
       const int it = tid + k * NT;
@@ -427,11 +444,14 @@ struct Stager {
         const int pl = it / (S::TH * S::SEGS);
         const int r = it - pl * (S::TH * S::SEGS);
         const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
-        const int c = CHROMA ? 1 + pl : 0;
+        const uint8_t *sp = CHROMA ? (pl ? fp.src[2] : fp.src[1]) : fp.src[0];
+        const uint8_t *dp = CHROMA ? (pl ? fp.den[2] : fp.den[1]) : fp.den[0];
+        const uint32_t sst = CHROMA ? (pl ? fp.src_stride[2] : fp.src_stride[1]) : fp.src_stride[0];
+        const uint32_t dst = CHROMA ? (pl ? fp.den_stride[2] : fp.den_stride[1]) : fp.den_stride[0];
         const int X0 = x_o - 8 + 8 * sg, Y = y_o - S::UP + ty;
         uint32_t hs[4], hv[4], d[4];
-        to16(ps[k][0], fp.src[c], fp.src_stride[c], g.src_bps, g.src_shift, X0, Y, pw, hs);
-        to16(pd[k][0], fp.den[c], fp.den_stride[c], g.den_bps, g.den_shift, X0, Y, pw, hv);
+        to16(ps[k][0], sp, sst, g.src_bps, g.src_shift, X0, Y, pw, hs);
+        to16(pd[k][0], dp, dst, g.den_bps, g.den_shift, X0, Y, pw, hv);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           d[q] = pk_sub(hs[q], hv[q]);
@@ -465,33 +485,31 @@ struct Stager {
           }
         }
         uint8_t *ta = lds + S::NPL * S::TILE_BYTES + y * S::PITCH + sg * S::LCH;
-        uint8_t *tb = ta + S::LTILE_BYTES;
         if (S::SX == 1) {
-          // L = horizontal pair sums: 4 chroma samples per item
-          uint32_t a0 = 0, b0 = 0;
+          // L = horizontal pair sums: 4 chroma samples per item; must fit int8 like d
+          uint32_t a0 = 0;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int L = (int)(short)(dsum[e] & 0xffffu) + (int)(short)(dsum[e] >> 16);
-            a0 |= ((uint32_t)(L >> 2) & 0xffu) << (8 * e);
-            b0 |= (uint32_t)(L & 3) << (8 * e);
+            lbad |= (L > 127) | (L < -127);
+            a0 |= ((uint32_t)L & 0xffu) << (8 * e);
           }
           *reinterpret_cast<uint32_t *>(ta) = a0;
-          *reinterpret_cast<uint32_t *>(tb) = b0;
         } else {
           // L = the (row-summed) luma residual itself: 8 chroma samples per item
-          uint32_t a[2] = {0, 0}, b[2] = {0, 0};
+          uint32_t lmx = 0, lmn = 0;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int L0 = (int)(short)(dsum[e] & 0xffffu), L1 = (int)(short)(dsum[e] >> 16);
-            a[e >> 1] |= (((uint32_t)(L0 >> 2) & 0xffu) | (((uint32_t)(L1 >> 2) & 0xffu) << 8)) << (16 * (e & 1));
-            b[e >> 1] |= ((uint32_t)(L0 & 3) | ((uint32_t)(L1 & 3) << 8)) << (16 * (e & 1));
+            lmx = pk_max(lmx, dsum[e]);
+            lmn = pk_min(lmn, dsum[e]);
           }
-          *reinterpret_cast<uint2 *>(ta) = make_uint2(a[0], a[1]);
-          *reinterpret_cast<uint2 *>(tb) = make_uint2(b[0], b[1]);
+          lbad |= range_bad(lmx, lmn);
+          *reinterpret_cast<uint2 *>(ta) = make_uint2(__builtin_amdgcn_perm(dsum[1], dsum[0], 0x06040200u),
+                                                       __builtin_amdgcn_perm(dsum[3], dsum[2], 0x06040200u));
         }
       }
     }
-    return range_bad(mx, mn);
+    return range_bad(mx, mn) || lbad;
   }
 };
 
@@ -661,9 +679,8 @@ __global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(c
       if (CHROMA) {
         // p-centric L terms under the block's own window (Wc; all ones for INT areas)
         const uint32_t *ta = reinterpret_cast<const uint32_t *>(lds + S::NPL * S::TILE_BYTES);
-        const uint32_t Lar = ta[row * S::PITCH_DW + lg];
-        const uint32_t Lbr = ta[S::LTILE_BYTES / 4 + row * S::PITCH_DW + lg];
-        const uint32_t La = Lar & Wc, Lb = Lbr & Wc;
+        const uint32_t Lr = ta[row * S::PITCH_DW + lg];
+        const uint32_t Lm = Lr & Wc;
         int *al = acc + kNumLags;
 #pragma unroll
         for (int cy = -3; cy <= 0; ++cy) {
@@ -677,15 +694,11 @@ __global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(c
             if (cx < 0) v = alignbyte(u2, u1, 4 + cx);
             else if (cx == 0) v = u2;
             else v = alignbyte(u3, u2, cx);
-            al[2 * k] = sdot4((int)La, (int)v, al[2 * k]);
-            al[2 * k + 1] = sdot4((int)Lb, (int)v, al[2 * k + 1]);
+            al[k] = sdot4((int)Lm, (int)v, al[k]);
           }
         }
-        al[48] = sdot4((int)La, (int)Lar, al[48]);
-        al[49] = sdot4((int)La, (int)Lbr, al[49]);
-        al[50] = sdot4((int)Lb, (int)Lbr, al[50]);
-        al[51] = sdot4((int)La, (int)c0, al[51]);
-        al[52] = sdot4((int)Lb, (int)c0, al[52]);
+        al[24] = sdot4((int)Lm, (int)Lr, al[24]);
+        al[25] = sdot4((int)Lm, (int)c0, al[25]);
       }
     }
     // block statistics (only meaningful / stored for flat blocks)
@@ -1147,7 +1160,7 @@ __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *_
   if (threadIdx.x < kQN) {
     const int i = threadIdx.x;
     ar[nc * nc + i] += lag[lag_index(-coord_x(i), -coord_y(i))];  // Sb[i]
-    if (chroma) ar[i * nc + kQN] += 4 * lag[kNumLags + 2 * i] + lag[kNumLags + 2 * i + 1];
+    if (chroma) ar[i * nc + kQN] += lag[kNumLags + i];
     // masked products of anchor i
     const int h = p_in_half(0, i) ? 0 : 1;
     int idx = 0;
@@ -1159,9 +1172,8 @@ __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *_
     ar[nc * nc + i] += t[k];
   }
   if (chroma && threadIdx.x == 32) {
-    const long long *t = lag + kNumLags + 48;
-    ar[kQN * nc + kQN] += 16 * t[0] + 8 * t[1] + t[2];
-    ar[nc * nc + kQN] += 4 * t[3] + t[4];
+    ar[kQN * nc + kQN] += lag[kNumLags + 24];  // S[L][L]
+    ar[nc * nc + kQN] += lag[kNumLags + 25];   // Sb[L]
   }
   if (threadIdx.x == 64) ar[nc * nc + nc] += lag[kQPart - 1];
 }
