@@ -128,7 +128,9 @@ struct Slot {
   uint8_t *h_records = nullptr;  // pinned
   uint8_t *d_flags = nullptr;
   int32_t *d_partials = nullptr;   // k3_interior chunk partials, then k3_mixed chunk partials
-  uint8_t *d_defer = nullptr;      // area classes [batch][2][nblocks] + todo list [batch][2][nblocks]
+  uint8_t *d_defer = nullptr;      // area classes, bad-block flags, area lists and their counts
+  uint8_t *d_k0 = nullptr;         // K0 int8 planes [batch] x PlaneSet::frame_bytes
+  uint32_t *d_pgl = nullptr;       // partial-group lists [batch][2][pg_cap] + counts [batch][2]
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
   hipEvent_t done = nullptr;
@@ -142,10 +144,12 @@ struct Slot {
 // (one per video, or one per bench step) reuse them.
 struct SlotKey {
   int device;
-  size_t planes, records, flags, partials, defer, stage;
+  size_t planes, records, flags, partials, defer, stage, k0, pgl;
+  int W, H, xdec, ydec, nplanes;  // the zeroed padding of the K0 planes depends on the exact geometry
   bool operator==(const SlotKey &o) const {
     return device == o.device && planes == o.planes && records == o.records && flags == o.flags &&
-           partials == o.partials && defer == o.defer && stage == o.stage;
+           partials == o.partials && defer == o.defer && stage == o.stage && k0 == o.k0 && pgl == o.pgl &&
+           W == o.W && H == o.H && xdec == o.xdec && ydec == o.ydec && nplanes == o.nplanes;
   }
 };
 struct CachedSlot {
@@ -177,6 +181,8 @@ struct g1s_diff {
   double *d_lut = nullptr;
   int fast_chunks = 0, mix_chunks = 0;
   size_t defer_bytes = 0;
+  PlaneSet ps{};
+  uint32_t pg_cap = 0;
   SlotKey slot_key{};
   Slot slots[2];
   int cur = 0;
@@ -268,21 +274,24 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     frame_bytes += ((pw * s->bytes_per_sample + 15) & ~size_t(15)) * ph;
     frame_bytes += ((pw * d->bytes_per_sample + 15) & ~size_t(15)) * ph;
   }
-  size_t partial_bytes = 0;
+  size_t partial_bytes = 0, k0_bytes = 0, pgl_bytes = 0;
   if (lag == kQLag) {
     // interior: ~24 areas per workgroup (many small workgroups hide the staging latency);
-    // mixed: fewer, larger workgroups (189 accumulators to reduce at the end), <= 128 areas each
-    // (multiples of 8: the list slices are XCD-aware)
+    // mixed: fewer, larger workgroups, <= 128 areas each (multiples of 8: the list slices are XCD-aware)
     fast_chunks = (std::max(64, (g.nblocks + 23) / 24) + 7) & ~7;
     mix_chunks = (std::max(64, (g.nblocks + 63) / 64) + 7) & ~7;
     partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart);
     const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
-    // [cls][todo][lists u32 x4 per frame][counts]
-    defer_bytes = 2 * cls_bytes + sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 8) +
-                  (size_t)batch * 2 * g.nblocks * 32;  // + windows per area
+    // [cls][bad][lists u32 x6 per frame][counts]
+    defer_bytes = 2 * cls_bytes + sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 8);
+    ps = make_planeset(g);
+    k0_bytes = (size_t)ps.frame_bytes * batch;
+    pg_cap = (uint32_t)g.nblocks * 256u;
+    pgl_bytes = sizeof(uint32_t) * ((size_t)batch * 2 * pg_cap + (size_t)batch * 2);
   }
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
-                     partial_bytes, defer_bytes, frame_bytes * batch};
+                     partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes,
+                     g.W, g.H, g.xdec, g.ydec, g.nplanes};
   for (Slot &sl : slots) {
     {
       std::lock_guard<std::mutex> lk(g_cache_mutex);
@@ -305,6 +314,9 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     if (partial_bytes) {
       HIP_TRY(hipMalloc((void **)&sl.d_partials, partial_bytes));
       HIP_TRY(hipMalloc((void **)&sl.d_defer, defer_bytes));
+      HIP_TRY(hipMalloc((void **)&sl.d_k0, k0_bytes));
+      HIP_TRY(hipMemset(sl.d_k0, 0, k0_bytes));  // the padding of the w8 planes stays zero for good
+      HIP_TRY(hipMalloc((void **)&sl.d_pgl, pgl_bytes));
     }
     HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
@@ -425,11 +437,28 @@ int g1s_diff::submit(int si) {
     HIP_TRY(hipMemsetAsync(sl.d_partials, 0, sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart), stream));
     const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
     qp.cls = sl.d_defer;
-    qp.todo = sl.d_defer + cls_bytes;
+    qp.bad = sl.d_defer + cls_bytes;
     qp.lists = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes);
     qp.counts = qp.lists + (size_t)batch * 6 * g.nblocks;
-    qp.winbuf = reinterpret_cast<uint8_t *>(qp.counts + (size_t)batch * 8);
+    qp.pg_cap = pg_cap;
+    qp.pglist = sl.d_pgl;
+    qp.pgcount = sl.d_pgl + (size_t)batch * 2 * pg_cap;
+    qp.planes = sl.d_k0;
+    qp.ps = ps;
+    HIP_TRY(hipMemsetAsync(qp.bad, 0, cls_bytes, stream));
     HIP_TRY(hipMemsetAsync(qp.counts, 0, sizeof(uint32_t) * (size_t)batch * 6, stream));
+    HIP_TRY(hipMemsetAsync(qp.pgcount, 0, sizeof(uint32_t) * (size_t)batch * 2, stream));
+    {
+      // K0: one pass over the source / denoised planes -> int8 residual, L and window planes + block statistics
+      const dim3 gr((g.nbw + 1) / 2, g.nbh, B);
+#define G1S_K0(SB, DB) \
+  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, stream, sl.d_planes, g, ps, sl.d_k0, qp.bad, sl.d_records)
+      if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);
+      else if (g.src_bps == 1) G1S_K0(1, 2);
+      else if (g.den_bps == 1) G1S_K0(2, 1);
+      else G1S_K0(2, 2);
+#undef G1S_K0
+    }
     const int kinds = g.nplanes == 3 ? 2 : 1;
     hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + 255) / 256, kinds, B), dim3(256), 0, stream, g,
                        (const uint8_t *)sl.d_records, qp);
@@ -441,39 +470,33 @@ int g1s_diff::submit(int si) {
     }
     auto launch_lag = [&](int K, bool mixed, hipStream_t st) {
       const dim3 gr(mixed ? mix_chunks : fast_chunks, 1, B);
-#define G1S_LAG(KK)                                                                                              \
-  if (mixed)                                                                                                     \
-    hipLaunchKernelGGL((k3_lag<KK, true, kLagWaves>), gr, dim3(QShape<KK>::THREADS), 0, st, sl.d_planes, g, qp, sl.d_records); \
-  else                                                                                                           \
-    hipLaunchKernelGGL((k3_lag<KK, false, kLagWaves>), gr, dim3(QShape<KK>::THREADS), 0, st, sl.d_planes, g, qp, sl.d_records);
+#define G1S_LAG(KK)                                                                                  \
+  if (mixed)                                                                                         \
+    hipLaunchKernelGGL((k3_lag<KK, true>), gr, dim3(QShape<KK>::THREADS), 0, st, g, qp);              \
+  else                                                                                               \
+    hipLaunchKernelGGL((k3_lag<KK, false>), gr, dim3(QShape<KK>::THREADS), 0, st, g, qp);
       if (K == 0) { G1S_LAG(0) }
       else if (K == 1) { G1S_LAG(1) }
       else if (K == 2) { G1S_LAG(2) }
       else { G1S_LAG(3) }
 #undef G1S_LAG
     };
-    auto launch_partial = [&](int K, hipStream_t st) {
-      const dim3 pg(mix_chunks, 1, B), pb(256);
-      if (K == 0) hipLaunchKernelGGL(k3_partial<0>, pg, pb, 0, st, sl.d_planes, g, qp, sl.d_records);
-      else if (K == 1) hipLaunchKernelGGL(k3_partial<1>, pg, pb, 0, st, sl.d_planes, g, qp, sl.d_records);
-      else if (K == 2) hipLaunchKernelGGL(k3_partial<2>, pg, pb, 0, st, sl.d_planes, g, qp, sl.d_records);
-      else hipLaunchKernelGGL(k3_partial<3>, pg, pb, 0, st, sl.d_planes, g, qp, sl.d_records);
-    };
     launch_lag(0, false, stream);
     if (ck) launch_lag(ck, false, ax[0]);
     if (qp.mixed_fast) {
       launch_lag(0, true, ax[1]);
-      launch_partial(0, ax[1]);
-      if (ck) {
-        launch_lag(ck, true, ax[2]);
-        launch_partial(ck, ax[2]);
-      }
+      if (ck) launch_lag(ck, true, ax[2]);
     }
     if (k3s) {
       for (int a = 0; a < 3; ++a) {  // join
         HIP_TRY(hipEventRecord(ev_join[si][a], aux[si][a]));
         HIP_TRY(hipStreamWaitEvent(stream, ev_join[si][a], 0));
       }
+    }
+    if (qp.mixed_fast) {
+      // <= pg_cap / (chunks * 256) = nblocks / chunks steps per lane; the int32 wave sums need < 520
+      const int chunks = std::max(std::max(8, std::min(64, g.nblocks / 128)), (g.nblocks + 255) / 256);
+      hipLaunchKernelGGL(k3_partial_dense, dim3(chunks, kPParts, B * g.nplanes), dim3(256), 0, stream, g, qp);
     }
     hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, qp, sl.d_records);
     const int chunks = std::min(64, g.nblocks);
@@ -613,6 +636,8 @@ void g1s_diff::release() {
     if (sl.d_flags) (void)hipFree(sl.d_flags);
     if (sl.d_partials) (void)hipFree(sl.d_partials);
     if (sl.d_defer) (void)hipFree(sl.d_defer);
+    if (sl.d_k0) (void)hipFree(sl.d_k0);
+    if (sl.d_pgl) (void)hipFree(sl.d_pgl);
     if (sl.d_stage) (void)hipFree(sl.d_stage);
     if (sl.done) (void)hipEventDestroy(sl.done);
     for (auto &e : sl.ev)

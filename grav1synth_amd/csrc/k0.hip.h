@@ -1,0 +1,356 @@
+// k0.hip.h -- K0: the one streaming pass over the source and denoised planes.
+//
+// Everything pixel-sized that the AR accumulation (K3, lag 3) needs is a function of
+//     d(q) = src8(q) - den8(q),   src8 = (v >> (bd - 8)) as u8   (av1-grain util.rs frame_into_u8)
+// so K0 reads the 8/16-bit planes ONCE (coalesced, vector loads) and leaves compact int8
+// planes behind for the many overlapping tile reads of K3:
+//     d8[c]   residual of component c, as int8 (a block with some |d| > 127 is flagged
+//             `bad` and its areas go to the exact int32 kernel instead);
+//     L8      chroma-resolution sum of the co-located luma residuals (the extra chroma
+//             regressor of add_block_observations before its division), int8, flagged likewise;
+//     w8[k]   0xFF / 0x00: sample lies in the observation window of its (flat) block,
+//             per plane kind k (luma, chroma);
+// plus the per-block noise statistics of the flat blocks (get_block_mean / get_noise_var:
+// exact integer sums of src8, d, d^2), straight into the frame record.
+//
+// Plane layout (one frame): sample (x, y) of a d8 / w8 plane at byte
+//     (y + kPadY) * pitch + kPadX + x,     pitch = nbw * bw + 16,  rows = nbh * bh + 2 * kPadY
+// so that the K3 tile of block area (bx, by), x in -8 .. bw+7, starts at the 16-byte aligned
+// byte bx * bw of its rows; the padding is zeroed once and never written.  L8 has no halo:
+// sample (x, y) at byte y * lpitch + x, lpitch = nbw * bw.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hip.h"
+
+namespace g1s {
+
+constexpr int kQLag = 3;
+constexpr int kPadX = 8, kPadY = 3;
+
+struct PlaneSet {
+  uint32_t pitch[2];   // d8 / w8 row pitch per kind (0 luma, 1 chroma)
+  uint32_t lpitch;     // L8 row pitch
+  uint32_t off_d[3];   // byte offsets inside one frame's plane set
+  uint32_t off_w[2];
+  uint32_t off_l;
+  uint32_t frame_bytes;
+};
+
+inline PlaneSet make_planeset(const Geom &g) {
+  PlaneSet ps{};
+  uint32_t off = 0;
+  auto take = [&](uint32_t bytes) {
+    const uint32_t o = off;
+    off += (bytes + 255u) & ~255u;
+    return o;
+  };
+  const int kinds = g.nplanes == 3 ? 2 : 1;
+  uint32_t plane_bytes[2] = {0, 0};
+  for (int k = 0; k < kinds; ++k) {
+    const int bw = kBlock >> (k ? g.xdec : 0), bh = kBlock >> (k ? g.ydec : 0);
+    ps.pitch[k] = (uint32_t)(g.nbw * bw + 16);
+    plane_bytes[k] = ps.pitch[k] * (uint32_t)(g.nbh * bh + 2 * kPadY) + 16;
+  }
+  ps.off_d[0] = take(plane_bytes[0]);
+  ps.off_w[0] = take(plane_bytes[0]);
+  if (kinds == 2) {
+    ps.off_d[1] = take(plane_bytes[1]);
+    ps.off_d[2] = take(plane_bytes[1]);
+    ps.off_w[1] = take(plane_bytes[1]);
+    ps.lpitch = (uint32_t)(g.nbw * (kBlock >> g.xdec));
+    ps.off_l = take(ps.lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec)) + 16);
+  }
+  ps.frame_bytes = off;
+  return ps;
+}
+
+// full-wave integer sum, all in the VALU (DPP): quad swaps, half-row / row mirrors, then
+// the row broadcasts; the total lands in lane 63 and is read back as a scalar.
+__device__ __forceinline__ int wave_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---------------------------------------------------------------------------------
+// window of a block (libaom add_block_observations), in samples of its plane
+// ---------------------------------------------------------------------------------
+struct Win {
+  int flat, xs, xe, ys, ye;
+};
+__device__ __forceinline__ Win block_window(const uint8_t *mask, int nbw, int nbh, int bx, int by, int bw, int bh,
+                                            int pw, int ph) {
+  Win w{0, 0, 0, 0, 0};
+  if (bx < 0 || by < 0 || bx >= nbw || by >= nbh) return w;
+  if (!mask[by * nbw + bx]) return w;
+  w.flat = 1;
+  w.ys = (by > 0 && mask[(by - 1) * nbw + bx]) ? 0 : kQLag;
+  w.xs = (bx > 0 && mask[by * nbw + bx - 1]) ? 0 : kQLag;
+  w.ye = min(ph - by * bh, bh);
+  w.xe = min(pw - bx * bw - kQLag, (bx + 1 < nbw && mask[by * nbw + bx + 1]) ? bw : (bw - kQLag));
+  if (w.xe <= w.xs || w.ye <= w.ys) w.flat = 0;  // empty window
+  return w;
+}
+__device__ __forceinline__ int window_at(const uint8_t *mask, int nbw, int nbh, int bw, int bh, int pw, int ph, int X,
+                                         int Y) {
+  if (X < 0 || Y < 0 || X >= pw || Y >= ph) return 0;
+  const int bx = X / bw, by = Y / bh;
+  const Win w = block_window(mask, nbw, nbh, bx, by, bw, bh, pw, ph);
+  const int lx = X - bx * bw, ly = Y - by * bh;
+  return w.flat && lx >= w.xs && lx < w.xe && ly >= w.ys && ly < w.ye;
+}
+// bytes lx0 .. lx0+N-1 of a window row as 0xFF / 0x00 (N = 4 or 8, little endian)
+__device__ __forceinline__ unsigned long long window_bytes(const Win &w, int lx0, int ly, int nbytes) {
+  if (!w.flat || ly < w.ys || ly >= w.ye) return 0ull;
+  const int lo = min(max(w.xs - lx0, 0), nbytes), hi = min(max(w.xe - lx0, 0), nbytes);
+  if (hi <= lo) return 0ull;
+  const unsigned long long upto_hi = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
+  const unsigned long long upto_lo = lo >= 8 ? ~0ull : ((1ull << (8 * lo)) - 1ull);
+  return upto_hi & ~upto_lo;
+}
+
+// ---- packed 16-bit arithmetic (two samples per dword) ------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ int pk_lo(uint32_t a) { return (int)(short)(a & 0xffffu); }
+__device__ __forceinline__ int pk_hi(uint32_t a) { return (int)a >> 16; }
+// running min / max of packed i16 -> does some value not fit int8 (symmetric: |v| > 127) ?
+__device__ __forceinline__ bool range_bad(uint32_t mx, uint32_t mn) {
+  return max(pk_lo(mx), pk_hi(mx)) > 127 || min(pk_lo(mn), pk_hi(mn)) < -127;
+}
+// two packed-i16 dwords (4 values) -> 4 bytes (low byte of each)
+__device__ __forceinline__ uint32_t pk_bytes(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
+
+// N (4 or 8) consecutive samples of a row, narrowed to 8 bits, two per dword.  Samples
+// outside the plane read as 0.
+template <int BPS, int N>
+__device__ __forceinline__ void load_narrow(const uint8_t *base, uint32_t stride, int shift, bool vec_ok, int X0, int Y,
+                                            int pw, int ph, uint32_t (&h)[N / 2]) {
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) h[k] = 0;
+  if (Y >= ph || X0 >= pw) return;
+  if (vec_ok && X0 + N <= pw) {
+    gptr_u8 p = as_global(base) + (size_t)Y * stride + (size_t)X0 * BPS;
+    if (BPS == 2) {
+      const u16x2 sh = {(unsigned short)shift, (unsigned short)shift};
+      uint32_t w[N / 2];
+      if constexpr (N == 8) {
+        const u32x4 v = *(gptr_u4)p;
+        w[0] = v.x;
+        w[1] = v.y;
+        w[N / 2 - 2] = v.z;
+        w[N / 2 - 1] = v.w;
+      } else {
+        const u32x2 v = *(gptr_u2)p;
+        w[0] = v.x;
+        w[1] = v.y;
+      }
+#pragma unroll
+      for (int k = 0; k < N / 2; ++k) h[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, w[k]) >> sh) & 0x00ff00ffu;
+    } else {
+      uint32_t b0, b1 = 0;
+      if constexpr (N == 8) {
+        const u32x2 v = *(gptr_u2)p;
+        b0 = v.x;
+        b1 = v.y;
+      } else {
+        b0 = *(const G1S_GLOBAL uint32_t *)p;
+      }
+      h[0] = __builtin_amdgcn_perm(0u, b0, 0x0c010c00u);
+      h[1] = __builtin_amdgcn_perm(0u, b0, 0x0c030c02u);
+      if constexpr (N == 8) {
+        h[N / 2 - 2] = __builtin_amdgcn_perm(0u, b1, 0x0c010c00u);
+        h[N / 2 - 1] = __builtin_amdgcn_perm(0u, b1, 0x0c030c02u);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int X = X0 + k;
+      const uint32_t v = X < pw ? (uint32_t)load_px<BPS>(base, stride, shift, X, Y) : 0u;
+      h[k >> 1] |= v << (16 * (k & 1));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k0_residual<SBPS, DBPS>: grid = (ceil(nbw / 2), nbh, batch), block = 256.
+// A workgroup owns two horizontally adjacent blocks (128-byte rows of 16-bit luma).
+//   luma:   wave w -> block w & 1, rows (w >> 1) * 16 .. +15; lane -> (row, 8-sample segment)
+//   chroma: wave w -> component 1 + (w >> 1), block w & 1; lanes stride over 4-sample items
+// Runs after K2 (it needs the flat mask for the windows and to know which statistics to keep).
+// ---------------------------------------------------------------------------------
+template <int SBPS, int DBPS>
+__global__ __launch_bounds__(256) void k0_residual(const FramePlanes *__restrict__ frames, Geom g, PlaneSet ps,
+                                                   uint8_t *__restrict__ planes, uint8_t *__restrict__ bad,
+                                                   uint8_t *__restrict__ records) {
+  __shared__ int s_luma[4][4];    // per wave: sum d, sum d^2, sum src8, flags (1: |d| > 127, 2: |L| > 127)
+  __shared__ int s_chroma[4][3];  // per wave: sum d, sum d^2, flag
+  const int frame = blockIdx.z, by = blockIdx.y;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int b = wave & 1;
+  const int bx = 2 * (int)blockIdx.x + b;
+  const bool active = bx < g.nbw;
+  const FramePlanes fp = frames[frame];
+  uint8_t *fbase = planes + (size_t)frame * ps.frame_bytes;
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  const uint8_t *mask = rec + g.off_mask;
+  const bool chroma = g.nplanes == 3;
+  const int sx = g.xdec, sy = g.ydec;
+
+  // ------------------------------- luma -------------------------------
+  {
+    const int row = (wave >> 1) * 16 + (lane >> 2), seg = lane & 3;
+    const int X0 = bx * kBlock + seg * 8, Y = by * kBlock + row;
+    uint32_t hs[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0}, d[4];
+    if (active) {
+      load_narrow<SBPS, 8>(fp.src[0], fp.src_stride[0], g.src_shift, (g.vec_mask & 1) != 0, X0, Y, g.W, g.H, hs);
+      load_narrow<DBPS, 8>(fp.den[0], fp.den_stride[0], g.den_shift, (g.vec_mask & 8) != 0, X0, Y, g.W, g.H, hv);
+    }
+    uint32_t mx = 0, mn = 0;
+    int sd = 0, sd2 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      d[k] = pk_sub(hs[k], hv[k]);
+      mx = pk_max(mx, d[k]);
+      mn = pk_min(mn, d[k]);
+      const int a0 = pk_lo(d[k]), a1 = pk_hi(d[k]);
+      sd += a0 + a1;
+      sd2 += a0 * a0 + a1 * a1;
+    }
+    int ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[0], hs[1]), 0u, 0u);
+    ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[2], hs[3]), 0u, (uint32_t)ls);
+    int flags = range_bad(mx, mn) ? 1 : 0;
+    if (active) {
+      const size_t o = (size_t)(Y + kPadY) * ps.pitch[0] + kPadX + X0;
+      *reinterpret_cast<uint2 *>(fbase + ps.off_d[0] + o) = make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
+      const Win w = block_window(mask, g.nbw, g.nbh, bx, by, kBlock, kBlock, g.W, g.H);
+      const unsigned long long wb = window_bytes(w, seg * 8, row, 8);
+      *reinterpret_cast<uint2 *>(fbase + ps.off_w[0] + o) = make_uint2((uint32_t)wb, (uint32_t)(wb >> 32));
+    }
+    if (chroma) {
+      // L = sum of the (1 << sx) x (1 << sy) luma residuals under a chroma sample
+      uint32_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = sy ? pk_add(d[k], (uint32_t)__shfl_down((int)d[k], 4, 64)) : d[k];  // + next row
+      const bool store_row = active && (sy == 0 || (row & 1) == 0);
+      const int cy = Y >> sy;
+      uint32_t lmx = 0, lmn = 0;
+      if (sx) {
+        int L[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L[k] = pk_lo(v[k]) + pk_hi(v[k]);
+        const uint32_t p0 = ((uint32_t)L[0] & 0xffffu) | ((uint32_t)L[1] << 16);
+        const uint32_t p1 = ((uint32_t)L[2] & 0xffffu) | ((uint32_t)L[3] << 16);
+        lmx = pk_max(p0, p1);
+        lmn = pk_min(p0, p1);
+        if (store_row)
+          *reinterpret_cast<uint32_t *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + (X0 >> 1)) = pk_bytes(p0, p1);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          lmx = pk_max(lmx, v[k]);
+          lmn = pk_min(lmn, v[k]);
+        }
+        if (store_row)
+          *reinterpret_cast<uint2 *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + X0) =
+              make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
+      }
+      if (store_row && range_bad(lmx, lmn)) flags |= 2;
+    }
+    sd = wave_sum(sd);
+    sd2 = wave_sum(sd2);
+    ls = wave_sum(ls);
+    const int f1 = __any(flags & 1) ? 1 : 0, f2 = __any(flags & 2) ? 2 : 0;
+    if (lane == 0) {
+      s_luma[wave][0] = sd;
+      s_luma[wave][1] = sd2;
+      s_luma[wave][2] = ls;
+      s_luma[wave][3] = f1 | f2;
+    }
+  }
+  // ------------------------------- chroma -------------------------------
+  if (chroma) {
+    const int c = 1 + (wave >> 1);
+    const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
+    const int segs = bw >> 2, items = segs * bh;
+    const uint8_t *sp = c == 1 ? fp.src[1] : fp.src[2];
+    const uint8_t *dp = c == 1 ? fp.den[1] : fp.den[2];
+    const uint32_t sst = c == 1 ? fp.src_stride[1] : fp.src_stride[2];
+    const uint32_t dst = c == 1 ? fp.den_stride[1] : fp.den_stride[2];
+    const bool vs = ((g.vec_mask >> c) & 1) != 0, vd = ((g.vec_mask >> (3 + c)) & 1) != 0;
+    uint8_t *dplane = fbase + (c == 1 ? ps.off_d[1] : ps.off_d[2]);
+    Win w{0, 0, 0, 0, 0};
+    if (active && c == 1) w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph);
+    uint32_t mx = 0, mn = 0;
+    int sd = 0, sd2 = 0;
+    if (active) {
+      for (int it = lane; it < items; it += 64) {
+        const int row = it / segs, seg = it - row * segs;
+        const int X0 = bx * bw + seg * 4, Y = by * bh + row;
+        uint32_t hs[2], hv[2];
+        load_narrow<SBPS, 4>(sp, sst, g.src_shift, vs, X0, Y, pw, ph, hs);
+        load_narrow<DBPS, 4>(dp, dst, g.den_shift, vd, X0, Y, pw, ph, hv);
+        const uint32_t d0 = pk_sub(hs[0], hv[0]), d1 = pk_sub(hs[1], hv[1]);
+        mx = pk_max(mx, pk_max(d0, d1));
+        mn = pk_min(mn, pk_min(d0, d1));
+        const int a0 = pk_lo(d0), a1 = pk_hi(d0), a2 = pk_lo(d1), a3 = pk_hi(d1);
+        sd += a0 + a1 + a2 + a3;
+        sd2 += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+        const size_t o = (size_t)(Y + kPadY) * ps.pitch[1] + kPadX + X0;
+        *reinterpret_cast<uint32_t *>(dplane + o) = pk_bytes(d0, d1);
+        if (c == 1) *reinterpret_cast<uint32_t *>(fbase + ps.off_w[1] + o) = (uint32_t)window_bytes(w, seg * 4, row, 4);
+      }
+    }
+    sd = wave_sum(sd);
+    sd2 = wave_sum(sd2);
+    const int f = __any(range_bad(mx, mn)) ? 1 : 0;
+    if (lane == 0) {
+      s_chroma[wave][0] = sd;
+      s_chroma[wave][1] = sd2;
+      s_chroma[wave][2] = f;
+    }
+  }
+  __syncthreads();
+  if (tid < 2) {
+    const int bxo = 2 * (int)blockIdx.x + tid;
+    if (bxo < g.nbw) {
+      const int blk = by * g.nbw + bxo;
+      const int lf = s_luma[tid][3] | s_luma[tid + 2][3];
+      if (lf & 1) bad[(size_t)frame * 2 * g.nblocks + blk] = 1;
+      if (chroma && ((lf & 2) || s_chroma[tid][2] || s_chroma[tid + 2][2]))
+        bad[((size_t)frame * 2 + 1) * g.nblocks + blk] = 1;
+      if (mask[blk]) {  // noise statistics of the flat blocks
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = s_luma[tid][0] + s_luma[tid + 2][0];
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)(s_luma[tid][1] + s_luma[tid + 2][1]);
+        reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)(s_luma[tid][2] + s_luma[tid + 2][2]);
+        if (chroma) {
+          reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = s_chroma[tid][0];
+          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)s_chroma[tid][1];
+          reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = s_chroma[tid + 2][0];
+          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)s_chroma[tid + 2][1];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace g1s

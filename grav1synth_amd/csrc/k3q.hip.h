@@ -17,25 +17,26 @@
 // The chroma cross terms sum_p w(p) L(p) d(p+c_i), sum w L^2, sum w L d stay p-centric
 // under the block's own window (a separate, consistent partition).
 //
-//   k3_classify          per (frame, kind, area): class + compacted INT / MIX lists
-//   k3_lag<KIND, false>  INT areas: 46 (+53 chroma) v_dot4c_i32_i8 per group
-//   k3_lag<KIND, true>   MIX areas: the same for their FULL groups (+ L terms, statistics)
-//   k3_partial<KIND>     MIX areas: PARTIAL groups, compacted per area, 324 masked products
-//   k3q_generic          deferred areas (|d| > 127) and oddballs, plain int32
-//   k3q_reduce           all chunk partials -> record int64 S / Sb / nobs
+// All kernels read the int8 planes K0 left behind (k0.hip.h): d8, L8, w8.
+//   k3_classify          per (frame, kind, area): class + compacted INT / MIX / GENERIC lists
+//   k3_lag<KIND, false>  INT areas: 46 (+26 chroma) v_dot4c_i32_i8 per group
+//   k3_lag<KIND, true>   MIX areas: the same for their FULL groups (+ L terms under the window); the
+//                        coordinates of their PARTIAL groups go to one dense list per (frame, kind)
+//   k3_partial_dense     the 324 masked products of every listed group, one lane per group
+//   k3q_generic          areas that touch a block with |d| > 127 (or |L| > 127), plain int32
+//   k3q_reduce           lag sums / masked products -> record int64 S / Sb / nobs
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "k0.hip.h"
 #include "kernels.hip.h"
 
 namespace g1s {
 
-constexpr int kQLag = 3;
 constexpr int kQN = 24;
 constexpr int kNumLags = 46;            // distinct c_j - c_i (incl. 0) and -c_i
-constexpr int kNumLTerms = 24 + 2;      // (i,L) for the 24 neighbours, L*L, L*y  (L as ONE int8: |L| <= 127 or the area is deferred)
-constexpr int kMaxAreasPerWG = 128;     // int32 accumulators stay exact
+constexpr int kNumLTerms = 24 + 2;      // (i,L) for the 24 neighbours, L*L, L*y  (L as ONE int8)
 enum : uint8_t { kClsExt = 0, kClsInt = 1, kClsMix = 2 };
 
 // lag index: dy = 0: dx 0..6 -> 0..6 ; dy = 1..3: dx -6..6 -> 7 + (dy-1)*13 + (dx+6)
@@ -43,47 +44,37 @@ __host__ __device__ constexpr int lag_index(int dx, int dy) { return dy == 0 ? d
 __host__ __device__ constexpr int coord_x(int k) { return k % 7 - 3; }
 __host__ __device__ constexpr int coord_y(int k) { return k / 7 - 3; }
 
-// lag-kernel partial per (frame, plane, chunk): [46 lag sums][53 L terms][nobs term]
+// lag-kernel sums per (frame, plane): [46 lag sums][26 L terms][nobs]
 constexpr int kQPart = kNumLags + kNumLTerms + 1;
-// partial-group kernel: two halves of 162 products, split by anchor
-constexpr int kPHalf = 162;
-constexpr int kPPart = 2 * kPHalf;
-// anchors of half 0: {0,3,4,7,8,11,12,15,16,19,20,23}: 25+22+21+18+17+14+13+10+9+6+5+2 = 162
-__host__ __device__ constexpr bool p_in_half(int half, int i) {
-  return (((i & 3) == 0 || (i & 3) == 3) ? 0 : 1) == half;
-}
+// masked products: anchor i owns (24 - i) + 1 of the 324; anchors i and 23 - i together 27.
+// The 12 such pairs are dealt round-robin to kPParts register-sized parts.
+constexpr int kPParts = 4;
+constexpr int kPPart = 324;
+constexpr int kPSub = kPPart / kPParts;
+__host__ __device__ constexpr bool p_in_part(int part, int i) { return ((i < 12 ? i : 23 - i) % kPParts) == part; }
 
 struct QParams {
   int nchunks;       // workgroups per frame of k3_lag<.., false>
-  int nchunks_mix;   // workgroups per frame of k3_lag<.., true> and k3_partial
-  int mixed_fast;    // 1: MIX areas by k3_lag<true> + k3_partial; 0: by k3q_generic (debug)
+  int nchunks_mix;   // workgroups per frame of k3_lag<.., true>
+  int mixed_fast;    // 1: MIX areas by k3_lag<true> + k3_partial_dense; 0: by k3q_generic (debug)
   long long *lagacc;   // [batch][3][kQPart]  int64 sums of all lag-kernel workgroups (zeroed per batch)
-  long long *paracc;   // [batch][3][kPPart]  int64 sums of all k3_partial workgroups (zeroed per batch)
+  long long *paracc;   // [batch][3][kPPart]  int64 sums of all k3_partial_dense workgroups (zeroed per batch)
   uint8_t *cls;        // [batch][2][nblocks]  area class per kind (luma, chroma)
-  uint8_t *todo;       // [batch][2][nblocks]  1 = area left to k3q_generic
-  uint32_t *lists;     // [batch][2 kinds][3 (INT, MIX, GENERIC)][nblocks] compacted area indices
+  uint8_t *bad;        // [batch][2][nblocks]  K0: block holds a residual (or L) outside int8 (zeroed per batch)
+  uint32_t *lists;     // [batch][2 kinds][3 (INT, MIX, GENERIC)][nblocks] compacted areas
   uint32_t *counts;    // [batch][2][3] list lengths (zeroed before k3_classify)
-  uint8_t *winbuf;     // [batch][2][nblocks][32] windows of the 6 blocks an area sees (flat,xs,xe,ys,ye) x 6
+  uint32_t *pglist;    // [batch][2][pg_cap] partial groups: x/4 + kPadX/4 .. | y << 16 (plane coordinates)
+  uint32_t *pgcount;   // [batch][2] (zeroed per batch)
+  uint32_t pg_cap;     // nblocks * 256: every group of every area, the list cannot overflow
+  uint8_t *planes;     // K0 planes, [batch] x ps.frame_bytes
+  PlaneSet ps;
 };
-constexpr uint32_t kEntryFlat = 0x80000000u;      // list entry = block index | (block is flat ? bit 31 : 0)
-constexpr uint32_t kEntryDeferred = 0x40000000u;  // set by k3_lag<.., true> on a MIX entry it deferred to k3q_generic
+// INT / MIX list entry: bx | by << 16.  GENERIC list entry: the block index.
 constexpr uint32_t kEntryNone = 0xffffffffu;
-constexpr uint32_t kEntryIndex = 0x3fffffffu;
 
 __device__ __forceinline__ int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, int sh) {
   return __builtin_amdgcn_alignbyte(hi, lo, sh);
-}
-// full-wave integer sum, all in the VALU (DPP): quad swaps, half-row / row mirrors, then
-// the row broadcasts; the total lands in lane 63 and is read back as a scalar.
-__device__ __forceinline__ int wave_sum(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
-  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
-  return __builtin_amdgcn_readlane(v, 63);
 }
 template <int N>
 __device__ __forceinline__ void wave_sum_all(int (&a)[N]) {
@@ -96,34 +87,7 @@ __device__ __forceinline__ void wave_sum_all(int (&a)[N]) {
     for (int i = 0; i < N; ++i) a[i] += t[i];
   }
 }
-
-// ---------------------------------------------------------------------------------
-// window of a block (libaom add_block_observations), in samples of its plane
-// ---------------------------------------------------------------------------------
-struct Win {
-  int flat, xs, xe, ys, ye;
-};
-__device__ __forceinline__ Win block_window(const uint8_t *mask, int nbw, int nbh, int bx, int by, int bw, int bh,
-                                            int pw, int ph) {
-  Win w{0, 0, 0, 0, 0};
-  if (bx < 0 || by < 0 || bx >= nbw || by >= nbh) return w;
-  if (!mask[by * nbw + bx]) return w;
-  w.flat = 1;
-  w.ys = (by > 0 && mask[(by - 1) * nbw + bx]) ? 0 : kQLag;
-  w.xs = (bx > 0 && mask[by * nbw + bx - 1]) ? 0 : kQLag;
-  w.ye = min(ph - by * bh, bh);
-  w.xe = min(pw - bx * bw - kQLag, (bx + 1 < nbw && mask[by * nbw + bx + 1]) ? bw : (bw - kQLag));
-  if (w.xe <= w.xs || w.ye <= w.ys) w.flat = 0;  // empty window
-  return w;
-}
-__device__ __forceinline__ int window_at(const uint8_t *mask, int nbw, int nbh, int bw, int bh, int pw, int ph, int X,
-                                         int Y) {
-  if (X < 0 || Y < 0 || X >= pw || Y >= ph) return 0;
-  const int bx = X / bw, by = Y / bh;
-  const Win w = block_window(mask, nbw, nbh, bx, by, bw, bh, pw, ph);
-  const int lx = X - bx * bw, ly = Y - by * bh;
-  return w.flat && lx >= w.xs && lx < w.xe && ly >= w.ys && ly < w.ye;
-}
+typedef const G1S_GLOBAL uint32_t *gptr_u1;
 
 // ---------------------------------------------------------------------------------
 // k3_classify: one thread per block area and plane kind.  The area of block (bx, by)
@@ -134,27 +98,26 @@ __global__ __launch_bounds__(256) void k3_classify(Geom g, const uint8_t *__rest
   const int blk = blockIdx.x * 256 + threadIdx.x;
   const int kind = blockIdx.y, frame = blockIdx.z;
   const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
+  const uint8_t *bad = qp.bad + ((size_t)frame * 2 + kind) * g.nblocks;
   uint8_t c = kClsExt;
+  bool gen = false;
+  int bx = 0, by = 0;
   if (blk < g.nblocks) {
     const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
     const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
-    const int bx = blk % g.nbw, by = blk / g.nbw;
+    bx = blk % g.nbw;
+    by = blk / g.nbw;
     const int AX0 = bx * bw - kQLag, AX1 = bx * bw + bw + kQLag, AY0 = by * bh, AY1 = by * bh + bh + kQLag;
     bool all1 = !(AX0 < 0 || AX1 > pw || AY1 > ph);
-    bool any1 = false;
-    uint8_t *wb = qp.winbuf + (((size_t)frame * 2 + kind) * g.nblocks + blk) * 32;
-    for (int dby = 0; dby <= 1; ++dby) {
+    bool any1 = false, anybad = false;
+    for (int dby = -1; dby <= 1; ++dby) {
       for (int dbx = -1; dbx <= 1; ++dbx) {
         const int Bx = bx + dbx, By = by + dby;
+        if (Bx < 0 || By < 0 || Bx >= g.nbw || By >= g.nbh) continue;
+        // the tiles of this area reach into these blocks (chroma: also the row above, for the L terms)
+        if ((dby >= 0 || kind) && bad[By * g.nbw + Bx]) anybad = true;
+        if (dby < 0) continue;
         const Win w = block_window(mask, g.nbw, g.nbh, Bx, By, bw, bh, pw, ph);
-        {
-          uint8_t *o = wb + (dby * 3 + dbx + 1) * 5;
-          o[0] = (uint8_t)w.flat;
-          o[1] = (uint8_t)w.xs;
-          o[2] = (uint8_t)max(w.xe, 0);
-          o[3] = (uint8_t)w.ys;
-          o[4] = (uint8_t)max(w.ye, 0);
-        }
         const int rx0 = max(AX0, Bx * bw), rx1 = min(AX1, Bx * bw + bw);
         const int ry0 = max(AY0, By * bh), ry1 = min(AY1, By * bh + bh);
         if (rx0 >= rx1 || ry0 >= ry1) continue;
@@ -167,19 +130,17 @@ __global__ __launch_bounds__(256) void k3_classify(Geom g, const uint8_t *__rest
         if (!(w.xs <= ax0 && ax1 <= w.xe && w.ys <= ay0 && ay1 <= w.ye)) all1 = false;
       }
     }
+    // blocks outside the grid have no window: an area at the right / bottom rim is never INT
+    if (bx + 1 >= g.nbw || by + 1 >= g.nbh) all1 = false;
     c = all1 ? kClsInt : (any1 ? kClsMix : kClsExt);
-    const size_t o = ((size_t)frame * 2 + kind) * g.nblocks + blk;
-    qp.cls[o] = c;
-    // deferred-to-generic: MIX when the fast mixed path is off; a flat block whose own area
-    // is EXT still needs its block statistics
-    qp.todo[o] = ((c == kClsMix && !qp.mixed_fast) || (c == kClsExt && mask[blk])) ? 1 : 0;
+    qp.cls[((size_t)frame * 2 + kind) * g.nblocks + blk] = c;
+    gen = c != kClsExt && (anybad || (c == kClsMix && !qp.mixed_fast));
   }
   // compacted lists, one atomic per wave and class (any order: the sums are exact integers)
   const int lane = threadIdx.x & 63;
-  const bool gen = blk < g.nblocks && qp.todo[((size_t)frame * 2 + kind) * g.nblocks + blk] != 0;
   for (int which = 0; which < 3; ++which) {
     const bool mine = blk < g.nblocks &&
-                      (which == 0 ? c == kClsInt : (which == 1 ? (c == kClsMix && qp.mixed_fast) : gen));
+                      (which == 2 ? gen : (!gen && (which == 0 ? c == kClsInt : c == kClsMix)));
     const unsigned long long b = __ballot(mine);
     if (b == 0) continue;
     const size_t lo = ((size_t)frame * 2 + kind) * 3 + which;
@@ -188,7 +149,7 @@ __global__ __launch_bounds__(256) void k3_classify(Geom g, const uint8_t *__rest
     base = __shfl(base, 0, 64);
     if (mine)
       qp.lists[lo * g.nblocks + base + __popcll(b & ((1ull << lane) - 1ull))] =
-          (uint32_t)blk | (mask[blk] ? kEntryFlat : 0u);
+          which == 2 ? (uint32_t)blk : ((uint32_t)bx | ((uint32_t)by << 16));
   }
 }
 
@@ -202,115 +163,6 @@ __device__ __forceinline__ void list_slice(int b, int N, int n, int &begin, int 
   const int per = (n + N - 1) / N;
   begin = min(n, w * per);
   end = min(n, begin + per);
-}
-
-// ---- 8 consecutive samples of a row (vector global load, narrowed later) ----
-struct Px8 {
-  // plain scalars (not HIP's uint4 wrapper): arrays of this struct must stay in VGPRs
-  uint32_t x, y, z, w;  // u16: 8 samples; u8: x, y hold 8 samples
-  int state;            // 0 = zero (outside the plane), 1 = raw valid, 2 = edge segment: per-sample loads later
-};
-__device__ __forceinline__ Px8 fetch8(const uint8_t *base, uint32_t stride, int bps, bool vec_ok, int X0, int Y,
-                                      int pw, int ph) {
-  Px8 r;
-  r.x = r.y = r.z = r.w = 0;
-  r.state = 0;
-  if (Y < 0 || Y >= ph || X0 + 8 <= 0 || X0 >= pw) return r;
-  if (X0 >= 0 && X0 + 8 <= pw && vec_ok) {
-    gptr_u8 p = as_global(base) + (size_t)Y * stride + (size_t)X0 * bps;
-    if (bps == 2) {
-      const u32x4 v = *(gptr_u4)p;
-      r.x = v.x;
-      r.y = v.y;
-      r.z = v.z;
-      r.w = v.w;
-    } else {
-      const u32x2 v = *(gptr_u2)p;
-      r.x = v.x;
-      r.y = v.y;
-    }
-    r.state = 1;
-  } else {
-    r.state = 2;
-  }
-  return r;
-}
-__device__ __forceinline__ void unpack8(const Px8 &p, const uint8_t *base, uint32_t stride, int bps, int shift,
-                                        int X0, int Y, int pw, int (&v)[8]) {
-  if (p.state == 1) {
-    if (bps == 2) {
-      const uint32_t w[4] = {p.x, p.y, p.z, p.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[2 * k] = (int)(((w[k] & 0xffffu) >> shift) & 0xffu);
-        v[2 * k + 1] = (int)(((w[k] >> 16) >> shift) & 0xffu);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[k] = (int)((p.x >> (8 * k)) & 0xffu);
-        v[4 + k] = (int)((p.y >> (8 * k)) & 0xffu);
-      }
-    }
-  } else if (p.state == 2) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int X = X0 + k;
-      v[k] = (X >= 0 && X < pw) ? load_px_rt(base, stride, bps, shift, X, Y) : 0;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = 0;
-  }
-}
-
-// ---- packed 16-bit staging arithmetic ---------------------------------------------
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b));
-}
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b));
-}
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-}
-// 8 samples -> 4 dwords of two u16 each, already narrowed to 8 bits (frame_into_u8:
-// `(v >> (bd - 8)) as u8`).  Edge segments (state 2) take the per-sample path.
-__device__ __forceinline__ void to16(const Px8 &p, const uint8_t *base, uint32_t stride, int bps, int shift, int X0,
-                                     int Y, int pw, uint32_t (&h)[4]) {
-  if (p.state == 1) {
-    if (bps == 2) {
-      const uint32_t w[4] = {p.x, p.y, p.z, p.w};
-      const u16x2 sh = {(unsigned short)shift, (unsigned short)shift};
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        h[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, w[k]) >> sh) & 0x00ff00ffu;
-    } else {
-      h[0] = __builtin_amdgcn_perm(0u, p.x, 0x0c010c00u);
-      h[1] = __builtin_amdgcn_perm(0u, p.x, 0x0c030c02u);
-      h[2] = __builtin_amdgcn_perm(0u, p.y, 0x0c010c00u);
-      h[3] = __builtin_amdgcn_perm(0u, p.y, 0x0c030c02u);
-    }
-  } else if (p.state == 2) {
-    int v[8];
-    unpack8(p, base, stride, bps, shift, X0, Y, pw, v);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) h[k] = (uint32_t)v[2 * k] | ((uint32_t)v[2 * k + 1] << 16);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) h[k] = 0;
-  }
-}
-// running min / max of packed i16 -> any |d| > 127 ?
-__device__ __forceinline__ bool range_bad(uint32_t mx, uint32_t mn) {
-  const int mxa = max((int)(short)(mx & 0xffffu), (int)(short)(mx >> 16));
-  const int mna = min((int)(short)(mn & 0xffffu), (int)(short)(mn >> 16));
-  return mxa > 127 || mna < -127;
 }
 
 // KIND: 0 = luma; 1 = chroma 4:2:0; 2 = chroma 4:2:2; 3 = chroma 4:4:4.
@@ -332,14 +184,8 @@ struct QShape {
   static constexpr int PITCH = PITCH_DW * 4;
   static constexpr int UP = kChroma ? kQLag : 0;  // rows above the area (chroma L terms are p-centric)
   static constexpr int TH = BH + kQLag + UP;      // tile rows: -UP .. BH+2
-  static constexpr int SEGS = (BW + 16) / 8;      // 8-sample segments per tile row: x = -8 .. BW+7
-  static constexpr int NTILE = TH * SEGS * NPL;
-  static constexpr int LCH = 8 >> SX;  // chroma samples per L item (8 luma samples wide)
-  static constexpr int LSEGS = BW / LCH;
-  static constexpr int NL = kChroma ? BH * LSEGS : 0;
-  static constexpr int LROWS = 1 << SY;
-  static constexpr int NITEMS = NTILE + NL;
-  static constexpr int SLOT = kChroma ? LROWS : 1;
+  static constexpr int SEG = (BW + 16) / 16;      // 16-byte segments per tile row: x = -8 .. BW+7
+  static constexpr int LSEG = BW / 16;
   static constexpr int TILE_BYTES = TH * PITCH;
   static constexpr int LTILE_BYTES = BH * PITCH;
   static constexpr int DATA_BYTES = NPL * TILE_BYTES + (kChroma ? LTILE_BYTES : 0);
@@ -348,181 +194,74 @@ struct QShape {
 };
 
 // ---------------------------------------------------------------------------------
-// Stager: HBM -> registers (prefetch, vector loads) -> LDS tiles of one area.
+// TileRegs: the tiles of one area, HBM/L2 -> registers (prefetch) -> LDS, 16 bytes a piece.
 // LDS layout: plane tile pl at lds + pl*TILE_BYTES, sample (x, y) (x in -8..BW+7,
 // y in -UP..BH+2) at byte (y + UP) * PITCH + 8 + x, so group g (x = 4g) is dword g + 2;
-// then La, Lb tiles (block proper, byte y*PITCH + x); then (WTILE) the window-indicator
+// then the L tile (block proper, byte y*PITCH + x); then (MIXED) the window-indicator
 // tile, rows 0..BH+2, same column layout, bytes 0xFF / 0x00.
 // ---------------------------------------------------------------------------------
-template <int KIND, int NT, bool WTILE, bool LTERMS>
-struct Stager {
+template <int KIND, bool MIXED, int NT>
+struct TileRegs {
   using S = QShape<KIND>;
-  static constexpr int NITEMS = S::NTILE + (LTERMS ? S::NL : 0);
+  static constexpr int ND = S::TH * S::SEG * S::NPL;
+  static constexpr int NLI = S::kChroma ? S::BH * S::LSEG : 0;
+  static constexpr int NWI = MIXED ? (S::BH + kQLag) * S::SEG : 0;
+  static constexpr int NITEMS = ND + NLI + NWI;
   static constexpr int MAXIT = (NITEMS + NT - 1) / NT;
-  Px8 ps[MAXIT][S::SLOT], pd[MAXIT][S::SLOT];
+  u32x4 regs[MAXIT];
 
-  __device__ __forceinline__ void fetch(const FramePlanes &fp, const Geom &g, int tid, int blk) {
+  __device__ __forceinline__ void fetch(const uint8_t *fbase, const PlaneSet &ps, int tid, int bx, int by) {
     constexpr bool CHROMA = S::kChroma;
-    const int pw = g.W >> S::SX, ph = g.H >> S::SY;
-    const int bx = blk % g.nbw, by = blk / g.nbw;
-    const int x_o = bx * S::BW, y_o = by * S::BH;
-#pragma unroll
-    for (int k = 0; k < MAXIT; ++k) {
-      // ONE straight-line path per (k, q) slot, parameters chosen by selects: every slot is
-      // written exactly once with a static index, so ps / pd stay in VGPRs.
-      const int it = tid + k * NT;
-      const bool tile = it < S::NTILE;
-      const bool lit = LTERMS && !tile && it < NITEMS;
-      const int pl = it / (S::TH * S::SEGS);
-      const int r = it - pl * (S::TH * S::SEGS);
-      const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
-      const int rl = it - S::NTILE;
-      const int yl = rl / S::LSEGS, sgl = rl - yl * S::LSEGS;
-      // (no runtime index into fp: that would push the frame table to scratch memory)
-      const uint8_t *spt = CHROMA ? (pl ? fp.src[2] : fp.src[1]) : fp.src[0];
-      const uint8_t *dpt = CHROMA ? (pl ? fp.den[2] : fp.den[1]) : fp.den[0];
-      const uint32_t sstt = CHROMA ? (pl ? fp.src_stride[2] : fp.src_stride[1]) : fp.src_stride[0];
-      const uint32_t dstt = CHROMA ? (pl ? fp.den_stride[2] : fp.den_stride[1]) : fp.den_stride[0];
-      const int vst = CHROMA ? (pl ? (g.vec_mask >> 2) : (g.vec_mask >> 1)) : g.vec_mask;
-      const int vdt = CHROMA ? (pl ? (g.vec_mask >> 5) : (g.vec_mask >> 4)) : (g.vec_mask >> 3);
-      const uint8_t *sp = tile ? spt : fp.src[0];
-      const uint8_t *dp = tile ? dpt : fp.den[0];
-      const uint32_t sst = tile ? sstt : fp.src_stride[0];
-      const uint32_t dst = tile ? dstt : fp.den_stride[0];
-      const bool vs = ((tile ? vst : g.vec_mask) & 1) != 0, vd = ((tile ? vdt : (g.vec_mask >> 3)) & 1) != 0;
-      const int X0 = tile ? (x_o - 8 + 8 * sg) : ((x_o + sgl * S::LCH) << S::SX);
-      const int Yb = tile ? (y_o - S::UP + ty) : ((y_o + yl) << S::SY);
-      const int pwq = tile ? pw : g.W, phq = tile ? ph : g.H;
-#pragma unroll
-      for (int q = 0; q < S::SLOT; ++q) {
-        const bool valid = tile ? (q == 0) : lit;
-        ps[k][q] = fetch8(sp, sst, g.src_bps, vs, valid ? X0 : -64, Yb + q, pwq, phq);  // X0 = -64: outside -> zero
-        pd[k][q] = fetch8(dp, dst, g.den_bps, vd, valid ? X0 : -64, Yb + q, pwq, phq);
-      }
-    }
-  }
-
-  // narrow, subtract, range-check, write LDS.  Returns true if some |d| > 127.
-  // window-indicator tile (rows 0..BH+2 of the area) from the six windows in s_win
-  __device__ __forceinline__ void build_wtile(int tid, uint8_t *lds, const uint8_t *s_win) {
-    constexpr int bw = S::BW, bh = S::BH;
-    constexpr int NW = (bh + kQLag) * S::SEGS;
-#pragma unroll
-    for (int k = 0; k < (NW + NT - 1) / NT; ++k) {
-      const int it = tid + k * NT;
-      if (it < NW) {
-        const int y = it / S::SEGS, sg = it - y * S::SEGS;
-        const int dby = y >= bh ? 1 : 0, ly = y - dby * bh;
-        uint32_t wlo = 0, whi = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int x = -8 + 8 * sg + q;
-          const int dbx = x < 0 ? -1 : (x >= bw ? 1 : 0), lx = x - dbx * bw;
-          const uint8_t *wn = s_win + (dby * 3 + dbx + 1) * 5;
-          const bool in = wn[0] && lx >= wn[1] && lx < wn[2] && ly >= wn[3] && ly < wn[4];
-          const uint32_t b = in ? 0xffu : 0u;
-          if (q < 4) wlo |= b << (8 * q); else whi |= b << (8 * (q - 4));
-        }
-        *reinterpret_cast<uint2 *>(lds + S::DATA_BYTES + y * S::PITCH + 8 * sg) = make_uint2(wlo, whi);
-      }
-    }
-  }
-
-  __device__ __forceinline__ bool store(const FramePlanes &fp, const Geom &g, int tid, int blk, uint8_t *lds,
-                                        int &lsum) {
-    constexpr bool CHROMA = S::kChroma;
-    constexpr int bw = S::BW, bh = S::BH;
-    const int pw = g.W >> S::SX;
-    const int bx = blk % g.nbw, by = blk / g.nbw;
-    const int x_o = bx * bw, y_o = by * bh;
-    uint32_t mx = 0, mn = 0;  // packed running max / min of the residuals
-    bool lbad = false;        // the luma residual sum L does not fit int8
+    const uint32_t pitch = CHROMA ? ps.pitch[1] : ps.pitch[0];
+    const uint32_t off_w = CHROMA ? ps.off_w[1] : ps.off_w[0];
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
       const int it = tid + k * NT;
-      if (it < S::NTILE) {
-        const int pl = it / (S::TH * S::SEGS);
-        const int r = it - pl * (S::TH * S::SEGS);
-        const int ty = r / S::SEGS, sg = r - ty * S::SEGS;
-        const uint8_t *sp = CHROMA ? (pl ? fp.src[2] : fp.src[1]) : fp.src[0];
-        const uint8_t *dp = CHROMA ? (pl ? fp.den[2] : fp.den[1]) : fp.den[0];
-        const uint32_t sst = CHROMA ? (pl ? fp.src_stride[2] : fp.src_stride[1]) : fp.src_stride[0];
-        const uint32_t dst = CHROMA ? (pl ? fp.den_stride[2] : fp.den_stride[1]) : fp.den_stride[0];
-        const int X0 = x_o - 8 + 8 * sg, Y = y_o - S::UP + ty;
-        uint32_t hs[4], hv[4], d[4];
-        to16(ps[k][0], sp, sst, g.src_bps, g.src_shift, X0, Y, pw, hs);
-        to16(pd[k][0], dp, dst, g.den_bps, g.den_shift, X0, Y, pw, hv);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          d[q] = pk_sub(hs[q], hv[q]);
-          mx = pk_max(mx, d[q]);
-          mn = pk_min(mn, d[q]);
-        }
-        const uint32_t lo = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u);
-        const uint32_t hi = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u);
-        if (!CHROMA && sg >= 1 && sg <= 4 && ty < bh) {  // block proper -> luma sum of the source
-          lsum = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(hs[1], hs[0], 0x06040200u), 0u, (uint32_t)lsum);
-          lsum = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(hs[3], hs[2], 0x06040200u), 0u, (uint32_t)lsum);
-        }
-        *reinterpret_cast<uint2 *>(lds + pl * S::TILE_BYTES + ty * S::PITCH + 8 * sg) = make_uint2(lo, hi);
-      } else if (LTERMS && it < NITEMS) {
-        const int r = it - S::NTILE;
-        const int y = r / S::LSEGS, sg = r - y * S::LSEGS;
-        const int X0 = (x_o + sg * S::LCH) << S::SX;
-        uint32_t dsum[4] = {0, 0, 0, 0};  // packed i16 residuals, summed over the LROWS luma rows
-#pragma unroll
-        for (int q = 0; q < S::LROWS; ++q) {
-          const int Y = ((y_o + y) << S::SY) + q;
-          uint32_t hs[4], hv[4];
-          to16(ps[k][q], fp.src[0], fp.src_stride[0], g.src_bps, g.src_shift, X0, Y, g.W, hs);
-          to16(pd[k][q], fp.den[0], fp.den_stride[0], g.den_bps, g.den_shift, X0, Y, g.W, hv);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t d = pk_sub(hs[e], hv[e]);
-            mx = pk_max(mx, d);
-            mn = pk_min(mn, d);
-            dsum[e] = pk_add(dsum[e], d);
-          }
-        }
-        uint8_t *ta = lds + S::NPL * S::TILE_BYTES + y * S::PITCH + sg * S::LCH;
-        if (S::SX == 1) {
-          // L = horizontal pair sums: 4 chroma samples per item; must fit int8 like d
-          uint32_t a0 = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int L = (int)(short)(dsum[e] & 0xffffu) + (int)(short)(dsum[e] >> 16);
-            lbad |= (L > 127) | (L < -127);
-            a0 |= ((uint32_t)L & 0xffu) << (8 * e);
-          }
-          *reinterpret_cast<uint32_t *>(ta) = a0;
-        } else {
-          // L = the (row-summed) luma residual itself: 8 chroma samples per item
-          uint32_t lmx = 0, lmn = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            lmx = pk_max(lmx, dsum[e]);
-            lmn = pk_min(lmn, dsum[e]);
-          }
-          lbad |= range_bad(lmx, lmn);
-          *reinterpret_cast<uint2 *>(ta) = make_uint2(__builtin_amdgcn_perm(dsum[1], dsum[0], 0x06040200u),
-                                                       __builtin_amdgcn_perm(dsum[3], dsum[2], 0x06040200u));
-        }
-      }
+      // one straight-line path, parameters chosen by selects
+      const bool isd = it < ND, isl = !isd && it < ND + NLI;
+      const int pl = it / (S::TH * S::SEG);
+      const int rd = it - pl * (S::TH * S::SEG);
+      const int rl = it - ND, rw = it - ND - NLI;
+      const int r = isd ? rd : (isl ? rl : rw);
+      const int segs = isl ? S::LSEG : S::SEG;
+      const int y = r / segs, sg = r - y * segs;
+      const uint32_t off = isd ? (CHROMA ? (pl ? ps.off_d[2] : ps.off_d[1]) : ps.off_d[0]) : (isl ? ps.off_l : off_w);
+      const uint32_t pt = isl ? ps.lpitch : pitch;
+      const int row = by * S::BH + y + (isd ? kPadY - S::UP : (isl ? 0 : kPadY));
+      gptr_u8 p = as_global(fbase) + off + (size_t)row * pt + (size_t)(bx * S::BW + 16 * sg);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (it < NITEMS) v = *(gptr_u4)p;
+      regs[k] = v;
     }
-    return range_bad(mx, mn) || lbad;
+  }
+  __device__ __forceinline__ void store(uint8_t *lds, int tid) const {
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+      const int it = tid + k * NT;
+      const bool isd = it < ND, isl = !isd && it < ND + NLI;
+      const int pl = it / (S::TH * S::SEG);
+      const int rd = it - pl * (S::TH * S::SEG);
+      const int rl = it - ND, rw = it - ND - NLI;
+      const int r = isd ? rd : (isl ? rl : rw);
+      const int segs = isl ? S::LSEG : S::SEG;
+      const int y = r / segs, sg = r - y * segs;
+      const int base = isd ? pl * S::TILE_BYTES : (isl ? S::NPL * S::TILE_BYTES : S::DATA_BYTES);
+      if (it < NITEMS) *reinterpret_cast<u32x4 *>(lds + base + y * S::PITCH + 16 * sg) = regs[k];
+    }
   }
 };
 
-// Group classification from the w tile: w32 points at dword (row*PITCH_DW + g) of the w
-// tile; the group's own samples are dword +2.  FULL / EMPTY are decided on the bytes
-// x-3 .. x+6 of rows 0..3 (a superset of what the 24 masks read; both kernels use this
-// same predicate, so the partition into full / partial / empty groups is consistent).
-template <int PITCH_DW>
-__device__ __forceinline__ void group_state(const uint32_t *w32, bool &full, bool &empty) {
+// Group classification from window bytes: w32 points at the dword of x = 4g - 8 in row 0 of
+// the group, rows are `pitch_dw` dwords apart; the group's own samples are dword +2.
+// FULL / EMPTY are decided on the bytes x-3 .. x+6 of rows 0..3 (a superset of what the 24
+// masks read; every kernel uses this same predicate, so the partition into full / partial /
+// empty groups is consistent).
+template <typename P>
+__device__ __forceinline__ void group_state(P w32, int pitch_dw, bool &full, bool &empty) {
   uint32_t all_and = 0xffffffffu, all_or = 0;
 #pragma unroll
   for (int dy = 0; dy <= 3; ++dy) {
-    const uint32_t *rp = w32 + dy * PITCH_DW;
+    P rp = w32 + dy * pitch_dw;
     const uint32_t q1 = rp[1], q2 = rp[2], q3 = rp[3];
     all_and &= (q1 | 0x000000ffu) & q2 & (q3 | 0xff000000u);
     all_or |= (q1 & 0xffffff00u) | q2 | (q3 & 0x00ffffffu);
@@ -532,41 +271,37 @@ __device__ __forceinline__ void group_state(const uint32_t *w32, bool &full, boo
 }
 
 // ---------------------------------------------------------------------------------
-// k3_lag<KIND, MIXED>: 46 lag sums (+53 chroma L terms) per group.
+// k3_lag<KIND, MIXED>: 46 lag sums (+26 chroma L terms) per group.
 //   MIXED = false: the INT list (every group full, own window = whole block)
-//   MIXED = true : the MIX list; only FULL groups enter the lag sums; L terms, nobs and
-//                  block statistics use the block's own window / flat flag.
-// grid = (nchunks or nchunks_mix, 1, batch), block = QShape::THREADS.
+//   MIXED = true : the MIX list; only FULL groups enter the lag sums; L terms and nobs use the
+//                  block's own window.
+// grid = (nchunks or nchunks_mix, 1, batch), block = QShape::THREADS.  The tiles are double
+// buffered in LDS: one barrier per area, the loads of area k+1 fly during the products of k.
 // int32 safety: per step |sum| <= 4*127^2; <= 128 areas * STEPS_PER_WAVE(<=2); x64 lanes < 2^31.
 // ---------------------------------------------------------------------------------
-// WV = waves per workgroup.  WV = 1 makes a wave autonomous: it stages and multiplies whole
-// areas alone, workgroup barriers degenerate, and a CU runs 8-12 independent area pipelines.
-constexpr int kLagWaves = 0;  // 0 = QShape<KIND>::WAVES (4 luma, 2 chroma 4:2:0); 1 was measured slower and is invalid for chroma
-template <int KIND, bool MIXED, int WV>
-__global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(const FramePlanes *__restrict__ frames,
-                                                                              Geom g, QParams qp,
-                                                                              uint8_t *__restrict__ records) {
+template <int KIND, bool MIXED>
+__global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(Geom g, QParams qp) {
   using S = QShape<KIND>;
   constexpr bool CHROMA = S::kChroma;
-  constexpr int WAVES = WV ? WV : S::WAVES;
+  constexpr int WAVES = S::WAVES;
   constexpr int NACC = S::NACC, NT = 64 * WAVES;
-  constexpr int STEPS_PER_WAVE = S::NPL * S::NS / WAVES;
+  constexpr int STEPS_PER_WAVE = S::STEPS_PER_WAVE;
   static_assert(S::NPL * S::NS % WAVES == 0 && WAVES % S::NPL == 0, "a wave owns the accumulators of ONE plane");
-  __shared__ __attribute__((aligned(16))) uint8_t lds[S::DATA_BYTES + (MIXED ? S::WTILE_BYTES : 0)];
-  __shared__ int s_flag[2];
-  __shared__ int s_stat[2][4][4];
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[32];  // windows of the six blocks the current MIX area sees
+  constexpr int BUF = S::DATA_BYTES + (MIXED ? S::WTILE_BYTES : 0);
+  __shared__ __attribute__((aligned(16))) uint8_t lds2[2][BUF];
+  // MIXED: coordinates of the partial groups met so far, flushed to the (frame, kind) list with
+  // ONE global atomic per flush (a per-wave global atomic would serialise on that counter)
+  constexpr int PGBUF = MIXED ? 2048 : 1;
+  __shared__ uint32_t s_pg[PGBUF];
+  __shared__ uint32_t s_pgn, s_pgbase, s_pgsnap;
+  __shared__ int s_flush[2];
 
   const int frame = blockIdx.z, chunk = blockIdx.x;
   const int stride = MIXED ? qp.nchunks_mix : qp.nchunks;
-  const FramePlanes fp = frames[frame];
-  uint8_t *rec = records + (size_t)frame * g.rec_size;
-  const uint8_t *mask = rec + g.off_mask;
   const size_t lsel = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + (MIXED ? 1 : 0);
-  uint32_t *list = qp.lists + lsel * g.nblocks;
+  const uint32_t *list = qp.lists + lsel * g.nblocks;
   const int nlist = (int)qp.counts[lsel];
-  uint8_t *todo = qp.todo + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks;
-  const uint8_t *winbase = qp.winbuf + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks * 32;
+  const uint8_t *fbase = qp.planes + (size_t)frame * qp.ps.frame_bytes;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lg = lane % S::G, lr = lane / S::G;
 
@@ -574,64 +309,49 @@ __global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(c
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0;
   int nobs = 0;  // INT: number of areas (x BW*BH in the reducer); MIX: window samples
-  if (tid < 2) s_flag[tid] = 0;
+  if (MIXED && tid == 0) {
+    s_pgn = 0;
+    s_flush[0] = s_flush[1] = 0;
+  }
+  uint32_t *pg_out = qp.pglist + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * qp.pg_cap;
+  uint32_t *pg_cnt = qp.pgcount + (size_t)frame * 2 + (CHROMA ? 1 : 0);
+  auto pg_flush = [&]() {  // uniform; every wave is between two areas
+    if (tid == 0) {
+      const uint32_t n = s_pgn;
+      s_pgsnap = n;
+      s_pgbase = atomicAdd(pg_cnt, n);
+      s_pgn = 0;
+    }
+    __syncthreads();
+    const uint32_t n = s_pgsnap, base = s_pgbase;
+    for (uint32_t i = tid; i < n; i += NT) pg_out[base + i] = s_pg[i];
+    __syncthreads();  // copied before the next appends overwrite s_pg
+  };
 
-  // Software pipeline over the list slice.  Per iteration k: the samples of area k were
-  // requested one iteration ago, the list entry of area k+1 two iterations ago; no load that
-  // is waited on is ever issued after the prefetch (vmcnt retires in order).
-  Stager<KIND, NT, MIXED, CHROMA> st;
+  TileRegs<KIND, MIXED, NT> tr;
   int li, li_end;
   list_slice(chunk, stride, nlist, li, li_end);
-  auto entry_at = [&](int pos) -> uint32_t { return pos < li_end ? list[pos] : kEntryNone; };
+  auto entry_at = [&](int pos) -> uint32_t {
+    return pos < li_end ? (uint32_t)__builtin_amdgcn_readfirstlane((int)list[pos]) : kEntryNone;
+  };
   uint32_t e_cur = entry_at(li), e_nxt = entry_at(li + 1);
-  uint32_t wreg = 0;  // threads 0..7: one dword of the windows of the area being prefetched
-  if (e_cur != kEntryNone) {
-    const int b0 = (int)(e_cur & kEntryIndex);
-    if (MIXED && tid < 8) wreg = reinterpret_cast<const uint32_t *>(winbase + (size_t)b0 * 32)[tid];
-    st.fetch(fp, g, tid, b0);
-  }
-  __syncthreads();
+  if (e_cur != kEntryNone) tr.fetch(fbase, qp.ps, tid, (int)(e_cur & 0xffffu), (int)(e_cur >> 16));
 
   int iter = 0;
   for (; e_cur != kEntryNone; e_cur = e_nxt, e_nxt = entry_at(li + 1)) {
-    const int blk = (int)(e_cur & kEntryIndex);
-    const bool isflat = (e_cur & kEntryFlat) != 0;
+    uint8_t *lds = lds2[iter & 1];
     const int fl = iter & 1;
     ++iter;
-    if (MIXED && tid < 8) reinterpret_cast<uint32_t *>(s_win)[tid] = wreg;
-    int lsum = 0;
-    const bool bad = st.store(fp, g, tid, blk, lds, lsum);
-    if (bad) s_flag[fl] = 1;
-    if (!CHROMA) {
-      lsum = wave_sum(lsum);
-      if (lane == 0) s_stat[fl][wave][3] = lsum;
-    }
-    __syncthreads();  // d tiles + s_win complete
+    tr.store(lds, tid);
+    // thread 0 may lag one area behind the other waves' appends: keep two areas of headroom
+    if (MIXED && tid == 0) s_flush[fl] = s_pgn + 2 * S::NG > (uint32_t)PGBUF ? 1 : 0;
+    __syncthreads();  // tiles of this area complete; every wave is done with the other buffer
+    if (MIXED && s_flush[fl]) pg_flush();
+    const int bx = (int)(e_cur & 0xffffu), by = (int)(e_cur >> 16);
     ++li;
-    if (e_nxt != kEntryNone) {  // prefetch area k+1 (in flight during the products below)
-      const int bn = (int)(e_nxt & kEntryIndex);
-      if (MIXED && tid < 8) wreg = reinterpret_cast<const uint32_t *>(winbase + (size_t)bn * 32)[tid];
-      st.fetch(fp, g, tid, bn);
-    }
-    const bool deferred = s_flag[fl] != 0;
-    if (tid == 0) s_flag[fl ^ 1] = 0;
-    if (deferred) {
-      if (tid == 0) {  // the generic kernel redoes this area in int32
-        todo[blk] = 1;
-        const size_t lg3 = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + 2;
-        qp.lists[lg3 * g.nblocks + atomicAdd(&qp.counts[lg3], 1u)] = (uint32_t)blk;
-        if (MIXED) list[li - 1] = e_cur | kEntryDeferred;  // k3_partial skips it as well
-      }
-      __syncthreads();
-      continue;
-    }
-    if (MIXED) {
-      st.build_wtile(tid, lds, s_win);
-      __syncthreads();
-    }
+    if (e_nxt != kEntryNone) tr.fetch(fbase, qp.ps, tid, (int)(e_nxt & 0xffffu), (int)(e_nxt >> 16));
     if (!MIXED && tid == 0) ++nobs;
 
-    int sd = 0, sd2 = 0;
 #pragma unroll 1
     for (int s = 0; s < STEPS_PER_WAVE; ++s) {
       const int widx = wave * STEPS_PER_WAVE + s;
@@ -643,10 +363,22 @@ __global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(c
       if (MIXED) {
         const uint32_t *w32 = reinterpret_cast<const uint32_t *>(lds + S::DATA_BYTES) + row * S::PITCH_DW + lg;
         bool full, empty;
-        group_state<S::PITCH_DW>(w32, full, empty);
+        group_state(w32, S::PITCH_DW, full, empty);
         Wc = w32[2];
-        if (!full) D0 = 0;  // partial groups belong to k3_partial, empty ones to nobody
-        if (pl == 0) nobs = sdot4((int)(Wc & 0x01010101u), 0x01010101, nobs);
+        if (!full) D0 = 0;  // partial groups belong to k3_partial_dense, empty ones to nobody
+        if (pl == 0) {
+          nobs = sdot4((int)(Wc & 0x01010101u), 0x01010101, nobs);
+          const bool part = !full && !empty;
+          const unsigned long long bal = __ballot(part);
+          if (bal != 0) {  // both chroma planes share the window: listed once, on plane 0
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_pgn, (uint32_t)__popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (part)
+              s_pg[base + __popcll(bal & ((1ull << lane) - 1ull))] =
+                  (uint32_t)(bx * S::G + lg) | ((uint32_t)(by * S::BH + row) << 16);
+          }
+        }
       }
       acc[0] = sdot4((int)D0, (int)c0, acc[0]);
       acc[1] = sdot4((int)D0, (int)alignbyte(c1, c0, 1), acc[1]);
@@ -674,8 +406,6 @@ __global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(c
         acc[b + 11] = sdot4((int)D0, (int)alignbyte(e4, e3, 1), acc[b + 11]);  // +5
         acc[b + 12] = sdot4((int)D0, (int)alignbyte(e4, e3, 2), acc[b + 12]);  // +6
       }
-      sd = sdot4((int)c0, 0x01010101, sd);
-      sd2 = sdot4((int)c0, (int)c0, sd2);
       if (CHROMA) {
         // p-centric L terms under the block's own window (Wc; all ones for INT areas)
         const uint32_t *ta = reinterpret_cast<const uint32_t *>(lds + S::NPL * S::TILE_BYTES);
@@ -701,40 +431,13 @@ __global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(c
         al[25] = sdot4((int)Lm, (int)c0, al[25]);
       }
     }
-    // block statistics (only meaningful / stored for flat blocks)
-    sd = wave_sum(sd);
-    sd2 = wave_sum(sd2);
-    if (lane == 0) {
-      s_stat[fl][wave][0] = sd;
-      s_stat[fl][wave][1] = sd2;
-    }
-    __syncthreads();
-    if (tid == 0 && (!MIXED || isflat)) {
-      const int(*sp)[4] = s_stat[fl];
-      int a[2] = {0, 0}, b[2] = {0, 0}, l = 0;
-      for (int w = 0; w < WAVES; ++w) {
-        const int pl = (w * STEPS_PER_WAVE) / S::NS;  // a wave's steps stay within one plane
-        a[pl] += sp[w][0];
-        b[pl] += sp[w][1];
-        l += sp[w][3];
-      }
-      if (!CHROMA) {
-        reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = a[0];
-        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)b[0];
-        reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)l;
-      } else {
-        for (int pl = 0; pl < 2; ++pl) {
-          reinterpret_cast<int32_t *>(rec + g.off_sum_d[1 + pl])[blk] = a[pl];
-          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1 + pl])[blk] = (uint32_t)b[pl];
-        }
-      }
-    }
   }
 
   // ---- wave reduction + partial store: waves of the same plane add up ----
   __syncthreads();
-  int *red = reinterpret_cast<int *>(lds);
-  static_assert(4 * (kQPart + 1) * 4 <= S::DATA_BYTES, "reduction scratch must fit");
+  if (MIXED && s_pgn != 0) pg_flush();
+  int *red = reinterpret_cast<int *>(&lds2[0][0]);
+  static_assert(4 * (kQPart + 1) * 4 <= 2 * BUF, "reduction scratch must fit");
   {
     constexpr int CH = 23;
 #pragma unroll
@@ -776,27 +479,22 @@ __global__ __launch_bounds__(64 * (WV ? WV : QShape<KIND>::WAVES)) void k3_lag(c
 }
 
 // ---------------------------------------------------------------------------------
-// k3_partial<KIND>: PARTIAL groups of MIX areas, compacted per area, 324 masked products
-//     acc(i, j) += dot4(D(q) & W(q - c_i), D(q + c_j - c_i)),  acc(i, y) likewise.
-// A wave owns one (plane, half) combo; waves sharing a combo interleave list steps.
-// grid = (nchunks_mix, 1, batch), block = 256.
+// k3_partial_dense: the 324 masked products of the listed PARTIAL groups,
+//     acc(i, j) += dot4(D(q) & W(q - c_i), D(q + c_j - c_i)),   acc(i, y) likewise,
+// barrier-free: a lane owns a group per step, gathers its 18 + 12 operand dwords from the
+// d8 / w8 planes (neighbouring groups share cache lines), rebuilds the 46 shifted operands
+// and multiplies.  blockIdx.y = which part of the anchors (kPSub accumulators a lane),
+// blockIdx.z = frame * nplanes + component.  grid = (chunks, kPParts, batch * nplanes).
+// int32 safety: <= 64516 per step and accumulator; the launch keeps steps per lane < 520.
 // ---------------------------------------------------------------------------------
-template <int HALF, int PITCH_DW>
-__device__ __forceinline__ void partial_products(int (&acc)[kPHalf], const uint32_t (&D)[kNumLags],
-                                                 const uint32_t *w32) {
-  // window dwords of rows 0..3: q1 = x-4.., q2 = x.., q3 = x+4..
-  uint32_t q1[4], q2[4], q3[4];
-#pragma unroll
-  for (int dy = 0; dy <= 3; ++dy) {
-    const uint32_t *rp = w32 + dy * PITCH_DW;
-    q1[dy] = rp[1];
-    q2[dy] = rp[2];
-    q3[dy] = rp[3];
-  }
+template <int PART>
+__device__ __forceinline__ void partial_products(int (&acc)[kPSub], const uint32_t (&D)[kNumLags],
+                                                 const uint32_t (&q1)[4], const uint32_t (&q2)[4],
+                                                 const uint32_t (&q3)[4]) {
   int idx = 0;
 #pragma unroll
   for (int i = 0; i < kQN; ++i) {
-    if (!p_in_half(HALF, i)) continue;
+    if (!p_in_part(PART, i)) continue;
     const int dx = -coord_x(i), dy = -coord_y(i);  // W(q - c_i)
     uint32_t wi;
     if (dx < 0) wi = alignbyte(q2[dy], q1[dy], 4 + dx);
@@ -813,173 +511,97 @@ __device__ __forceinline__ void partial_products(int (&acc)[kPHalf], const uint3
   }
 }
 
-template <int KIND>
-__global__ __launch_bounds__(256, 2) void k3_partial(const FramePlanes *__restrict__ frames, Geom g, QParams qp,
-                                                     uint8_t *__restrict__ records) {
-  using S = QShape<KIND>;
-  constexpr bool CHROMA = S::kChroma;
-  constexpr int NT = 256;
-  constexpr int NC = S::NPL * 2;   // (plane, half) combos
-  constexpr int WPC = 4 / NC;      // waves per combo
-  __shared__ __attribute__((aligned(16))) uint8_t lds[S::DATA_BYTES + S::WTILE_BYTES];
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[32];
-  __shared__ uint16_t s_plist[S::NG];
-  __shared__ int s_wcount[4];
-
-  const int frame = blockIdx.z, chunk = blockIdx.x;
-  const FramePlanes fp = frames[frame];
-  const size_t lsel = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + 1;
-  const uint32_t *list = qp.lists + lsel * g.nblocks;
-  const int nlist = (int)qp.counts[lsel];
-  const uint8_t *winbase = qp.winbuf + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * g.nblocks * 32;
+__global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
+  const int part = blockIdx.y;
+  const int frame = (int)blockIdx.z / g.nplanes, c = (int)blockIdx.z - frame * g.nplanes;
+  const int kind = c > 0 ? 1 : 0;
+  const uint32_t n = min(qp.pgcount[(size_t)frame * 2 + kind], qp.pg_cap);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int combo = wave % NC, sub = wave / NC;
-  const int my_pl = combo >> 1, my_half = combo & 1;
-
-  int acc[kPHalf];
+  gptr_u1 list = (gptr_u1)as_global(reinterpret_cast<const uint8_t *>(qp.pglist + ((size_t)frame * 2 + kind) * qp.pg_cap));
+  gptr_u8 fb = as_global(qp.planes) + (size_t)frame * qp.ps.frame_bytes;
+  gptr_u1 dplane = (gptr_u1)(fb + (c == 0 ? qp.ps.off_d[0] : (c == 1 ? qp.ps.off_d[1] : qp.ps.off_d[2])));
+  gptr_u1 wplane = (gptr_u1)(fb + (kind ? qp.ps.off_w[1] : qp.ps.off_w[0]));
+  const int pitch_dw = (int)((kind ? qp.ps.pitch[1] : qp.ps.pitch[0]) >> 2);
+  int acc[kPSub];
 #pragma unroll
-  for (int i = 0; i < kPHalf; ++i) acc[i] = 0;
-
-  // Same software pipeline as k3_lag.  Areas that k3_lag<.., true> (which ran before on this
-  // stream) deferred to the generic kernel carry kEntryDeferred and are skipped: one decision,
-  // taken once.
-  int li, li_end;
-  list_slice(chunk, qp.nchunks_mix, nlist, li, li_end);
-  auto entry_at = [&](int pos) -> uint32_t { return pos < li_end ? list[pos] : kEntryNone; };
-  Stager<KIND, NT, true, false> st;
-  uint32_t e_cur = entry_at(li), e_nxt = entry_at(li + 1);
-  uint32_t wreg = 0;
-  if (e_cur != kEntryNone && !(e_cur & kEntryDeferred)) {
-    const int b0 = (int)(e_cur & kEntryIndex);
-    if (tid < 8) wreg = reinterpret_cast<const uint32_t *>(winbase + (size_t)b0 * 32)[tid];
-    st.fetch(fp, g, tid, b0);
-  }
-  __syncthreads();
-
-  for (; e_cur != kEntryNone; e_cur = e_nxt, e_nxt = entry_at(li + 1)) {
-    const int blk = (int)(e_cur & kEntryIndex);
-    const bool skip = (e_cur & kEntryDeferred) != 0;
-    if (!skip) {
-      if (tid < 8) reinterpret_cast<uint32_t *>(s_win)[tid] = wreg;
-      int lsum = 0;
-      (void)st.store(fp, g, tid, blk, lds, lsum);
+  for (int i = 0; i < kPSub; ++i) acc[i] = 0;
+  for (uint32_t e = (uint32_t)blockIdx.x * 256u + tid; e < n; e += gridDim.x * 256u) {
+    const uint32_t ent = list[e];
+    const size_t o = (size_t)((ent >> 16) + kPadY) * pitch_dw + (ent & 0xffffu);
+    gptr_u1 t32 = dplane + o, w32 = wplane + o;
+    uint32_t D[kNumLags];
+    {
+      const uint32_t c0 = t32[2], c1 = t32[3], c2 = t32[4];
+      D[0] = c0;
+      D[1] = alignbyte(c1, c0, 1);
+      D[2] = alignbyte(c1, c0, 2);
+      D[3] = alignbyte(c1, c0, 3);
+      D[4] = c1;
+      D[5] = alignbyte(c2, c1, 1);
+      D[6] = alignbyte(c2, c1, 2);
     }
-    __syncthreads();
-    ++li;
-    if (e_nxt != kEntryNone && !(e_nxt & kEntryDeferred)) {
-      const int bn = (int)(e_nxt & kEntryIndex);
-      if (tid < 8) wreg = reinterpret_cast<const uint32_t *>(winbase + (size_t)bn * 32)[tid];
-      st.fetch(fp, g, tid, bn);
-    }
-    if (skip) continue;
-    st.build_wtile(tid, lds, s_win);
-    __syncthreads();
-    // ---- compact the partial groups of this area ----
-    const uint32_t *w32b = reinterpret_cast<const uint32_t *>(lds + S::DATA_BYTES);
-    bool part = false;
-    if (tid < S::NG) {
-      const int gr = tid / S::G, gg = tid - gr * S::G;
-      bool full, empty;
-      group_state<S::PITCH_DW>(w32b + gr * S::PITCH_DW + gg, full, empty);
-      part = !full && !empty;
-    }
-    const unsigned long long bal = __ballot(part);
-    if (lane == 0) s_wcount[wave] = __popcll(bal);
-    __syncthreads();
-    int off = 0, total = 0;
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) off += s_wcount[w];
-      total += s_wcount[w];
-    }
-    if (part) s_plist[off + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tid;
-    __syncthreads();
-
-    // ---- masked products over the compacted list ----
-    const uint32_t *t32b = reinterpret_cast<const uint32_t *>(lds + my_pl * S::TILE_BYTES);
-    const int nsteps = (total + 63) >> 6;
-#pragma unroll 1
-    for (int s = sub; s < nsteps; s += WPC) {
-      const int e = s * 64 + lane;
-      if (e < total) {
-        const int gi = s_plist[e];
-        const int row = gi / S::G, gg = gi - row * S::G;
-        const uint32_t *t32 = t32b + (row + S::UP) * S::PITCH_DW + gg;
-        uint32_t D[kNumLags];
-        {
-          const uint32_t c0 = t32[2], c1 = t32[3], c2 = t32[4];
-          D[0] = c0;
-          D[1] = alignbyte(c1, c0, 1);
-          D[2] = alignbyte(c1, c0, 2);
-          D[3] = alignbyte(c1, c0, 3);
-          D[4] = c1;
-          D[5] = alignbyte(c2, c1, 1);
-          D[6] = alignbyte(c2, c1, 2);
 #pragma unroll
-          for (int dy = 1; dy <= 3; ++dy) {
-            const uint32_t *rp = t32 + dy * S::PITCH_DW;
-            const uint32_t e0 = rp[0], e1 = rp[1], e2 = rp[2], e3 = rp[3], e4 = rp[4];
-            const int b = 7 + (dy - 1) * 13;
-            D[b + 0] = alignbyte(e1, e0, 2);
-            D[b + 1] = alignbyte(e1, e0, 3);
-            D[b + 2] = e1;
-            D[b + 3] = alignbyte(e2, e1, 1);
-            D[b + 4] = alignbyte(e2, e1, 2);
-            D[b + 5] = alignbyte(e2, e1, 3);
-            D[b + 6] = e2;
-            D[b + 7] = alignbyte(e3, e2, 1);
-            D[b + 8] = alignbyte(e3, e2, 2);
-            D[b + 9] = alignbyte(e3, e2, 3);
-            D[b + 10] = e3;
-            D[b + 11] = alignbyte(e4, e3, 1);
-            D[b + 12] = alignbyte(e4, e3, 2);
-          }
-        }
-        const uint32_t *w32 = w32b + row * S::PITCH_DW + gg;
-        if (my_half == 0)
-          partial_products<0, S::PITCH_DW>(acc, D, w32);
-        else
-          partial_products<1, S::PITCH_DW>(acc, D, w32);
-      }
+    for (int dy = 1; dy <= 3; ++dy) {
+      gptr_u1 rp = t32 + dy * pitch_dw;
+      const uint32_t e0 = rp[0], e1 = rp[1], e2 = rp[2], e3 = rp[3], e4 = rp[4];
+      const int b = 7 + (dy - 1) * 13;
+      D[b + 0] = alignbyte(e1, e0, 2);
+      D[b + 1] = alignbyte(e1, e0, 3);
+      D[b + 2] = e1;
+      D[b + 3] = alignbyte(e2, e1, 1);
+      D[b + 4] = alignbyte(e2, e1, 2);
+      D[b + 5] = alignbyte(e2, e1, 3);
+      D[b + 6] = e2;
+      D[b + 7] = alignbyte(e3, e2, 1);
+      D[b + 8] = alignbyte(e3, e2, 2);
+      D[b + 9] = alignbyte(e3, e2, 3);
+      D[b + 10] = e3;
+      D[b + 11] = alignbyte(e4, e3, 1);
+      D[b + 12] = alignbyte(e4, e3, 2);
     }
-    __syncthreads();  // tiles and list are rewritten by the next iteration
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int dy = 0; dy <= 3; ++dy) {
+      gptr_u1 rp = w32 + dy * pitch_dw;
+      q1[dy] = rp[1];
+      q2[dy] = rp[2];
+      q3[dy] = rp[3];
+    }
+    if (part == 0) partial_products<0>(acc, D, q1, q2, q3);
+    else if (part == 1) partial_products<1>(acc, D, q1, q2, q3);
+    else if (part == 2) partial_products<2>(acc, D, q1, q2, q3);
+    else partial_products<3>(acc, D, q1, q2, q3);
   }
-
-  // ---- wave reduction + partial store ----
-  __syncthreads();
-  int *red = reinterpret_cast<int *>(lds);
-  static_assert(4 * kPHalf * 4 <= S::DATA_BYTES, "reduction scratch must fit");
+  static_assert(kPParts == 4, "the dispatch above lists the parts");
+  if (n == 0) return;
+  __shared__ int red[4 * kPSub];
   {
     constexpr int CH = 27;
 #pragma unroll
-    for (int b0 = 0; b0 < kPHalf; b0 += CH) {
+    for (int b0 = 0; b0 < kPSub; b0 += CH) {
       int tmp[CH];
 #pragma unroll
-      for (int i = 0; i < CH; ++i) tmp[i] = (b0 + i < kPHalf) ? acc[b0 + i] : 0;
+      for (int i = 0; i < CH; ++i) tmp[i] = (b0 + i < kPSub) ? acc[b0 + i] : 0;
       wave_sum_all<CH>(tmp);
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
-          if (b0 + i < kPHalf) red[wave * kPHalf + b0 + i] = tmp[i];
+          if (b0 + i < kPSub) red[wave * kPSub + b0 + i] = tmp[i];
       }
     }
   }
   __syncthreads();
-  for (int pl = 0; pl < S::NPL; ++pl) {
-    unsigned long long *out =
-        reinterpret_cast<unsigned long long *>(qp.paracc) + ((size_t)frame * 3 + (CHROMA ? 1 + pl : 0)) * kPPart;
-    for (int i = tid; i < kPPart; i += NT) {
-      const int h = i / kPHalf, k = i - h * kPHalf;
-      int v = 0;
-      for (int w = 0; w < 4; ++w)
-        if (w % NC == pl * 2 + h) v += red[w * kPHalf + k];
-      if (v != 0) atomicAdd(&out[i], (unsigned long long)(long long)v);
-    }
+  unsigned long long *out =
+      reinterpret_cast<unsigned long long *>(qp.paracc) + ((size_t)frame * 3 + c) * kPPart + part * kPSub;
+  for (int i = tid; i < kPSub; i += 256) {
+    const long long v = (long long)red[i] + red[kPSub + i] + red[2 * kPSub + i] + red[3 * kPSub + i];
+    if (v != 0) atomicAdd(&out[i], (unsigned long long)v);
   }
 }
 
 // ---------------------------------------------------------------------------------
-// k3q_generic: areas marked in `todo` (deferred because |d| > 127, EXT-but-flat, or MIX
-// when the fast mixed path is off), plain int32.  Thread t owns up to two of the 350
+// k3q_generic: the GENERIC list (areas touching a block outside int8, or MIX when the fast
+// mixed path is off), plain int32 from the original planes.  Thread t owns up to two of the 350
 // products:
 //   (i, j):  sum_q W(q - c_i) d(q) d(q + c_j - c_i)        (i, y): ... d(q - c_i)
 //   (i, L):  sum_p w(p) L(p) d(p + c_i);  (L,L), (L,y) likewise      [chroma]
@@ -1140,7 +762,7 @@ __global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict
 // ---------------------------------------------------------------------------------
 // k3q_reduce: every chunk partial of one (frame, plane) -> record (upper triangle).
 //   S[i][j] += G(c_j - c_i);  Sb[i] += G(-c_i);  chroma: S[i][L] += 4 Xa_i + Xb_i, ...
-//   + the 324 masked products of k3_partial.
+//   + the 324 masked products of k3_partial_dense.
 // grid = (nplanes, batch), block = 256: 4 lanes-groups of 64 split the chunk range.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *__restrict__ records) {
@@ -1162,11 +784,11 @@ __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *_
     ar[nc * nc + i] += lag[lag_index(-coord_x(i), -coord_y(i))];  // Sb[i]
     if (chroma) ar[i * nc + kQN] += lag[kNumLags + i];
     // masked products of anchor i
-    const int h = p_in_half(0, i) ? 0 : 1;
+    const int h = (i < 12 ? i : 23 - i) % kPParts;
     int idx = 0;
     for (int a = 0; a < i; ++a)
-      if (p_in_half(h, a)) idx += (kQN - a) + 1;
-    const long long *t = par + h * kPHalf + idx;
+      if (p_in_part(h, a)) idx += (kQN - a) + 1;
+    const long long *t = par + h * kPSub + idx;
     int k = 0;
     for (int j = i; j < kQN; ++j) ar[i * nc + j] += t[k++];
     ar[nc * nc + i] += t[k];
