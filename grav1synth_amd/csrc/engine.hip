@@ -159,6 +159,40 @@ struct CachedSlot {
 std::mutex g_cache_mutex;
 std::vector<CachedSlot> g_slot_cache;
 
+// Streams and their events are process-wide too (0.1-0.2 ms to create each): a generator
+// borrows a compute stream, a copy stream (records D2H overlaps the next batch's kernels)
+// and one event per slot, and hands them back when it is freed.
+struct StreamSet {
+  int device = -1;
+  hipStream_t compute = nullptr, copy = nullptr;
+  hipEvent_t kernels_done[2] = {nullptr, nullptr};
+};
+std::vector<StreamSet> g_stream_cache;
+bool acquire_streams(int device, StreamSet &out) {
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    for (size_t i = 0; i < g_stream_cache.size(); ++i) {
+      if (g_stream_cache[i].device == device) {
+        out = g_stream_cache[i];
+        g_stream_cache.erase(g_stream_cache.begin() + i);
+        return true;
+      }
+    }
+  }
+  out = StreamSet{};
+  out.device = device;
+  bool ok = hipStreamCreateWithFlags(&out.compute, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess;
+  return ok;
+}
+void release_streams(StreamSet &ss) {
+  if (!ss.compute) return;
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  g_stream_cache.push_back(ss);
+  ss = StreamSet{};
+}
+
 }  // namespace
 
 struct g1s_diff {
@@ -170,6 +204,7 @@ struct g1s_diff {
   int device = 0;
   hipStream_t stream = nullptr;       // == slot_stream[0]
   hipStream_t slot_stream[2] = {nullptr, nullptr};  // one stream per batch slot: consecutive batches overlap
+  StreamSet ss;                       // borrowed: ss.compute == slot_stream[0]
   hipStream_t aux[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // K3 kernels of one batch run side by side
   hipEvent_t ev_fork[2] = {nullptr, nullptr};
   hipEvent_t ev_join[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
@@ -409,16 +444,35 @@ int g1s_diff::submit(int si) {
   hipStream_t stream = (slot_streams && slot_stream[si]) ? slot_stream[si] : slot_stream[0];  // (shadows the member)
   const bool k3s = k3_streams && aux[si][0];
   hipStream_t ax[3] = {k3s ? aux[si][0] : stream, k3s ? aux[si][1] : stream, k3s ? aux[si][2] : stream};
-  HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(sl.d_records, 0, L.size * B, stream));
+  FrameTable ft;
+  std::memcpy(ft.f, sl.h_planes, sizeof(FramePlanes) * B);
+  if (B < (uint32_t)kMaxBatch) std::memset(ft.f + B, 0, sizeof(FramePlanes) * (kMaxBatch - B));
+  {
+    // all per-batch zero fills in one launch: records, lag / masked accumulators, bad flags + list counters
+    ZeroJob z{};
+    z.ptr[0] = reinterpret_cast<uint32_t *>(sl.d_records);
+    z.ndw[0] = (uint32_t)(L.size * B / 4);
+    if ((int)lag == kQLag) {
+      const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
+      z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_partials);
+      z.ndw[1] = (uint32_t)(sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart) / 4);
+      z.ptr[2] = reinterpret_cast<uint32_t *>(sl.d_defer + cls_bytes);  // bad flags
+      z.ndw[2] = (uint32_t)(cls_bytes / 4);
+      z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes) + (size_t)batch * 6 * g.nblocks;  // list counts
+      z.ndw[3] = (uint32_t)batch * 8;
+      z.ptr[4] = sl.d_pgl + (size_t)batch * 2 * pg_cap;  // partial-group list counts
+      z.ndw[4] = (uint32_t)batch * 2;
+    }
+    hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, stream, z);
+  }
   sl.timed = timing;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], stream));
   {
     dim3 grid((g.nblocks + 63) / 64, B);
     if (g.src_bps == 1)
-      hipLaunchKernelGGL(k1_flat_features<1>, grid, dim3(64), 0, stream, sl.d_planes, g, fc, d_lut, sl.d_records, sl.d_flags);
+      hipLaunchKernelGGL(k1_flat_features<1>, grid, dim3(64), 0, stream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
     else
-      hipLaunchKernelGGL(k1_flat_features<2>, grid, dim3(64), 0, stream, sl.d_planes, g, fc, d_lut, sl.d_records, sl.d_flags);
+      hipLaunchKernelGGL(k1_flat_features<2>, grid, dim3(64), 0, stream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], stream));
   hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(256), 0, stream, g, sl.d_records, sl.d_flags);
@@ -434,7 +488,6 @@ int g1s_diff::submit(int si) {
     qp.mixed_fast = force_generic ? 0 : 1;
     qp.lagacc = reinterpret_cast<long long *>(sl.d_partials);
     qp.paracc = qp.lagacc + (size_t)batch * 3 * kQPart;
-    HIP_TRY(hipMemsetAsync(sl.d_partials, 0, sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart), stream));
     const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
     qp.cls = sl.d_defer;
     qp.bad = sl.d_defer + cls_bytes;
@@ -445,14 +498,11 @@ int g1s_diff::submit(int si) {
     qp.pgcount = sl.d_pgl + (size_t)batch * 2 * pg_cap;
     qp.planes = sl.d_k0;
     qp.ps = ps;
-    HIP_TRY(hipMemsetAsync(qp.bad, 0, cls_bytes, stream));
-    HIP_TRY(hipMemsetAsync(qp.counts, 0, sizeof(uint32_t) * (size_t)batch * 6, stream));
-    HIP_TRY(hipMemsetAsync(qp.pgcount, 0, sizeof(uint32_t) * (size_t)batch * 2, stream));
     {
       // K0: one pass over the source / denoised planes -> int8 residual, L and window planes + block statistics
       const dim3 gr((g.nbw + 1) / 2, g.nbh, B);
 #define G1S_K0(SB, DB) \
-  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, stream, sl.d_planes, g, ps, sl.d_k0, qp.bad, sl.d_records)
+  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, stream, ft, g, ps, sl.d_k0, qp.bad, sl.d_records)
       if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);
       else if (g.src_bps == 1) G1S_K0(1, 2);
       else if (g.den_bps == 1) G1S_K0(2, 1);
@@ -495,21 +545,26 @@ int g1s_diff::submit(int si) {
     }
     if (qp.mixed_fast) {
       // <= pg_cap / (chunks * 256) = nblocks / chunks steps per lane; the int32 wave sums need < 520
-      const int chunks = std::max(std::max(8, std::min(64, g.nblocks / 128)), (g.nblocks + 255) / 256);
+      static const int dense_env = getenv("G1S_DENSE_CHUNKS") ? atoi(getenv("G1S_DENSE_CHUNKS")) : 0;  // tuning aid
+      int chunks = std::max(std::max(8, std::min(16, g.nblocks / 512)), (g.nblocks + 255) / 256);
+      if (dense_env > 0) chunks = std::max(dense_env, (g.nblocks + 255) / 256);
       hipLaunchKernelGGL(k3_partial_dense, dim3(chunks, kPParts, B * g.nplanes), dim3(256), 0, stream, g, qp);
     }
     hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, qp, sl.d_records);
     const int chunks = std::min(64, g.nblocks);
-    hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, B), dim3(256), 0, stream, sl.d_planes, g, qp, sl.d_records);
+    hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, B), dim3(256), 0, stream, ft, g, qp, sl.d_records);
   } else {
     const int chunks = std::min(kK3Chunks, g.nblocks);
-    hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, sl.d_planes, g, sl.d_records,
+    hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g, sl.d_records,
                        (const uint8_t *)nullptr, (const uint32_t *)nullptr);
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[3], stream));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipEventRecord(sl.done, stream));
+  // records D2H on the copy stream: the compute stream goes straight on to the next batch
+  HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
+  HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
+  HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, ss.copy));
+  HIP_TRY(hipEventRecord(sl.done, ss.copy));
   in_flight.push_back(si);
   stats.launches_flat_features++;
   stats.launches_flat_select++;
@@ -619,6 +674,9 @@ void g1s_diff::release() {
     for (int a = 0; a < 3; ++a)
       if (aux[i][a]) (void)hipStreamSynchronize(aux[i][a]);
   }
+  if (ss.copy) (void)hipStreamSynchronize(ss.copy);
+  slot_stream[0] = nullptr;  // borrowed
+  release_streams(ss);
   for (Slot &sl : slots) {
     if (sl.h_planes && geometry_set) {  // park the buffers for the next generator of this geometry
       std::lock_guard<std::mutex> lk(g_cache_mutex);
@@ -689,7 +747,7 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
       return nullptr;
     }
     if (opts->ar_coeff_lag) lag = opts->ar_coeff_lag;
-    if (opts->batch_frames) batch = opts->batch_frames;
+    if (opts->batch_frames) batch = std::min<uint32_t>(opts->batch_frames, (uint32_t)kMaxBatch);
     luma_only = opts->luma_only != 0;
     records_only = opts->records_only != 0;
     device = opts->device;
@@ -727,7 +785,8 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   // One stream by default; per-slot and per-kernel streams only for experiments
   // (G1S_SLOT_STREAMS / G1S_K3_STREAMS): creating streams costs ~0.1-0.2 ms each.
   const bool want_slot = getenv("G1S_SLOT_STREAMS") != nullptr, want_k3 = getenv("G1S_K3_STREAMS") != nullptr;
-  bool streams_ok = hipStreamCreateWithFlags(&g->slot_stream[0], hipStreamNonBlocking) == hipSuccess;
+  bool streams_ok = acquire_streams(device, g->ss);
+  g->slot_stream[0] = g->ss.compute;
   if (streams_ok && want_slot)
     streams_ok = hipStreamCreateWithFlags(&g->slot_stream[1], hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < 2 && streams_ok && want_k3; ++i) {

@@ -199,7 +199,7 @@ __device__ __forceinline__ void load_narrow(const uint8_t *base, uint32_t stride
 // Runs after K2 (it needs the flat mask for the windows and to know which statistics to keep).
 // ---------------------------------------------------------------------------------
 template <int SBPS, int DBPS>
-__global__ __launch_bounds__(256) void k0_residual(const FramePlanes *__restrict__ frames, Geom g, PlaneSet ps,
+__global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, PlaneSet ps,
                                                    uint8_t *__restrict__ planes, uint8_t *__restrict__ bad,
                                                    uint8_t *__restrict__ records) {
   __shared__ int s_luma[4][4];    // per wave: sum d, sum d^2, sum src8, flags (1: |d| > 127, 2: |L| > 127)
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k0_residual(const FramePlanes *__restrict
   const int b = wave & 1;
   const int bx = 2 * (int)blockIdx.x + b;
   const bool active = bx < g.nbw;
-  const FramePlanes fp = frames[frame];
+  const FramePlanes fp = ft.f[frame];
   uint8_t *fbase = planes + (size_t)frame * ps.frame_bytes;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
@@ -350,6 +350,24 @@ __global__ __launch_bounds__(256) void k0_residual(const FramePlanes *__restrict
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k_zero: every per-batch zero fill in ONE launch (records, accumulators, flags, counters);
+// separate memset nodes each cost a dispatch gap in the launch chain.
+// ---------------------------------------------------------------------------------
+struct ZeroJob {
+  uint32_t *ptr[5];
+  uint32_t ndw[5];  // dwords
+};
+__global__ __launch_bounds__(256) void k_zero(ZeroJob z) {
+  const uint32_t stride = gridDim.x * 256u;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    uint32_t *p = z.ptr[r];
+    const uint32_t n = z.ndw[r];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) p[i] = 0u;
   }
 }
 

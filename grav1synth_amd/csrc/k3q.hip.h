@@ -88,6 +88,9 @@ __device__ __forceinline__ void wave_sum_all(int (&a)[N]) {
   }
 }
 typedef const G1S_GLOBAL uint32_t *gptr_u1;
+// dword-aligned wide global loads (global_load_dwordx3 / x4 need no more than that)
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // ---------------------------------------------------------------------------------
 // k3_classify: one thread per block area and plane kind.  The area of block (bx, by)
@@ -525,13 +528,40 @@ __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
   int acc[kPSub];
 #pragma unroll
   for (int i = 0; i < kPSub; ++i) acc[i] = 0;
-  for (uint32_t e = (uint32_t)blockIdx.x * 256u + tid; e < n; e += gridDim.x * 256u) {
-    const uint32_t ent = list[e];
-    const size_t o = (size_t)((ent >> 16) + kPadY) * pitch_dw + (ent & 0xffffu);
-    gptr_u1 t32 = dplane + o, w32 = wplane + o;
+  // operand dwords of one group: d row 0 (3), d rows 1..3 (5 each), w rows 0..3 (3 each)
+  struct Ops {
+    u32x3_a4 cv, qv[4];
+    u32x4_a4 ev[3];
+    uint32_t e4[3];
+  };
+  auto gather = [&](uint32_t ent, Ops &o) {
+    const size_t off = (size_t)((ent >> 16) + kPadY) * pitch_dw + (ent & 0xffffu);
+    gptr_u1 t32 = dplane + off, w32 = wplane + off;
+    o.cv = *(const G1S_GLOBAL u32x3_a4 *)(t32 + 2);
+#pragma unroll
+    for (int dy = 1; dy <= 3; ++dy) {
+      gptr_u1 rp = t32 + dy * pitch_dw;
+      o.ev[dy - 1] = *(const G1S_GLOBAL u32x4_a4 *)rp;
+      o.e4[dy - 1] = rp[4];
+    }
+#pragma unroll
+    for (int dy = 0; dy <= 3; ++dy) o.qv[dy] = *(const G1S_GLOBAL u32x3_a4 *)(w32 + dy * pitch_dw + 1);
+  };
+  // software pipeline: the operands of step k+1 and the list entry of step k+2 are in flight
+  // during the products of step k
+  const uint32_t stride = gridDim.x * 256u;
+  uint32_t e = (uint32_t)blockIdx.x * 256u + tid;
+  Ops cur, nxt;
+  uint32_t ent_nxt = 0;
+  if (e < n) gather(list[e], cur);
+  if (e + stride < n) ent_nxt = list[e + stride];
+  for (; e < n; e += stride) {
+    const bool more = e + stride < n;
+    if (more) gather(ent_nxt, nxt);
+    if (e + 2 * stride < n) ent_nxt = list[e + 2 * stride];
     uint32_t D[kNumLags];
     {
-      const uint32_t c0 = t32[2], c1 = t32[3], c2 = t32[4];
+      const uint32_t c0 = cur.cv.x, c1 = cur.cv.y, c2 = cur.cv.z;
       D[0] = c0;
       D[1] = alignbyte(c1, c0, 1);
       D[2] = alignbyte(c1, c0, 2);
@@ -542,8 +572,8 @@ __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
     }
 #pragma unroll
     for (int dy = 1; dy <= 3; ++dy) {
-      gptr_u1 rp = t32 + dy * pitch_dw;
-      const uint32_t e0 = rp[0], e1 = rp[1], e2 = rp[2], e3 = rp[3], e4 = rp[4];
+      const uint32_t e0 = cur.ev[dy - 1].x, e1 = cur.ev[dy - 1].y, e2 = cur.ev[dy - 1].z, e3 = cur.ev[dy - 1].w,
+                     e4 = cur.e4[dy - 1];
       const int b = 7 + (dy - 1) * 13;
       D[b + 0] = alignbyte(e1, e0, 2);
       D[b + 1] = alignbyte(e1, e0, 3);
@@ -562,15 +592,15 @@ __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
     uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
     for (int dy = 0; dy <= 3; ++dy) {
-      gptr_u1 rp = w32 + dy * pitch_dw;
-      q1[dy] = rp[1];
-      q2[dy] = rp[2];
-      q3[dy] = rp[3];
+      q1[dy] = cur.qv[dy].x;
+      q2[dy] = cur.qv[dy].y;
+      q3[dy] = cur.qv[dy].z;
     }
     if (part == 0) partial_products<0>(acc, D, q1, q2, q3);
     else if (part == 1) partial_products<1>(acc, D, q1, q2, q3);
     else if (part == 2) partial_products<2>(acc, D, q1, q2, q3);
     else partial_products<3>(acc, D, q1, q2, q3);
+    if (more) cur = nxt;
   }
   static_assert(kPParts == 4, "the dispatch above lists the parts");
   if (n == 0) return;
@@ -609,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
 // grid = (chunks, nplanes, batch), block = 256.
 // ---------------------------------------------------------------------------------
 constexpr int kGW = kBlock + 12, kGH = kBlock + 6;  // d tile: cols -6..37, rows -3..34
-__global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict__ frames, Geom g, QParams qp,
+__global__ __launch_bounds__(256) void k3q_generic(const FrameTable ft, Geom g, QParams qp,
                                                    uint8_t *__restrict__ records) {
   __shared__ int dt[kGH * kGW];        // d(q), x in -6..bw+5, y in -3..bh+2
   __shared__ uint8_t wt[kGH * kGW];    // w at the same positions
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(256) void k3q_generic(const FramePlanes *__restrict
   const int nlist = (int)qp.counts[lsel];
   if ((int)blockIdx.x >= nlist) return;  // the common case: nothing deferred
   const uint32_t *list = qp.lists + lsel * g.nblocks;
-  const FramePlanes fp = frames[frame];
+  const FramePlanes fp = ft.f[frame];
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
   const int sx = c ? g.xdec : 0, sy = c ? g.ydec : 0;

@@ -29,6 +29,12 @@ struct FramePlanes {
   uint32_t den_stride[3];
 };
 
+// The frame table of a batch travels in the kernel arguments (no H2D copy in the launch chain).
+constexpr int kMaxBatch = 16;
+struct FrameTable {
+  FramePlanes f[kMaxBatch];
+};
+
 struct Geom {
   int W, H, xdec, ydec, nplanes;
   int nbw, nbh, nblocks;
@@ -126,7 +132,7 @@ __device__ __forceinline__ void load_row32(const uint8_t *base, uint32_t stride,
 // grid = (ceil(nblocks/64), batch), block = 64.
 // ----------------------------------------------------------------------------
 template <int BPS>
-__global__ __launch_bounds__(64) void k1_flat_features(const FramePlanes *__restrict__ frames, Geom g,
+__global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom g,
                                                        FlatConsts fc, const double *__restrict__ lut_g,
                                                        uint8_t *__restrict__ records,
                                                        uint8_t *__restrict__ flags) {
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FramePlanes *__rest
   const int frame = blockIdx.y;
   const int blk = blockIdx.x * 64 + threadIdx.x;
   if (blk >= g.nblocks) return;
-  const FramePlanes fp = frames[frame];
+  const FramePlanes fp = ft.f[frame];
   const uint8_t *base = fp.src[0];
   const uint32_t stride = fp.src_stride[0];
   const int shift = g.src_shift;
@@ -310,7 +316,7 @@ __device__ __forceinline__ int block_reduce_sum(int v, int *scratch) {
 // `only` (optional): per-frame block lists [batch][2][nblocks] (luma, chroma); when given, only the
 // blocks marked there are processed (the blocks the lag-3 fast kernel deferred
 // because |d| > 127), and frames with only_any[frame] == 0 exit at once.
-__global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FramePlanes *__restrict__ frames, Geom g,
+__global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FrameTable ft, Geom g,
                                                             uint8_t *__restrict__ records,
                                                             const uint8_t *__restrict__ only,
                                                             const uint32_t *__restrict__ only_any) {
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FramePlanes *_
   const int frame = blockIdx.z;
   if (only_any && only_any[frame] == 0) return;
   const uint8_t *only_f = only ? only + ((size_t)frame * 2 + (c > 0 ? 1 : 0)) * g.nblocks : nullptr;
-  const FramePlanes fp = frames[frame];
+  const FramePlanes fp = ft.f[frame];
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
   const int lag = g.lag, n = g.n;
