@@ -500,7 +500,7 @@ int g1s_diff::submit(int si) {
     qp.ps = ps;
     {
       // K0: one pass over the source / denoised planes -> int8 residual, L and window planes + block statistics
-      const dim3 gr((g.nbw + 1) / 2, g.nbh, B);
+      const dim3 gr((g.nbw + 3) / 4, g.nbh, B);
 #define G1S_K0(SB, DB) \
   hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, stream, ft, g, ps, sl.d_k0, qp.bad, sl.d_records)
       if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);

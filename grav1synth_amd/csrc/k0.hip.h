@@ -192,162 +192,172 @@ __device__ __forceinline__ void load_narrow(const uint8_t *base, uint32_t stride
 }
 
 // ---------------------------------------------------------------------------------
-// k0_residual<SBPS, DBPS>: grid = (ceil(nbw / 2), nbh, batch), block = 256.
-// A workgroup owns two horizontally adjacent blocks (128-byte rows of 16-bit luma).
-//   luma:   wave w -> block w & 1, rows (w >> 1) * 16 .. +15; lane -> (row, 8-sample segment)
-//   chroma: wave w -> component 1 + (w >> 1), block w & 1; lanes stride over 4-sample items
+// k0_residual<SBPS, DBPS>: grid = (ceil(nbw / 4), nbh, batch), block = 256.
+// A workgroup owns four horizontally adjacent blocks: every row it touches is at least one
+// full 128-byte line per plane, every lane moves 8 samples (16-byte loads of 16-bit input).
+//   luma:   512 items of 8 samples, two per thread: item -> (row = i / 16, segment = i % 16)
+//   chroma: (128 >> xdec) / 8 segments x (32 >> ydec) rows per component, one or more per thread
+// Block sums go through LDS atomics (block = segment / segments-per-block).
 // Runs after K2 (it needs the flat mask for the windows and to know which statistics to keep).
 // ---------------------------------------------------------------------------------
 template <int SBPS, int DBPS>
 __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, PlaneSet ps,
                                                    uint8_t *__restrict__ planes, uint8_t *__restrict__ bad,
                                                    uint8_t *__restrict__ records) {
-  __shared__ int s_luma[4][4];    // per wave: sum d, sum d^2, sum src8, flags (1: |d| > 127, 2: |L| > 127)
-  __shared__ int s_chroma[4][3];  // per wave: sum d, sum d^2, flag
-  const int frame = blockIdx.z, by = blockIdx.y;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int b = wave & 1;
-  const int bx = 2 * (int)blockIdx.x + b;
-  const bool active = bx < g.nbw;
+  __shared__ int s_sum[3][4][3];  // [component][block][sum d, sum d^2, sum src8 (luma)]
+  __shared__ int s_bad[2][4];     // [kind][block]
+  __shared__ Win s_win[2][4];     // [kind][block]
+  const int frame = blockIdx.z, by = blockIdx.y, bx0 = 4 * (int)blockIdx.x;
+  const int tid = threadIdx.x;
   const FramePlanes fp = ft.f[frame];
   uint8_t *fbase = planes + (size_t)frame * ps.frame_bytes;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
   const bool chroma = g.nplanes == 3;
   const int sx = g.xdec, sy = g.ydec;
+  if (tid < 36) (&s_sum[0][0][0])[tid] = 0;
+  if (tid < 8) {
+    (&s_bad[0][0])[tid] = 0;
+    const int k = tid >> 2, b = tid & 3;
+    s_win[k][b] = block_window(mask, g.nbw, g.nbh, bx0 + b, by, kBlock >> (k ? sx : 0), kBlock >> (k ? sy : 0),
+                               g.W >> (k ? sx : 0), g.H >> (k ? sy : 0));
+  }
+  __syncthreads();
 
   // ------------------------------- luma -------------------------------
   {
-    const int row = (wave >> 1) * 16 + (lane >> 2), seg = lane & 3;
-    const int X0 = bx * kBlock + seg * 8, Y = by * kBlock + row;
-    uint32_t hs[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0}, d[4];
-    if (active) {
-      load_narrow<SBPS, 8>(fp.src[0], fp.src_stride[0], g.src_shift, (g.vec_mask & 1) != 0, X0, Y, g.W, g.H, hs);
-      load_narrow<DBPS, 8>(fp.den[0], fp.den_stride[0], g.den_shift, (g.vec_mask & 8) != 0, X0, Y, g.W, g.H, hv);
-    }
-    uint32_t mx = 0, mn = 0;
-    int sd = 0, sd2 = 0;
+    const int seg = tid & 15, b = seg >> 2;
+    const bool active = bx0 + b < g.nbw;
+    const int X0 = bx0 * kBlock + seg * 8;
+    const Win w = s_win[0][b];
+    int sd = 0, sd2 = 0, ls = 0;
+    uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      d[k] = pk_sub(hs[k], hv[k]);
-      mx = pk_max(mx, d[k]);
-      mn = pk_min(mn, d[k]);
-      const int a0 = pk_lo(d[k]), a1 = pk_hi(d[k]);
-      sd += a0 + a1;
-      sd2 += a0 * a0 + a1 * a1;
-    }
-    int ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[0], hs[1]), 0u, 0u);
-    ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[2], hs[3]), 0u, (uint32_t)ls);
-    int flags = range_bad(mx, mn) ? 1 : 0;
-    if (active) {
-      const size_t o = (size_t)(Y + kPadY) * ps.pitch[0] + kPadX + X0;
-      *reinterpret_cast<uint2 *>(fbase + ps.off_d[0] + o) = make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
-      const Win w = block_window(mask, g.nbw, g.nbh, bx, by, kBlock, kBlock, g.W, g.H);
-      const unsigned long long wb = window_bytes(w, seg * 8, row, 8);
-      *reinterpret_cast<uint2 *>(fbase + ps.off_w[0] + o) = make_uint2((uint32_t)wb, (uint32_t)(wb >> 32));
-    }
-    if (chroma) {
-      // L = sum of the (1 << sx) x (1 << sy) luma residuals under a chroma sample
-      uint32_t v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = sy ? pk_add(d[k], (uint32_t)__shfl_down((int)d[k], 4, 64)) : d[k];  // + next row
-      const bool store_row = active && (sy == 0 || (row & 1) == 0);
-      const int cy = Y >> sy;
-      uint32_t lmx = 0, lmn = 0;
-      if (sx) {
-        int L[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) L[k] = pk_lo(v[k]) + pk_hi(v[k]);
-        const uint32_t p0 = ((uint32_t)L[0] & 0xffffu) | ((uint32_t)L[1] << 16);
-        const uint32_t p1 = ((uint32_t)L[2] & 0xffffu) | ((uint32_t)L[3] << 16);
-        lmx = pk_max(p0, p1);
-        lmn = pk_min(p0, p1);
-        if (store_row)
-          *reinterpret_cast<uint32_t *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + (X0 >> 1)) = pk_bytes(p0, p1);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          lmx = pk_max(lmx, v[k]);
-          lmn = pk_min(lmn, v[k]);
-        }
-        if (store_row)
-          *reinterpret_cast<uint2 *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + X0) =
-              make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
+    for (int k = 0; k < 2; ++k) {
+      const int row = (tid >> 4) + 16 * k;
+      const int Y = by * kBlock + row;
+      uint32_t hs[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0}, d[4];
+      if (active) {
+        load_narrow<SBPS, 8>(fp.src[0], fp.src_stride[0], g.src_shift, (g.vec_mask & 1) != 0, X0, Y, g.W, g.H, hs);
+        load_narrow<DBPS, 8>(fp.den[0], fp.den_stride[0], g.den_shift, (g.vec_mask & 8) != 0, X0, Y, g.W, g.H, hv);
       }
-      if (store_row && range_bad(lmx, lmn)) flags |= 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        d[q] = pk_sub(hs[q], hv[q]);
+        mx = pk_max(mx, d[q]);
+        mn = pk_min(mn, d[q]);
+        const int a0 = pk_lo(d[q]), a1 = pk_hi(d[q]);
+        sd += a0 + a1;
+        sd2 += a0 * a0 + a1 * a1;
+      }
+      ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[0], hs[1]), 0u, (uint32_t)ls);
+      ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[2], hs[3]), 0u, (uint32_t)ls);
+      if (active) {
+        const size_t o = (size_t)(Y + kPadY) * ps.pitch[0] + kPadX + X0;
+        *reinterpret_cast<uint2 *>(fbase + ps.off_d[0] + o) = make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
+        const unsigned long long wb = window_bytes(w, (seg & 3) * 8, row, 8);
+        *reinterpret_cast<uint2 *>(fbase + ps.off_w[0] + o) = make_uint2((uint32_t)wb, (uint32_t)(wb >> 32));
+      }
+      if (chroma) {
+        // L = sum of the (1 << sx) x (1 << sy) luma residuals under a chroma sample; the next
+        // row of the item sits 16 lanes up (same wave: a wave is 4 rows of 16 segments)
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = sy ? pk_add(d[q], (uint32_t)__shfl_down((int)d[q], 16, 64)) : d[q];
+        const bool store_row = active && (sy == 0 || (row & 1) == 0);
+        const int cy = Y >> sy;
+        uint32_t tmx = 0, tmn = 0;
+        if (sx) {
+          int L[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) L[q] = pk_lo(v[q]) + pk_hi(v[q]);
+          const uint32_t p0 = ((uint32_t)L[0] & 0xffffu) | ((uint32_t)L[1] << 16);
+          const uint32_t p1 = ((uint32_t)L[2] & 0xffffu) | ((uint32_t)L[3] << 16);
+          tmx = pk_max(p0, p1);
+          tmn = pk_min(p0, p1);
+          if (store_row)
+            *reinterpret_cast<uint32_t *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + (X0 >> 1)) = pk_bytes(p0, p1);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            tmx = pk_max(tmx, v[q]);
+            tmn = pk_min(tmn, v[q]);
+          }
+          if (store_row)
+            *reinterpret_cast<uint2 *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + X0) =
+                make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
+        }
+        if (store_row) {
+          lmx = pk_max(lmx, tmx);
+          lmn = pk_min(lmn, tmn);
+        }
+      }
     }
-    sd = wave_sum(sd);
-    sd2 = wave_sum(sd2);
-    ls = wave_sum(ls);
-    const int f1 = __any(flags & 1) ? 1 : 0, f2 = __any(flags & 2) ? 2 : 0;
-    if (lane == 0) {
-      s_luma[wave][0] = sd;
-      s_luma[wave][1] = sd2;
-      s_luma[wave][2] = ls;
-      s_luma[wave][3] = f1 | f2;
+    if (active) {
+      atomicAdd(&s_sum[0][b][0], sd);
+      atomicAdd(&s_sum[0][b][1], sd2);
+      atomicAdd(&s_sum[0][b][2], ls);
+      if (range_bad(mx, mn)) s_bad[0][b] = 1;
+      if (range_bad(lmx, lmn)) s_bad[1][b] = 1;
     }
   }
   // ------------------------------- chroma -------------------------------
   if (chroma) {
-    const int c = 1 + (wave >> 1);
     const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
-    const int segs = bw >> 2, items = segs * bh;
-    const uint8_t *sp = c == 1 ? fp.src[1] : fp.src[2];
-    const uint8_t *dp = c == 1 ? fp.den[1] : fp.den[2];
-    const uint32_t sst = c == 1 ? fp.src_stride[1] : fp.src_stride[2];
-    const uint32_t dst = c == 1 ? fp.den_stride[1] : fp.den_stride[2];
-    const bool vs = ((g.vec_mask >> c) & 1) != 0, vd = ((g.vec_mask >> (3 + c)) & 1) != 0;
-    uint8_t *dplane = fbase + (c == 1 ? ps.off_d[1] : ps.off_d[2]);
-    Win w{0, 0, 0, 0, 0};
-    if (active && c == 1) w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph);
-    uint32_t mx = 0, mn = 0;
-    int sd = 0, sd2 = 0;
-    if (active) {
-      for (int it = lane; it < items; it += 64) {
-        const int row = it / segs, seg = it - row * segs;
-        const int X0 = bx * bw + seg * 4, Y = by * bh + row;
-        uint32_t hs[2], hv[2];
-        load_narrow<SBPS, 4>(sp, sst, g.src_shift, vs, X0, Y, pw, ph, hs);
-        load_narrow<DBPS, 4>(dp, dst, g.den_shift, vd, X0, Y, pw, ph, hv);
-        const uint32_t d0 = pk_sub(hs[0], hv[0]), d1 = pk_sub(hs[1], hv[1]);
-        mx = pk_max(mx, pk_max(d0, d1));
-        mn = pk_min(mn, pk_min(d0, d1));
-        const int a0 = pk_lo(d0), a1 = pk_hi(d0), a2 = pk_lo(d1), a3 = pk_hi(d1);
-        sd += a0 + a1 + a2 + a3;
-        sd2 += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-        const size_t o = (size_t)(Y + kPadY) * ps.pitch[1] + kPadX + X0;
-        *reinterpret_cast<uint32_t *>(dplane + o) = pk_bytes(d0, d1);
-        if (c == 1) *reinterpret_cast<uint32_t *>(fbase + ps.off_w[1] + o) = (uint32_t)window_bytes(w, seg * 4, row, 4);
+    const int segs = (4 * bw) >> 3, spb = bw >> 3;  // 8-sample segments per region row / per block
+    const int ipp = segs * bh;                       // items per component: 128, 256 or 512
+    for (int i = tid; i < 2 * ipp; i += 256) {
+      const int c = 1 + (i >= ipp ? 1 : 0);
+      const int it = i - (c - 1) * ipp;
+      const int row = it / segs, seg = it - row * segs;
+      const int b = seg / spb;
+      if (bx0 + b >= g.nbw) continue;
+      const uint8_t *sp = c == 1 ? fp.src[1] : fp.src[2];
+      const uint8_t *dp = c == 1 ? fp.den[1] : fp.den[2];
+      const uint32_t sst = c == 1 ? fp.src_stride[1] : fp.src_stride[2];
+      const uint32_t dst = c == 1 ? fp.den_stride[1] : fp.den_stride[2];
+      const bool vs = ((g.vec_mask >> c) & 1) != 0, vd = ((g.vec_mask >> (3 + c)) & 1) != 0;
+      const int X0 = bx0 * bw + seg * 8, Y = by * bh + row;
+      uint32_t hs[4], hv[4], d[4];
+      load_narrow<SBPS, 8>(sp, sst, g.src_shift, vs, X0, Y, pw, ph, hs);
+      load_narrow<DBPS, 8>(dp, dst, g.den_shift, vd, X0, Y, pw, ph, hv);
+      uint32_t mx = 0, mn = 0;
+      int sd = 0, sd2 = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        d[q] = pk_sub(hs[q], hv[q]);
+        mx = pk_max(mx, d[q]);
+        mn = pk_min(mn, d[q]);
+        const int a0 = pk_lo(d[q]), a1 = pk_hi(d[q]);
+        sd += a0 + a1;
+        sd2 += a0 * a0 + a1 * a1;
       }
-    }
-    sd = wave_sum(sd);
-    sd2 = wave_sum(sd2);
-    const int f = __any(range_bad(mx, mn)) ? 1 : 0;
-    if (lane == 0) {
-      s_chroma[wave][0] = sd;
-      s_chroma[wave][1] = sd2;
-      s_chroma[wave][2] = f;
+      const size_t o = (size_t)(Y + kPadY) * ps.pitch[1] + kPadX + X0;
+      *reinterpret_cast<uint2 *>(fbase + (c == 1 ? ps.off_d[1] : ps.off_d[2]) + o) =
+          make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
+      if (c == 1) {
+        const unsigned long long wb = window_bytes(s_win[1][b], (seg - b * spb) * 8, row, 8);
+        *reinterpret_cast<uint2 *>(fbase + ps.off_w[1] + o) = make_uint2((uint32_t)wb, (uint32_t)(wb >> 32));
+      }
+      atomicAdd(&s_sum[c][b][0], sd);
+      atomicAdd(&s_sum[c][b][1], sd2);
+      if (range_bad(mx, mn)) s_bad[1][b] = 1;
     }
   }
   __syncthreads();
-  if (tid < 2) {
-    const int bxo = 2 * (int)blockIdx.x + tid;
-    if (bxo < g.nbw) {
-      const int blk = by * g.nbw + bxo;
-      const int lf = s_luma[tid][3] | s_luma[tid + 2][3];
-      if (lf & 1) bad[(size_t)frame * 2 * g.nblocks + blk] = 1;
-      if (chroma && ((lf & 2) || s_chroma[tid][2] || s_chroma[tid + 2][2]))
-        bad[((size_t)frame * 2 + 1) * g.nblocks + blk] = 1;
-      if (mask[blk]) {  // noise statistics of the flat blocks
-        reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = s_luma[tid][0] + s_luma[tid + 2][0];
-        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)(s_luma[tid][1] + s_luma[tid + 2][1]);
-        reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)(s_luma[tid][2] + s_luma[tid + 2][2]);
-        if (chroma) {
-          reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = s_chroma[tid][0];
-          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)s_chroma[tid][1];
-          reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = s_chroma[tid + 2][0];
-          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)s_chroma[tid + 2][1];
-        }
+  if (tid < 4 && bx0 + tid < g.nbw) {
+    const int blk = by * g.nbw + bx0 + tid;
+    if (s_bad[0][tid]) bad[(size_t)frame * 2 * g.nblocks + blk] = 1;
+    if (chroma && s_bad[1][tid]) bad[((size_t)frame * 2 + 1) * g.nblocks + blk] = 1;
+    if (mask[blk]) {  // noise statistics of the flat blocks
+      reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = s_sum[0][tid][0];
+      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)s_sum[0][tid][1];
+      reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)s_sum[0][tid][2];
+      if (chroma) {
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = s_sum[1][tid][0];
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)s_sum[1][tid][1];
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = s_sum[2][tid][0];
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)s_sum[2][tid][1];
       }
     }
   }
