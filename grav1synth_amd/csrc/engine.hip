@@ -193,6 +193,32 @@ void release_streams(StreamSet &ss) {
   ss = StreamSet{};
 }
 
+// Workgroups of k3_lag<K, mixed> that are resident at once on the current device.
+int lag_resident_blocks(int K, bool mixed) {
+  static std::mutex m;
+  static int cache[64][4][2];  // [device][K][mixed], 0 = unknown
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(m);
+  int &c = cache[dev & 63][K][mixed ? 1 : 0];
+  if (c == 0) {
+    int per_cu = 0, cus = 0;
+    hipError_t e = hipSuccess;
+#define G1S_OCC(KK)                                                                                                   \
+  e = mixed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_lag<KK, true>, QShape<KK>::THREADS, 0)         \
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_lag<KK, false>, QShape<KK>::THREADS, 0)
+    if (K == 0) G1S_OCC(0);
+    else if (K == 1) G1S_OCC(1);
+    else if (K == 2) G1S_OCC(2);
+    else G1S_OCC(3);
+#undef G1S_OCC
+    if (e != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    c = per_cu * cus;
+  }
+  return c;
+}
+
 }  // namespace
 
 struct g1s_diff {
@@ -214,7 +240,6 @@ struct g1s_diff {
   RecLayout L{};
   FlatConsts fc{};
   double *d_lut = nullptr;
-  int fast_chunks = 0, mix_chunks = 0;
   size_t defer_bytes = 0;
   PlaneSet ps{};
   uint32_t pg_cap = 0;
@@ -311,10 +336,6 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   }
   size_t partial_bytes = 0, k0_bytes = 0, pgl_bytes = 0;
   if (lag == kQLag) {
-    // interior: ~24 areas per workgroup (many small workgroups hide the staging latency);
-    // mixed: fewer, larger workgroups, <= 128 areas each (multiples of 8: the list slices are XCD-aware)
-    fast_chunks = (std::max(64, (g.nblocks + 23) / 24) + 7) & ~7;
-    mix_chunks = (std::max(64, (g.nblocks + 63) / 64) + 7) & ~7;
     partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart);
     const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
     // [cls][bad][lists u32 x6 per frame][counts]
@@ -482,8 +503,6 @@ int g1s_diff::submit(int si) {
     // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
     // then the generic int32 kernel on mixed / deferred areas
     QParams qp;
-    qp.nchunks = fast_chunks;
-    qp.nchunks_mix = mix_chunks;
     static const bool force_generic = getenv("G1S_MIXED_GENERIC") != nullptr;  // debugging aid
     qp.mixed_fast = force_generic ? 0 : 1;
     qp.lagacc = reinterpret_cast<long long *>(sl.d_partials);
@@ -518,8 +537,13 @@ int g1s_diff::submit(int si) {
       HIP_TRY(hipEventRecord(ev_fork[si], stream));
       for (int a = 0; a < 3; ++a) HIP_TRY(hipStreamWaitEvent(aux[si][a], ev_fork[si], 0));
     }
+    // One round of workgroups: as many per frame as stay resident together (occupancy x CUs / batch,
+    // a multiple of 8 for the XCD-aware list slices), but never more than 128 areas each (int32 sums).
     auto launch_lag = [&](int K, bool mixed, hipStream_t st) {
-      const dim3 gr(mixed ? mix_chunks : fast_chunks, 1, B);
+      const int resident = lag_resident_blocks(K, mixed);
+      int chunks = std::max(8, (resident / (int)B) & ~7);
+      chunks = std::max(chunks, ((g.nblocks + 127) / 128 + 7) & ~7);
+      const dim3 gr(chunks, 1, B);
 #define G1S_LAG(KK)                                                                                  \
   if (mixed)                                                                                         \
     hipLaunchKernelGGL((k3_lag<KK, true>), gr, dim3(QShape<KK>::THREADS), 0, st, g, qp);              \

@@ -54,8 +54,6 @@ constexpr int kPSub = kPPart / kPParts;
 __host__ __device__ constexpr bool p_in_part(int part, int i) { return ((i < 12 ? i : 23 - i) % kPParts) == part; }
 
 struct QParams {
-  int nchunks;       // workgroups per frame of k3_lag<.., false>
-  int nchunks_mix;   // workgroups per frame of k3_lag<.., true>
   int mixed_fast;    // 1: MIX areas by k3_lag<true> + k3_partial_dense; 0: by k3q_generic (debug)
   long long *lagacc;   // [batch][3][kQPart]  int64 sums of all lag-kernel workgroups (zeroed per batch)
   long long *paracc;   // [batch][3][kPPart]  int64 sums of all k3_partial_dense workgroups (zeroed per batch)
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(Geom g, QParams 
   __shared__ int s_flush[2];
 
   const int frame = blockIdx.z, chunk = blockIdx.x;
-  const int stride = MIXED ? qp.nchunks_mix : qp.nchunks;
+  const int stride = (int)gridDim.x;  // a multiple of 8 (list_slice)
   const size_t lsel = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + (MIXED ? 1 : 0);
   const uint32_t *list = qp.lists + lsel * g.nblocks;
   const int nlist = (int)qp.counts[lsel];
