@@ -496,7 +496,7 @@ int g1s_diff::submit(int si) {
       hipLaunchKernelGGL(k1_flat_features<2>, grid, dim3(64), 0, stream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], stream));
-  hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(256), 0, stream, g, sl.d_records, sl.d_flags);
+  hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, stream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], stream));
   const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   if (fast_ok) {
@@ -528,8 +528,7 @@ int g1s_diff::submit(int si) {
       else G1S_K0(2, 2);
 #undef G1S_K0
     }
-    const int kinds = g.nplanes == 3 ? 2 : 1;
-    hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + 255) / 256, kinds, B), dim3(256), 0, stream, g,
+    hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, B), dim3(kClsThreads), 0, stream, g,
                        (const uint8_t *)sl.d_records, qp);
     const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
     // fork: the six accumulation kernels are independent and latency-bound -> four streams

@@ -91,66 +91,115 @@ typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // ---------------------------------------------------------------------------------
-// k3_classify: one thread per block area and plane kind.  The area of block (bx, by)
-// needs w on rows by*bh .. by*bh+bh+2, cols bx*bw-3 .. bx*bw+bw+2.
-// grid = (ceil(nblocks/256), kinds, batch), block = 256.
+// k3_classify: one thread per block area, both plane kinds.  The area of block (bx, by)
+// needs w on rows by*bh .. by*bh+bh+2, cols bx*bw-3 .. bx*bw+bw+2: the windows of the six
+// blocks (bx-1..bx+1, by..by+1), which are functions of the flat mask on (bx-2..bx+2,
+// by-1..by+1).  That neighbourhood is read once into registers and serves both kinds.
+// grid = (ceil(nblocks/kClsThreads), 1, batch), block = kClsThreads: large workgroups, so that each
+// of the six lists takes ONE global atomic per workgroup (they all hit the same six counters).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k3_classify(Geom g, const uint8_t *__restrict__ records, QParams qp) {
-  const int blk = blockIdx.x * 256 + threadIdx.x;
-  const int kind = blockIdx.y, frame = blockIdx.z;
+constexpr int kClsThreads = 1024;
+__global__ __launch_bounds__(kClsThreads) void k3_classify(Geom g, const uint8_t *__restrict__ records, QParams qp) {
+  __shared__ uint32_t s_cnt[6][kClsThreads / 64];  // [kind * 3 + which][wave] -> count, then list position
+  const int blk = blockIdx.x * kClsThreads + threadIdx.x;
+  const int frame = blockIdx.z;
   const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
-  const uint8_t *bad = qp.bad + ((size_t)frame * 2 + kind) * g.nblocks;
-  uint8_t c = kClsExt;
-  bool gen = false;
-  int bx = 0, by = 0;
-  if (blk < g.nblocks) {
-    const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
-    const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
-    bx = blk % g.nbw;
-    by = blk / g.nbw;
-    const int AX0 = bx * bw - kQLag, AX1 = bx * bw + bw + kQLag, AY0 = by * bh, AY1 = by * bh + bh + kQLag;
-    bool all1 = !(AX0 < 0 || AX1 > pw || AY1 > ph);
-    bool any1 = false, anybad = false;
-    for (int dby = -1; dby <= 1; ++dby) {
-      for (int dbx = -1; dbx <= 1; ++dbx) {
-        const int Bx = bx + dbx, By = by + dby;
-        if (Bx < 0 || By < 0 || Bx >= g.nbw || By >= g.nbh) continue;
-        // the tiles of this area reach into these blocks (chroma: also the row above, for the L terms)
-        if ((dby >= 0 || kind) && bad[By * g.nbw + Bx]) anybad = true;
-        if (dby < 0) continue;
-        const Win w = block_window(mask, g.nbw, g.nbh, Bx, By, bw, bh, pw, ph);
-        const int rx0 = max(AX0, Bx * bw), rx1 = min(AX1, Bx * bw + bw);
-        const int ry0 = max(AY0, By * bh), ry1 = min(AY1, By * bh + bh);
-        if (rx0 >= rx1 || ry0 >= ry1) continue;
-        if (!w.flat) {
-          all1 = false;
-          continue;
-        }
-        const int ax0 = rx0 - Bx * bw, ax1 = rx1 - Bx * bw, ay0 = ry0 - By * bh, ay1 = ry1 - By * bh;
-        if (max(ax0, w.xs) < min(ax1, w.xe) && max(ay0, w.ys) < min(ay1, w.ye)) any1 = true;
-        if (!(w.xs <= ax0 && ax1 <= w.xe && w.ys <= ay0 && ay1 <= w.ye)) all1 = false;
-      }
+  const bool valid = blk < g.nblocks;
+  const int bx = valid ? blk % g.nbw : 0, by = valid ? blk / g.nbw : 0;
+  uint8_t m[3][5];  // m[1 + dy][2 + dx] = mask(bx + dx, by + dy), 0 outside the grid
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int X = bx + dx, Y = by + dy;
+      m[1 + dy][2 + dx] = (valid && X >= 0 && Y >= 0 && X < g.nbw && Y < g.nbh) ? mask[Y * g.nbw + X] : (uint8_t)0;
     }
-    // blocks outside the grid have no window: an area at the right / bottom rim is never INT
-    if (bx + 1 >= g.nbw || by + 1 >= g.nbh) all1 = false;
-    c = all1 ? kClsInt : (any1 ? kClsMix : kClsExt);
-    qp.cls[((size_t)frame * 2 + kind) * g.nblocks + blk] = c;
-    gen = c != kClsExt && (anybad || (c == kClsMix && !qp.mixed_fast));
   }
-  // compacted lists, one atomic per wave and class (any order: the sums are exact integers)
-  const int lane = threadIdx.x & 63;
-  for (int which = 0; which < 3; ++which) {
-    const bool mine = blk < g.nblocks &&
-                      (which == 2 ? gen : (!gen && (which == 0 ? c == kClsInt : c == kClsMix)));
-    const unsigned long long b = __ballot(mine);
-    if (b == 0) continue;
-    const size_t lo = ((size_t)frame * 2 + kind) * 3 + which;
+  const int kinds = g.nplanes == 3 ? 2 : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int which_of[2] = {-1, -1};  // list of this area per kind: 0 INT, 1 MIX, 2 GENERIC, -1 none
+#pragma unroll
+  for (int kind = 0; kind < 2; ++kind) {
+    if (kind >= kinds) break;
+    const uint8_t *bad = qp.bad + ((size_t)frame * 2 + kind) * g.nblocks;
+    uint8_t c = kClsExt;
+    bool gen = false;
+    if (valid) {
+      const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
+      const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
+      const int AX0 = bx * bw - kQLag, AX1 = bx * bw + bw + kQLag, AY0 = by * bh, AY1 = by * bh + bh + kQLag;
+      bool all1 = !(AX0 < 0 || AX1 > pw || AY1 > ph);
+      bool any1 = false, anybad = false;
+#pragma unroll
+      for (int dby = -1; dby <= 1; ++dby) {
+#pragma unroll
+        for (int dbx = -1; dbx <= 1; ++dbx) {
+          const int Bx = bx + dbx, By = by + dby;
+          if (Bx < 0 || By < 0 || Bx >= g.nbw || By >= g.nbh) continue;
+          // the tiles of this area reach into these blocks (chroma: also the row above, for the L terms)
+          if ((dby >= 0 || kind) && bad[By * g.nbw + Bx]) anybad = true;
+          if (dby < 0) continue;
+          // window of block (Bx, By), as block_window() computes it
+          Win w{0, 0, 0, 0, 0};
+          if (m[1 + dby][2 + dbx]) {
+            w.flat = 1;
+            w.ys = m[dby][2 + dbx] ? 0 : kQLag;
+            w.xs = m[1 + dby][1 + dbx] ? 0 : kQLag;
+            w.ye = min(ph - By * bh, bh);
+            w.xe = min(pw - Bx * bw - kQLag, m[1 + dby][3 + dbx] ? bw : (bw - kQLag));
+            if (w.xe <= w.xs || w.ye <= w.ys) w.flat = 0;
+          }
+          const int rx0 = max(AX0, Bx * bw), rx1 = min(AX1, Bx * bw + bw);
+          const int ry0 = max(AY0, By * bh), ry1 = min(AY1, By * bh + bh);
+          if (rx0 >= rx1 || ry0 >= ry1) continue;
+          if (!w.flat) {
+            all1 = false;
+            continue;
+          }
+          const int ax0 = rx0 - Bx * bw, ax1 = rx1 - Bx * bw, ay0 = ry0 - By * bh, ay1 = ry1 - By * bh;
+          if (max(ax0, w.xs) < min(ax1, w.xe) && max(ay0, w.ys) < min(ay1, w.ye)) any1 = true;
+          if (!(w.xs <= ax0 && ax1 <= w.xe && w.ys <= ay0 && ay1 <= w.ye)) all1 = false;
+        }
+      }
+      c = all1 ? kClsInt : (any1 ? kClsMix : kClsExt);
+      qp.cls[((size_t)frame * 2 + kind) * g.nblocks + blk] = c;
+      gen = c != kClsExt && (anybad || (c == kClsMix && !qp.mixed_fast));
+    }
+    if (valid) which_of[kind] = gen ? 2 : (c == kClsInt ? 0 : (c == kClsMix ? 1 : -1));
+  }
+  // compacted lists (any order: the sums are exact integers): wave counts -> LDS, one global
+  // atomic per workgroup and list, then every lane writes its entry
+  unsigned long long bal[2][3];
+#pragma unroll
+  for (int kind = 0; kind < 2; ++kind) {
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+      bal[kind][which] = __ballot(which_of[kind] == which);
+      if (lane == 0) s_cnt[kind * 3 + which][wave] = (uint32_t)__popcll(bal[kind][which]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int l = threadIdx.x;
+    uint32_t total = 0;
+    for (int w = 0; w < kClsThreads / 64; ++w) total += s_cnt[l][w];
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&qp.counts[lo], (uint32_t)__popcll(b));
-    base = __shfl(base, 0, 64);
-    if (mine)
-      qp.lists[lo * g.nblocks + base + __popcll(b & ((1ull << lane) - 1ull))] =
-          which == 2 ? (uint32_t)blk : ((uint32_t)bx | ((uint32_t)by << 16));
+    if (total) base = atomicAdd(&qp.counts[(size_t)frame * 6 + l], total);
+    for (int w = 0; w < kClsThreads / 64; ++w) {
+      const uint32_t n = s_cnt[l][w];
+      s_cnt[l][w] = base;
+      base += n;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int kind = 0; kind < 2; ++kind) {
+    const int which = which_of[kind];
+    if (which < 0) continue;
+    const unsigned long long b = which == 0 ? bal[kind][0] : (which == 1 ? bal[kind][1] : bal[kind][2]);
+    const size_t lo = ((size_t)frame * 2 + kind) * 3 + which;
+    qp.lists[lo * g.nblocks + s_cnt[kind * 3 + which][wave] + __popcll(b & ((1ull << lane) - 1ull))] =
+        which == 2 ? (uint32_t)blk : ((uint32_t)bx | ((uint32_t)by << 16));
   }
 }
 

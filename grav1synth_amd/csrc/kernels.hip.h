@@ -246,47 +246,53 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom
 // ----------------------------------------------------------------------------
 // K2: per frame, threshold = scores_sorted_ascending[nblocks*90/100]; every
 // block with score >= threshold gets `|= 1` (union with the 4-threshold flag).
-// All scores are >= +0.0f, so their bit patterns order like the floats.
-// grid = (batch), block = 256.
+// All scores are >= +0.0f, so their bit patterns order like the floats, and the
+// k-th smallest pattern is the largest T with #{v < T} <= k: T is built bit by
+// bit (32 counting rounds over register-resident scores, no atomics).
+// grid = (batch), block = kK2Threads.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
-                                                      const uint8_t *__restrict__ flags) {
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t s_prefix, s_rank;
+constexpr int kK2Threads = 1024;
+constexpr int kK2PerThread = 8;  // scores kept in registers: up to 8192 blocks (a 4K frame has 8160)
+__global__ __launch_bounds__(kK2Threads) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
+                                                             const uint8_t *__restrict__ flags) {
+  __shared__ uint32_t s_cnt[2][kK2Threads / 64];
   const int frame = blockIdx.x;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint32_t *sc = reinterpret_cast<const uint32_t *>(rec + g.off_scores);
   const int nb = g.nblocks;
-  uint32_t prefix = 0, prefix_mask = 0;
-  uint32_t rank = (uint32_t)(nb * 90 / 100);  // 0-based rank in ascending order
-  for (int pass = 3; pass >= 0; --pass) {
-    for (int i = threadIdx.x; i < 256; i += 256) hist[i] = 0;
-    __syncthreads();
-    const int sh = 8 * pass;
-    for (int i = threadIdx.x; i < nb; i += 256) {
-      const uint32_t v = sc[i];
-      if ((v & prefix_mask) == prefix) atomicAdd(&hist[(v >> sh) & 0xffu], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t r = rank, b = 0;
-      for (; b < 256; ++b) {
-        if (r < hist[b]) break;
-        r -= hist[b];
-      }
-      s_prefix = prefix | (b << sh);
-      s_rank = r;
-    }
-    __syncthreads();
-    prefix = s_prefix;
-    rank = s_rank;
-    prefix_mask |= 0xffu << sh;
-    __syncthreads();
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool in_regs = nb <= kK2Threads * kK2PerThread;
+  uint32_t v[kK2PerThread];
+#pragma unroll
+  for (int k = 0; k < kK2PerThread; ++k) {
+    const int i = tid + k * kK2Threads;
+    v[k] = i < nb ? sc[i] : 0xffffffffu;  // the filler is never below a candidate
   }
-  const uint32_t thr = prefix;  // bit pattern of the threshold score
+  const uint32_t rank = (uint32_t)(nb * 90 / 100);  // 0-based rank in ascending order
+  uint32_t thr = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = thr | (1u << bit);
+    int c = 0;
+    if (in_regs) {
+#pragma unroll
+      for (int k = 0; k < kK2PerThread; ++k) c += v[k] < cand ? 1 : 0;
+    } else {
+      for (int i = tid; i < nb; i += kK2Threads) c += sc[i] < cand ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    uint32_t *slot = s_cnt[bit & 1];  // double buffered: one barrier per round
+    if (lane == 0) slot[wave] = (uint32_t)c;
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kK2Threads / 64; ++w) total += slot[w];
+    if (total <= rank) thr = cand;
+  }
+  // thr = bit pattern of the threshold score
   uint8_t *mask = rec + g.off_mask;
   const uint8_t *fl = flags + (size_t)frame * nb;
-  for (int i = threadIdx.x; i < nb; i += 256) mask[i] = fl[i] | (sc[i] >= thr ? 1 : 0);
+  for (int i = tid; i < nb; i += kK2Threads) mask[i] = fl[i] | (sc[i] >= thr ? 1 : 0);
 }
 
 // ----------------------------------------------------------------------------
