@@ -205,8 +205,8 @@ int lag_resident_blocks(int K, bool mixed) {
     int per_cu = 0, cus = 0;
     hipError_t e = hipSuccess;
 #define G1S_OCC(KK)                                                                                                   \
-  e = mixed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_lag<KK, true>, QShape<KK>::THREADS, 0)         \
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_lag<KK, false>, QShape<KK>::THREADS, 0)
+  e = mixed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_lag<KK, true>, 64 * kLagWaves, 0)         \
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_lag<KK, false>, 64 * kLagWaves, 0)
     if (K == 0) G1S_OCC(0);
     else if (K == 1) G1S_OCC(1);
     else if (K == 2) G1S_OCC(2);
@@ -545,9 +545,9 @@ int g1s_diff::submit(int si) {
       const dim3 gr(chunks, 1, B);
 #define G1S_LAG(KK)                                                                                  \
   if (mixed)                                                                                         \
-    hipLaunchKernelGGL((k3_lag<KK, true>), gr, dim3(QShape<KK>::THREADS), 0, st, g, qp);              \
+    hipLaunchKernelGGL((k3_lag<KK, true>), gr, dim3(64 * kLagWaves), 0, st, g, qp);              \
   else                                                                                               \
-    hipLaunchKernelGGL((k3_lag<KK, false>), gr, dim3(QShape<KK>::THREADS), 0, st, g, qp);
+    hipLaunchKernelGGL((k3_lag<KK, false>), gr, dim3(64 * kLagWaves), 0, st, g, qp);
       if (K == 0) { G1S_LAG(0) }
       else if (K == 1) { G1S_LAG(1) }
       else if (K == 2) { G1S_LAG(2) }

@@ -230,7 +230,9 @@ struct QShape {
   static constexpr int WAVES = (NPL * NS) < 4 ? (NPL * NS) : 4;
   static constexpr int THREADS = WAVES * 64;
   static constexpr int STEPS_PER_WAVE = NPL * NS / WAVES;
-  static constexpr int PITCH_DW = 32 + G;  // conflict-free for the (group, row) lane map
+  // LDS row pitch: 3*G dwords (>= the G+4 payload dwords, a multiple of 16 bytes).  A half wave reads
+  // 32/G rows x G groups; row r starts at bank 3*G*r mod 32 = 24r (G=8) or 12r (G=4): disjoint runs of G banks.
+  static constexpr int PITCH_DW = 3 * G;
   static constexpr int PITCH = PITCH_DW * 4;
   static constexpr int UP = kChroma ? kQLag : 0;  // rows above the area (chroma L terms are p-centric)
   static constexpr int TH = BH + kQLag + UP;      // tile rows: -UP .. BH+2
@@ -244,38 +246,39 @@ struct QShape {
 };
 
 // ---------------------------------------------------------------------------------
-// TileRegs: the tiles of one area, HBM/L2 -> registers (prefetch) -> LDS, 16 bytes a piece.
-// LDS layout: plane tile pl at lds + pl*TILE_BYTES, sample (x, y) (x in -8..BW+7,
-// y in -UP..BH+2) at byte (y + UP) * PITCH + 8 + x, so group g (x = 4g) is dword g + 2;
-// then the L tile (block proper, byte y*PITCH + x); then (MIXED) the window-indicator
-// tile, rows 0..BH+2, same column layout, bytes 0xFF / 0x00.
+// TileRegs: the tiles ONE WAVE needs of one area, HBM/L2 -> registers (prefetch) -> LDS,
+// 16 bytes a piece: the d tile of the wave's plane, (chroma) the L tile, (MIXED) the window
+// tile.  LDS layout of a wave's region: d tile, sample (x, y) (x in -8..BW+7, y in -UP..BH+2)
+// at byte (y + UP) * PITCH + 8 + x, so group g (x = 4g) is dword g + 2; then the L tile
+// (block proper, byte y*PITCH + x); then the window-indicator tile, rows 0..BH+2, same
+// column layout, bytes 0xFF / 0x00.
 // ---------------------------------------------------------------------------------
-template <int KIND, bool MIXED, int NT>
+template <int KIND, bool MIXED>
 struct TileRegs {
   using S = QShape<KIND>;
-  static constexpr int ND = S::TH * S::SEG * S::NPL;
+  static constexpr int ND = S::TH * S::SEG;
   static constexpr int NLI = S::kChroma ? S::BH * S::LSEG : 0;
   static constexpr int NWI = MIXED ? (S::BH + kQLag) * S::SEG : 0;
   static constexpr int NITEMS = ND + NLI + NWI;
-  static constexpr int MAXIT = (NITEMS + NT - 1) / NT;
+  static constexpr int MAXIT = (NITEMS + 63) / 64;
+  static constexpr int L_OFF = S::TILE_BYTES, W_OFF = S::TILE_BYTES + (S::kChroma ? S::LTILE_BYTES : 0);
+  static constexpr int BYTES = W_OFF + (MIXED ? S::WTILE_BYTES : 0);
   u32x4 regs[MAXIT];
 
-  __device__ __forceinline__ void fetch(const uint8_t *fbase, const PlaneSet &ps, int tid, int bx, int by) {
+  __device__ __forceinline__ void fetch(const uint8_t *fbase, const PlaneSet &ps, int lane, int pl, int bx, int by) {
     constexpr bool CHROMA = S::kChroma;
     const uint32_t pitch = CHROMA ? ps.pitch[1] : ps.pitch[0];
     const uint32_t off_w = CHROMA ? ps.off_w[1] : ps.off_w[0];
+    const uint32_t off_d = CHROMA ? (pl ? ps.off_d[2] : ps.off_d[1]) : ps.off_d[0];
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
-      const int it = tid + k * NT;
+      const int it = lane + k * 64;
       // one straight-line path, parameters chosen by selects
       const bool isd = it < ND, isl = !isd && it < ND + NLI;
-      const int pl = it / (S::TH * S::SEG);
-      const int rd = it - pl * (S::TH * S::SEG);
-      const int rl = it - ND, rw = it - ND - NLI;
-      const int r = isd ? rd : (isl ? rl : rw);
+      const int r = isd ? it : (isl ? it - ND : it - ND - NLI);
       const int segs = isl ? S::LSEG : S::SEG;
       const int y = r / segs, sg = r - y * segs;
-      const uint32_t off = isd ? (CHROMA ? (pl ? ps.off_d[2] : ps.off_d[1]) : ps.off_d[0]) : (isl ? ps.off_l : off_w);
+      const uint32_t off = isd ? off_d : (isl ? ps.off_l : off_w);
       const uint32_t pt = isl ? ps.lpitch : pitch;
       const int row = by * S::BH + y + (isd ? kPadY - S::UP : (isl ? 0 : kPadY));
       gptr_u8 p = as_global(fbase) + off + (size_t)row * pt + (size_t)(bx * S::BW + 16 * sg);
@@ -284,18 +287,15 @@ struct TileRegs {
       regs[k] = v;
     }
   }
-  __device__ __forceinline__ void store(uint8_t *lds, int tid) const {
+  __device__ __forceinline__ void store(uint8_t *lds, int lane) const {
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
-      const int it = tid + k * NT;
+      const int it = lane + k * 64;
       const bool isd = it < ND, isl = !isd && it < ND + NLI;
-      const int pl = it / (S::TH * S::SEG);
-      const int rd = it - pl * (S::TH * S::SEG);
-      const int rl = it - ND, rw = it - ND - NLI;
-      const int r = isd ? rd : (isl ? rl : rw);
+      const int r = isd ? it : (isl ? it - ND : it - ND - NLI);
       const int segs = isl ? S::LSEG : S::SEG;
       const int y = r / segs, sg = r - y * segs;
-      const int base = isd ? pl * S::TILE_BYTES : (isl ? S::NPL * S::TILE_BYTES : S::DATA_BYTES);
+      const int base = isd ? 0 : (isl ? L_OFF : W_OFF);
       if (it < NITEMS) *reinterpret_cast<u32x4 *>(lds + base + y * S::PITCH + 16 * sg) = regs[k];
     }
   }
@@ -324,110 +324,98 @@ __device__ __forceinline__ void group_state(P w32, int pitch_dw, bool &full, boo
 // k3_lag<KIND, MIXED>: 46 lag sums (+26 chroma L terms) per group.
 //   MIXED = false: the INT list (every group full, own window = whole block)
 //   MIXED = true : the MIX list; only FULL groups enter the lag sums; L terms and nobs use the
-//                  block's own window.
-// grid = (nchunks or nchunks_mix, 1, batch), block = QShape::THREADS.  The tiles are double
-// buffered in LDS: one barrier per area, the loads of area k+1 fly during the products of k.
-// int32 safety: per step |sum| <= 4*127^2; <= 128 areas * STEPS_PER_WAVE(<=2); x64 lanes < 2^31.
+//                  block's own window; the PARTIAL groups are listed for k3_partial_dense.
+// grid = (chunks, 1, batch), block = 256 = four AUTONOMOUS waves: a wave walks its own slice of
+// the list (chroma: and owns one of the two planes), stages its tiles alone in its own LDS
+// region and multiplies them; no workgroup barrier until the final reduction.  LDS operations
+// of one wave execute in order, so a single tile buffer per wave is enough: the loads of area
+// k+1 fly (in registers) during the products of area k.
+// int32 safety: per step |sum| <= 4*127^2; the launch keeps <= 128 area steps per wave; x64 lanes < 2^31.
 // ---------------------------------------------------------------------------------
+constexpr int kLagWaves = 4;
 template <int KIND, bool MIXED>
-__global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(Geom g, QParams qp) {
+__global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
   using S = QShape<KIND>;
   constexpr bool CHROMA = S::kChroma;
-  constexpr int WAVES = S::WAVES;
-  constexpr int NACC = S::NACC, NT = 64 * WAVES;
-  constexpr int STEPS_PER_WAVE = S::STEPS_PER_WAVE;
-  static_assert(S::NPL * S::NS % WAVES == 0 && WAVES % S::NPL == 0, "a wave owns the accumulators of ONE plane");
-  constexpr int BUF = S::DATA_BYTES + (MIXED ? S::WTILE_BYTES : 0);
-  __shared__ __attribute__((aligned(16))) uint8_t lds2[2][BUF];
-  // MIXED: coordinates of the partial groups met so far, flushed to the (frame, kind) list with
-  // ONE global atomic per flush (a per-wave global atomic would serialise on that counter)
-  constexpr int PGBUF = MIXED ? 2048 : 1;
-  __shared__ uint32_t s_pg[PGBUF];
-  __shared__ uint32_t s_pgn, s_pgbase, s_pgsnap;
-  __shared__ int s_flush[2];
+  constexpr int NACC = S::NACC;
+  using Tile = TileRegs<KIND, MIXED>;
+  // partial-group coordinates of this wave; normally flushed ONCE, by the whole workgroup at the
+  // end (every flush is a returning atomic on the one counter of the (frame, kind) list)
+  constexpr int PGBUF = MIXED ? (S::NG < 256 ? 256 : 2 * S::NG) : 1;
+  __shared__ __attribute__((aligned(16))) uint8_t lds_all[kLagWaves][Tile::BYTES];
+  __shared__ uint32_t s_pg_all[kLagWaves][PGBUF];
+  __shared__ int red[kLagWaves][kQPart + 1];
+  __shared__ uint32_t s_pgn[kLagWaves];
 
-  const int frame = blockIdx.z, chunk = blockIdx.x;
-  const int stride = (int)gridDim.x;  // a multiple of 8 (list_slice)
+  const int frame = blockIdx.z;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // global wave index -> (list slice, plane).  The slice count is a multiple of 8 (list_slice).
+  const int gw = (int)blockIdx.x * kLagWaves + wave;
+  const int pl = CHROMA ? (gw & 1) : 0;
+  const int slice = CHROMA ? (gw >> 1) : gw;
+  const int nslices = (int)gridDim.x * kLagWaves / S::NPL;
   const size_t lsel = ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * 3 + (MIXED ? 1 : 0);
-  const uint32_t *list = qp.lists + lsel * g.nblocks;
+  gptr_u1 list = (gptr_u1)as_global(reinterpret_cast<const uint8_t *>(qp.lists + lsel * g.nblocks));
   const int nlist = (int)qp.counts[lsel];
   const uint8_t *fbase = qp.planes + (size_t)frame * qp.ps.frame_bytes;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  uint8_t *lds = lds_all[wave];
+  uint32_t *s_pg = s_pg_all[wave];
   const int lg = lane % S::G, lr = lane / S::G;
 
   int acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0;
-  int nobs = 0;  // INT: number of areas (x BW*BH in the reducer); MIX: window samples
-  if (MIXED && tid == 0) {
-    s_pgn = 0;
-    s_flush[0] = s_flush[1] = 0;
-  }
+  int nobs = 0;  // INT: number of areas (x BW*BH in the reducer); MIX: window samples (plane 0 waves)
+  uint32_t pgn = 0;  // wave-uniform: entries in s_pg
   uint32_t *pg_out = qp.pglist + ((size_t)frame * 2 + (CHROMA ? 1 : 0)) * qp.pg_cap;
   uint32_t *pg_cnt = qp.pgcount + (size_t)frame * 2 + (CHROMA ? 1 : 0);
-  auto pg_flush = [&]() {  // uniform; every wave is between two areas
-    if (tid == 0) {
-      const uint32_t n = s_pgn;
-      s_pgsnap = n;
-      s_pgbase = atomicAdd(pg_cnt, n);
-      s_pgn = 0;
-    }
-    __syncthreads();
-    const uint32_t n = s_pgsnap, base = s_pgbase;
-    for (uint32_t i = tid; i < n; i += NT) pg_out[base + i] = s_pg[i];
-    __syncthreads();  // copied before the next appends overwrite s_pg
+  auto pg_flush = [&]() {  // one global atomic per flush (a per-step atomic would serialise on the counter)
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(pg_cnt, pgn);
+    base = __shfl(base, 0, 64);
+    for (uint32_t i = lane; i < pgn; i += 64) pg_out[base + i] = s_pg[i];
+    pgn = 0;
   };
 
-  TileRegs<KIND, MIXED, NT> tr;
+  Tile tr;
   int li, li_end;
-  list_slice(chunk, stride, nlist, li, li_end);
+  list_slice(slice, nslices, nlist, li, li_end);
   auto entry_at = [&](int pos) -> uint32_t {
     return pos < li_end ? (uint32_t)__builtin_amdgcn_readfirstlane((int)list[pos]) : kEntryNone;
   };
   uint32_t e_cur = entry_at(li), e_nxt = entry_at(li + 1);
-  if (e_cur != kEntryNone) tr.fetch(fbase, qp.ps, tid, (int)(e_cur & 0xffffu), (int)(e_cur >> 16));
+  if (e_cur != kEntryNone) tr.fetch(fbase, qp.ps, lane, pl, (int)(e_cur & 0xffffu), (int)(e_cur >> 16));
 
-  int iter = 0;
   for (; e_cur != kEntryNone; e_cur = e_nxt, e_nxt = entry_at(li + 1)) {
-    uint8_t *lds = lds2[iter & 1];
-    const int fl = iter & 1;
-    ++iter;
-    tr.store(lds, tid);
-    // thread 0 may lag one area behind the other waves' appends: keep two areas of headroom
-    if (MIXED && tid == 0) s_flush[fl] = s_pgn + 2 * S::NG > (uint32_t)PGBUF ? 1 : 0;
-    __syncthreads();  // tiles of this area complete; every wave is done with the other buffer
-    if (MIXED && s_flush[fl]) pg_flush();
+    __builtin_amdgcn_wave_barrier();
+    tr.store(lds, lane);  // in order after the reads of the previous area
+    __builtin_amdgcn_wave_barrier();
     const int bx = (int)(e_cur & 0xffffu), by = (int)(e_cur >> 16);
     ++li;
-    if (e_nxt != kEntryNone) tr.fetch(fbase, qp.ps, tid, (int)(e_nxt & 0xffffu), (int)(e_nxt >> 16));
-    if (!MIXED && tid == 0) ++nobs;
+    if (e_nxt != kEntryNone) tr.fetch(fbase, qp.ps, lane, pl, (int)(e_nxt & 0xffffu), (int)(e_nxt >> 16));
+    if (!MIXED && pl == 0) ++nobs;
+    if (MIXED && pl == 0 && pgn + S::NG > (uint32_t)PGBUF) pg_flush();
 
 #pragma unroll 1
-    for (int s = 0; s < STEPS_PER_WAVE; ++s) {
-      const int widx = wave * STEPS_PER_WAVE + s;
-      const int pl = widx / S::NS, step = widx - pl * S::NS;
+    for (int step = 0; step < S::NS; ++step) {
       const int row = step * S::ROWS_PER_STEP + lr;  // sample row of the area
-      const uint32_t *t32 = reinterpret_cast<const uint32_t *>(lds + pl * S::TILE_BYTES) + (row + S::UP) * S::PITCH_DW + lg;
+      const uint32_t *t32 = reinterpret_cast<const uint32_t *>(lds) + (row + S::UP) * S::PITCH_DW + lg;
       const uint32_t c0 = t32[2], c1 = t32[3], c2 = t32[4];
       uint32_t D0 = c0, Wc = 0xffffffffu;
       if (MIXED) {
-        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(lds + S::DATA_BYTES) + row * S::PITCH_DW + lg;
+        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(lds + Tile::W_OFF) + row * S::PITCH_DW + lg;
         bool full, empty;
         group_state(w32, S::PITCH_DW, full, empty);
         Wc = w32[2];
         if (!full) D0 = 0;  // partial groups belong to k3_partial_dense, empty ones to nobody
-        if (pl == 0) {
+        if (pl == 0) {      // both chroma planes share the window: counted and listed once
           nobs = sdot4((int)(Wc & 0x01010101u), 0x01010101, nobs);
           const bool part = !full && !empty;
           const unsigned long long bal = __ballot(part);
-          if (bal != 0) {  // both chroma planes share the window: listed once, on plane 0
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_pgn, (uint32_t)__popcll(bal));
-            base = __shfl(base, 0, 64);
-            if (part)
-              s_pg[base + __popcll(bal & ((1ull << lane) - 1ull))] =
-                  (uint32_t)(bx * S::G + lg) | ((uint32_t)(by * S::BH + row) << 16);
-          }
+          if (part)
+            s_pg[pgn + __popcll(bal & ((1ull << lane) - 1ull))] =
+                (uint32_t)(bx * S::G + lg) | ((uint32_t)(by * S::BH + row) << 16);
+          pgn += (uint32_t)__popcll(bal);
         }
       }
       acc[0] = sdot4((int)D0, (int)c0, acc[0]);
@@ -458,7 +446,7 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(Geom g, QParams 
       }
       if (CHROMA) {
         // p-centric L terms under the block's own window (Wc; all ones for INT areas)
-        const uint32_t *ta = reinterpret_cast<const uint32_t *>(lds + S::NPL * S::TILE_BYTES);
+        const uint32_t *ta = reinterpret_cast<const uint32_t *>(lds + Tile::L_OFF);
         const uint32_t Lr = ta[row * S::PITCH_DW + lg];
         const uint32_t Lm = Lr & Wc;
         int *al = acc + kNumLags;
@@ -482,47 +470,47 @@ __global__ __launch_bounds__(QShape<KIND>::THREADS) void k3_lag(Geom g, QParams 
       }
     }
   }
+  if (MIXED && lane == 0) s_pgn[wave] = pgn;
 
-  // ---- wave reduction + partial store: waves of the same plane add up ----
+  // ---- wave reduction (DPP), then the waves of the same plane add up: one atomic set per workgroup ----
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int t = wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = t;
+  }
+  if (MIXED) nobs = wave_sum(nobs);
+  if (lane == 0) red[wave][kQPart] = nobs;
   __syncthreads();
-  if (MIXED && s_pgn != 0) pg_flush();
-  int *red = reinterpret_cast<int *>(&lds2[0][0]);
-  static_assert(4 * (kQPart + 1) * 4 <= 2 * BUF, "reduction scratch must fit");
-  {
-    constexpr int CH = 23;
-#pragma unroll
-    for (int b0 = 0; b0 < NACC; b0 += CH) {
-      int tmp[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) tmp[i] = (b0 + i < NACC) ? acc[b0 + i] : 0;
-      wave_sum_all<CH>(tmp);
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-          if (b0 + i < NACC) red[wave * (kQPart + 1) + b0 + i] = tmp[i];
+  if (MIXED) {  // the partial groups of the four waves: one atomic
+    if (tid == 0) {
+      uint32_t total = 0;
+      for (int w = 0; w < kLagWaves; ++w) total += s_pgn[w];
+      uint32_t base = total ? atomicAdd(pg_cnt, total) : 0u;
+      for (int w = 0; w < kLagWaves; ++w) {
+        const uint32_t n = s_pgn[w];
+        s_pgn[w] = base;
+        base += n;
       }
     }
-    if (MIXED) nobs = wave_sum(nobs);
-    if (lane == 0) red[wave * (kQPart + 1) + kQPart] = nobs;
+    __syncthreads();
+    const uint32_t base = s_pgn[wave];
+    for (uint32_t i = lane; i < pgn; i += 64) pg_out[base + i] = s_pg[i];
   }
-  __syncthreads();
-  for (int pl = 0; pl < S::NPL; ++pl) {
+  for (int p = 0; p < S::NPL; ++p) {
     unsigned long long *out =
-        reinterpret_cast<unsigned long long *>(qp.lagacc) + ((size_t)frame * 3 + (CHROMA ? 1 + pl : 0)) * kQPart;
-    for (int i = tid; i < NACC; i += NT) {
+        reinterpret_cast<unsigned long long *>(qp.lagacc) + ((size_t)frame * 3 + (CHROMA ? 1 + p : 0)) * kQPart;
+    // waves of plane p: CHROMA: wave & 1 == p (blockIdx.x * 4 is even); luma: all
+    for (int i = tid; i < NACC; i += 64 * kLagWaves) {
       int v = 0;
-      for (int w = 0; w < WAVES; ++w)
-        if ((w * STEPS_PER_WAVE) / S::NS == pl) v += red[w * (kQPart + 1) + i];
+      for (int w = 0; w < kLagWaves; ++w)
+        if (!CHROMA || (w & 1) == p) v += red[w][i];
       if (v != 0) atomicAdd(&out[i], (unsigned long long)(long long)v);
     }
     if (tid == 0) {
       long long v = 0;
-      if (MIXED) {
-        for (int w = 0; w < WAVES; ++w)
-          if ((w * STEPS_PER_WAVE) / S::NS == 0) v += red[w * (kQPart + 1) + kQPart];  // counted on plane 0
-      } else {
-        v = (long long)red[kQPart] * S::BW * S::BH;  // thread 0 counted the areas
-      }
+      for (int w = 0; w < kLagWaves; ++w)
+        if (!CHROMA || (w & 1) == 0) v += red[w][kQPart];  // counted by the plane-0 waves
+      if (!MIXED) v *= S::BW * S::BH;
       if (v != 0) atomicAdd(&out[kQPart - 1], (unsigned long long)v);
     }
   }

@@ -31,6 +31,10 @@ __global__ __launch_bounds__(256) void rate(int *out, int a0, int b0) {
       if (OP == 7) acc[i] = __builtin_amdgcn_alignbyte(a, acc[i], 1);
       if (OP == 8) acc[i] = (acc[i] & a) + b;
       if (OP == 9) acc[i] = __builtin_amdgcn_sdot8(a, b + i, acc[i], false);
+      if (OP == 10) acc[i] = __builtin_amdgcn_perm(a, acc[i], 0x04030201u);
+      if (OP == 11) acc[i] = __builtin_amdgcn_alignbit(a, acc[i], 8);
+      if (OP == 12) acc[i] = (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)(b + i), (unsigned)acc[i]);
+      if (OP == 13) acc[i] = (acc[i] >> 8) | (a << 24);
     }
     a += it;
   }
@@ -70,5 +74,9 @@ int main() {
   run<7>("v_alignbyte_b32", 0);
   run<8>("v_and+v_add", 0);
   run<9>("v_dot8_i32_i4", 8);
+  run<10>("v_perm_b32", 0);
+  run<11>("v_alignbit_b32", 0);
+  run<12>("v_sad_u8", 0);
+  run<13>("v_lshr+v_lshl_or (2)", 0);
   return 0;
 }
