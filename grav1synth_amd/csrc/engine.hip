@@ -164,8 +164,9 @@ std::vector<CachedSlot> g_slot_cache;
 // and one event per slot, and hands them back when it is freed.
 struct StreamSet {
   int device = -1;
-  hipStream_t compute = nullptr, copy = nullptr;
+  hipStream_t compute = nullptr, copy = nullptr, flat = nullptr;
   hipEvent_t kernels_done[2] = {nullptr, nullptr};
+  hipEvent_t mask_done[2] = {nullptr, nullptr};
 };
 std::vector<StreamSet> g_stream_cache;
 bool acquire_streams(int device, StreamSet &out) {
@@ -182,8 +183,11 @@ bool acquire_streams(int device, StreamSet &out) {
   out = StreamSet{};
   out.device = device;
   bool ok = hipStreamCreateWithFlags(&out.compute, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess;
+            hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&out.flat, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess;
   return ok;
 }
 void release_streams(StreamSet &ss) {
@@ -465,6 +469,10 @@ int g1s_diff::submit(int si) {
   hipStream_t stream = (slot_streams && slot_stream[si]) ? slot_stream[si] : slot_stream[0];  // (shadows the member)
   const bool k3s = k3_streams && aux[si][0];
   hipStream_t ax[3] = {k3s ? aux[si][0] : stream, k3s ? aux[si][1] : stream, k3s ? aux[si][2] : stream};
+  // The flat-block finder of batch N+1 (K1: one f64 lane per block, one wave per SIMD, latency bound)
+  // runs on its own stream next to the accumulation kernels of batch N.
+  static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
+  hipStream_t fstream = (one_stream || !ss.flat) ? stream : ss.flat;
   FrameTable ft;
   std::memcpy(ft.f, sl.h_planes, sizeof(FramePlanes) * B);
   if (B < (uint32_t)kMaxBatch) std::memset(ft.f + B, 0, sizeof(FramePlanes) * (kMaxBatch - B));
@@ -484,19 +492,23 @@ int g1s_diff::submit(int si) {
       z.ptr[4] = sl.d_pgl + (size_t)batch * 2 * pg_cap;  // partial-group list counts
       z.ndw[4] = (uint32_t)batch * 2;
     }
-    hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, stream, z);
+    hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, fstream, z);
   }
   sl.timed = timing;
-  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], stream));
+  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], fstream));
   {
     dim3 grid((g.nblocks + 63) / 64, B);
     if (g.src_bps == 1)
-      hipLaunchKernelGGL(k1_flat_features<1>, grid, dim3(64), 0, stream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
+      hipLaunchKernelGGL(k1_flat_features<1>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
     else
-      hipLaunchKernelGGL(k1_flat_features<2>, grid, dim3(64), 0, stream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
+      hipLaunchKernelGGL(k1_flat_features<2>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
   }
-  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], stream));
-  hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, stream, g, sl.d_records, sl.d_flags);
+  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
+  hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
+  if (fstream != stream) {  // the accumulation chain of this batch starts when its mask is there
+    HIP_TRY(hipEventRecord(ss.mask_done[si], fstream));
+    HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));
+  }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], stream));
   const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   if (fast_ok) {
@@ -698,6 +710,7 @@ void g1s_diff::release() {
       if (aux[i][a]) (void)hipStreamSynchronize(aux[i][a]);
   }
   if (ss.copy) (void)hipStreamSynchronize(ss.copy);
+  if (ss.flat) (void)hipStreamSynchronize(ss.flat);
   slot_stream[0] = nullptr;  // borrowed
   release_streams(ss);
   for (Slot &sl : slots) {
