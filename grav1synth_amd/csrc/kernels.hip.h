@@ -124,6 +124,43 @@ __device__ __forceinline__ void load_row32(const uint8_t *base, uint32_t stride,
   }
 }
 
+// The 32 samples of a block row as loaded (fast path: 16-byte aligned rows inside the plane):
+// kept raw in registers so that the loads of later rows are in flight while a row is
+// processed (one lane per block and one wave per SIMD: nothing else hides the latency).
+template <int BPS>
+struct RowRaw {
+  u32x4 v[BPS == 2 ? 4 : 2];
+};
+template <int BPS>
+__device__ __forceinline__ void load_row_raw(const uint8_t *base, uint32_t stride, int ox, int y, RowRaw<BPS> &r) {
+  gptr_u4 p = (gptr_u4)(as_global(base) + (size_t)y * stride + (size_t)ox * BPS);
+#pragma unroll
+  for (int q = 0; q < (BPS == 2 ? 4 : 2); ++q) r.v[q] = p[q];
+}
+template <int BPS>
+__device__ __forceinline__ void narrow_row(const RowRaw<BPS> &r, int shift, uint32_t (&pk)[8]) {
+  if (BPS == 1) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      pk[4 * q + 0] = r.v[q].x;
+      pk[4 * q + 1] = r.v[q].y;
+      pk[4 * q + 2] = r.v[q].z;
+      pk[4 * q + 3] = r.v[q].w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t w[4] = {r.v[q].x, r.v[q].y, r.v[q].z, r.v[q].w};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t lo = w[2 * h], hi = w[2 * h + 1];
+        pk[2 * q + h] = (((lo & 0xffffu) >> shift) & 0xffu) | ((((lo >> 16) >> shift) & 0xffu) << 8) |
+                        ((((hi & 0xffffu) >> shift) & 0xffu) << 16) | ((((hi >> 16) >> shift) & 0xffu) << 24);
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------
 // K1: flat-block features.  One lane per 32x32 block; every f64 sum runs in the
 // reference's order (k = 0..1023 raster for the plane fit, (yi, xi) raster over
@@ -152,10 +189,7 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom
 
   // ---- pass 1: t = block(1x1024) * A(1024x3), sequential sums from 0.0 ----
   double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-  for (int yi = 0; yi < kBlock; ++yi) {
-    const int y = min(oy + yi, g.H - 1);
-    uint32_t pk[8];
-    load_row32<BPS>(base, stride, shift, ox, y, g.W, fast, pk);
+  auto fit_row = [&](int yi, const uint32_t (&pk)[8]) {
     const double yd = (double)(yi - 16) * 0.0625;
 #pragma unroll
     for (int xi = 0; xi < kBlock; ++xi) {
@@ -164,6 +198,32 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom
       t0 += v * yd;
       t1 += v * xd;
       t2 += v;  // v * 1.0
+    }
+  };
+  if (fast) {
+    // rows in groups of four: the next group's loads fly during this group's sums
+    RowRaw<BPS> ra4[4], rb4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_row_raw<BPS>(base, stride, ox, min(oy + k, g.H - 1), ra4[k]);
+    for (int y0 = 0; y0 < kBlock; y0 += 4) {
+      if (y0 + 4 < kBlock) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_row_raw<BPS>(base, stride, ox, min(oy + y0 + 4 + k, g.H - 1), rb4[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t pk[8];
+        narrow_row<BPS>(ra4[k], shift, pk);
+        fit_row(y0 + k, pk);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ra4[k] = rb4[k];
+    }
+  } else {
+    for (int yi = 0; yi < kBlock; ++yi) {
+      uint32_t pk[8];
+      load_row32<BPS>(base, stride, shift, ox, min(oy + yi, g.H - 1), g.W, false, pk);
+      fit_row(yi, pk);
     }
   }
   // coef = AtA_inv(3x3) * t, each a sequential sum from 0.0
@@ -175,10 +235,22 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom
   // ---- pass 2: residual rows + gradient covariance over the interior ----
   // residual(yi, xi) = block - (((0 + yd*c0) + xd*c1) + 1*c2)
   double ra[kBlock], rb[kBlock];
+  // rows of pass 2 in order: 0, 1, then yi + 1 for yi = 1 .. 30, i.e. rows 0 .. 31; row r + 1 is
+  // requested before row r is used
+  RowRaw<BPS> nxt;
+  if (fast) load_row_raw<BPS>(base, stride, ox, min(oy, g.H - 1), nxt);
+  auto take_row = [&](int yi, uint32_t (&pk)[8]) {
+    if (fast) {
+      const RowRaw<BPS> cur = nxt;
+      if (yi + 1 < kBlock) load_row_raw<BPS>(base, stride, ox, min(oy + yi + 1, g.H - 1), nxt);
+      narrow_row<BPS>(cur, shift, pk);
+    } else {
+      load_row32<BPS>(base, stride, shift, ox, min(oy + yi, g.H - 1), g.W, false, pk);
+    }
+  };
   auto resid_row = [&](int yi, double (&out)[kBlock]) {
-    const int y = min(oy + yi, g.H - 1);
     uint32_t pk[8];
-    load_row32<BPS>(base, stride, shift, ox, y, g.W, fast, pk);
+    take_row(yi, pk);
     const double yc = 0.0 + ((double)(yi - 16) * 0.0625) * c0;
 #pragma unroll
     for (int xi = 0; xi < kBlock; ++xi) {
@@ -190,9 +262,8 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom
   double Gxx = 0.0, Gxy = 0.0, Gyy = 0.0, var = 0.0, mean = 0.0;
   // `up` holds row yi-1 and is overwritten in place by row yi+1 as we go
   auto grad_row = [&](int yi, double (&up)[kBlock], const double (&cur)[kBlock]) {
-    const int y = min(oy + yi + 1, g.H - 1);
     uint32_t pk[8];
-    load_row32<BPS>(base, stride, shift, ox, y, g.W, fast, pk);
+    take_row(yi + 1, pk);
     const double yc = 0.0 + ((double)(yi + 1 - 16) * 0.0625) * c0;
 #pragma unroll
     for (int xi = 0; xi < kBlock; ++xi) {
