@@ -183,6 +183,13 @@ def main() -> None:
             "alg_bytes_per_launch": alg_bytes_per_launch,
             "all_kernels_ms_per_frame": {k: v[0] / F for k, v in kernels.items()},
             "host_fold_ms_per_frame": st.ms_host_fold / F,
+            # inside k3_ar_accumulate: K0, the one pass over the source / denoised planes (the HBM-streaming kernel)
+            "k0_residual": {
+                "ms_per_frame": st.ms_residual / F,
+                "achieved": (bpp * W * H * F / (st.ms_residual * 1e-3) / 1e9) if st.ms_residual > 0 else None,
+                "unit": "GB/s",
+                "frac": (bpp * W * H * F / (st.ms_residual * 1e-3) / 1e9 / HBM_PEAK_GBS) if st.ms_residual > 0 else None,
+            },
         },
     }
 

@@ -94,6 +94,7 @@ class G1SStats(C.Structure):
         ("launches_flat_select", C.c_uint64),
         ("launches_ar_accumulate", C.c_uint64),
         ("ms_host_fold", C.c_double),
+        ("ms_residual", C.c_double),
     ]
 
 

@@ -134,7 +134,7 @@ struct Slot {
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
   hipEvent_t done = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // timing: k1 start, k2 start, k3 start, k3 end
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: k1 start, k2 start, k3 start, k3 end, k0 end
   uint32_t count = 0;
   bool timed = false;
 };
@@ -472,7 +472,7 @@ int g1s_diff::submit(int si) {
   // The flat-block finder of batch N+1 (K1: one f64 lane per block, one wave per SIMD, latency bound)
   // runs on its own stream next to the accumulation kernels of batch N.
   static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
-  hipStream_t fstream = (one_stream || !ss.flat) ? stream : ss.flat;
+  hipStream_t fstream = (one_stream || timing || !ss.flat) ? stream : ss.flat;  // per-kernel timing: one stream
   FrameTable ft;
   std::memcpy(ft.f, sl.h_planes, sizeof(FramePlanes) * B);
   if (B < (uint32_t)kMaxBatch) std::memset(ft.f + B, 0, sizeof(FramePlanes) * (kMaxBatch - B));
@@ -539,6 +539,7 @@ int g1s_diff::submit(int si) {
       else if (g.den_bps == 1) G1S_K0(2, 1);
       else G1S_K0(2, 2);
 #undef G1S_K0
+      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], stream));
     }
     hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, B), dim3(kClsThreads), 0, stream, g,
                        (const uint8_t *)sl.d_records, qp);
@@ -628,6 +629,10 @@ int g1s_diff::drain_one() {
     stats.ms_flat_select += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
     stats.ms_ar_accumulate += ms;
+    if ((int)lag == kQLag && !(geom.nplanes == 3 && geom.xdec == 0 && geom.ydec == 1)) {
+      HIP_TRY(hipEventElapsedTime(&ms, sl.ev[2], sl.ev[4]));
+      stats.ms_residual += ms;
+    }
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
     stats.ms_total_gpu += ms;
   }

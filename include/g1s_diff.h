@@ -160,6 +160,7 @@ typedef struct {
   double ms_flat_features, ms_flat_select, ms_ar_accumulate, ms_total_gpu;
   uint64_t launches_flat_features, launches_flat_select, launches_ar_accumulate;
   double ms_host_fold;        /* wall time spent in the ordered host fold */
+  double ms_residual;         /* part of ms_ar_accumulate: the K0 residual pass over the input planes */
 } g1s_stats_t;
 int g1s_diff_get_stats(const g1s_diff_t *, g1s_stats_t *out);
 /* Enable per-kernel HIP-event timing (off by default: events serialise batches). */
