@@ -529,9 +529,16 @@ int g1s_diff::submit(int si) {
     qp.pgcount = sl.d_pgl + (size_t)batch * 2 * pg_cap;
     qp.planes = sl.d_k0;
     qp.ps = ps;
+    // The K0 -> K3 chain runs in sub-batches: the int8 planes of one sub-batch (27 MB per 4K frame) should
+    // still be in the 256 MB Infinity Cache when the accumulation kernels read them back.
+    static const int sub_env = getenv("G1S_SUB") ? atoi(getenv("G1S_SUB")) : 0;  // tuning aid
+    const uint32_t sub = sub_env > 0 ? (uint32_t)sub_env : B;
+    for (uint32_t f0 = 0; f0 < B; f0 += sub) {
+    const uint32_t Bs = std::min(sub, B - f0);
+    g.frame0 = (int)f0;
     {
       // K0: one pass over the source / denoised planes -> int8 residual, L and window planes + block statistics
-      const dim3 gr((g.nbw + 3) / 4, g.nbh, B);
+      const dim3 gr((g.nbw + 3) / 4, g.nbh, Bs);
 #define G1S_K0(SB, DB) \
   hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, stream, ft, g, ps, sl.d_k0, qp.bad, sl.d_records)
       if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);
@@ -539,9 +546,9 @@ int g1s_diff::submit(int si) {
       else if (g.den_bps == 1) G1S_K0(2, 1);
       else G1S_K0(2, 2);
 #undef G1S_K0
-      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], stream));
+      if (sl.timed && f0 == 0) HIP_TRY(hipEventRecord(sl.ev[4], stream));
     }
-    hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, B), dim3(kClsThreads), 0, stream, g,
+    hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, Bs), dim3(kClsThreads), 0, stream, g,
                        (const uint8_t *)sl.d_records, qp);
     const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
     // fork: the six accumulation kernels are independent and latency-bound -> four streams
@@ -553,9 +560,9 @@ int g1s_diff::submit(int si) {
     // a multiple of 8 for the XCD-aware list slices), but never more than 128 areas each (int32 sums).
     auto launch_lag = [&](int K, bool mixed, hipStream_t st) {
       const int resident = lag_resident_blocks(K, mixed);
-      int chunks = std::max(8, (resident / (int)B) & ~7);
+      int chunks = std::max(8, (resident / (int)Bs) & ~7);
       chunks = std::max(chunks, ((g.nblocks + 127) / 128 + 7) & ~7);
-      const dim3 gr(chunks, 1, B);
+      const dim3 gr(chunks, 1, Bs);
 #define G1S_LAG(KK)                                                                                  \
   if (mixed)                                                                                         \
     hipLaunchKernelGGL((k3_lag<KK, true>), gr, dim3(64 * kLagWaves), 0, st, g, qp);              \
@@ -584,11 +591,13 @@ int g1s_diff::submit(int si) {
       static const int dense_env = getenv("G1S_DENSE_CHUNKS") ? atoi(getenv("G1S_DENSE_CHUNKS")) : 0;  // tuning aid
       int chunks = std::max(std::max(8, std::min(16, g.nblocks / 512)), (g.nblocks + 255) / 256);
       if (dense_env > 0) chunks = std::max(dense_env, (g.nblocks + 255) / 256);
-      hipLaunchKernelGGL(k3_partial_dense, dim3(chunks, kPParts, B * g.nplanes), dim3(256), 0, stream, g, qp);
+      hipLaunchKernelGGL(k3_partial_dense, dim3(chunks, kPParts, Bs * g.nplanes), dim3(256), 0, stream, g, qp);
     }
-    hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, qp, sl.d_records);
+    hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, Bs), dim3(256), 0, stream, g, qp, sl.d_records);
     const int chunks = std::min(64, g.nblocks);
-    hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, B), dim3(256), 0, stream, ft, g, qp, sl.d_records);
+    hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, Bs), dim3(256), 0, stream, ft, g, qp, sl.d_records);
+    }
+    g.frame0 = 0;
   } else {
     const int chunks = std::min(kK3Chunks, g.nblocks);
     hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g, sl.d_records,

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
   __shared__ int s_sum[3][4][3];  // [component][block][sum d, sum d^2, sum src8 (luma)]
   __shared__ int s_bad[2][4];     // [kind][block]
   __shared__ Win s_win[2][4];     // [kind][block]
-  const int frame = blockIdx.z, by = blockIdx.y, bx0 = 4 * (int)blockIdx.x;
+  const int frame = g.frame0 + (int)blockIdx.z, by = blockIdx.y, bx0 = 4 * (int)blockIdx.x;
   const int tid = threadIdx.x;
   const FramePlanes fp = ft.f[frame];
   uint8_t *fbase = planes + (size_t)frame * ps.frame_bytes;

@@ -102,7 +102,7 @@ constexpr int kClsThreads = 1024;
 __global__ __launch_bounds__(kClsThreads) void k3_classify(Geom g, const uint8_t *__restrict__ records, QParams qp) {
   __shared__ uint32_t s_cnt[6][kClsThreads / 64];  // [kind * 3 + which][wave] -> count, then list position
   const int blk = blockIdx.x * kClsThreads + threadIdx.x;
-  const int frame = blockIdx.z;
+  const int frame = g.frame0 + (int)blockIdx.z;
   const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
   const bool valid = blk < g.nblocks;
   const int bx = valid ? blk % g.nbw : 0, by = valid ? blk / g.nbw : 0;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
   __shared__ int red[kLagWaves][kQPart + 1];
   __shared__ uint32_t s_pgn[kLagWaves];
 
-  const int frame = blockIdx.z;
+  const int frame = g.frame0 + (int)blockIdx.z;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // global wave index -> (list slice, plane).  The slice count is a multiple of 8 (list_slice).
   const int gw = (int)blockIdx.x * kLagWaves + wave;
@@ -551,7 +551,8 @@ __device__ __forceinline__ void partial_products(int (&acc)[kPSub], const uint32
 
 __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
   const int part = blockIdx.y;
-  const int frame = (int)blockIdx.z / g.nplanes, c = (int)blockIdx.z - frame * g.nplanes;
+  const int fz = (int)blockIdx.z / g.nplanes, c = (int)blockIdx.z - fz * g.nplanes;
+  const int frame = g.frame0 + fz;
   const int kind = c > 0 ? 1 : 0;
   const uint32_t n = min(qp.pgcount[(size_t)frame * 2 + kind], qp.pg_cap);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256) void k3q_generic(const FrameTable ft, Geom g, 
   __shared__ uint8_t wt[kGH * kGW];    // w at the same positions
   __shared__ int lt[kBlock * kBlock];  // L(p) on the block proper
   __shared__ int red[4];
-  const int c = blockIdx.y, frame = blockIdx.z;
+  const int c = blockIdx.y, frame = g.frame0 + (int)blockIdx.z;
   const int kind = c > 0 ? 1 : 0;
   const size_t lsel = ((size_t)frame * 2 + kind) * 3 + 2;
   const int nlist = (int)qp.counts[lsel];
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(256) void k3q_generic(const FrameTable ft, Geom g, 
 // grid = (nplanes, batch), block = 256: 4 lanes-groups of 64 split the chunk range.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *__restrict__ records) {
-  const int c = blockIdx.x, frame = blockIdx.y;
+  const int c = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;
   const bool chroma = c > 0;
   const int nc = kQN + (chroma ? 1 : 0);
   uint8_t *rec = records + (size_t)frame * g.rec_size;

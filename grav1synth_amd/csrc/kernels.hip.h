@@ -40,6 +40,7 @@ struct Geom {
   int nbw, nbh, nblocks;
   int src_bps, den_bps, src_shift, den_shift;
   int lag, n;
+  int frame0;     // first frame of the batch this launch covers (the K0 / K3 chain may run in sub-batches)
   int fast_rows;  // all luma source rows 16-byte aligned (base and stride)
   int vec_mask;   // bit c: src plane c rows 16-byte aligned in every frame of the batch; bit 3+c: den plane c
   // record layout (bytes from the start of a frame's record)
