@@ -8,13 +8,14 @@
 //             `bad` and its areas go to the exact int32 kernel instead);
 //     L8      chroma-resolution sum of the co-located luma residuals (the extra chroma
 //             regressor of add_block_observations before its division), int8, flagged likewise;
-//     w8[k]   0xFF / 0x00: sample lies in the observation window of its (flat) block,
+//     w1[k]   one BIT per sample: it lies in the observation window of its (flat) block,
 //             per plane kind k (luma, chroma);
 // plus the per-block noise statistics of the flat blocks (get_block_mean / get_noise_var:
 // exact integer sums of src8, d, d^2), straight into the frame record.
 //
-// Plane layout (one frame): sample (x, y) of a d8 / w8 plane at byte
+// Plane layout (one frame): sample (x, y) of a d8 plane at byte
 //     (y + kPadY) * pitch + kPadX + x,     pitch = nbw * bw + 16,  rows = nbh * bh + 2 * kPadY
+// and its window bit at bit (kPadX + x) of bit row (y + kPadY), wpitch = pitch / 8 bytes per bit row,
 // so that the K3 tile of block area (bx, by), x in -8 .. bw+7, starts at the 16-byte aligned
 // byte bx * bw of its rows; the padding is zeroed once and never written.  L8 has no halo:
 // sample (x, y) at byte y * lpitch + x, lpitch = nbw * bw.
@@ -30,7 +31,8 @@ constexpr int kQLag = 3;
 constexpr int kPadX = 8, kPadY = 3;
 
 struct PlaneSet {
-  uint32_t pitch[2];   // d8 / w8 row pitch per kind (0 luma, 1 chroma)
+  uint32_t pitch[2];   // d8 row pitch per kind (0 luma, 1 chroma)
+  uint32_t wpitch[2];  // w1 bit-row pitch in bytes (a multiple of 4)
   uint32_t lpitch;     // L8 row pitch
   uint32_t off_d[3];   // byte offsets inside one frame's plane set
   uint32_t off_w[2];
@@ -47,18 +49,20 @@ inline PlaneSet make_planeset(const Geom &g) {
     return o;
   };
   const int kinds = g.nplanes == 3 ? 2 : 1;
-  uint32_t plane_bytes[2] = {0, 0};
+  uint32_t plane_bytes[2] = {0, 0}, wplane_bytes[2] = {0, 0};
   for (int k = 0; k < kinds; ++k) {
     const int bw = kBlock >> (k ? g.xdec : 0), bh = kBlock >> (k ? g.ydec : 0);
     ps.pitch[k] = (uint32_t)(g.nbw * bw + 16);
     plane_bytes[k] = ps.pitch[k] * (uint32_t)(g.nbh * bh + 2 * kPadY) + 16;
+    ps.wpitch[k] = ((ps.pitch[k] >> 3) + 3u) & ~3u;
+    wplane_bytes[k] = ps.wpitch[k] * (uint32_t)(g.nbh * bh + 2 * kPadY) + 16;
   }
   ps.off_d[0] = take(plane_bytes[0]);
-  ps.off_w[0] = take(plane_bytes[0]);
+  ps.off_w[0] = take(wplane_bytes[0]);
   if (kinds == 2) {
     ps.off_d[1] = take(plane_bytes[1]);
     ps.off_d[2] = take(plane_bytes[1]);
-    ps.off_w[1] = take(plane_bytes[1]);
+    ps.off_w[1] = take(wplane_bytes[1]);
     ps.lpitch = (uint32_t)(g.nbw * (kBlock >> g.xdec));
     ps.off_l = take(ps.lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec)) + 16);
   }
@@ -113,6 +117,19 @@ __device__ __forceinline__ unsigned long long window_bytes(const Win &w, int lx0
   const unsigned long long upto_hi = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
   const unsigned long long upto_lo = lo >= 8 ? ~0ull : ((1ull << (8 * lo)) - 1ull);
   return upto_hi & ~upto_lo;
+}
+
+// bits lx0 .. lx0+7 of a window row (bit k = sample lx0 + k)
+__device__ __forceinline__ uint32_t window_bits8(const Win &w, int lx0, int ly) {
+  if (!w.flat || ly < w.ys || ly >= w.ye) return 0u;
+  const int lo = min(max(w.xs - lx0, 0), 8), hi = min(max(w.xe - lx0, 0), 8);
+  if (hi <= lo) return 0u;
+  return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+}
+// 4 window bits -> 4 bytes 0xFF / 0x00 (bit k -> byte k)
+__device__ __forceinline__ uint32_t expand_bits4(uint32_t n) {
+  const uint32_t m = (n * 0x00204081u) & 0x01010101u;  // n <= 15: a 24-bit multiply
+  return (m << 8) - m;
 }
 
 // ---- packed 16-bit arithmetic (two samples per dword) ------------------------------
@@ -255,8 +272,7 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
       if (active) {
         const size_t o = (size_t)(Y + kPadY) * ps.pitch[0] + kPadX + X0;
         *reinterpret_cast<uint2 *>(fbase + ps.off_d[0] + o) = make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
-        const unsigned long long wb = window_bytes(w, (seg & 3) * 8, row, 8);
-        *reinterpret_cast<uint2 *>(fbase + ps.off_w[0] + o) = make_uint2((uint32_t)wb, (uint32_t)(wb >> 32));
+        fbase[ps.off_w[0] + (size_t)(Y + kPadY) * ps.wpitch[0] + ((kPadX + X0) >> 3)] = (uint8_t)window_bits8(w, (seg & 3) * 8, row);
       }
       if (chroma) {
         // L = sum of the (1 << sx) x (1 << sy) luma residuals under a chroma sample; the next
@@ -336,8 +352,8 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
       *reinterpret_cast<uint2 *>(fbase + (c == 1 ? ps.off_d[1] : ps.off_d[2]) + o) =
           make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
       if (c == 1) {
-        const unsigned long long wb = window_bytes(s_win[1][b], (seg - b * spb) * 8, row, 8);
-        *reinterpret_cast<uint2 *>(fbase + ps.off_w[1] + o) = make_uint2((uint32_t)wb, (uint32_t)(wb >> 32));
+        fbase[ps.off_w[1] + (size_t)(Y + kPadY) * ps.wpitch[1] + ((kPadX + X0) >> 3)] =
+            (uint8_t)window_bits8(s_win[1][b], (seg - b * spb) * 8, row);
       }
       atomicAdd(&s_sum[c][b][0], sd);
       atomicAdd(&s_sum[c][b][1], sd2);

@@ -17,7 +17,7 @@
 // The chroma cross terms sum_p w(p) L(p) d(p+c_i), sum w L^2, sum w L d stay p-centric
 // under the block's own window (a separate, consistent partition).
 //
-// All kernels read the int8 planes K0 left behind (k0.hip.h): d8, L8, w8.
+// All kernels read the planes K0 left behind (k0.hip.h): int8 d8, L8 and the window bits w1.
 //   k3_classify          per (frame, kind, area): class + compacted INT / MIX / GENERIC lists
 //   k3_lag<KIND, false>  INT areas: 46 (+26 chroma) v_dot4c_i32_i8 per group
 //   k3_lag<KIND, true>   MIX areas: the same for their FULL groups (+ L terms under the window); the
@@ -89,6 +89,7 @@ typedef const G1S_GLOBAL uint32_t *gptr_u1;
 // dword-aligned wide global loads (global_load_dwordx3 / x4 need no more than that)
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 // ---------------------------------------------------------------------------------
 // k3_classify: one thread per block area, both plane kinds.  The area of block (bx, by)
@@ -269,6 +270,7 @@ struct TileRegs {
     constexpr bool CHROMA = S::kChroma;
     const uint32_t pitch = CHROMA ? ps.pitch[1] : ps.pitch[0];
     const uint32_t off_w = CHROMA ? ps.off_w[1] : ps.off_w[0];
+    const uint32_t wpitch = CHROMA ? ps.wpitch[1] : ps.wpitch[0];
     const uint32_t off_d = CHROMA ? (pl ? ps.off_d[2] : ps.off_d[1]) : ps.off_d[0];
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
@@ -279,11 +281,14 @@ struct TileRegs {
       const int segs = isl ? S::LSEG : S::SEG;
       const int y = r / segs, sg = r - y * segs;
       const uint32_t off = isd ? off_d : (isl ? ps.off_l : off_w);
-      const uint32_t pt = isl ? ps.lpitch : pitch;
+      const uint32_t pt = isl ? ps.lpitch : (isd ? pitch : wpitch);
       const int row = by * S::BH + y + (isd ? kPadY - S::UP : (isl ? 0 : kPadY));
-      gptr_u8 p = as_global(fbase) + off + (size_t)row * pt + (size_t)(bx * S::BW + 16 * sg);
+      // d / L items: 16 bytes of samples; window items: the 16 bits of the same 16 samples
+      const int col = isd || isl ? bx * S::BW + 16 * sg : (bx * S::BW + 16 * sg) >> 3;
+      gptr_u8 p = as_global(fbase) + off + (size_t)row * pt + (size_t)col;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (it < NITEMS) v = *(gptr_u4)p;
+      if (it < ND + NLI) v = *(gptr_u4)p;
+      else if (it < NITEMS) v.x = *(const G1S_GLOBAL uint16_t *)p;
       regs[k] = v;
     }
   }
@@ -296,7 +301,15 @@ struct TileRegs {
       const int segs = isl ? S::LSEG : S::SEG;
       const int y = r / segs, sg = r - y * segs;
       const int base = isd ? 0 : (isl ? L_OFF : W_OFF);
-      if (it < NITEMS) *reinterpret_cast<u32x4 *>(lds + base + y * S::PITCH + 16 * sg) = regs[k];
+      u32x4 v = regs[k];
+      if (!isd && !isl) {  // window bits -> bytes
+        const uint32_t b16 = v.x;
+        v.x = expand_bits4(b16 & 15u);
+        v.y = expand_bits4((b16 >> 4) & 15u);
+        v.z = expand_bits4((b16 >> 8) & 15u);
+        v.w = expand_bits4((b16 >> 12) & 15u);
+      }
+      if (it < NITEMS) *reinterpret_cast<u32x4 *>(lds + base + y * S::PITCH + 16 * sg) = v;
     }
   }
 };
@@ -527,17 +540,14 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
 // ---------------------------------------------------------------------------------
 template <int PART>
 __device__ __forceinline__ void partial_products(int (&acc)[kPSub], const uint32_t (&D)[kNumLags],
-                                                 const uint32_t (&q1)[4], const uint32_t (&q2)[4],
-                                                 const uint32_t (&q3)[4]) {
+                                                 const uint32_t (&wb)[4]) {
+  // wb[dy]: window bits of samples x-4 .. x+7 of row dy (bit 0 = x-4)
   int idx = 0;
 #pragma unroll
   for (int i = 0; i < kQN; ++i) {
     if (!p_in_part(PART, i)) continue;
-    const int dx = -coord_x(i), dy = -coord_y(i);  // W(q - c_i)
-    uint32_t wi;
-    if (dx < 0) wi = alignbyte(q2[dy], q1[dy], 4 + dx);
-    else if (dx == 0) wi = q2[dy];
-    else wi = alignbyte(q3[dy], q2[dy], dx);
+    const int dx = -coord_x(i), dy = -coord_y(i);  // W(q - c_i): samples x+dx .. x+dx+3 of row dy
+    const uint32_t wi = expand_bits4((wb[dy] >> (4 + dx)) & 15u);
     const uint32_t md = D[0] & wi;
 #pragma unroll
     for (int j = i; j < kQN; ++j) {
@@ -559,20 +569,24 @@ __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
   gptr_u1 list = (gptr_u1)as_global(reinterpret_cast<const uint8_t *>(qp.pglist + ((size_t)frame * 2 + kind) * qp.pg_cap));
   gptr_u8 fb = as_global(qp.planes) + (size_t)frame * qp.ps.frame_bytes;
   gptr_u1 dplane = (gptr_u1)(fb + (c == 0 ? qp.ps.off_d[0] : (c == 1 ? qp.ps.off_d[1] : qp.ps.off_d[2])));
-  gptr_u1 wplane = (gptr_u1)(fb + (kind ? qp.ps.off_w[1] : qp.ps.off_w[0]));
+  gptr_u8 wplane = fb + (kind ? qp.ps.off_w[1] : qp.ps.off_w[0]);
+  const uint32_t wpitch = kind ? qp.ps.wpitch[1] : qp.ps.wpitch[0];
   const int pitch_dw = (int)((kind ? qp.ps.pitch[1] : qp.ps.pitch[0]) >> 2);
   int acc[kPSub];
 #pragma unroll
   for (int i = 0; i < kPSub; ++i) acc[i] = 0;
-  // operand dwords of one group: d row 0 (3), d rows 1..3 (5 each), w rows 0..3 (3 each)
+  // operands of one group: d row 0 (3 dwords), d rows 1..3 (5 each), the window bit words of rows 0..3
   struct Ops {
-    u32x3_a4 cv, qv[4];
+    u32x3_a4 cv;
+    u32x2_a4 wv[4];
     u32x4_a4 ev[3];
     uint32_t e4[3];
   };
   auto gather = [&](uint32_t ent, Ops &o) {
     const size_t off = (size_t)((ent >> 16) + kPadY) * pitch_dw + (ent & 0xffffu);
-    gptr_u1 t32 = dplane + off, w32 = wplane + off;
+    gptr_u1 t32 = dplane + off;
+    // window bits of samples x-4 .. x+7: bit kPadX + x - 4 = 4 * gx + 4 of the bit row
+    gptr_u8 wrow = wplane + (size_t)((ent >> 16) + kPadY) * wpitch + ((((ent & 0xffffu) * 4u + 4u) >> 5) << 2);
     o.cv = *(const G1S_GLOBAL u32x3_a4 *)(t32 + 2);
 #pragma unroll
     for (int dy = 1; dy <= 3; ++dy) {
@@ -581,19 +595,26 @@ __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
       o.e4[dy - 1] = rp[4];
     }
 #pragma unroll
-    for (int dy = 0; dy <= 3; ++dy) o.qv[dy] = *(const G1S_GLOBAL u32x3_a4 *)(w32 + dy * pitch_dw + 1);
+    for (int dy = 0; dy <= 3; ++dy) o.wv[dy] = *(const G1S_GLOBAL u32x2_a4 *)(wrow + (size_t)dy * wpitch);
   };
   // software pipeline: the operands of step k+1 and the list entry of step k+2 are in flight
   // during the products of step k
   const uint32_t stride = gridDim.x * 256u;
   uint32_t e = (uint32_t)blockIdx.x * 256u + tid;
   Ops cur, nxt;
-  uint32_t ent_nxt = 0;
-  if (e < n) gather(list[e], cur);
+  uint32_t ent_cur = 0, ent_nxt = 0;
+  if (e < n) {
+    ent_cur = list[e];
+    gather(ent_cur, cur);
+  }
   if (e + stride < n) ent_nxt = list[e + stride];
   for (; e < n; e += stride) {
     const bool more = e + stride < n;
-    if (more) gather(ent_nxt, nxt);
+    const uint32_t wshift = ((ent_cur & 0xffffu) * 4u + 4u) & 31u;
+    if (more) {
+      gather(ent_nxt, nxt);
+      ent_cur = ent_nxt;
+    }
     if (e + 2 * stride < n) ent_nxt = list[e + 2 * stride];
     uint32_t D[kNumLags];
     {
@@ -625,17 +646,13 @@ __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
       D[b + 11] = alignbyte(e4, e3, 1);
       D[b + 12] = alignbyte(e4, e3, 2);
     }
-    uint32_t q1[4], q2[4], q3[4];
+    uint32_t wb[4];
 #pragma unroll
-    for (int dy = 0; dy <= 3; ++dy) {
-      q1[dy] = cur.qv[dy].x;
-      q2[dy] = cur.qv[dy].y;
-      q3[dy] = cur.qv[dy].z;
-    }
-    if (part == 0) partial_products<0>(acc, D, q1, q2, q3);
-    else if (part == 1) partial_products<1>(acc, D, q1, q2, q3);
-    else if (part == 2) partial_products<2>(acc, D, q1, q2, q3);
-    else partial_products<3>(acc, D, q1, q2, q3);
+    for (int dy = 0; dy <= 3; ++dy) wb[dy] = __builtin_amdgcn_alignbit(cur.wv[dy].y, cur.wv[dy].x, wshift) & 0xfffu;
+    if (part == 0) partial_products<0>(acc, D, wb);
+    else if (part == 1) partial_products<1>(acc, D, wb);
+    else if (part == 2) partial_products<2>(acc, D, wb);
+    else partial_products<3>(acc, D, wb);
     if (more) cur = nxt;
   }
   static_assert(kPParts == 4, "the dispatch above lists the parts");
