@@ -534,8 +534,8 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
 //     acc(i, j) += dot4(D(q) & W(q - c_i), D(q + c_j - c_i)),   acc(i, y) likewise,
 // barrier-free: a lane owns a group per step, gathers its 18 + 12 operand dwords from the
 // d8 / w8 planes (neighbouring groups share cache lines), rebuilds the 46 shifted operands
-// and multiplies.  blockIdx.y = which part of the anchors (kPSub accumulators a lane),
-// blockIdx.z = frame * nplanes + component.  grid = (chunks, kPParts, batch * nplanes).
+// and multiplies.  wave = which part of the anchors (kPSub accumulators a lane),
+// blockIdx.y = frame * nplanes + component.  grid = (chunks, batch * nplanes).
 // int32 safety: <= 64516 per step and accumulator; the launch keeps steps per lane < 520.
 // ---------------------------------------------------------------------------------
 template <int PART>
@@ -560,12 +560,19 @@ __device__ __forceinline__ void partial_products(int (&acc)[kPSub], const uint32
 }
 
 __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
-  const int part = blockIdx.y;
-  const int fz = (int)blockIdx.z / g.nplanes, c = (int)blockIdx.z - fz * g.nplanes;
+  // operand dwords of the 64 groups of a step, structure of arrays: [field][lane]
+  //   0..2 d row 0 (x .. x+11) | 3..6, 7 d row 1 (x-8 .. x+11) | 8..11, 12 row 2 | 13..16, 17 row 3
+  //   18..25 window bit words of rows 0..3 (two dwords each)
+  constexpr int kFields = 26;
+  __shared__ uint32_t s_ops[2][kFields][64];
+  __shared__ long long red[4][kPSub];
+  static_assert(kPParts == 4, "a wave per anchor part");
+  const int fz = (int)blockIdx.y / g.nplanes, c = (int)blockIdx.y - fz * g.nplanes;
   const int frame = g.frame0 + fz;
   const int kind = c > 0 ? 1 : 0;
   const uint32_t n = min(qp.pgcount[(size_t)frame * 2 + kind], qp.pg_cap);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (n == 0) return;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   gptr_u1 list = (gptr_u1)as_global(reinterpret_cast<const uint8_t *>(qp.pglist + ((size_t)frame * 2 + kind) * qp.pg_cap));
   gptr_u8 fb = as_global(qp.planes) + (size_t)frame * qp.ps.frame_bytes;
   gptr_u1 dplane = (gptr_u1)(fb + (c == 0 ? qp.ps.off_d[0] : (c == 1 ? qp.ps.off_d[1] : qp.ps.off_d[2])));
@@ -575,109 +582,130 @@ __global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
   int acc[kPSub];
 #pragma unroll
   for (int i = 0; i < kPSub; ++i) acc[i] = 0;
-  // operands of one group: d row 0 (3 dwords), d rows 1..3 (5 each), the window bit words of rows 0..3
-  struct Ops {
-    u32x3_a4 cv;
-    u32x2_a4 wv[4];
-    u32x4_a4 ev[3];
-    uint32_t e4[3];
-  };
-  auto gather = [&](uint32_t ent, Ops &o) {
+
+  // The four waves of a workgroup take the four anchor parts of the SAME 64 groups: each wave
+  // gathers a quarter of the operand dwords (next step's, during this step's products) and
+  // hands them over through LDS, so every dword is fetched once per group, not once per part.
+  // gather duty of a wave: wave 0: d row 0 (3 dwords) + window rows 0, 1; waves 1..3: d row `wave`
+  // (5 dwords) + (waves 1, 2) window row wave + 1.  Plain scalars: they must stay in registers.
+  uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+  auto gather = [&](uint32_t ent) {
     const size_t off = (size_t)((ent >> 16) + kPadY) * pitch_dw + (ent & 0xffffu);
-    gptr_u1 t32 = dplane + off;
     // window bits of samples x-4 .. x+7: bit kPadX + x - 4 = 4 * gx + 4 of the bit row
     gptr_u8 wrow = wplane + (size_t)((ent >> 16) + kPadY) * wpitch + ((((ent & 0xffffu) * 4u + 4u) >> 5) << 2);
-    o.cv = *(const G1S_GLOBAL u32x3_a4 *)(t32 + 2);
-#pragma unroll
-    for (int dy = 1; dy <= 3; ++dy) {
-      gptr_u1 rp = t32 + dy * pitch_dw;
-      o.ev[dy - 1] = *(const G1S_GLOBAL u32x4_a4 *)rp;
-      o.e4[dy - 1] = rp[4];
-    }
-#pragma unroll
-    for (int dy = 0; dy <= 3; ++dy) o.wv[dy] = *(const G1S_GLOBAL u32x2_a4 *)(wrow + (size_t)dy * wpitch);
+    // one straight-line path: the row and the load width are selected, not branched on
+    gptr_u1 rp = dplane + off + (wave == 0 ? 2 : wave * pitch_dw);
+    const u32x4_a4 a = *(const G1S_GLOBAL u32x4_a4 *)rp;  // wave 0 uses .x .y .z
+    r0 = a.x;
+    r1 = a.y;
+    r2 = a.z;
+    r3 = a.w;
+    r4 = rp[4];
+    const u32x2_a4 wa = *(const G1S_GLOBAL u32x2_a4 *)(wrow + (size_t)(wave == 0 ? 0 : min(wave + 1, 3)) * wpitch);
+    const u32x2_a4 wb2 = *(const G1S_GLOBAL u32x2_a4 *)(wrow + wpitch);
+    u0 = wa.x;
+    u1 = wa.y;
+    u2 = wb2.x;
+    u3 = wb2.y;
   };
-  // software pipeline: the operands of step k+1 and the list entry of step k+2 are in flight
-  // during the products of step k
-  const uint32_t stride = gridDim.x * 256u;
-  uint32_t e = (uint32_t)blockIdx.x * 256u + tid;
-  Ops cur, nxt;
-  uint32_t ent_cur = 0, ent_nxt = 0;
-  if (e < n) {
-    ent_cur = list[e];
-    gather(ent_cur, cur);
-  }
-  if (e + stride < n) ent_nxt = list[e + stride];
-  for (; e < n; e += stride) {
-    const bool more = e + stride < n;
-    const uint32_t wshift = ((ent_cur & 0xffffu) * 4u + 4u) & 31u;
-    if (more) {
-      gather(ent_nxt, nxt);
-      ent_cur = ent_nxt;
-    }
-    if (e + 2 * stride < n) ent_nxt = list[e + 2 * stride];
-    uint32_t D[kNumLags];
-    {
-      const uint32_t c0 = cur.cv.x, c1 = cur.cv.y, c2 = cur.cv.z;
-      D[0] = c0;
-      D[1] = alignbyte(c1, c0, 1);
-      D[2] = alignbyte(c1, c0, 2);
-      D[3] = alignbyte(c1, c0, 3);
-      D[4] = c1;
-      D[5] = alignbyte(c2, c1, 1);
-      D[6] = alignbyte(c2, c1, 2);
-    }
-#pragma unroll
-    for (int dy = 1; dy <= 3; ++dy) {
-      const uint32_t e0 = cur.ev[dy - 1].x, e1 = cur.ev[dy - 1].y, e2 = cur.ev[dy - 1].z, e3 = cur.ev[dy - 1].w,
-                     e4 = cur.e4[dy - 1];
-      const int b = 7 + (dy - 1) * 13;
-      D[b + 0] = alignbyte(e1, e0, 2);
-      D[b + 1] = alignbyte(e1, e0, 3);
-      D[b + 2] = e1;
-      D[b + 3] = alignbyte(e2, e1, 1);
-      D[b + 4] = alignbyte(e2, e1, 2);
-      D[b + 5] = alignbyte(e2, e1, 3);
-      D[b + 6] = e2;
-      D[b + 7] = alignbyte(e3, e2, 1);
-      D[b + 8] = alignbyte(e3, e2, 2);
-      D[b + 9] = alignbyte(e3, e2, 3);
-      D[b + 10] = e3;
-      D[b + 11] = alignbyte(e4, e3, 1);
-      D[b + 12] = alignbyte(e4, e3, 2);
-    }
-    uint32_t wb[4];
-#pragma unroll
-    for (int dy = 0; dy <= 3; ++dy) wb[dy] = __builtin_amdgcn_alignbit(cur.wv[dy].y, cur.wv[dy].x, wshift) & 0xfffu;
-    if (part == 0) partial_products<0>(acc, D, wb);
-    else if (part == 1) partial_products<1>(acc, D, wb);
-    else if (part == 2) partial_products<2>(acc, D, wb);
-    else partial_products<3>(acc, D, wb);
-    if (more) cur = nxt;
-  }
-  static_assert(kPParts == 4, "the dispatch above lists the parts");
-  if (n == 0) return;
-  __shared__ int red[4 * kPSub];
-  {
-    constexpr int CH = 27;
-#pragma unroll
-    for (int b0 = 0; b0 < kPSub; b0 += CH) {
-      int tmp[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) tmp[i] = (b0 + i < kPSub) ? acc[b0 + i] : 0;
-      wave_sum_all<CH>(tmp);
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-          if (b0 + i < kPSub) red[wave * kPSub + b0 + i] = tmp[i];
+  auto hand_over = [&](uint32_t (*ops)[64]) {
+    if (wave == 0) {
+      ops[0][lane] = r0;
+      ops[1][lane] = r1;
+      ops[2][lane] = r2;
+      ops[18][lane] = u0;
+      ops[19][lane] = u1;
+      ops[20][lane] = u2;
+      ops[21][lane] = u3;
+    } else {
+      const int f = 3 + (wave - 1) * 5;
+      ops[f][lane] = r0;
+      ops[f + 1][lane] = r1;
+      ops[f + 2][lane] = r2;
+      ops[f + 3][lane] = r3;
+      ops[f + 4][lane] = r4;
+      if (wave < 3) {
+        ops[22 + (wave - 1) * 2][lane] = u0;
+        ops[23 + (wave - 1) * 2][lane] = u1;
       }
     }
+  };
+
+  const uint32_t stride = gridDim.x * 64u;
+  uint32_t base = (uint32_t)blockIdx.x * 64u;
+  // lanes past the end of the list gather the last entry (valid memory) and skip the products
+  auto entry = [&](uint32_t b0) -> uint32_t { return list[min(b0 + (uint32_t)lane, n - 1u)]; };
+  uint32_t ent_cur = 0, ent_nxt = 0;
+  if (base < n) {
+    ent_cur = entry(base);
+    gather(ent_cur);
+  }
+  if (base + stride < n) ent_nxt = entry(base + stride);
+  int it = 0;
+  for (; base < n; base += stride) {
+    uint32_t(*ops)[64] = s_ops[it & 1];
+    ++it;
+    hand_over(ops);
+    __syncthreads();  // operands of this step complete; the other buffer is free again
+    const uint32_t wshift = ((ent_cur & 0xffffu) * 4u + 4u) & 31u;
+    const bool valid = base + (uint32_t)lane < n;
+    if (base + stride < n) {
+      gather(ent_nxt);
+      ent_cur = ent_nxt;
+    }
+    if (base + 2 * stride < n) ent_nxt = entry(base + 2 * stride);
+    if (valid) {
+      uint32_t D[kNumLags];
+      {
+        const uint32_t c0 = ops[0][lane], c1 = ops[1][lane], c2 = ops[2][lane];
+        D[0] = c0;
+        D[1] = alignbyte(c1, c0, 1);
+        D[2] = alignbyte(c1, c0, 2);
+        D[3] = alignbyte(c1, c0, 3);
+        D[4] = c1;
+        D[5] = alignbyte(c2, c1, 1);
+        D[6] = alignbyte(c2, c1, 2);
+      }
+#pragma unroll
+      for (int dy = 1; dy <= 3; ++dy) {
+        const int f = 3 + (dy - 1) * 5;
+        const uint32_t e0 = ops[f][lane], e1 = ops[f + 1][lane], e2 = ops[f + 2][lane], e3 = ops[f + 3][lane],
+                       e4 = ops[f + 4][lane];
+        const int b = 7 + (dy - 1) * 13;
+        D[b + 0] = alignbyte(e1, e0, 2);
+        D[b + 1] = alignbyte(e1, e0, 3);
+        D[b + 2] = e1;
+        D[b + 3] = alignbyte(e2, e1, 1);
+        D[b + 4] = alignbyte(e2, e1, 2);
+        D[b + 5] = alignbyte(e2, e1, 3);
+        D[b + 6] = e2;
+        D[b + 7] = alignbyte(e3, e2, 1);
+        D[b + 8] = alignbyte(e3, e2, 2);
+        D[b + 9] = alignbyte(e3, e2, 3);
+        D[b + 10] = e3;
+        D[b + 11] = alignbyte(e4, e3, 1);
+        D[b + 12] = alignbyte(e4, e3, 2);
+      }
+      uint32_t wb[4];
+#pragma unroll
+      for (int dy = 0; dy <= 3; ++dy)
+        wb[dy] = __builtin_amdgcn_alignbit(ops[19 + 2 * dy][lane], ops[18 + 2 * dy][lane], wshift) & 0xfffu;
+      if (wave == 0) partial_products<0>(acc, D, wb);
+      else if (wave == 1) partial_products<1>(acc, D, wb);
+      else if (wave == 2) partial_products<2>(acc, D, wb);
+      else partial_products<3>(acc, D, wb);
+    }
+  }
+  // cross-lane sums on 16-bit halves (a lane may exceed 2^31 / 64)
+#pragma unroll
+  for (int i = 0; i < kPSub; ++i) {
+    const int lo = wave_sum(acc[i] & 0xffff), hi = wave_sum(acc[i] >> 16);
+    if (lane == 0) red[wave][i] = ((long long)hi << 16) + lo;
   }
   __syncthreads();
-  unsigned long long *out =
-      reinterpret_cast<unsigned long long *>(qp.paracc) + ((size_t)frame * 3 + c) * kPPart + part * kPSub;
-  for (int i = tid; i < kPSub; i += 256) {
-    const long long v = (long long)red[i] + red[kPSub + i] + red[2 * kPSub + i] + red[3 * kPSub + i];
+  unsigned long long *out = reinterpret_cast<unsigned long long *>(qp.paracc) + ((size_t)frame * 3 + c) * kPPart;
+  for (int i = tid; i < kPPart; i += 256) {
+    const long long v = red[i / kPSub][i % kPSub];
     if (v != 0) atomicAdd(&out[i], (unsigned long long)v);
   }
 }
