@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "k0.hip.h"
 #include "kernels.hip.h"
 
@@ -84,6 +86,24 @@ __device__ __forceinline__ void wave_sum_all(int (&a)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) a[i] += t[i];
   }
+}
+// N wave sums at once: every DPP stage runs over all N values before the next stage, so no
+// instruction waits on its predecessor (a lone wave_sum() is a chain of dependent DPP adds
+// with wait states between them).  Totals in lane 63.
+template <int N>
+__device__ __forceinline__ void wave_sums_dpp(int (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x4E, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x141, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x140, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x142, 0xa, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x143, 0xc, 0xf, false);
 }
 typedef const G1S_GLOBAL uint32_t *gptr_u1;
 // dword-aligned wide global loads (global_load_dwordx3 / x4 need no more than that)
@@ -559,148 +579,166 @@ __device__ __forceinline__ void partial_products(int (&acc)[kPSub], const uint32
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k3_partial_dense(Geom g, QParams qp) {
-  // operand dwords of the 64 groups of a step, structure of arrays: [field][lane]
-  //   0..2 d row 0 (x .. x+11) | 3..6, 7 d row 1 (x-8 .. x+11) | 8..11, 12 row 2 | 13..16, 17 row 3
-  //   18..25 window bit words of rows 0..3 (two dwords each)
-  constexpr int kFields = 26;
-  __shared__ uint32_t s_ops[2][kFields][64];
+// Asynchronous gathers straight into LDS (gfx950 global_load_lds_dword / _dwordx4): lane l's data
+// lands at dst + l * size, no VGPRs are held while the load is in flight and vmcnt counts it.
+// Issued through inline asm on purpose: the compiler would otherwise wait for vmcnt(0) before
+// every LDS read that may alias the destination; the waits are placed by hand below.
+typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+__device__ __forceinline__ uint32_t lds_address(const void *p) {
+  return (uint32_t)(uintptr_t)(lds_u32_ptr)(uint32_t *)p;
+}
+__device__ __forceinline__ void dma16(gptr_u8 src, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(gptr_u8 src, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(lds_dst) : "memory");
+}
+// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+constexpr int kDStages = 5;     // ring of step buffers: the gathers of four later steps are in flight
+constexpr int kDEnt = 2048;     // list entries staged per block (32 steps)
+struct DenseStep {              // operand dwords of the 64 groups of a step
+  uint32_t A[4][64][4];         // A[0]: d row 0, samples x .. x+15; A[r]: d row r, samples x-8 .. x+7
+  uint32_t B[3][64];            // d row r+1, samples x+8 .. x+11
+  uint32_t W[9][64];            // window bit words: row dy -> W[2 dy], W[2 dy + 1]; W[8] is a dummy slot
+};
+__global__ __launch_bounds__(256, 3) void k3_partial_dense(Geom g, QParams qp) {
+  __shared__ __attribute__((aligned(16))) DenseStep ring[kDStages];
+  __shared__ uint32_t s_ent[kDEnt];
   __shared__ long long red[4][kPSub];
   static_assert(kPParts == 4, "a wave per anchor part");
   const int fz = (int)blockIdx.y / g.nplanes, c = (int)blockIdx.y - fz * g.nplanes;
   const int frame = g.frame0 + fz;
   const int kind = c > 0 ? 1 : 0;
   const uint32_t n = min(qp.pgcount[(size_t)frame * 2 + kind], qp.pg_cap);
-  if (n == 0) return;
+  // contiguous share of the list for this workgroup, in whole steps
+  const uint32_t per = (((n + gridDim.x - 1) / gridDim.x) + 63u) & ~63u;
+  const uint32_t lo = min(n, (uint32_t)blockIdx.x * per), hi = min(n, lo + per);
+  if (lo >= hi) return;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   gptr_u1 list = (gptr_u1)as_global(reinterpret_cast<const uint8_t *>(qp.pglist + ((size_t)frame * 2 + kind) * qp.pg_cap));
   gptr_u8 fb = as_global(qp.planes) + (size_t)frame * qp.ps.frame_bytes;
-  gptr_u1 dplane = (gptr_u1)(fb + (c == 0 ? qp.ps.off_d[0] : (c == 1 ? qp.ps.off_d[1] : qp.ps.off_d[2])));
+  gptr_u8 dplane = fb + (c == 0 ? qp.ps.off_d[0] : (c == 1 ? qp.ps.off_d[1] : qp.ps.off_d[2]));
   gptr_u8 wplane = fb + (kind ? qp.ps.off_w[1] : qp.ps.off_w[0]);
   const uint32_t wpitch = kind ? qp.ps.wpitch[1] : qp.ps.wpitch[0];
-  const int pitch_dw = (int)((kind ? qp.ps.pitch[1] : qp.ps.pitch[0]) >> 2);
+  const uint32_t pitch = kind ? qp.ps.pitch[1] : qp.ps.pitch[0];
   int acc[kPSub];
 #pragma unroll
   for (int i = 0; i < kPSub; ++i) acc[i] = 0;
 
-  // The four waves of a workgroup take the four anchor parts of the SAME 64 groups: each wave
-  // gathers a quarter of the operand dwords (next step's, during this step's products) and
-  // hands them over through LDS, so every dword is fetched once per group, not once per part.
-  // gather duty of a wave: wave 0: d row 0 (3 dwords) + window rows 0, 1; waves 1..3: d row `wave`
-  // (5 dwords) + (waves 1, 2) window row wave + 1.  Plain scalars: they must stay in registers.
-  uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-  auto gather = [&](uint32_t ent) {
-    const size_t off = (size_t)((ent >> 16) + kPadY) * pitch_dw + (ent & 0xffffu);
+  // The four waves take the four anchor parts of the SAME 64 groups; each wave gathers a
+  // quarter of the operands of a step (one 16-byte and three 4-byte pieces per lane, exactly
+  // four loads per wave and step so that the in-order vmcnt can be counted):
+  //   wave 0: A0 W0 W1 W2 | wave 1: A1 B0 W3 W4 | wave 2: A2 B1 W5 W6 | wave 3: A3 B2 W7 (W7 again -> dummy)
+  auto issue = [&](uint32_t ent, int stage) {
+    const uint32_t gx = ent & 0xffffu, gy = ent >> 16;
+    gptr_u8 drow = dplane + (size_t)(gy + kPadY + wave) * pitch + 4u * gx;  // row `wave`, sample x-8
     // window bits of samples x-4 .. x+7: bit kPadX + x - 4 = 4 * gx + 4 of the bit row
-    gptr_u8 wrow = wplane + (size_t)((ent >> 16) + kPadY) * wpitch + ((((ent & 0xffffu) * 4u + 4u) >> 5) << 2);
-    // one straight-line path: the row and the load width are selected, not branched on
-    gptr_u1 rp = dplane + off + (wave == 0 ? 2 : wave * pitch_dw);
-    const u32x4_a4 a = *(const G1S_GLOBAL u32x4_a4 *)rp;  // wave 0 uses .x .y .z
-    r0 = a.x;
-    r1 = a.y;
-    r2 = a.z;
-    r3 = a.w;
-    r4 = rp[4];
-    const u32x2_a4 wa = *(const G1S_GLOBAL u32x2_a4 *)(wrow + (size_t)(wave == 0 ? 0 : min(wave + 1, 3)) * wpitch);
-    const u32x2_a4 wb2 = *(const G1S_GLOBAL u32x2_a4 *)(wrow + wpitch);
-    u0 = wa.x;
-    u1 = wa.y;
-    u2 = wb2.x;
-    u3 = wb2.y;
-  };
-  auto hand_over = [&](uint32_t (*ops)[64]) {
-    if (wave == 0) {
-      ops[0][lane] = r0;
-      ops[1][lane] = r1;
-      ops[2][lane] = r2;
-      ops[18][lane] = u0;
-      ops[19][lane] = u1;
-      ops[20][lane] = u2;
-      ops[21][lane] = u3;
-    } else {
-      const int f = 3 + (wave - 1) * 5;
-      ops[f][lane] = r0;
-      ops[f + 1][lane] = r1;
-      ops[f + 2][lane] = r2;
-      ops[f + 3][lane] = r3;
-      ops[f + 4][lane] = r4;
-      if (wave < 3) {
-        ops[22 + (wave - 1) * 2][lane] = u0;
-        ops[23 + (wave - 1) * 2][lane] = u1;
-      }
-    }
+    gptr_u8 wbase = wplane + (size_t)(gy + kPadY) * wpitch + (((gx * 4u + 4u) >> 5) << 2);
+    const uint32_t st = lds_address(&ring[stage]);
+    const uint32_t oA = st + (uint32_t)wave * 1024u, oB = st + 4096u, oW = st + 4096u + 768u;
+    dma16(drow + (wave == 0 ? 8 : 0), oA);
+    const int k1 = wave == 0 ? 0 : -1, k2 = 2 * wave + 1, k3 = wave == 3 ? 7 : 2 * wave + 2;
+    // piece 1: wave 0: W0; others: B[wave-1]
+    dma4(wave == 0 ? wbase : drow + 16, wave == 0 ? oW : oB + (uint32_t)(wave - 1) * 256u);
+    (void)k1;
+    dma4(wbase + (size_t)(k2 >> 1) * wpitch + 4u * (k2 & 1), oW + (uint32_t)k2 * 256u);
+    dma4(wbase + (size_t)(k3 >> 1) * wpitch + 4u * (k3 & 1), oW + (uint32_t)(wave == 3 ? 8 : k3) * 256u);
   };
 
-  const uint32_t stride = gridDim.x * 64u;
-  uint32_t base = (uint32_t)blockIdx.x * 64u;
-  // lanes past the end of the list gather the last entry (valid memory) and skip the products
-  auto entry = [&](uint32_t b0) -> uint32_t { return list[min(b0 + (uint32_t)lane, n - 1u)]; };
-  uint32_t ent_cur = 0, ent_nxt = 0;
-  if (base < n) {
-    ent_cur = entry(base);
-    gather(ent_cur);
-  }
-  if (base + stride < n) ent_nxt = entry(base + stride);
-  int it = 0;
-  for (; base < n; base += stride) {
-    uint32_t(*ops)[64] = s_ops[it & 1];
-    ++it;
-    hand_over(ops);
-    __syncthreads();  // operands of this step complete; the other buffer is free again
-    const uint32_t wshift = ((ent_cur & 0xffffu) * 4u + 4u) & 31u;
-    const bool valid = base + (uint32_t)lane < n;
-    if (base + stride < n) {
-      gather(ent_nxt);
-      ent_cur = ent_nxt;
-    }
-    if (base + 2 * stride < n) ent_nxt = entry(base + 2 * stride);
-    if (valid) {
-      uint32_t D[kNumLags];
-      {
-        const uint32_t c0 = ops[0][lane], c1 = ops[1][lane], c2 = ops[2][lane];
-        D[0] = c0;
-        D[1] = alignbyte(c1, c0, 1);
-        D[2] = alignbyte(c1, c0, 2);
-        D[3] = alignbyte(c1, c0, 3);
-        D[4] = c1;
-        D[5] = alignbyte(c2, c1, 1);
-        D[6] = alignbyte(c2, c1, 2);
+  // the whole step loop is instantiated per anchor part (a dispatch inside the loop would merge
+  // the 81 accumulators of the four variants after every step: 81 register copies per step)
+  auto run = [&](auto part_tag) {
+  for (uint32_t blo = lo; blo < hi; blo += kDEnt) {
+    const uint32_t cnt = min((uint32_t)kDEnt, hi - blo);
+    const int S = (int)((cnt + 63u) >> 6);
+    __syncthreads();  // everybody is done with the previous block's entries (and all its loads have landed)
+    for (uint32_t i = tid; i < cnt; i += 256) s_ent[i] = list[blo + i];
+    __syncthreads();
+    // lanes past the end of the list gather the last entry (valid memory) and skip the products
+    auto entry = [&](int st) -> uint32_t { return s_ent[min((uint32_t)(st * 64 + lane), cnt - 1u)]; };
+    for (int st = 0; st < kDStages - 1 && st < S; ++st) issue(entry(st), st % kDStages);
+    for (int st = 0; st < S; ++st) {
+      // this wave's loads of step st have landed when at most 4 * (steps issued after it) are outstanding
+      const int ahead = min(S - 1, st + kDStages - 2) - st;
+      if (ahead >= 4) wait_vmcnt<16>();
+      else if (ahead == 3) wait_vmcnt<12>();
+      else if (ahead == 2) wait_vmcnt<8>();
+      else if (ahead == 1) wait_vmcnt<4>();
+      else wait_vmcnt<0>();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // ... and so have the other waves'; the buffer of step st-1 is free
+      asm volatile("" ::: "memory");  // (a bare s_barrier: no fence, hence no vmcnt(0); keep LDS reads below it)
+      if (st + kDStages - 1 < S) issue(entry(st + kDStages - 1), (st + kDStages - 1) % kDStages);
+      const DenseStep &ops = ring[st % kDStages];
+      if ((uint32_t)(st * 64 + lane) < cnt) {
+        const uint32_t wshift = ((s_ent[st * 64 + lane] & 0xffffu) * 4u + 4u) & 31u;
+        uint32_t D[kNumLags];
+        {
+          const uint32_t c0 = ops.A[0][lane][0], c1 = ops.A[0][lane][1], c2 = ops.A[0][lane][2];
+          D[0] = c0;
+          D[1] = alignbyte(c1, c0, 1);
+          D[2] = alignbyte(c1, c0, 2);
+          D[3] = alignbyte(c1, c0, 3);
+          D[4] = c1;
+          D[5] = alignbyte(c2, c1, 1);
+          D[6] = alignbyte(c2, c1, 2);
+        }
+#pragma unroll
+        for (int dy = 1; dy <= 3; ++dy) {
+          const uint32_t e0 = ops.A[dy][lane][0], e1 = ops.A[dy][lane][1], e2 = ops.A[dy][lane][2],
+                         e3 = ops.A[dy][lane][3], e4 = ops.B[dy - 1][lane];
+          const int b = 7 + (dy - 1) * 13;
+          D[b + 0] = alignbyte(e1, e0, 2);
+          D[b + 1] = alignbyte(e1, e0, 3);
+          D[b + 2] = e1;
+          D[b + 3] = alignbyte(e2, e1, 1);
+          D[b + 4] = alignbyte(e2, e1, 2);
+          D[b + 5] = alignbyte(e2, e1, 3);
+          D[b + 6] = e2;
+          D[b + 7] = alignbyte(e3, e2, 1);
+          D[b + 8] = alignbyte(e3, e2, 2);
+          D[b + 9] = alignbyte(e3, e2, 3);
+          D[b + 10] = e3;
+          D[b + 11] = alignbyte(e4, e3, 1);
+          D[b + 12] = alignbyte(e4, e3, 2);
+        }
+        uint32_t wb[4];
+#pragma unroll
+        for (int dy = 0; dy <= 3; ++dy)
+          wb[dy] = __builtin_amdgcn_alignbit(ops.W[2 * dy + 1][lane], ops.W[2 * dy][lane], wshift) & 0xfffu;
+        partial_products<decltype(part_tag)::value>(acc, D, wb);
       }
-#pragma unroll
-      for (int dy = 1; dy <= 3; ++dy) {
-        const int f = 3 + (dy - 1) * 5;
-        const uint32_t e0 = ops[f][lane], e1 = ops[f + 1][lane], e2 = ops[f + 2][lane], e3 = ops[f + 3][lane],
-                       e4 = ops[f + 4][lane];
-        const int b = 7 + (dy - 1) * 13;
-        D[b + 0] = alignbyte(e1, e0, 2);
-        D[b + 1] = alignbyte(e1, e0, 3);
-        D[b + 2] = e1;
-        D[b + 3] = alignbyte(e2, e1, 1);
-        D[b + 4] = alignbyte(e2, e1, 2);
-        D[b + 5] = alignbyte(e2, e1, 3);
-        D[b + 6] = e2;
-        D[b + 7] = alignbyte(e3, e2, 1);
-        D[b + 8] = alignbyte(e3, e2, 2);
-        D[b + 9] = alignbyte(e3, e2, 3);
-        D[b + 10] = e3;
-        D[b + 11] = alignbyte(e4, e3, 1);
-        D[b + 12] = alignbyte(e4, e3, 2);
-      }
-      uint32_t wb[4];
-#pragma unroll
-      for (int dy = 0; dy <= 3; ++dy)
-        wb[dy] = __builtin_amdgcn_alignbit(ops[19 + 2 * dy][lane], ops[18 + 2 * dy][lane], wshift) & 0xfffu;
-      if (wave == 0) partial_products<0>(acc, D, wb);
-      else if (wave == 1) partial_products<1>(acc, D, wb);
-      else if (wave == 2) partial_products<2>(acc, D, wb);
-      else partial_products<3>(acc, D, wb);
     }
   }
-  // cross-lane sums on 16-bit halves (a lane may exceed 2^31 / 64)
+  };
+  if (wave == 0) run(std::integral_constant<int, 0>{});
+  else if (wave == 1) run(std::integral_constant<int, 1>{});
+  else if (wave == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+  // cross-lane sums on 16-bit halves (a lane may exceed 2^31 / 64), 27 values a round
+  {
+    constexpr int CH = 27;
+    static_assert(kPSub % CH == 0, "");
 #pragma unroll
-  for (int i = 0; i < kPSub; ++i) {
-    const int lo = wave_sum(acc[i] & 0xffff), hi = wave_sum(acc[i] >> 16);
-    if (lane == 0) red[wave][i] = ((long long)hi << 16) + lo;
+    for (int b0 = 0; b0 < kPSub; b0 += CH) {
+      int lo16[CH], hi16[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        lo16[i] = acc[b0 + i] & 0xffff;
+        hi16[i] = acc[b0 + i] >> 16;
+      }
+      wave_sums_dpp<CH>(lo16);
+      wave_sums_dpp<CH>(hi16);
+      if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) red[wave][b0 + i] = ((long long)hi16[i] << 16) + lo16[i];
+      }
+    }
   }
   __syncthreads();
   unsigned long long *out = reinterpret_cast<unsigned long long *>(qp.paracc) + ((size_t)frame * 3 + c) * kPPart;
