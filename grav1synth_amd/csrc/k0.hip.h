@@ -129,7 +129,8 @@ __device__ __forceinline__ uint32_t window_bits8(const Win &w, int lx0, int ly) 
 // 4 window bits -> 4 bytes 0xFF / 0x00 (bit k -> byte k)
 __device__ __forceinline__ uint32_t expand_bits4(uint32_t n) {
   const uint32_t m = (n * 0x00204081u) & 0x01010101u;  // n <= 15: a 24-bit multiply
-  return (m << 8) - m;
+  // bytes 0 / 1 -> 0x00 / 0xFF without a multiply by 255: 0x80 - {0,1} = {0x80,0x7F} never borrows across bytes
+  return (0x80808080u - m) ^ 0x80808080u;
 }
 
 // ---- packed 16-bit arithmetic (two samples per dword) ------------------------------
