@@ -59,17 +59,27 @@ def main() -> None:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the diff path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; G1S_BENCH_SHARE_GPU=1 lets several ranks share a device (single-GPU smoke test of
+    # the N > 1 code path, with the gloo backend: RCCL refuses two ranks on one device)
+    share = os.environ.get("G1S_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if world > 1:  # the host fold pools of the ranks share the node's cores
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        os.environ.setdefault("G1S_FOLD_THREADS", str(max(2, min(32, (os.cpu_count() or 8) // max(lws, 1)))))
     from grav1synth_amd.diff import DiffGenerator, format_tbl
-    from grav1synth_amd.dist import ShardedDiff
+    from grav1synth_amd.dist import ShardedDiff, StreamingShardedDiff
     from grav1synth_amd.synth import SynthSpec, make_pair
 
     W, H, bd, xdec, ydec, lag, chroma, bpp = WORKLOADS[args.workload]
@@ -78,9 +88,12 @@ def main() -> None:
     fps = Fraction(24, 1)
 
     # ---- synthetic frame pairs, resident in HBM before any timed region ----
+    # N > 1: the video is dealt to the ranks batch by batch (global batch j -> rank j % N)
+    B = max(1, min(args.batch, 16))
     frames = []
     for k in range(F):
-        s, d = make_pair(spec, rank * F + k, device=dev)
+        gid = ((k // B) * world + rank) * B + (k % B) if world > 1 else k
+        s, d = make_pair(spec, gid, device=dev)
         if not chroma:
             s, d = s[:1], d[:1]
         frames.append((s, d))
@@ -88,6 +101,7 @@ def main() -> None:
     # FFI frame descriptors (pointers, strides) are built once, outside the timed region:
     # a native caller hands over an array of frame structs just like this
     prepared = DiffGenerator.prepare_frames(frames, xdec, ydec)
+    prepared_batches = [DiffGenerator.prepare_frames(frames[i:i + B], xdec, ydec) for i in range(0, F, B)] if world > 1 else []
     nplanes = 3 if chroma else 1
 
     stats_total = None
@@ -95,11 +109,19 @@ def main() -> None:
 
     def one_step(timing: bool):
         nonlocal stats_total, last_tbl
-        sd = ShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=local_rank,
-                         batch_frames=args.batch, group=dist if world > 1 else None)
-        sd.generator.set_timing(timing)
-        sd.diff_prepared(prepared, W, H, nplanes, sync_torch=False)
-        segs = sd.finish()  # exchange + ordered fold (rank 0 holds the table)
+        if world > 1:
+            # streaming frame shards: per batch one small all-gather of latest states, rank 0 merges in order
+            sd = StreamingShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
+                                      batch_frames=B, group=dist)
+            sd.generator.set_timing(timing)
+            for pb in prepared_batches:
+                sd.diff_prepared(pb, sync_torch=False)
+        else:
+            sd = ShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
+                             batch_frames=args.batch, group=None)
+            sd.generator.set_timing(timing)
+            sd.diff_prepared(prepared, W, H, nplanes, sync_torch=False)
+        segs = sd.finish()  # (exchange +) ordered fold; rank 0 holds the table
         st = sd.generator.stats()
         if segs is not None:
             last_tbl = format_tbl(segs)
@@ -121,7 +143,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=torch.device("cpu") if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -168,7 +190,7 @@ def main() -> None:
             "frames_per_rank_per_step": F,
             "batch_frames": args.batch,
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
-            "parallelism": f"frame-shard x{world}, one RCCL all-gather of integer records per step" if world > 1 else "single GPU",
+            "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if world > 1 else "single GPU",
         },
         "hbm_roofline_frac_whole_job": (value * bpp * 1e6 / 1e9) / (HBM_PEAK_GBS * world),
         "roofline": {

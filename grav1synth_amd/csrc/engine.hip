@@ -230,6 +230,7 @@ struct g1s_diff {
   uint32_t src_bd, den_bd;
   uint32_t lag, n;
   bool luma_only, records_only;
+  bool latest_only = false;  // keep the per-frame latest states (blobs) instead of folding them here
   uint32_t batch;
   int device = 0;
   hipStream_t stream = nullptr;       // == slot_stream[0]
@@ -256,7 +257,10 @@ struct g1s_diff {
   std::vector<FrameLatest> latest;  // one per frame of a batch, reused
   std::vector<uint8_t> records_out;
   size_t records_out_frames = 0;
+  std::vector<uint8_t> latest_out;  // latest_only: blobs of the drained frames, in frame order
+  size_t latest_out_frames = 0;
   std::vector<uint8_t> last_record;
+  std::vector<uint8_t> latest_stage;
   std::string err;
   int deferred = G1S_OK;
   int sticky = G1S_OK;  // a fold error kills the generator (the reference `?`-propagates out of main)
@@ -650,6 +654,8 @@ int g1s_diff::drain_one() {
   if (latest.size() < sl.count) latest.resize(sl.count);
   std::vector<uint32_t> nflat_v(sl.count, 0);
   // ---- per-frame half, concurrent: header, symmetric mirror, latest noise state ----
+  const size_t blob = latest_only ? latest_blob_size(lag) : 0;
+  if (latest_only) latest_stage.resize(blob * sl.count);
   auto per_frame = [&](int i) {
     uint8_t *rec = sl.h_records + L.size * i;
     RecHeader h{};
@@ -678,6 +684,7 @@ int g1s_diff::drain_one() {
         for (int b = a + 1; b < nc; ++b) S[b * nc + a] = S[a * nc + b];
     }
     if (!records_only) compute_latest(rec, L.size, lag, latest[i]);
+    if (latest_only) latest_to_blob(latest[i], lag, latest_stage.data() + (size_t)i * blob);
   };
   if (pool && sl.count > 1) {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
@@ -694,6 +701,9 @@ int g1s_diff::drain_one() {
     if (records_only) {
       records_out.insert(records_out.end(), rec, rec + L.size);
       records_out_frames++;
+    } else if (latest_only) {
+      latest_out.insert(latest_out.end(), latest_stage.begin() + blob * i, latest_stage.begin() + blob * (i + 1));
+      latest_out_frames++;
     } else if (sticky == G1S_OK) {
       rc = fold->push_latest(latest[i]);
       if (rc) {
@@ -789,7 +799,7 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
     return nullptr;
   }
   uint32_t lag = 3, batch = kDefaultBatch;
-  bool luma_only = false, records_only = false;
+  bool luma_only = false, records_only = false, latest_only = false;
   int device = -1;
   if (opts) {
     if (opts->struct_size != sizeof(g1s_opts_t)) {
@@ -799,7 +809,8 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
     if (opts->ar_coeff_lag) lag = opts->ar_coeff_lag;
     if (opts->batch_frames) batch = std::min<uint32_t>(opts->batch_frames, (uint32_t)kMaxBatch);
     luma_only = opts->luma_only != 0;
-    records_only = opts->records_only != 0;
+    records_only = opts->records_only == 1;
+    latest_only = opts->records_only == 2;
     device = opts->device;
   }
   if (lag < 1 || lag > 3) {
@@ -829,6 +840,7 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   g->n = num_coeffs(lag);
   g->luma_only = luma_only;
   g->records_only = records_only;
+  g->latest_only = latest_only;
   g->batch = batch;
   g->device = device;
   make_flat_consts(g->fc);
@@ -869,7 +881,7 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
     delete g;
     return nullptr;
   }
-  if (!records_only) {
+  if (!records_only && !latest_only) {
     g->fold = new NoiseFold(fps_num, fps_den, lag);
     g->pool = shared_pool();
   }
@@ -917,7 +929,8 @@ int g1s_diff_sync(g1s_diff_t *g) {
 int g1s_diff_finish(g1s_diff_t *g, g1s_segment_t *out, size_t cap, size_t *n_out) {
   if (!g) return G1S_ERR_INVALID;
   if (g->finished) return g->fail(G1S_ERR_STATE, "generator already finished");
-  if (g->records_only) return g->fail(G1S_ERR_STATE, "records_only generator: use g1s_diff_take_records + g1s_fold_*");
+  if (g->records_only || g->latest_only)
+    return g->fail(G1S_ERR_STATE, "records_only / latest_only generator: use g1s_diff_take_* + g1s_fold_*");
   const int rc = g1s_diff_sync(g);
   if (rc) return rc;
   g->finished = true;
@@ -980,6 +993,32 @@ int g1s_diff_take_records(g1s_diff_t *g, void *buf, size_t cap_bytes, size_t *n_
   return G1S_OK;
 }
 
+int g1s_diff_take_latest(g1s_diff_t *g, int sync, void *buf, size_t cap_bytes, size_t *n_frames) {
+  if (!g) return G1S_ERR_INVALID;
+  if (!g->latest_only) return g->fail(G1S_ERR_STATE, "not a latest_only generator");
+  if (sync) {
+    const int rc = g1s_diff_sync(g);
+    if (rc) return rc;
+  }
+  if (n_frames) *n_frames = g->latest_out_frames;
+  if (g->latest_out.size() > cap_bytes) return g->fail(G1S_ERR_CAPACITY, "latest buffer too small");
+  if (!g->latest_out.empty()) std::memcpy(buf, g->latest_out.data(), g->latest_out.size());
+  g->latest_out.clear();
+  g->latest_out_frames = 0;
+  return G1S_OK;
+}
+
+size_t g1s_latest_size(uint32_t ar_coeff_lag) { return ar_coeff_lag >= 1 && ar_coeff_lag <= 3 ? latest_blob_size(ar_coeff_lag) : 0; }
+
+int g1s_latest_from_record(const void *record, size_t size_bytes, uint32_t ar_coeff_lag, void *blob, size_t cap_bytes) {
+  if (!record || !blob || ar_coeff_lag < 1 || ar_coeff_lag > 3) return G1S_ERR_INVALID;
+  if (cap_bytes < latest_blob_size(ar_coeff_lag)) return G1S_ERR_CAPACITY;
+  FrameLatest fl;
+  compute_latest((const uint8_t *)record, size_bytes, ar_coeff_lag, fl);  // a failure travels inside the blob
+  latest_to_blob(fl, ar_coeff_lag, (uint8_t *)blob);
+  return G1S_OK;
+}
+
 struct g1s_fold {
   NoiseFold fold;
   uint32_t lag;
@@ -1022,6 +1061,25 @@ int g1s_fold_push_many(g1s_fold_t *f, const void *records, size_t stride_bytes, 
         f->err = f->fold.error();
         return rc;
       }
+    }
+  }
+  return G1S_OK;
+}
+int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, size_t n) {
+  if (!f || (!blobs && n)) return G1S_ERR_INVALID;
+  if (f->finished) return G1S_ERR_STATE;
+  if (f->latest.empty()) f->latest.resize(1);
+  const uint8_t *base = (const uint8_t *)blobs;
+  for (size_t i = 0; i < n; ++i) {
+    int rc = latest_from_blob(base + i * stride_bytes, stride_bytes, f->lag, f->latest[0]);
+    if (rc) {
+      f->err = "bad latest blob";
+      return rc;
+    }
+    rc = f->fold.push_latest(f->latest[0]);
+    if (rc) {
+      f->err = f->fold.error();
+      return rc;
     }
   }
   return G1S_OK;

@@ -395,6 +395,97 @@ void NoiseFold::finalize_chroma() const {
   chroma_dirty_ = false;
 }
 
+// ---- FrameLatest <-> blob ----
+namespace {
+constexpr uint32_t kLatestMagic = 0x4c315347u;  // "GS1L"
+struct LatestHeader {
+  uint32_t magic, lag, nplanes;
+  int32_t status;
+  uint32_t size_bytes, reserved;
+  char err[104];
+};
+struct LatestPlaneHead {
+  int64_t num_observations;
+  double ar_gain;
+  int32_t num_equations, reserved;
+  double total;
+};
+inline size_t plane_blob_bytes(int nc_max) {
+  return sizeof(LatestPlaneHead) + sizeof(double) * ((size_t)nc_max * nc_max + 2 * (size_t)nc_max + (size_t)kNumBins * kNumBins + 2 * kNumBins);
+}
+}  // namespace
+
+size_t latest_blob_size(uint32_t lag) { return sizeof(LatestHeader) + 3 * plane_blob_bytes((int)num_coeffs(lag) + 1); }
+
+void latest_to_blob(const FrameLatest &fl, uint32_t lag, uint8_t *blob) {
+  const size_t total = latest_blob_size(lag);
+  std::memset(blob, 0, total);
+  LatestHeader h{};
+  h.magic = kLatestMagic;
+  h.lag = lag;
+  h.nplanes = fl.nplanes;
+  h.status = fl.status;
+  h.size_bytes = (uint32_t)total;
+  std::snprintf(h.err, sizeof(h.err), "%s", fl.err.c_str());
+  std::memcpy(blob, &h, sizeof(h));
+  const int ncm = (int)num_coeffs(lag) + 1;
+  for (int c = 0; c < 3; ++c) {
+    uint8_t *p = blob + sizeof(LatestHeader) + c * plane_blob_bytes(ncm);
+    const PlaneState &s = fl.st[c];
+    LatestPlaneHead ph{};
+    ph.num_observations = s.num_observations;
+    ph.ar_gain = s.ar_gain;
+    ph.num_equations = s.strength.num_equations;
+    ph.total = s.strength.total;
+    std::memcpy(p, &ph, sizeof(ph));
+    double *d = reinterpret_cast<double *>(p + sizeof(ph));
+    const int nc = s.ar.n;
+    if (nc > 0 && nc <= ncm) {
+      std::memcpy(d, s.ar.A.data(), sizeof(double) * nc * nc);
+      std::memcpy(d + ncm * ncm, s.ar.b.data(), sizeof(double) * nc);
+      std::memcpy(d + ncm * ncm + ncm, s.ar.x.data(), sizeof(double) * nc);
+    }
+    double *q = d + ncm * ncm + 2 * ncm;
+    std::memcpy(q, s.strength.eq.A.data(), sizeof(double) * kNumBins * kNumBins);
+    std::memcpy(q + kNumBins * kNumBins, s.strength.eq.b.data(), sizeof(double) * kNumBins);
+    std::memcpy(q + kNumBins * kNumBins + kNumBins, s.strength.eq.x.data(), sizeof(double) * kNumBins);
+  }
+}
+
+int latest_from_blob(const uint8_t *blob, size_t size, uint32_t lag, FrameLatest &out) {
+  LatestHeader h;
+  if (size < sizeof(h)) return G1S_ERR_INVALID;
+  std::memcpy(&h, blob, sizeof(h));
+  if (h.magic != kLatestMagic || h.lag != lag || h.size_bytes != latest_blob_size(lag) || h.size_bytes > size || h.nplanes > 3)
+    return G1S_ERR_INVALID;
+  out.nplanes = h.nplanes;
+  out.status = h.status;
+  h.err[sizeof(h.err) - 1] = 0;
+  out.err = h.err;
+  const int n = (int)num_coeffs(lag), ncm = n + 1;
+  for (int c = 0; c < 3; ++c) {
+    const uint8_t *p = blob + sizeof(LatestHeader) + c * plane_blob_bytes(ncm);
+    PlaneState &s = out.st[c];
+    LatestPlaneHead ph;
+    std::memcpy(&ph, p, sizeof(ph));
+    s.num_observations = ph.num_observations;
+    s.ar_gain = ph.ar_gain;
+    s.strength.num_equations = ph.num_equations;
+    s.strength.total = ph.total;
+    const int nc = n + (c > 0);
+    if (s.ar.n != nc) s.ar.resize(nc);
+    const double *d = reinterpret_cast<const double *>(p + sizeof(ph));
+    std::memcpy(s.ar.A.data(), d, sizeof(double) * nc * nc);
+    std::memcpy(s.ar.b.data(), d + ncm * ncm, sizeof(double) * nc);
+    std::memcpy(s.ar.x.data(), d + ncm * ncm + ncm, sizeof(double) * nc);
+    const double *q = d + ncm * ncm + 2 * ncm;
+    std::memcpy(s.strength.eq.A.data(), q, sizeof(double) * kNumBins * kNumBins);
+    std::memcpy(s.strength.eq.b.data(), q + kNumBins * kNumBins, sizeof(double) * kNumBins);
+    std::memcpy(s.strength.eq.x.data(), q + kNumBins * kNumBins + kNumBins, sizeof(double) * kNumBins);
+  }
+  return G1S_OK;
+}
+
 int NoiseFold::push_latest(FrameLatest &fl) {
   if (fl.status != G1S_OK) {
     err_ = fl.err;

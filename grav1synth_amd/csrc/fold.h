@@ -75,6 +75,13 @@ struct FrameLatest {
 // Thread-safe: record -> latest state (AR solve, measurements, strength solve).
 int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &out);
 
+// A FrameLatest as a flat, fixed-size blob (what frame-shard ranks exchange instead of the ~10x larger
+// records: the per-frame half of the fold runs where the frame was processed, only the ordered half
+// runs on rank 0).  Doubles are copied bit for bit.
+size_t latest_blob_size(uint32_t lag);
+void latest_to_blob(const FrameLatest &fl, uint32_t lag, uint8_t *blob);
+int latest_from_blob(const uint8_t *blob, size_t size, uint32_t lag, FrameLatest &out);
+
 class NoiseFold {
  public:
   NoiseFold(int64_t fps_num, int64_t fps_den, uint32_t lag);

@@ -164,7 +164,9 @@ class DiffGenerator:
     """
 
     def __init__(self, fps, source_bit_depth: int, denoised_bit_depth: int, *, ar_coeff_lag: int = 3,
-                 luma_only: bool = False, device: int = -1, batch_frames: int = 0, records_only: bool = False):
+                 luma_only: bool = False, device: int = -1, batch_frames: int = 0, records_only=False):
+        """records_only: False / 0 = fold locally; True / 1 = keep per-frame records (frame-shard mode);
+        2 = keep per-frame latest states (frame-shard mode, per-frame half of the fold done here)."""
         self._L = _lib.lib()
         fr = Fraction(fps)
         opts = G1SOpts()
@@ -237,6 +239,17 @@ class DiffGenerator:
         self._check(self._L.g1s_diff_take_records(self._h, buf.ctypes.data, buf.size, C.byref(n)))
         self._keep.clear()
         return buf[: rs * n.value].reshape(n.value, rs), n.value
+
+    def take_latest(self, max_frames: int, sync: bool = False) -> np.ndarray:
+        """records_only == 2: the latest states [n, g1s_latest_size] of the frames whose batches are
+        complete (sync=False) or of everything queued so far (sync=True)."""
+        bs = self._L.g1s_latest_size(self.ar_coeff_lag)
+        buf = np.zeros(bs * max(max_frames, 1), dtype=np.uint8)
+        n = C.c_size_t()
+        self._check(self._L.g1s_diff_take_latest(self._h, int(sync), buf.ctypes.data, buf.size, C.byref(n)))
+        if sync:
+            self._keep.clear()
+        return buf[: bs * n.value].reshape(n.value, bs)
 
     # -- measurement / parity hooks ------------------------------------------------------
     def set_timing(self, enable: bool) -> None:
@@ -369,6 +382,15 @@ class RecordFold:
         if rc != 0:
             raise G1SError(rc, self._L.g1s_fold_last_error(self._h).decode())
 
+    def push_latest_many(self, blobs: np.ndarray) -> None:
+        """blobs: [n, g1s_latest_size] uint8 latest states, frame order: the ordered half only."""
+        blobs = np.ascontiguousarray(blobs, dtype=np.uint8)
+        if blobs.shape[0] == 0:
+            return
+        rc = self._L.g1s_fold_push_latest(self._h, blobs.ctypes.data, blobs.shape[1], blobs.shape[0])
+        if rc != 0:
+            raise G1SError(rc, self._L.g1s_fold_last_error(self._h).decode())
+
     def finish(self) -> List[GrainTableSegment]:
         arr = (G1SSegment * 1024)()
         n = C.c_size_t()
@@ -387,6 +409,23 @@ class RecordFold:
             self.close()
         except Exception:
             pass
+
+
+def latest_size(ar_coeff_lag: int = 3) -> int:
+    return int(_lib.lib().g1s_latest_size(ar_coeff_lag))
+
+
+def latest_from_records(records: np.ndarray, ar_coeff_lag: int = 3) -> np.ndarray:
+    """The per-frame half of the fold on the host: [n, record_size] records -> [n, latest_size] blobs."""
+    L = _lib.lib()
+    records = np.ascontiguousarray(records, dtype=np.uint8)
+    bs = int(L.g1s_latest_size(ar_coeff_lag))
+    out = np.zeros((records.shape[0], bs), dtype=np.uint8)
+    for i in range(records.shape[0]):
+        rc = L.g1s_latest_from_record(records[i].ctypes.data, records.shape[1], ar_coeff_lag, out[i].ctypes.data, bs)
+        if rc != 0:
+            raise G1SError(rc, "g1s_latest_from_record failed")
+    return out
 
 
 def format_tbl(segments: Sequence[GrainTableSegment]) -> bytes:

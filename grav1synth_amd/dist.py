@@ -60,6 +60,96 @@ def fold_records(per_rank: List[np.ndarray], fps, ar_coeff_lag: int = 3) -> List
     return segs
 
 
+def gather_latest_round(blobs: np.ndarray, blob_size: int, max_frames: int, dist,
+                        device: Optional[torch.device] = None) -> List[np.ndarray]:
+    """One round of the streaming exchange: every rank contributes the latest states of ONE batch
+    ([n_r, blob_size], n_r <= max_frames; fixed-size message: [count | blobs]).  Returns the per-rank
+    arrays in rank order on every rank."""
+    world = dist.get_world_size()
+    backend = dist.get_backend()
+    dev = device if (backend == "nccl" and device is not None) else torch.device("cpu")
+    n_local = int(blobs.shape[0])
+    msg = torch.zeros(16 + max_frames * blob_size, dtype=torch.uint8)
+    msg[:8] = torch.from_numpy(np.array([n_local], dtype=np.int64).view(np.uint8))
+    if n_local:
+        msg[16 : 16 + n_local * blob_size] = torch.from_numpy(np.ascontiguousarray(blobs).reshape(-1))
+    msg = msg.to(dev)
+    if backend == "nccl":  # RCCL: one flat all-gather over xGMI
+        out = torch.empty((world, msg.numel()), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, msg)
+        host = out.cpu().numpy()
+    else:  # gloo (CPU tests, shared-GPU smoke test)
+        parts = [torch.empty_like(msg) for _ in range(world)]
+        dist.all_gather(parts, msg)
+        host = torch.stack(parts).numpy()
+    res = []
+    for r in range(world):
+        n_r = int(host[r, :8].view(np.int64)[0])
+        res.append(host[r, 16 : 16 + n_r * blob_size].reshape(n_r, blob_size))
+    return res
+
+
+class StreamingShardedDiff:
+    """Frame-shard mode with the fold streamed: the video is dealt to the ranks batch by batch
+    (global batch j goes to rank j % N), every rank runs the kernels AND the per-frame half of the
+    fold on its batches, and after each batch ONE small all-gather (a latest state is ~27 KB a frame)
+    brings the round's states to rank 0, which merges them in global frame order while the GPUs are
+    already on the next batch.  The ordered merge (~8 us a frame) is all that stays serial.
+
+    Every rank must feed the same number of batches of `batch_frames` frames (the last may be short)."""
+
+    def __init__(self, fps, source_bit_depth: int, denoised_bit_depth: int, *, ar_coeff_lag: int = 3,
+                 luma_only: bool = False, device: int = -1, batch_frames: int = 16, group=None):
+        self.dist = group
+        self.fps = Fraction(fps)
+        self.lag = ar_coeff_lag
+        self.device = device
+        self.batch = batch_frames
+        self.generator = DiffGenerator(fps, source_bit_depth, denoised_bit_depth, ar_coeff_lag=ar_coeff_lag,
+                                       luma_only=luma_only, device=device, batch_frames=batch_frames,
+                                       records_only=2 if group is not None else False)
+        self._blob = 0
+        self._fold = None
+        if group is not None:
+            from .diff import latest_size
+            self._blob = latest_size(ar_coeff_lag)
+            if group.get_rank() == 0:
+                self._fold = RecordFold(fps, ar_coeff_lag)
+        self._dev = None
+        if torch.cuda.is_available():
+            self._dev = torch.device("cuda", device if device >= 0 else torch.cuda.current_device())
+
+    def _round(self, sync: bool) -> None:
+        blobs = self.generator.take_latest(2 * self.batch, sync=sync)
+        per_rank = gather_latest_round(blobs, self._blob, 2 * self.batch, self.dist, self._dev)
+        if self._fold is not None:
+            for b in per_rank:  # rank order == global batch order within the round
+                self._fold.push_latest_many(b)
+
+    def diff_prepared(self, prepared, sync_torch: bool = True) -> None:
+        """Feeds ONE batch (this rank's next batch in the global order)."""
+        self.generator.diff_prepared(prepared, sync_torch=sync_torch)
+        if self.dist is not None:
+            self._round(sync=False)  # the states of the batch before this one (nothing on the first call)
+
+    def finish(self) -> Optional[List[GrainTableSegment]]:
+        if self.dist is None:
+            return self.generator.finish()
+        self._round(sync=True)
+        if self._fold is None:
+            return None
+        segs = self._fold.finish()
+        self._fold.close()
+        self._fold = None
+        return segs
+
+    def close(self) -> None:
+        self.generator.close()
+        if self._fold is not None:
+            self._fold.close()
+            self._fold = None
+
+
 class ShardedDiff:
     """DiffGenerator over a frame shard.  With `group=None` it is the plain
     single-GPU generator; with a torch.distributed module/group, each rank feeds

@@ -94,9 +94,13 @@ typedef struct {
   uint32_t ar_coeff_lag;  /* 1..3; 0 = default (3, the reference's NOISE_MODEL_LAG) */
   uint32_t luma_only;     /* 1 = skip chroma planes (extension; reference: 0) */
   uint32_t batch_frames;  /* frames per kernel batch; 0 = default */
-  uint32_t records_only;  /* 1 = frame-shard mode: emit per-frame records, do not
-                             fold (the ordered fold runs after the exchange, see
-                             g1s_fold_*).  0 = fold locally (single GPU). */
+  uint32_t records_only;  /* frame-shard mode: do not fold here (the ordered fold runs
+                             after the exchange, see g1s_fold_*).
+                             0 = fold locally (single GPU);
+                             1 = emit the per-frame records;
+                             2 = run the per-frame half of the fold here as well and emit
+                                 the per-frame "latest" states (~27 KB instead of ~250 KB a
+                                 4K frame): only the ordered merge is left for rank 0. */
 } g1s_opts_t;
 
 typedef struct g1s_diff g1s_diff_t;
@@ -134,6 +138,16 @@ int g1s_record_init(void *rec, size_t cap_bytes, uint32_t width, uint32_t height
 /* Copies the records of all frames queued so far (frame order) into buf and
  * clears the internal list.  records_only generators only. */
 int g1s_diff_take_records(g1s_diff_t *, void *buf, size_t cap_bytes, size_t *n_frames);
+/* records_only == 2: the latest states (g1s_latest_size() bytes each, frame order) of the
+ * frames whose batches are complete (sync = 0: without waiting; a batch is complete at the
+ * latest when the next one has been queued) or of all frames queued so far (sync = 1). */
+int g1s_diff_take_latest(g1s_diff_t *, int sync, void *buf, size_t cap_bytes, size_t *n_frames);
+size_t g1s_latest_size(uint32_t ar_coeff_lag);
+/* The per-frame half of the fold on the host: record -> latest state.  Thread-safe.  A frame
+ * that fails (not enough flat blocks, singular system) yields a blob that carries the error;
+ * it surfaces when the blob is pushed. */
+int g1s_latest_from_record(const void *record, size_t size_bytes, uint32_t ar_coeff_lag, void *blob,
+                           size_t cap_bytes);
 
 typedef struct g1s_fold g1s_fold_t;
 /* The sequential part of DiffGenerator (noise-model update, segmentation,
@@ -143,6 +157,8 @@ int g1s_fold_push(g1s_fold_t *, const void *record, size_t size_bytes);
 /* n records, stride_bytes apart, in frame order: the per-frame half runs on a
  * host thread pool, the ordered half serially.  Same result as n pushes. */
 int g1s_fold_push_many(g1s_fold_t *, const void *records, size_t stride_bytes, size_t n);
+/* n latest states, stride_bytes apart, in frame order: the ordered half only. */
+int g1s_fold_push_latest(g1s_fold_t *, const void *blobs, size_t stride_bytes, size_t n);
 int g1s_fold_finish(g1s_fold_t *, g1s_segment_t *out, size_t cap, size_t *n_out);
 void g1s_fold_free(g1s_fold_t *);
 const char *g1s_fold_last_error(const g1s_fold_t *);

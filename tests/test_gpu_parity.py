@@ -91,6 +91,31 @@ def test_batched_equals_unbatched_and_oracle():
     assert format_tbl(g.finish()) == tbl
 
 
+def test_latest_only_generator_streams_the_fold():
+    """Frame-shard streaming mode (records_only = 2): the generator keeps per-frame latest states; taking
+    them batch by batch and merging them in order gives the single-GPU table, byte for byte."""
+    from grav1synth_amd.diff import RecordFold, latest_size
+
+    spec = SynthSpec(320, 192, 8)
+    tbl, _ = oracle_run(spec, range(7))
+    g = DiffGenerator(Fraction(24, 1), 8, 8, batch_frames=3, records_only=2)
+    fold = RecordFold(Fraction(24, 1), 3)
+    seen = 0
+    for k in range(7):
+        s, d = make_pair(spec, k, device="cuda")
+        g.diff_frame(s, d, spec.xdec, spec.ydec)
+        blobs = g.take_latest(16)  # complete batches only, no waiting
+        assert blobs.shape[1] == latest_size(3)
+        seen += blobs.shape[0]
+        fold.push_latest_many(blobs)
+    blobs = g.take_latest(16, sync=True)
+    seen += blobs.shape[0]
+    fold.push_latest_many(blobs)
+    assert seen == 7
+    assert format_tbl(fold.finish()) == tbl
+    g.close()
+
+
 def test_scene_cut_emits_two_segments():
     """is_different(): doubling the noise gain mid-stream must cut a segment at
     the same frame, with the same timestamps, as the oracle."""
