@@ -23,14 +23,17 @@ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
 }  // namespace
 
 // ---------------------------------------------------------------- solver ---
-bool gauss_solve(int n, double *A, double *b, double *x) {
+// (clones: the row operations are elementwise, AVX2 does four at a time with the same roundings)
+__attribute__((target_clones("avx2", "default"))) bool gauss_solve(int n, double *A, double *b, double *x) {
   // forward elimination with the reference's "bubble the larger magnitude up
-  // one row at a time" pivoting
+  // one row at a time" pivoting.  Columns left of the pivot column are never read again
+  // (pivoting looks at column k, back substitution at columns >= i), so the row operations
+  // run over columns >= k only: every value that is used is bit for bit the reference's.
   for (int k = 0; k < n - 1; ++k) {
     for (int i = n - 1; i > k; --i) {
       double *lo = A + (i - 1) * n, *hi = A + i * n;
       if (std::fabs(lo[k]) < std::fabs(hi[k])) {
-        for (int j = 0; j < n; ++j) std::swap(lo[j], hi[j]);
+        for (int j = k; j < n; ++j) std::swap(lo[j], hi[j]);
         std::swap(b[i], b[i - 1]);
       }
     }
@@ -39,7 +42,7 @@ bool gauss_solve(int n, double *A, double *b, double *x) {
       if (std::fabs(pivot[k]) < kTiny) return false;
       double *row = A + (i + 1) * n;
       const double c = row[k] / pivot[k];
-      for (int j = 0; j < n; ++j) row[j] -= c * pivot[j];
+      for (int j = k + 1; j < n; ++j) row[j] -= c * pivot[j];
       b[i + 1] -= c * b[k];
     }
   }
