@@ -564,7 +564,9 @@ int g1s_diff::submit(int si) {
     // a multiple of 8 for the XCD-aware list slices), but never more than 128 areas each (int32 sums).
     auto launch_lag = [&](int K, bool mixed, hipStream_t st) {
       const int resident = lag_resident_blocks(K, mixed);
-      int chunks = std::max(8, (resident / (int)Bs) & ~7);
+      static const int lag_div = getenv("G1S_LAG_DIV") ? std::max(1, atoi(getenv("G1S_LAG_DIV"))) : 1;  // tuning aid
+      // (measured: the INT kernels are better off with half a round of longer-lived waves)
+      int chunks = std::max(8, (resident / (lag_div * (mixed ? 1 : 2)) / (int)Bs) & ~7);
       chunks = std::max(chunks, ((g.nblocks + 127) / 128 + 7) & ~7);
       const dim3 gr(chunks, 1, Bs);
 #define G1S_LAG(KK)                                                                                  \

@@ -505,11 +505,24 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
   }
   if (MIXED && lane == 0) s_pgn[wave] = pgn;
 
-  // ---- wave reduction (DPP), then the waves of the same plane add up: one atomic set per workgroup ----
+  // ---- wave reduction (batched DPP: no dependent-instruction bubbles), then the waves of the same
+  //      plane add up: one atomic set per workgroup ----
+  {
+    constexpr int CH = 23;
 #pragma unroll
-  for (int i = 0; i < NACC; ++i) {
-    const int t = wave_sum(acc[i]);
-    if (lane == 0) red[wave][i] = t;
+    for (int b0 = 0; b0 < NACC; b0 += CH) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      int tmp[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) tmp[i] = (b0 + i < NACC) ? acc[b0 + i] : 0;
+      wave_sums_dpp<CH>(tmp);
+      if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if (b0 + i < NACC) red[wave][b0 + i] = tmp[i];
+      }
+    }
   }
   if (MIXED) nobs = wave_sum(nobs);
   if (lane == 0) red[wave][kQPart] = nobs;
