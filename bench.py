@@ -190,6 +190,7 @@ def main() -> None:
             "frames_per_rank_per_step": F,
             "batch_frames": args.batch,
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
+            "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
             "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if world > 1 else "single GPU",
         },
         "hbm_roofline_frac_whole_job": (value * bpp * 1e6 / 1e9) / (HBM_PEAK_GBS * world),

@@ -95,6 +95,7 @@ class G1SStats(C.Structure):
         ("launches_ar_accumulate", C.c_uint64),
         ("ms_host_fold", C.c_double),
         ("ms_residual", C.c_double),
+        ("literal_blocks", C.c_uint64),
     ]
 
 

@@ -22,6 +22,7 @@
 #include "../../include/g1s_diff.h"
 #include "fold.h"
 #include "kernels.hip.h"
+#include "k1f.hip.h"
 #include "k3q.hip.h"
 #include "record.h"
 
@@ -130,6 +131,7 @@ struct Slot {
   int32_t *d_partials = nullptr;   // k3_interior chunk partials, then k3_mixed chunk partials
   uint8_t *d_defer = nullptr;      // area classes, bad-block flags, area lists and their counts
   uint8_t *d_k0 = nullptr;         // K0 int8 planes [batch] x PlaneSet::frame_bytes
+  int32_t *d_k1 = nullptr;         // flat-block fast path: moments [batch][nblocks][16], literal list [batch][nblocks], counts [batch]
   uint32_t *d_pgl = nullptr;       // partial-group lists [batch][2][pg_cap] + counts [batch][2]
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
@@ -375,6 +377,7 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     HIP_TRY(hipMalloc((void **)&sl.d_records, slot_key.records));
     HIP_TRY(hipHostMalloc((void **)&sl.h_records, slot_key.records, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&sl.d_flags, slot_key.flags));
+    HIP_TRY(hipMalloc((void **)&sl.d_k1, sizeof(int32_t) * ((size_t)g.nblocks * batch * (kMomInts + 1) + batch)));
     if (partial_bytes) {
       HIP_TRY(hipMalloc((void **)&sl.d_partials, partial_bytes));
       HIP_TRY(hipMalloc((void **)&sl.d_defer, defer_bytes));
@@ -496,16 +499,34 @@ int g1s_diff::submit(int si) {
       z.ptr[4] = sl.d_pgl + (size_t)batch * 2 * pg_cap;  // partial-group list counts
       z.ndw[4] = (uint32_t)batch * 2;
     }
+    z.ptr[5] = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * (kMomInts + 1);  // literal-list counts
+    z.ndw[5] = (uint32_t)batch;
     hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, fstream, z);
   }
   sl.timed = timing;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], fstream));
   {
+    // flat-block features: integer moments + certified evaluation; the literal f64 kernel only for
+    // the blocks the certificate leaves open (G1S_K1_LITERAL=1: for every block)
+    static const int force_literal = getenv("G1S_K1_LITERAL") ? atoi(getenv("G1S_K1_LITERAL")) : 0;
+    int32_t *mom = sl.d_k1;
+    CertifyLists cl;
+    cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
+    cl.count = cl.list + (size_t)g.nblocks * batch;
+    if (!force_literal) {
+      const dim3 mg((g.nblocks + 7) / 8, B);
+      if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, fstream, ft, g, mom);
+      else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, fstream, ft, g, mom);
+    }
+    hipLaunchKernelGGL(k1_certify, dim3((g.nblocks + 255) / 256, B), dim3(256), 0, fstream, g, fc, (const int32_t *)mom,
+                       sl.d_records, sl.d_flags, cl, force_literal);
     dim3 grid((g.nblocks + 63) / 64, B);
     if (g.src_bps == 1)
-      hipLaunchKernelGGL(k1_flat_features<1>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
+      hipLaunchKernelGGL((k1_flat_features<1, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
+                         (const uint32_t *)cl.list, (const uint32_t *)cl.count);
     else
-      hipLaunchKernelGGL(k1_flat_features<2>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags);
+      hipLaunchKernelGGL((k1_flat_features<2, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
+                         (const uint32_t *)cl.list, (const uint32_t *)cl.count);
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
   hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
@@ -650,6 +671,12 @@ int g1s_diff::drain_one() {
     }
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
     stats.ms_total_gpu += ms;
+    {
+      std::vector<uint32_t> cnt(batch);
+      HIP_TRY(hipMemcpy(cnt.data(), reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)geom.nblocks * batch * (kMomInts + 1),
+                        sizeof(uint32_t) * batch, hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < sl.count; ++i) stats.literal_blocks += cnt[i];
+    }
   }
   const auto t0 = std::chrono::steady_clock::now();
   int rc = G1S_OK;
@@ -754,6 +781,7 @@ void g1s_diff::release() {
     if (sl.d_records) (void)hipFree(sl.d_records);
     if (sl.h_records) (void)hipHostFree(sl.h_records);
     if (sl.d_flags) (void)hipFree(sl.d_flags);
+    if (sl.d_k1) (void)hipFree(sl.d_k1);
     if (sl.d_partials) (void)hipFree(sl.d_partials);
     if (sl.d_defer) (void)hipFree(sl.d_defer);
     if (sl.d_k0) (void)hipFree(sl.d_k0);

@@ -385,13 +385,13 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
 // separate memset nodes each cost a dispatch gap in the launch chain.
 // ---------------------------------------------------------------------------------
 struct ZeroJob {
-  uint32_t *ptr[5];
-  uint32_t ndw[5];  // dwords
+  uint32_t *ptr[6];
+  uint32_t ndw[6];  // dwords
 };
 __global__ __launch_bounds__(256) void k_zero(ZeroJob z) {
   const uint32_t stride = gridDim.x * 256u;
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
+  for (int r = 0; r < 6; ++r) {
     uint32_t *p = z.ptr[r];
     const uint32_t n = z.ndw[r];
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) p[i] = 0u;

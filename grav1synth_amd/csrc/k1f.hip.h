@@ -1,0 +1,340 @@
+// k1f.hip.h -- the certified fast path of the flat-block finder.
+//
+// The literal K1 (kernels.hip.h) reproduces FlatBlockFinder::run in the reference's f64
+// operation order, one lane per block: 21 k dependent f64 operations per block.  Every
+// feature it computes is, in exact arithmetic, a function of fourteen INTEGER sums over the
+// block's 8-bit pixels p (v = p / 255, plane fit (yd c0 + xd c1) + c2 with c = M t):
+//     gx = dx / 510 - c1 / 16,   gy = dy / 510 - c0 / 16,   dx = p(x+1) - p(x-1), dy likewise
+//     sum gx^2 = DXX / 510^2 - c1 DX / 4080 + 900 c1^2 / 256,  ...  (see k1_certify)
+// So:
+//   k1_moments   the fourteen sums per block with v_dot4_u32_u8 / v_sad_u8 (exact, any order);
+//   k1_certify   the features from the sums in double-double arithmetic (no cancellation),
+//                TOGETHER WITH a running bound on |what the reference's rounded evaluation
+//                gives - this value| (standard forward error analysis of its sequential sums,
+//                carried through every later operation).  A block whose four threshold tests
+//                and whose f32 score are unambiguous within that bound gets them written;
+//                any other block goes on a list;
+//   k1_flat_features<.., true>   the literal kernel, for the listed blocks only.
+// The result is bit for bit the literal kernel's wherever the bound holds; the bound carries a
+// safety factor, and the tests compare every block of every test frame with the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hip.h"
+
+namespace g1s {
+
+constexpr int kMomInts = 16;  // ints per block in the moments buffer
+enum {
+  kM_S0 = 0, kM_SXU, kM_SYU, kM_SAX, kM_SAY,        // full block: sum p, sum p xi, sum p yi, sum p |xi-16|, sum p |yi-16|
+  kM_I0, kM_IXU, kM_IYU, kM_IPP,                    // interior (1..30)^2: sum p, sum p xi, sum p yi, sum p^2
+  kM_DXX, kM_DYY, kM_DXY, kM_DX, kM_DY              // interior central differences
+};
+
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+__device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
+
+// ---------------------------------------------------------------------------------
+// k1_moments<BPS>: lane = one row of a block (32 pixels as 8 packed dwords, loaded like the
+// literal kernel does, edge replication included); 32 lanes = a block, two blocks per wave.
+// grid = (ceil(nblocks / 8), batch), block = 256.
+// ---------------------------------------------------------------------------------
+template <int BPS>
+__global__ __launch_bounds__(256) void k1_moments(const FrameTable ft, Geom g, int32_t *__restrict__ mom) {
+  const int frame = blockIdx.y;
+  const int tid = threadIdx.x, yi = tid & 31;
+  const int blk = (int)blockIdx.x * 8 + (tid >> 5);
+  const bool live = blk < g.nblocks;
+  const FramePlanes fp = ft.f[frame];
+  const int bx = live ? blk % g.nbw : 0, by = live ? blk / g.nbw : 0;
+  const int ox = bx * kBlock, oy = by * kBlock;
+  const bool fast = g.fast_rows && (ox + kBlock <= g.W);
+  uint32_t pk[8];
+  load_row32<BPS>(fp.src[0], fp.src_stride[0], g.src_shift, ox, min(oy + yi, g.H - 1), g.W, fast, pk);
+  // rows above / below (same block: shuffles within 32 lanes)
+  uint32_t pu[8], pd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    pu[k] = (uint32_t)__shfl_up((int)pk[k], 1, 32);
+    pd[k] = (uint32_t)__shfl_down((int)pk[k], 1, 32);
+  }
+  int32_t s[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) s[i] = 0;
+  uint32_t rowsum = 0, sxu = 0, sax = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    rowsum = sad4(pk[k], rowsum);
+    sxu = udot4(pk[k], 0x03020100u + 0x04040404u * (uint32_t)k, sxu);
+    // |xi - 16| for xi = 4k .. 4k+3
+    const int a0 = abs(4 * k - 16), a1 = abs(4 * k + 1 - 16), a2 = abs(4 * k + 2 - 16), a3 = abs(4 * k + 3 - 16);
+    sax = udot4(pk[k], (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24), sax);
+  }
+  s[kM_S0] = (int32_t)rowsum;
+  s[kM_SXU] = (int32_t)sxu;
+  s[kM_SYU] = (int32_t)rowsum * yi;
+  s[kM_SAX] = (int32_t)sax;
+  s[kM_SAY] = (int32_t)rowsum * abs(yi - 16);
+  if (yi >= 1 && yi <= kBlock - 2) {
+    uint32_t i0 = 0, ixu = 0, ipp = 0, rr = 0, ll = 0, rl = 0, sr = 0, sl = 0, dd = 0, uu = 0, du = 0, sd = 0, su = 0;
+    uint32_t rd = 0, ru = 0, ld = 0, lu = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t m = k == 0 ? 0xffffff00u : (k == 7 ? 0x00ffffffu : 0xffffffffu);  // interior columns 1..30
+      const uint32_t pm = pk[k] & m;
+      i0 = sad4(pm, i0);
+      ixu = udot4(pm, 0x03020100u + 0x04040404u * (uint32_t)k, ixu);
+      ipp = udot4(pm, pk[k], ipp);
+      // p(xi + 1), p(xi - 1) for xi = 4k .. 4k+3
+      const uint32_t pr = __builtin_amdgcn_alignbyte(k < 7 ? pk[k + 1] : 0u, pk[k], 1) & m;
+      const uint32_t pl = __builtin_amdgcn_alignbyte(pk[k], k > 0 ? pk[k - 1] : 0u, 3) & m;
+      const uint32_t dn = pd[k] & m, up = pu[k] & m;
+      rr = udot4(pr, pr, rr);
+      ll = udot4(pl, pl, ll);
+      rl = udot4(pr, pl, rl);
+      sr = sad4(pr, sr);
+      sl = sad4(pl, sl);
+      dd = udot4(dn, dn, dd);
+      uu = udot4(up, up, uu);
+      du = udot4(dn, up, du);
+      sd = sad4(dn, sd);
+      su = sad4(up, su);
+      rd = udot4(pr, dn, rd);
+      ru = udot4(pr, up, ru);
+      ld = udot4(pl, dn, ld);
+      lu = udot4(pl, up, lu);
+    }
+    s[kM_I0] = (int32_t)i0;
+    s[kM_IXU] = (int32_t)ixu;
+    s[kM_IYU] = (int32_t)i0 * yi;
+    s[kM_IPP] = (int32_t)ipp;
+    s[kM_DXX] = (int32_t)(rr + ll - 2u * rl);
+    s[kM_DYY] = (int32_t)(dd + uu - 2u * du);
+    s[kM_DXY] = (int32_t)rd - (int32_t)ru - (int32_t)ld + (int32_t)lu;
+    s[kM_DX] = (int32_t)sr - (int32_t)sl;
+    s[kM_DY] = (int32_t)sd - (int32_t)su;
+  }
+  // sum over the 32 rows of the block
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 14; ++i) s[i] += __shfl_xor(s[i], o, 32);
+  }
+  if (live && yi == 0) {
+    int32_t *out = mom + ((size_t)frame * g.nblocks + blk) * kMomInts;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) out[i] = s[i];
+  }
+}
+
+// ---- double-double arithmetic (error-free transformations; FMA is explicit here) ----
+struct dd {
+  double hi, lo;
+};
+__device__ __forceinline__ dd dd_from(double a) { return dd{a, 0.0}; }
+__device__ __forceinline__ dd two_sum(double a, double b) {
+  const double s = a + b, bb = s - a;
+  return dd{s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd two_prod(double a, double b) {
+  const double p = a * b;
+  return dd{p, __builtin_fma(a, b, -p)};
+}
+__device__ __forceinline__ dd dd_add(dd a, dd b) {
+  dd s = two_sum(a.hi, b.hi);
+  s.lo += a.lo + b.lo;
+  return two_sum(s.hi, s.lo);
+}
+__device__ __forceinline__ dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
+__device__ __forceinline__ dd dd_mul(dd a, dd b) {
+  dd p = two_prod(a.hi, b.hi);
+  p.lo += a.hi * b.lo + a.lo * b.hi;
+  return two_sum(p.hi, p.lo);
+}
+__device__ __forceinline__ dd dd_mul_d(dd a, double b) { return dd_mul(a, dd_from(b)); }
+// a / b for a double divisor, to ~2^-100
+__device__ __forceinline__ dd dd_div_d(dd a, double b) {
+  const double q1 = a.hi / b;
+  const dd p = two_prod(q1, b);
+  const double r = ((a.hi - p.hi) - p.lo) + a.lo;
+  const double q2 = r / b;
+  return two_sum(q1, q2);
+}
+
+// ---- a value the way the reference computes it, known up to a bound ----
+// v: this kernel's f64 evaluation; e: bound on |reference's rounded evaluation - v|.
+struct VE {
+  double v, e;
+};
+constexpr double kU = 1.1102230246251565e-16;  // 2^-53
+__device__ __forceinline__ VE ve_add(VE a, VE b) {
+  const double v = a.v + b.v;
+  return VE{v, a.e + b.e + 2.0 * kU * fabs(v)};
+}
+__device__ __forceinline__ VE ve_sub(VE a, VE b) {
+  const double v = a.v - b.v;
+  return VE{v, a.e + b.e + 2.0 * kU * fabs(v)};
+}
+__device__ __forceinline__ VE ve_mul(VE a, VE b) {
+  const double v = a.v * b.v;
+  return VE{v, fabs(a.v) * b.e + fabs(b.v) * a.e + a.e * b.e + 2.0 * kU * fabs(v)};
+}
+__device__ __forceinline__ VE ve_mul_c(double c, VE a) {  // exact constant
+  const double v = c * a.v;
+  return VE{v, fabs(c) * a.e + 2.0 * kU * fabs(v)};
+}
+__device__ __forceinline__ VE ve_div_c(VE a, double c) {
+  const double v = a.v / c;
+  return VE{v, a.e / fabs(c) + 2.0 * kU * fabs(v)};
+}
+__device__ __forceinline__ VE ve_add_c(VE a, double c) {
+  const double v = a.v + c;
+  return VE{v, a.e + 2.0 * kU * fabs(v)};
+}
+// 1: certainly a < K; 0: certainly not; -1: cannot tell
+__device__ __forceinline__ int ve_lt(VE a, double K) { return a.v + a.e < K ? 1 : (a.v - a.e >= K ? 0 : -1); }
+__device__ __forceinline__ int ve_gt(VE a, double K) { return a.v - a.e > K ? 1 : (a.v + a.e <= K ? 0 : -1); }
+
+struct CertifyLists {
+  uint32_t *list;   // [batch][nblocks] blocks left to the literal kernel
+  uint32_t *count;  // [batch]
+};
+
+// ---------------------------------------------------------------------------------
+// k1_certify: one thread per block.  grid = (ceil(nblocks / 256), batch), block = 256.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1_certify(Geom g, FlatConsts fc, const int32_t *__restrict__ mom,
+                                                  uint8_t *__restrict__ records, uint8_t *__restrict__ flags,
+                                                  CertifyLists cl, int force_literal) {
+  const int frame = blockIdx.y;
+  const int blk = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  bool certain = false;
+  float score_out = 0.0f;
+  uint8_t flag_out = 0;
+  if (blk < g.nblocks && !force_literal) {
+    const int32_t *m = mom + ((size_t)frame * g.nblocks + blk) * kMomInts;
+    const double S0 = m[kM_S0], SX = (double)m[kM_SXU] - 16.0 * m[kM_S0], SY = (double)m[kM_SYU] - 16.0 * m[kM_S0];
+    const double SAX = m[kM_SAX], SAY = m[kM_SAY];
+    const double I0 = m[kM_I0], IX = (double)m[kM_IXU] - 16.0 * m[kM_I0], IY = (double)m[kM_IYU] - 16.0 * m[kM_I0];
+    const double IPP = m[kM_IPP], DXX = m[kM_DXX], DYY = m[kM_DYY], DXY = m[kM_DXY], DX = m[kM_DX], DY = m[kM_DY];
+    const double N = 900.0;
+    // ---- plane fit: t = (sum v yd, sum v xd, sum v), c = M t ----
+    const dd t0 = dd_div_d(dd_from(SY), 4080.0), t1 = dd_div_d(dd_from(SX), 4080.0), t2 = dd_div_d(dd_from(S0), 255.0);
+    // reference: 1024 products v*yd (v itself rounded) summed sequentially
+    const double Et0 = 1030.0 * kU * SAY / 4080.0, Et1 = 1030.0 * kU * SAX / 4080.0, Et2 = 1026.0 * kU * S0 / 255.0;
+    dd c[3];
+    double Ec[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double m0 = fc.ata_inv[3 * i], m1 = fc.ata_inv[3 * i + 1], m2 = fc.ata_inv[3 * i + 2];
+      c[i] = dd_add(dd_add(dd_mul_d(t0, m0), dd_mul_d(t1, m1)), dd_mul_d(t2, m2));
+      Ec[i] = fabs(m0) * (Et0 + 4.0 * kU * fabs(t0.hi)) + fabs(m1) * (Et1 + 4.0 * kU * fabs(t1.hi)) +
+              fabs(m2) * (Et2 + 4.0 * kU * fabs(t2.hi));
+    }
+    const double F = fabs(c[0].hi) + fabs(c[1].hi) + fabs(c[2].hi) + Ec[0] + Ec[1] + Ec[2];
+    const double Eg0 = kU * (3.0 + 5.0 * F);
+    const double Egx = Ec[1] / 16.0 + Eg0, Egy = Ec[0] / 16.0 + Eg0;
+    const double Er = kU * (2.0 + 5.0 * F) + Ec[0] + Ec[1] + Ec[2];
+    // ---- the five interior sums, exactly ----
+    const dd c0 = c[0], c1 = c[1], c2 = c[2];
+    const dd c00 = dd_mul(c0, c0), c11 = dd_mul(c1, c1), c01 = dd_mul(c0, c1);
+    // sum gx^2 = DXX/510^2 - c1 DX/4080 + N c1^2/256
+    const dd sGxx = dd_add(dd_add(dd_div_d(dd_from(DXX), 260100.0), dd_neg(dd_div_d(dd_mul_d(c1, DX), 4080.0))),
+                           dd_mul_d(c11, N / 256.0));
+    const dd sGyy = dd_add(dd_add(dd_div_d(dd_from(DYY), 260100.0), dd_neg(dd_div_d(dd_mul_d(c0, DY), 4080.0))),
+                           dd_mul_d(c00, N / 256.0));
+    // sum gx gy = DXY/510^2 - c0 DX/8160 - c1 DY/8160 + N c0 c1/256
+    const dd sGxy = dd_add(dd_add(dd_div_d(dd_from(DXY), 260100.0), dd_neg(dd_div_d(dd_mul_d(c0, DX), 8160.0))),
+                           dd_add(dd_neg(dd_div_d(dd_mul_d(c1, DY), 8160.0)), dd_mul_d(c01, N / 256.0)));
+    // sum r = I0/255 - c0 sumY/16 - c1 sumX/16 - N c2,  sumX = sumY = -450 over the interior
+    const dd sR = dd_add(dd_add(dd_div_d(dd_from(I0), 255.0), dd_mul_d(dd_add(c0, c1), 450.0 / 16.0)), dd_neg(dd_mul_d(c2, N)));
+    // sum r^2 = IPP/255^2 - 2 [c0 IY/4080 + c1 IX/4080 + c2 I0/255] + sum fit^2
+    const dd cross = dd_add(dd_add(dd_div_d(dd_mul_d(c0, IY), 4080.0), dd_div_d(dd_mul_d(c1, IX), 4080.0)),
+                            dd_div_d(dd_mul_d(c2, I0), 255.0));
+    // sum fit^2 = (c0^2 + c1^2) 67650/256 + N c2^2 + 2 c0 c1 225/256 + 2 (c0 + c1) c2 (-450)/16
+    const dd fit2 = dd_add(dd_add(dd_mul_d(dd_add(c00, c11), 67650.0 / 256.0), dd_mul_d(dd_mul(c2, c2), N)),
+                           dd_add(dd_mul_d(c01, 450.0 / 256.0), dd_neg(dd_mul_d(dd_mul(dd_add(c0, c1), c2), 900.0 / 16.0))));
+    const dd sR2 = dd_add(dd_add(dd_div_d(dd_from(IPP), 65025.0), dd_neg(dd_mul_d(cross, 2.0))), fit2);
+    const double gxx = fmax(sGxx.hi, 0.0), gyy = fmax(sGyy.hi, 0.0), r2 = fmax(sR2.hi, 0.0);
+    // ---- how far the reference's rounded sequential sums can be from these ----
+    const double kSafety = 4.0;
+    const double sxx = sqrt(N * gxx), syy = sqrt(N * gyy), sr2 = sqrt(N * r2);
+    VE Gxx{sGxx.hi, kSafety * (905.0 * kU * gxx + 2.0 * Egx * sxx + N * Egx * Egx)};
+    VE Gyy{sGyy.hi, kSafety * (905.0 * kU * gyy + 2.0 * Egy * syy + N * Egy * Egy)};
+    VE Gxy{sGxy.hi, kSafety * (905.0 * kU * 0.5 * (gxx + gyy) + Egy * sxx + Egx * syy + N * Egx * Egy)};
+    VE mean{sR.hi, kSafety * (905.0 * kU * sr2 + N * (kU * (2.0 + 5.0 * F) + Ec[2] + (Ec[0] + Ec[1]) / 32.0))};
+    VE var{sR2.hi, kSafety * (905.0 * kU * r2 + 2.0 * Er * sr2 + N * Er * Er)};
+    // ---- the rest of the reference's evaluation, bound carried along ----
+    mean = ve_div_c(mean, N);
+    Gxx = ve_div_c(Gxx, N);
+    Gxy = ve_div_c(Gxy, N);
+    Gyy = ve_div_c(Gyy, N);
+    var = ve_sub(ve_div_c(var, N), ve_mul(mean, mean));
+    const VE trace = ve_add(Gxx, Gyy);
+    const VE det = ve_sub(ve_mul(Gxx, Gyy), ve_mul(Gxy, Gxy));
+    VE disc = ve_sub(ve_mul(trace, trace), ve_mul_c(4.0, det));
+    if (!(disc.v > 0.0)) disc.v = 0.0;  // (the reference clamps too: |max(a,0) - max(b,0)| <= |a - b|)
+    VE sq;
+    sq.v = sqrt(disc.v);
+    {
+      const double lo = disc.v - disc.e;
+      sq.e = (lo > 0.0 ? disc.e / (2.0 * sqrt(lo)) : sqrt(disc.e + disc.v)) + 2.0 * kU * sq.v;
+      sq.e = fmin(sq.e, sqrt(disc.e) + 2.0 * kU * sq.v + (lo > 0.0 ? 0.0 : 0.0));
+    }
+    const VE e1 = ve_div_c(ve_add(trace, sq), 2.0);
+    const VE e2 = ve_div_c(ve_sub(trace, sq), 2.0);
+    const VE norm = e1;
+    VE den = e2;
+    if (!(den.v > 1e-6)) den.v = 1e-6;  // max(e2, 1e-6): 1-Lipschitz
+    VE ratio{e1.v / den.v, 0.0};
+    const double den_lo = den.v - den.e;
+    const bool ratio_ok = den_lo > 0.0;
+    ratio.e = ratio_ok ? (e1.e + fabs(ratio.v) * den.e) / den_lo + 2.0 * kU * fabs(ratio.v) : 1e300;
+    const double kTrace = 0.15 / 1024.0, kRatio = 1.25, kNorm = 0.08 / 1024.0, kVar = 0.005 / 1024.0;
+    const int tr_lt = ve_lt(trace, kTrace), ra_lt = ve_lt(ratio, kRatio), no_lt = ve_lt(norm, kNorm), va_gt = ve_gt(var, kVar);
+    // is_flat = all four; certain if every test is, or if one is certainly false
+    int flat;
+    if (tr_lt == 0 || ra_lt == 0 || no_lt == 0 || va_gt == 0) flat = 0;
+    else if (tr_lt == 1 && ra_lt == 1 && no_lt == 1 && va_gt == 1) flat = 1;
+    else flat = -1;
+    // score
+    VE sw = ve_mul_c(-6682.0, var);
+    sw = ve_add(sw, ve_mul_c(-0.2056, ratio));
+    sw = ve_add(sw, ve_mul_c(13087.0, trace));
+    sw = ve_add(sw, ve_mul_c(-12434.0, norm));
+    sw = ve_add_c(sw, 2.5694);
+    // clamp, then s = 1 / (1 + exp(-sw)), monotone in sw: the reference's sw lies in [sw.v - e, sw.v + e],
+    // so its s lies between the images of the ends (widened by the roundings of exp, + and /)
+    auto clamp_sw = [](double x) { return x < -25.0 ? -25.0 : (x > 100.0 ? 100.0 : x); };
+    auto sigmoid = [](double x) { return 1.0 / (1.0 + exp(-x)); };
+    const double sv = sigmoid(clamp_sw(sw.v));
+    const double s_lo = sigmoid(clamp_sw(sw.v - sw.e)), s_hi = sigmoid(clamp_sw(sw.v + sw.e));
+    const float f_lo = (float)(s_lo * (1.0 - 16.0 * kU)), f_hi = (float)(s_hi * (1.0 + 16.0 * kU));
+    const bool score_ok = ratio_ok && (f_lo == f_hi) && isfinite(sw.e);
+    if (flat >= 0 && va_gt >= 0 && (va_gt == 0 || score_ok)) {
+      certain = true;
+      flag_out = flat ? 255 : 0;
+      score_out = va_gt ? (float)sv : 0.0f;
+    }
+  }
+  if (blk < g.nblocks) {
+    if (certain) {
+      uint8_t *rec = records + (size_t)frame * g.rec_size;
+      reinterpret_cast<float *>(rec + g.off_scores)[blk] = score_out;
+      flags[(size_t)frame * g.nblocks + blk] = flag_out;
+    }
+  }
+  // the rest: compacted for the literal kernel (one atomic per wave)
+  const bool todo = blk < g.nblocks && !certain;
+  const unsigned long long bal = __ballot(todo);
+  if (bal != 0) {
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cl.count[frame], (uint32_t)__popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (todo) cl.list[(size_t)frame * g.nblocks + base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)blk;
+  }
+}
+
+}  // namespace g1s

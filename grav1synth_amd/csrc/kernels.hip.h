@@ -169,16 +169,24 @@ __device__ __forceinline__ void narrow_row(const RowRaw<BPS> &r, int shift, uint
 // and the f32 score are those of the scalar CPU algorithm.
 // grid = (ceil(nblocks/64), batch), block = 64.
 // ----------------------------------------------------------------------------
-template <int BPS>
+// LISTED: the lane's block comes from a per-frame list (the blocks the certified fast path, k1f.hip.h,
+// could not decide); otherwise lane = block.
+template <int BPS, bool LISTED>
 __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom g,
                                                        FlatConsts fc, const double *__restrict__ lut_g,
                                                        uint8_t *__restrict__ records,
-                                                       uint8_t *__restrict__ flags) {
+                                                       uint8_t *__restrict__ flags,
+                                                       const uint32_t *__restrict__ list,
+                                                       const uint32_t *__restrict__ count) {
   __shared__ double lut[256];
   for (int i = threadIdx.x; i < 256; i += 64) lut[i] = lut_g[i];
   __syncthreads();
   const int frame = blockIdx.y;
-  const int blk = blockIdx.x * 64 + threadIdx.x;
+  int blk = blockIdx.x * 64 + threadIdx.x;
+  if (LISTED) {
+    if (blk >= (int)count[frame]) return;
+    blk = (int)list[(size_t)frame * g.nblocks + blk];
+  }
   if (blk >= g.nblocks) return;
   const FramePlanes fp = ft.f[frame];
   const uint8_t *base = fp.src[0];

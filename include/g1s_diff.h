@@ -177,6 +177,7 @@ typedef struct {
   uint64_t launches_flat_features, launches_flat_select, launches_ar_accumulate;
   double ms_host_fold;        /* wall time spent in the ordered host fold */
   double ms_residual;         /* part of ms_ar_accumulate: the K0 residual pass over the input planes */
+  uint64_t literal_blocks;    /* timed batches only: blocks the certified flat-block fast path left to the literal f64 kernel */
 } g1s_stats_t;
 int g1s_diff_get_stats(const g1s_diff_t *, g1s_stats_t *out);
 /* Enable per-kernel HIP-event timing (off by default: events serialise batches). */
