@@ -126,6 +126,7 @@ SYMBOLS = [
     ("g1s_write_tbl", C.c_int, [C.c_char_p, C.POINTER(G1SSegment), C.c_size_t]),
     ("g1s_diff_get_stats", C.c_int, [C.c_void_p, C.POINTER(G1SStats)]),
     ("g1s_diff_set_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("g1s_diff_set_flat_finder", C.c_int, [C.c_void_p, C.c_int]),
     ("g1s_diff_last_record", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("g1s_record_geometry", C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4),
     ("g1s_record_flat_mask", C.POINTER(C.c_uint8), [C.c_void_p]),

@@ -268,6 +268,7 @@ struct g1s_diff {
   int sticky = G1S_OK;  // a fold error kills the generator (the reference `?`-propagates out of main)
   bool finished = false;
   bool timing = false;
+  bool flat_literal = false;  // flat-block finder: literal f64 kernel for every block
   g1s_stats_t stats{};
 
   int fail(int code, const std::string &msg) {
@@ -508,7 +509,8 @@ int g1s_diff::submit(int si) {
   {
     // flat-block features: integer moments + certified evaluation; the literal f64 kernel only for
     // the blocks the certificate leaves open (G1S_K1_LITERAL=1: for every block)
-    static const int force_literal = getenv("G1S_K1_LITERAL") ? atoi(getenv("G1S_K1_LITERAL")) : 0;
+    static const int env_literal = getenv("G1S_K1_LITERAL") ? atoi(getenv("G1S_K1_LITERAL")) : 0;
+    const int force_literal = (env_literal || flat_literal) ? 1 : 0;
     int32_t *mom = sl.d_k1;
     CertifyLists cl;
     cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
@@ -1148,6 +1150,11 @@ int g1s_write_tbl(const char *path, const g1s_segment_t *segs, size_t n) {
 int g1s_diff_get_stats(const g1s_diff_t *g, g1s_stats_t *out) {
   if (!g || !out) return G1S_ERR_INVALID;
   *out = g->stats;
+  return G1S_OK;
+}
+int g1s_diff_set_flat_finder(g1s_diff_t *g, int literal_only) {
+  if (!g) return G1S_ERR_INVALID;
+  g->flat_literal = literal_only != 0;
   return G1S_OK;
 }
 int g1s_diff_set_timing(g1s_diff_t *g, int enable) {

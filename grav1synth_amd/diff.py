@@ -255,6 +255,10 @@ class DiffGenerator:
     def set_timing(self, enable: bool) -> None:
         self._L.g1s_diff_set_timing(self._h, int(enable))
 
+    def set_flat_finder(self, literal_only: bool) -> None:
+        """False (default): certified fast path; True: the literal f64 kernel for every block."""
+        self._L.g1s_diff_set_flat_finder(self._h, int(literal_only))
+
     def stats(self) -> G1SStats:
         st = G1SStats()
         self._L.g1s_diff_get_stats(self._h, C.byref(st))

@@ -116,6 +116,37 @@ def test_latest_only_generator_streams_the_fold():
     g.close()
 
 
+@pytest.mark.parametrize("bd,w,h", [(8, 1920, 1080), (10, 2048, 1152), (12, 1280, 736)])
+def test_certified_flat_finder_equals_literal_kernel(bd, w, h):
+    """The flat-block finder's fast path (integer moments + certified evaluation, literal kernel for the
+    blocks it cannot decide) must give the literal kernel's mask bytes and f32 score bits for EVERY
+    block: tens of thousands of blocks here, textured and flat, on top of the oracle cases above."""
+    spec = SynthSpec(w, h, bd)
+    res = []
+    for literal in (False, True):
+        g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=4)
+        g.set_flat_finder(literal)
+        g.set_timing(True)
+        masks, scores = [], []
+        for k in range(4):
+            s, d = make_pair(spec, 100 + k, device="cuda")
+            g.diff_frame(s, d, spec.xdec, spec.ydec)
+            g.sync()
+            r = g.last_record()
+            masks.append(r.flat_mask().copy())
+            scores.append(r.scores().view(np.uint32).copy())
+        st = g.stats()
+        res.append((masks, scores, st.literal_blocks, st.blocks))
+        g.close()
+    (m0, s0, lit0, nb0), (m1, s1, lit1, nb1) = res
+    for a, b in zip(m0, m1):
+        assert np.array_equal(a, b)
+    for a, b in zip(s0, s1):
+        assert np.array_equal(a, b)
+    assert lit1 == nb1          # literal mode: every block through the literal kernel
+    assert lit0 < nb0 // 20     # fast path: only the undecidable few
+
+
 def test_scene_cut_emits_two_segments():
     """is_different(): doubling the noise gain mid-stream must cut a segment at
     the same frame, with the same timestamps, as the oracle."""
