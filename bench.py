@@ -43,7 +43,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=128, help="frame pairs per rank per step (one video chunk per step)")
+    ap.add_argument("--frames", type=int, default=256, help="frame pairs per rank per step (one video chunk per step)")
     ap.add_argument("--batch", type=int, default=16, help="frames per kernel launch group (<= 16)")
     ap.add_argument("--workload", default="4k10", choices=sorted(WORKLOADS))
     ap.add_argument("--flat", action="store_true", help="all-flat stress variant (no textured region)")
