@@ -29,6 +29,11 @@ CASES = [
     (SynthSpec(320, 192, 8), 1, True, 2, True),
     (SynthSpec(300, 180, 8, textured=False), 3, True, 2, False),  # width not a multiple of 32
     (SynthSpec(320, 192, 12), 3, True, 2, True),
+    (SynthSpec(326, 198, 8), 3, True, 2, True),            # nothing a multiple of 4 or 8; unaligned device rows
+    (SynthSpec(322, 190, 10), 3, True, 2, False),          # same through the host staging path, 10-bit
+    (SynthSpec(64, 64, 8), 3, True, 2, True),              # 2 x 2 blocks: every area touches the frame edge
+    (SynthSpec(512, 40, 8, textured=False), 3, True, 2, True),   # a 1.25-block-high strip
+    (SynthSpec(288, 160, 8, xdec=0, ydec=0), 3, True, 2, True),  # 4:4:4 8-bit
 ]
 
 
