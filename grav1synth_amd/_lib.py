@@ -151,6 +151,13 @@ def lib() -> C.CDLL:
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C grav1synth_amd/csrc). "
             "grav1synth_amd has no CPU fallback for the diff path."
         )
+    # PyTorch-ROCm ships its own libamdhip64: it must be the HIP runtime of the process (device pointers of
+    # torch tensors are handed to the kernels), so it has to be mapped before libg1s_diff.so asks the
+    # dynamic linker for that soname -- two runtimes in one process do not see each other's device state.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # host-only use (fold, .tbl writer): the system HIP runtime will do
+        pass
     L = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if the symbol is not exported
