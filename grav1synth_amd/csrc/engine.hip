@@ -136,7 +136,7 @@ struct Slot {
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
   hipEvent_t done = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: k1 start, k2 start, k3 start, k3 end, k0 end
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: finder start, k2 start, k3 start, k3 end, k0 end, k0 start
   uint32_t count = 0;
   bool timed = false;
 };
@@ -506,22 +506,39 @@ int g1s_diff::submit(int si) {
   }
   sl.timed = timing;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], fstream));
+  const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
+  const size_t cls_bytes_q = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   {
     // flat-block features: integer moments + certified evaluation; the literal f64 kernel only for
-    // the blocks the certificate leaves open (G1S_K1_LITERAL=1: for every block)
+    // the blocks the certificate leaves open (G1S_K1_LITERAL=1 / g1s_diff_set_flat_finder: for every block)
     static const int env_literal = getenv("G1S_K1_LITERAL") ? atoi(getenv("G1S_K1_LITERAL")) : 0;
     const int force_literal = (env_literal || flat_literal) ? 1 : 0;
     int32_t *mom = sl.d_k1;
     CertifyLists cl;
     cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
     cl.count = cl.list + (size_t)g.nblocks * batch;
-    if (!force_literal) {
+    if (fast_ok) {
+      // K0: one pass over the source / denoised planes -> int8 residual and L planes, block statistics and
+      // the finder's moments of the luma source (it needs nothing from the finder: it runs before it)
+      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], fstream));
+      const dim3 gr((g.nbw + 3) / 4, g.nbh, B);
+      uint8_t *badp = sl.d_defer + cls_bytes_q;
+#define G1S_K0(SB, DB) \
+  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, fstream, ft, g, ps, sl.d_k0, badp, sl.d_records, mom)
+      if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);
+      else if (g.src_bps == 1) G1S_K0(1, 2);
+      else if (g.den_bps == 1) G1S_K0(2, 1);
+      else G1S_K0(2, 2);
+#undef G1S_K0
+      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], fstream));
+    } else if (!force_literal) {
       const dim3 mg((g.nblocks + 7) / 8, B);
       if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, fstream, ft, g, mom);
       else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, fstream, ft, g, mom);
     }
+    // K0 leaves out blocks that reach over the plane (the finder replicates edge pixels there): literal kernel
     hipLaunchKernelGGL(k1_certify, dim3((g.nblocks + 255) / 256, B), dim3(256), 0, fstream, g, fc, (const int32_t *)mom,
-                       sl.d_records, sl.d_flags, cl, force_literal);
+                       sl.d_records, sl.d_flags, cl, force_literal, fast_ok ? 1 : 0);
     dim3 grid((g.nblocks + 63) / 64, B);
     if (g.src_bps == 1)
       hipLaunchKernelGGL((k1_flat_features<1, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
@@ -537,7 +554,6 @@ int g1s_diff::submit(int si) {
     HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], stream));
-  const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   if (fast_ok) {
     // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
     // then the generic int32 kernel on mixed / deferred areas
@@ -564,16 +580,11 @@ int g1s_diff::submit(int si) {
     const uint32_t Bs = std::min(sub, B - f0);
     g.frame0 = (int)f0;
     {
-      // K0: one pass over the source / denoised planes -> int8 residual, L and window planes + block statistics
-      const dim3 gr((g.nbw + 3) / 4, g.nbh, Bs);
-#define G1S_K0(SB, DB) \
-  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, stream, ft, g, ps, sl.d_k0, qp.bad, sl.d_records)
-      if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);
-      else if (g.src_bps == 1) G1S_K0(1, 2);
-      else if (g.den_bps == 1) G1S_K0(2, 1);
-      else G1S_K0(2, 2);
-#undef G1S_K0
-      if (sl.timed && f0 == 0) HIP_TRY(hipEventRecord(sl.ev[4], stream));
+      // the window bit planes need the flat mask: a small kernel after K2
+      const int kinds = g.nplanes == 3 ? 2 : 1;
+      const uint32_t wdw = std::max(ps.wpitch[0], kinds == 2 ? ps.wpitch[1] : 0u) / 4;
+      hipLaunchKernelGGL(k3_windows, dim3((wdw + 63) / 64, 4 * g.nbh, Bs * kinds), dim3(64), 0, stream, g, ps, sl.d_k0,
+                         (const uint8_t *)sl.d_records);
     }
     hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, Bs), dim3(kClsThreads), 0, stream, g,
                        (const uint8_t *)sl.d_records, qp);
@@ -661,16 +672,16 @@ int g1s_diff::drain_one() {
   HIP_TRY(hipEventSynchronize(sl.done));
   if (sl.timed) {
     float ms = 0;
+    const bool k0_timed = (int)lag == kQLag && !(geom.nplanes == 3 && geom.xdec == 0 && geom.ydec == 1);
+    float ms_k0 = 0;
+    if (k0_timed) HIP_TRY(hipEventElapsedTime(&ms_k0, sl.ev[5], sl.ev[4]));
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
-    stats.ms_flat_features += ms;
+    stats.ms_flat_features += ms - ms_k0;  // (K0 sits between the finder's launches)
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
     stats.ms_flat_select += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
-    stats.ms_ar_accumulate += ms;
-    if ((int)lag == kQLag && !(geom.nplanes == 3 && geom.xdec == 0 && geom.ydec == 1)) {
-      HIP_TRY(hipEventElapsedTime(&ms, sl.ev[2], sl.ev[4]));
-      stats.ms_residual += ms;
-    }
+    stats.ms_ar_accumulate += ms + ms_k0;
+    stats.ms_residual += ms_k0;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
     stats.ms_total_gpu += ms;
     {

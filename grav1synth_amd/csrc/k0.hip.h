@@ -10,8 +10,11 @@
 //             regressor of add_block_observations before its division), int8, flagged likewise;
 //     w1[k]   one BIT per sample: it lies in the observation window of its (flat) block,
 //             per plane kind k (luma, chroma);
-// plus the per-block noise statistics of the flat blocks (get_block_mean / get_noise_var:
-// exact integer sums of src8, d, d^2), straight into the frame record.
+// plus the per-block noise statistics (get_block_mean / get_noise_var: exact integer sums of src8,
+// d, d^2; the fold reads those of the flat blocks) straight into the frame record, and the fourteen
+// integer moments of every full 32x32 luma source block for the flat-block finder (k1f.hip.h).
+// K0 needs nothing from the flat-block finder, so it runs BEFORE it; the window bits, which need the
+// flat mask, are written by k3_windows afterwards.
 //
 // Plane layout (one frame): sample (x, y) of a d8 plane at byte
 //     (y + kPadY) * pitch + kPadX + x,     pitch = nbw * bw + 16,  rows = nbh * bh + 2 * kPadY
@@ -209,37 +212,101 @@ __device__ __forceinline__ void load_narrow(const uint8_t *base, uint32_t stride
   }
 }
 
+// ---- the flat-block finder's integer moments of one block row (see k1f.hip.h) ----
+constexpr int kMomInts = 16;  // ints per block in the moments buffer
+enum {
+  kM_S0 = 0, kM_SXU, kM_SYU, kM_SAX, kM_SAY,        // full block: sum p, sum p xi, sum p yi, sum p |xi-16|, sum p |yi-16|
+  kM_I0, kM_IXU, kM_IYU, kM_IPP,                    // interior (1..30)^2: sum p, sum p xi, sum p yi, sum p^2
+  kM_DXX, kM_DYY, kM_DXY, kM_DX, kM_DY              // interior central differences
+};
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+__device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
+// pk / pu / pd: the 32 packed pixels of row yi and of the rows above / below it
+__device__ __forceinline__ void row_moments(const uint32_t (&pk)[8], const uint32_t (&pu)[8], const uint32_t (&pd)[8], int yi,
+                                            int32_t (&s)[14]) {
+#pragma unroll
+  for (int i = 0; i < 14; ++i) s[i] = 0;
+  uint32_t rowsum = 0, sxu = 0, sax = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    rowsum = sad4(pk[k], rowsum);
+    sxu = udot4(pk[k], 0x03020100u + 0x04040404u * (uint32_t)k, sxu);
+    // |xi - 16| for xi = 4k .. 4k+3
+    const int a0 = abs(4 * k - 16), a1 = abs(4 * k + 1 - 16), a2 = abs(4 * k + 2 - 16), a3 = abs(4 * k + 3 - 16);
+    sax = udot4(pk[k], (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24), sax);
+  }
+  s[kM_S0] = (int32_t)rowsum;
+  s[kM_SXU] = (int32_t)sxu;
+  s[kM_SYU] = (int32_t)rowsum * yi;
+  s[kM_SAX] = (int32_t)sax;
+  s[kM_SAY] = (int32_t)rowsum * abs(yi - 16);
+  if (yi >= 1 && yi <= kBlock - 2) {
+    uint32_t i0 = 0, ixu = 0, ipp = 0, rr = 0, ll = 0, rl = 0, sr = 0, sl = 0, dd = 0, uu = 0, du = 0, sd = 0, su = 0;
+    uint32_t rd = 0, ru = 0, ld = 0, lu = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t m = k == 0 ? 0xffffff00u : (k == 7 ? 0x00ffffffu : 0xffffffffu);  // interior columns 1..30
+      const uint32_t pm = pk[k] & m;
+      i0 = sad4(pm, i0);
+      ixu = udot4(pm, 0x03020100u + 0x04040404u * (uint32_t)k, ixu);
+      ipp = udot4(pm, pk[k], ipp);
+      // p(xi + 1), p(xi - 1) for xi = 4k .. 4k+3
+      const uint32_t pr = __builtin_amdgcn_alignbyte(k < 7 ? pk[k + 1] : 0u, pk[k], 1) & m;
+      const uint32_t pl = __builtin_amdgcn_alignbyte(pk[k], k > 0 ? pk[k - 1] : 0u, 3) & m;
+      const uint32_t dn = pd[k] & m, up = pu[k] & m;
+      rr = udot4(pr, pr, rr);
+      ll = udot4(pl, pl, ll);
+      rl = udot4(pr, pl, rl);
+      sr = sad4(pr, sr);
+      sl = sad4(pl, sl);
+      dd = udot4(dn, dn, dd);
+      uu = udot4(up, up, uu);
+      du = udot4(dn, up, du);
+      sd = sad4(dn, sd);
+      su = sad4(up, su);
+      rd = udot4(pr, dn, rd);
+      ru = udot4(pr, up, ru);
+      ld = udot4(pl, dn, ld);
+      lu = udot4(pl, up, lu);
+    }
+    s[kM_I0] = (int32_t)i0;
+    s[kM_IXU] = (int32_t)ixu;
+    s[kM_IYU] = (int32_t)i0 * yi;
+    s[kM_IPP] = (int32_t)ipp;
+    s[kM_DXX] = (int32_t)(rr + ll - 2u * rl);
+    s[kM_DYY] = (int32_t)(dd + uu - 2u * du);
+    s[kM_DXY] = (int32_t)rd - (int32_t)ru - (int32_t)ld + (int32_t)lu;
+    s[kM_DX] = (int32_t)sr - (int32_t)sl;
+    s[kM_DY] = (int32_t)sd - (int32_t)su;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // k0_residual<SBPS, DBPS>: grid = (ceil(nbw / 4), nbh, batch), block = 256.
 // A workgroup owns four horizontally adjacent blocks: every row it touches is at least one
 // full 128-byte line per plane, every lane moves 8 samples (16-byte loads of 16-bit input).
 //   luma:   512 items of 8 samples, two per thread: item -> (row = i / 16, segment = i % 16)
 //   chroma: (128 >> xdec) / 8 segments x (32 >> ydec) rows per component, one or more per thread
-// Block sums go through LDS atomics (block = segment / segments-per-block).
-// Runs after K2 (it needs the flat mask for the windows and to know which statistics to keep).
+// Block sums go through LDS atomics (block = segment / segments-per-block).  The 8-bit luma source
+// of the four blocks is also kept in LDS; 128 lanes (block, row) then take the flat-block finder's
+// moments from it.
 // ---------------------------------------------------------------------------------
 template <int SBPS, int DBPS>
 __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, PlaneSet ps,
                                                    uint8_t *__restrict__ planes, uint8_t *__restrict__ bad,
-                                                   uint8_t *__restrict__ records) {
+                                                   uint8_t *__restrict__ records, int32_t *__restrict__ mom) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_src[kBlock][4 * 8 + 1];  // [row][dword of the 128-px row], +1: banks
   __shared__ int s_sum[3][4][3];  // [component][block][sum d, sum d^2, sum src8 (luma)]
   __shared__ int s_bad[2][4];     // [kind][block]
-  __shared__ Win s_win[2][4];     // [kind][block]
   const int frame = g.frame0 + (int)blockIdx.z, by = blockIdx.y, bx0 = 4 * (int)blockIdx.x;
   const int tid = threadIdx.x;
   const FramePlanes fp = ft.f[frame];
   uint8_t *fbase = planes + (size_t)frame * ps.frame_bytes;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
-  const uint8_t *mask = rec + g.off_mask;
   const bool chroma = g.nplanes == 3;
   const int sx = g.xdec, sy = g.ydec;
   if (tid < 36) (&s_sum[0][0][0])[tid] = 0;
-  if (tid < 8) {
-    (&s_bad[0][0])[tid] = 0;
-    const int k = tid >> 2, b = tid & 3;
-    s_win[k][b] = block_window(mask, g.nbw, g.nbh, bx0 + b, by, kBlock >> (k ? sx : 0), kBlock >> (k ? sy : 0),
-                               g.W >> (k ? sx : 0), g.H >> (k ? sy : 0));
-  }
+  if (tid < 8) (&s_bad[0][0])[tid] = 0;
   __syncthreads();
 
   // ------------------------------- luma -------------------------------
@@ -247,7 +314,6 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
     const int seg = tid & 15, b = seg >> 2;
     const bool active = bx0 + b < g.nbw;
     const int X0 = bx0 * kBlock + seg * 8;
-    const Win w = s_win[0][b];
     int sd = 0, sd2 = 0, ls = 0;
     uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0;
 #pragma unroll
@@ -268,12 +334,14 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
         sd += a0 + a1;
         sd2 += a0 * a0 + a1 * a1;
       }
-      ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[0], hs[1]), 0u, (uint32_t)ls);
-      ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[2], hs[3]), 0u, (uint32_t)ls);
+      const uint32_t s_lo = pk_bytes(hs[0], hs[1]), s_hi = pk_bytes(hs[2], hs[3]);  // the 8 source pixels, packed
+      ls = (int)__builtin_amdgcn_sad_u8(s_lo, 0u, (uint32_t)ls);
+      ls = (int)__builtin_amdgcn_sad_u8(s_hi, 0u, (uint32_t)ls);
+      s_src[row][2 * seg] = s_lo;
+      s_src[row][2 * seg + 1] = s_hi;
       if (active) {
         const size_t o = (size_t)(Y + kPadY) * ps.pitch[0] + kPadX + X0;
         *reinterpret_cast<uint2 *>(fbase + ps.off_d[0] + o) = make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
-        fbase[ps.off_w[0] + (size_t)(Y + kPadY) * ps.wpitch[0] + ((kPadX + X0) >> 3)] = (uint8_t)window_bits8(w, (seg & 3) * 8, row);
       }
       if (chroma) {
         // L = sum of the (1 << sx) x (1 << sy) luma residuals under a chroma sample; the next
@@ -352,10 +420,6 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
       const size_t o = (size_t)(Y + kPadY) * ps.pitch[1] + kPadX + X0;
       *reinterpret_cast<uint2 *>(fbase + (c == 1 ? ps.off_d[1] : ps.off_d[2]) + o) =
           make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
-      if (c == 1) {
-        fbase[ps.off_w[1] + (size_t)(Y + kPadY) * ps.wpitch[1] + ((kPadX + X0) >> 3)] =
-            (uint8_t)window_bits8(s_win[1][b], (seg - b * spb) * 8, row);
-      }
       atomicAdd(&s_sum[c][b][0], sd);
       atomicAdd(&s_sum[c][b][1], sd2);
       if (range_bad(mx, mn)) s_bad[1][b] = 1;
@@ -366,17 +430,87 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
     const int blk = by * g.nbw + bx0 + tid;
     if (s_bad[0][tid]) bad[(size_t)frame * 2 * g.nblocks + blk] = 1;
     if (chroma && s_bad[1][tid]) bad[((size_t)frame * 2 + 1) * g.nblocks + blk] = 1;
-    if (mask[blk]) {  // noise statistics of the flat blocks
-      reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = s_sum[0][tid][0];
-      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)s_sum[0][tid][1];
-      reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)s_sum[0][tid][2];
-      if (chroma) {
-        reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = s_sum[1][tid][0];
-        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)s_sum[1][tid][1];
-        reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = s_sum[2][tid][0];
-        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)s_sum[2][tid][1];
-      }
+    // noise statistics of every block (the fold reads those of the flat blocks)
+    reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = s_sum[0][tid][0];
+    reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)s_sum[0][tid][1];
+    reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)s_sum[0][tid][2];
+    if (chroma) {
+      reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = s_sum[1][tid][0];
+      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)s_sum[1][tid][1];
+      reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = s_sum[2][tid][0];
+      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)s_sum[2][tid][1];
     }
+  }
+  // ---- flat-block finder moments of the four luma source blocks (k1f.hip.h), from the LDS copy ----
+  if (mom != nullptr && tid < 128) {
+    const int b = tid >> 5, yi = tid & 31;
+    uint32_t pk[8], pu[8], pd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      pk[k] = s_src[yi][8 * b + k];
+      pu[k] = s_src[max(yi - 1, 0)][8 * b + k];
+      pd[k] = s_src[min(yi + 1, kBlock - 1)][8 * b + k];
+    }
+    int32_t m[14];
+    row_moments(pk, pu, pd, yi, m);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 14; ++i) m[i] += __shfl_xor(m[i], o, 32);
+    }
+    const int bxo = bx0 + b;
+    // only blocks that lie inside the plane: the finder replicates edge pixels for the others, K0 does not
+    if (yi == 0 && bxo < g.nbw) {
+      int32_t *out = mom + ((size_t)frame * g.nblocks + (size_t)by * g.nbw + bxo) * kMomInts;
+#pragma unroll
+      for (int i = 0; i < 14; ++i) out[i] = m[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k3_windows: the window bit planes w1[kind] from the flat mask (after K2).  Lane = one aligned
+// dword column j of a block row by: bits 32 j .. 32 j + 31 = samples 32 j - 8 .. 32 j + 23, which
+// belong to up to three blocks; their windows are worked out once and written for a quarter of
+// the block's rows.  Every dword of the sample rows is written (zeros where no window is); the
+// padding rows stay zero from the allocation.
+// grid = (ceil(dwords per bit row / 64), 4 * nbh, batch * kinds), block = 64.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k3_windows(Geom g, PlaneSet ps, uint8_t *__restrict__ planes,
+                                                 const uint8_t *__restrict__ records) {
+  const int kinds = g.nplanes == 3 ? 2 : 1;
+  const int frame = g.frame0 + (int)blockIdx.z / kinds, kind = (int)blockIdx.z % kinds;
+  const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
+  const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
+  const int j = (int)blockIdx.x * 64 + (int)threadIdx.x;  // dword of the bit row
+  const int by = (int)blockIdx.y >> 2, quarter = (int)blockIdx.y & 3;
+  const uint32_t wpitch = ps.wpitch[kind];
+  if (j * 4 >= (int)wpitch) return;
+  const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
+  const int x_first = 32 * j - kPadX;  // sample of bit 0
+  const int b_first = max(x_first, 0) / bw, b_last = min((x_first + 31) / bw, g.nbw - 1);
+  // bits of the window columns, and the window rows, of the (up to three) blocks under this dword
+  uint32_t colbits[3] = {0, 0, 0};
+  int ys[3] = {0, 0, 0}, ye[3] = {0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int bx = b_first + t;
+    if (bx > b_last) continue;
+    const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph);
+    if (!w.flat) continue;
+    const int lo = max(bx * bw + w.xs - x_first, 0), hi = min(bx * bw + w.xe - x_first, 32);
+    if (hi > lo) colbits[t] = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+    ys[t] = w.ys;
+    ye[t] = w.ye;
+  }
+  const int rows = bh >> 2;
+  uint8_t *dst = planes + (size_t)frame * ps.frame_bytes + ps.off_w[kind] + 4 * (size_t)j;
+  for (int r = 0; r < rows; ++r) {
+    const int ly = quarter * rows + r;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bits |= (ly >= ys[t] && ly < ye[t]) ? colbits[t] : 0u;
+    *reinterpret_cast<uint32_t *>(dst + (size_t)(by * bh + ly + kPadY) * wpitch) = bits;
   }
 }
 

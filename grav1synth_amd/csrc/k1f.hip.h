@@ -21,19 +21,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "k0.hip.h"
 #include "kernels.hip.h"
 
 namespace g1s {
-
-constexpr int kMomInts = 16;  // ints per block in the moments buffer
-enum {
-  kM_S0 = 0, kM_SXU, kM_SYU, kM_SAX, kM_SAY,        // full block: sum p, sum p xi, sum p yi, sum p |xi-16|, sum p |yi-16|
-  kM_I0, kM_IXU, kM_IYU, kM_IPP,                    // interior (1..30)^2: sum p, sum p xi, sum p yi, sum p^2
-  kM_DXX, kM_DYY, kM_DXY, kM_DX, kM_DY              // interior central differences
-};
-
-__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
-__device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
 
 // ---------------------------------------------------------------------------------
 // k1_moments<BPS>: lane = one row of a block (32 pixels as 8 packed dwords, loaded like the
@@ -60,61 +51,7 @@ __global__ __launch_bounds__(256) void k1_moments(const FrameTable ft, Geom g, i
     pd[k] = (uint32_t)__shfl_down((int)pk[k], 1, 32);
   }
   int32_t s[14];
-#pragma unroll
-  for (int i = 0; i < 14; ++i) s[i] = 0;
-  uint32_t rowsum = 0, sxu = 0, sax = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    rowsum = sad4(pk[k], rowsum);
-    sxu = udot4(pk[k], 0x03020100u + 0x04040404u * (uint32_t)k, sxu);
-    // |xi - 16| for xi = 4k .. 4k+3
-    const int a0 = abs(4 * k - 16), a1 = abs(4 * k + 1 - 16), a2 = abs(4 * k + 2 - 16), a3 = abs(4 * k + 3 - 16);
-    sax = udot4(pk[k], (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24), sax);
-  }
-  s[kM_S0] = (int32_t)rowsum;
-  s[kM_SXU] = (int32_t)sxu;
-  s[kM_SYU] = (int32_t)rowsum * yi;
-  s[kM_SAX] = (int32_t)sax;
-  s[kM_SAY] = (int32_t)rowsum * abs(yi - 16);
-  if (yi >= 1 && yi <= kBlock - 2) {
-    uint32_t i0 = 0, ixu = 0, ipp = 0, rr = 0, ll = 0, rl = 0, sr = 0, sl = 0, dd = 0, uu = 0, du = 0, sd = 0, su = 0;
-    uint32_t rd = 0, ru = 0, ld = 0, lu = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t m = k == 0 ? 0xffffff00u : (k == 7 ? 0x00ffffffu : 0xffffffffu);  // interior columns 1..30
-      const uint32_t pm = pk[k] & m;
-      i0 = sad4(pm, i0);
-      ixu = udot4(pm, 0x03020100u + 0x04040404u * (uint32_t)k, ixu);
-      ipp = udot4(pm, pk[k], ipp);
-      // p(xi + 1), p(xi - 1) for xi = 4k .. 4k+3
-      const uint32_t pr = __builtin_amdgcn_alignbyte(k < 7 ? pk[k + 1] : 0u, pk[k], 1) & m;
-      const uint32_t pl = __builtin_amdgcn_alignbyte(pk[k], k > 0 ? pk[k - 1] : 0u, 3) & m;
-      const uint32_t dn = pd[k] & m, up = pu[k] & m;
-      rr = udot4(pr, pr, rr);
-      ll = udot4(pl, pl, ll);
-      rl = udot4(pr, pl, rl);
-      sr = sad4(pr, sr);
-      sl = sad4(pl, sl);
-      dd = udot4(dn, dn, dd);
-      uu = udot4(up, up, uu);
-      du = udot4(dn, up, du);
-      sd = sad4(dn, sd);
-      su = sad4(up, su);
-      rd = udot4(pr, dn, rd);
-      ru = udot4(pr, up, ru);
-      ld = udot4(pl, dn, ld);
-      lu = udot4(pl, up, lu);
-    }
-    s[kM_I0] = (int32_t)i0;
-    s[kM_IXU] = (int32_t)ixu;
-    s[kM_IYU] = (int32_t)i0 * yi;
-    s[kM_IPP] = (int32_t)ipp;
-    s[kM_DXX] = (int32_t)(rr + ll - 2u * rl);
-    s[kM_DYY] = (int32_t)(dd + uu - 2u * du);
-    s[kM_DXY] = (int32_t)rd - (int32_t)ru - (int32_t)ld + (int32_t)lu;
-    s[kM_DX] = (int32_t)sr - (int32_t)sl;
-    s[kM_DY] = (int32_t)sd - (int32_t)su;
-  }
+  row_moments(pk, pu, pd, yi, s);
   // sum over the 32 rows of the block
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) {
@@ -206,13 +143,15 @@ struct CertifyLists {
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k1_certify(Geom g, FlatConsts fc, const int32_t *__restrict__ mom,
                                                   uint8_t *__restrict__ records, uint8_t *__restrict__ flags,
-                                                  CertifyLists cl, int force_literal) {
+                                                  CertifyLists cl, int force_literal, int full_blocks_only) {
   const int frame = blockIdx.y;
   const int blk = (int)blockIdx.x * 256 + (int)threadIdx.x;
   bool certain = false;
   float score_out = 0.0f;
   uint8_t flag_out = 0;
-  if (blk < g.nblocks && !force_literal) {
+  // moments from K0 exist only for blocks that lie inside the plane
+  const bool has_moments = !full_blocks_only || ((blk % g.nbw + 1) * kBlock <= g.W && (blk / g.nbw + 1) * kBlock <= g.H);
+  if (blk < g.nblocks && !force_literal && has_moments) {
     const int32_t *m = mom + ((size_t)frame * g.nblocks + blk) * kMomInts;
     const double S0 = m[kM_S0], SX = (double)m[kM_SXU] - 16.0 * m[kM_S0], SY = (double)m[kM_SYU] - 16.0 * m[kM_S0];
     const double SAX = m[kM_SAX], SAY = m[kM_SAY];
