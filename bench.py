@@ -44,7 +44,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=256, help="frame pairs per rank per step (one video chunk per step)")
-    ap.add_argument("--batch", type=int, default=16, help="frames per kernel launch group (<= 16)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per kernel launch group (<= 32)")
     ap.add_argument("--workload", default="4k10", choices=sorted(WORKLOADS))
     ap.add_argument("--flat", action="store_true", help="all-flat stress variant (no textured region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,7 +89,7 @@ def main() -> None:
 
     # ---- synthetic frame pairs, resident in HBM before any timed region ----
     # N > 1: the video is dealt to the ranks batch by batch (global batch j -> rank j % N)
-    B = max(1, min(args.batch, 16))
+    B = max(1, min(args.batch, 32))
     frames = []
     for k in range(F):
         gid = ((k // B) * world + rank) * B + (k % B) if world > 1 else k

@@ -32,7 +32,7 @@ namespace {
 
 thread_local std::string g_global_error;
 
-constexpr uint32_t kDefaultBatch = 16;
+constexpr uint32_t kDefaultBatch = 32;
 constexpr int kK3Chunks = 48;
 
 #define HIP_TRY(expr)                                                                      \

@@ -30,7 +30,7 @@ struct FramePlanes {
 };
 
 // The frame table of a batch travels in the kernel arguments (no H2D copy in the launch chain).
-constexpr int kMaxBatch = 16;
+constexpr int kMaxBatch = 32;
 struct FrameTable {
   FramePlanes f[kMaxBatch];
 };
