@@ -521,10 +521,11 @@ int g1s_diff::submit(int si) {
       // K0: one pass over the source / denoised planes -> int8 residual and L planes, block statistics and
       // the finder's moments of the luma source (it needs nothing from the finder: it runs before it)
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], fstream));
-      const dim3 gr((g.nbw + 3) / 4, g.nbh, B);
+      const dim3 gr(8 * ((((g.nbw + 3) / 4) * g.nbh + 7) / 8), 1, B);
       uint8_t *badp = sl.d_defer + cls_bytes_q;
 #define G1S_K0(SB, DB) \
-  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, fstream, ft, g, ps, sl.d_k0, badp, sl.d_records, mom)
+  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, fstream, ft, g, ps, sl.d_k0, badp, sl.d_records, \
+                     force_literal ? (int32_t *)nullptr : mom)
       if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);
       else if (g.src_bps == 1) G1S_K0(1, 2);
       else if (g.den_bps == 1) G1S_K0(2, 1);

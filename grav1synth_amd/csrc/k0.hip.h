@@ -282,7 +282,7 @@ __device__ __forceinline__ void row_moments(const uint32_t (&pk)[8], const uint3
 }
 
 // ---------------------------------------------------------------------------------
-// k0_residual<SBPS, DBPS>: grid = (ceil(nbw / 4), nbh, batch), block = 256.
+// k0_residual<SBPS, DBPS>: grid = (8 * ceil(ceil(nbw / 4) * nbh / 8), 1, batch), block = 256.
 // A workgroup owns four horizontally adjacent blocks: every row it touches is at least one
 // full 128-byte line per plane, every lane moves 8 samples (16-byte loads of 16-bit input).
 //   luma:   512 items of 8 samples, two per thread: item -> (row = i / 16, segment = i % 16)
@@ -298,7 +298,13 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
   __shared__ __attribute__((aligned(16))) uint32_t s_src[kBlock][4 * 8 + 1];  // [row][dword of the 128-px row], +1: banks
   __shared__ int s_sum[3][4][3];  // [component][block][sum d, sum d^2, sum src8 (luma)]
   __shared__ int s_bad[2][4];     // [kind][block]
-  const int frame = g.frame0 + (int)blockIdx.z, by = blockIdx.y, bx0 = 4 * (int)blockIdx.x;
+  // Workgroup b runs on XCD b % 8 (observed; speed only).  Regions are dealt so that an XCD owns a
+  // contiguous range of them: the int8 rows of horizontally adjacent regions share 128-byte lines
+  // (the planes are padded by 8 bytes), and the two partial writes of a line merge in one L2.
+  const int gx = (g.nbw + 3) / 4, nreg = gx * g.nbh, per = (nreg + 7) >> 3;
+  const int reg = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (reg >= nreg) return;
+  const int frame = g.frame0 + (int)blockIdx.z, by = reg / gx, bx0 = 4 * (reg - by * gx);
   const int tid = threadIdx.x;
   const FramePlanes fp = ft.f[frame];
   uint8_t *fbase = planes + (size_t)frame * ps.frame_bytes;
