@@ -184,9 +184,12 @@ bool acquire_streams(int device, StreamSet &out) {
   }
   out = StreamSet{};
   out.device = device;
-  bool ok = hipStreamCreateWithFlags(&out.compute, hipStreamNonBlocking) == hipSuccess &&
+  // the accumulation chain (many small latency-bound kernels) outranks the pixel pass of the next batch
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = more urgent
+  bool ok = hipStreamCreateWithPriority(&out.compute, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&out.flat, hipStreamNonBlocking) == hipSuccess;
+            hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_lo) == hipSuccess;
   for (int i = 0; i < 2 && ok; ++i)
     ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess;

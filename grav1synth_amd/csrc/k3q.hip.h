@@ -116,10 +116,10 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 // needs w on rows by*bh .. by*bh+bh+2, cols bx*bw-3 .. bx*bw+bw+2: the windows of the six
 // blocks (bx-1..bx+1, by..by+1), which are functions of the flat mask on (bx-2..bx+2,
 // by-1..by+1).  That neighbourhood is read once into registers and serves both kinds.
-// grid = (ceil(nblocks/kClsThreads), 1, batch), block = kClsThreads: large workgroups, so that each
-// of the six lists takes ONE global atomic per workgroup (they all hit the same six counters).
+// grid = (ceil(nblocks/kClsThreads), 1, batch), block = kClsThreads; each of the six lists takes ONE
+// global atomic per workgroup (they all hit the same six counters: a per-wave atomic serialises).
 // ---------------------------------------------------------------------------------
-constexpr int kClsThreads = 1024;
+constexpr int kClsThreads = 256;  // small workgroups: they must find room next to the pixel pass of the next batch
 __global__ __launch_bounds__(kClsThreads) void k3_classify(Geom g, const uint8_t *__restrict__ records, QParams qp) {
   __shared__ uint32_t s_cnt[6][kClsThreads / 64];  // [kind * 3 + which][wave] -> count, then list position
   const int blk = blockIdx.x * kClsThreads + threadIdx.x;
