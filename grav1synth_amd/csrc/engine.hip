@@ -122,6 +122,8 @@ Pool *shared_pool() {
 }
 std::mutex g_pool_mutex;  // parallel_for is not re-entrant: one fold batch at a time
 
+constexpr int kSlots = 3;  // batches in flight: one in the kernels, one in D2H + fold, one being filled
+
 struct Slot {
   FramePlanes *h_planes = nullptr;  // pinned
   FramePlanes *d_planes = nullptr;
@@ -167,8 +169,8 @@ std::vector<CachedSlot> g_slot_cache;
 struct StreamSet {
   int device = -1;
   hipStream_t compute = nullptr, copy = nullptr, flat = nullptr;
-  hipEvent_t kernels_done[2] = {nullptr, nullptr};
-  hipEvent_t mask_done[2] = {nullptr, nullptr};
+  hipEvent_t kernels_done[kSlots] = {};
+  hipEvent_t mask_done[kSlots] = {};
 };
 std::vector<StreamSet> g_stream_cache;
 bool acquire_streams(int device, StreamSet &out) {
@@ -190,7 +192,7 @@ bool acquire_streams(int device, StreamSet &out) {
   bool ok = hipStreamCreateWithPriority(&out.compute, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_lo) == hipSuccess;
-  for (int i = 0; i < 2 && ok; ++i)
+  for (int i = 0; i < kSlots && ok; ++i)
     ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess;
   return ok;
@@ -238,12 +240,8 @@ struct g1s_diff {
   bool latest_only = false;  // keep the per-frame latest states (blobs) instead of folding them here
   uint32_t batch;
   int device = 0;
-  hipStream_t stream = nullptr;       // == slot_stream[0]
-  hipStream_t slot_stream[2] = {nullptr, nullptr};  // one stream per batch slot: consecutive batches overlap
-  StreamSet ss;                       // borrowed: ss.compute == slot_stream[0]
-  hipStream_t aux[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // K3 kernels of one batch run side by side
-  hipEvent_t ev_fork[2] = {nullptr, nullptr};
-  hipEvent_t ev_join[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  hipStream_t stream = nullptr;       // == ss.compute
+  StreamSet ss;                       // borrowed from the process-wide cache
   bool geometry_set = false;
   g1s_frame_t shape{};  // geometry of the first frame
   Geom geom{};
@@ -254,9 +252,17 @@ struct g1s_diff {
   PlaneSet ps{};
   uint32_t pg_cap = 0;
   SlotKey slot_key{};
-  Slot slots[2];
+  Slot slots[kSlots];
   int cur = 0;
-  std::deque<int> in_flight;
+  // The API thread queues frames and launches batches; the drainer thread waits for a batch's records,
+  // runs the fold on them and frees the slot.  Everything below dm is shared between the two.
+  std::thread drainer;
+  std::mutex dm;
+  std::condition_variable cv_work, cv_free;
+  std::deque<int> in_flight;       // submitted, not yet picked up by the drainer
+  bool slot_busy[kSlots] = {};     // submitted and not yet drained
+  uint64_t submitted = 0, drained = 0;  // batches
+  bool drainer_stop = false;
   NoiseFold *fold = nullptr;
   Pool *pool = nullptr;
   std::vector<FrameLatest> latest;  // one per frame of a batch, reused
@@ -264,6 +270,8 @@ struct g1s_diff {
   size_t records_out_frames = 0;
   std::vector<uint8_t> latest_out;  // latest_only: blobs of the drained frames, in frame order
   size_t latest_out_frames = 0;
+  std::deque<uint32_t> latest_batches;  // frames per drained, not yet delivered batch
+  uint64_t delivered = 0;               // batches handed out by g1s_diff_take_latest
   std::vector<uint8_t> last_record;
   std::vector<uint8_t> latest_stage;
   std::string err;
@@ -286,8 +294,10 @@ struct g1s_diff {
   int set_geometry(const g1s_frame_t *s, const g1s_frame_t *d);
   int append(const g1s_frame_t *s, const g1s_frame_t *d);
   int submit(int si);
-  int drain_one();
-  int drain_all();
+  int drain_slot(int si);   // drainer thread
+  void drainer_main();
+  int drain_all();          // API thread: wait until everything submitted is drained
+  void wait_drained(uint64_t upto);
   void release();
 };
 
@@ -475,11 +485,7 @@ int g1s_diff::submit(int si) {
     }
   }
   g.vec_mask = vec_mask;
-  static const bool slot_streams = getenv("G1S_SLOT_STREAMS") != nullptr;  // experiments: default one stream
-  static const bool k3_streams = getenv("G1S_K3_STREAMS") != nullptr;
-  hipStream_t stream = (slot_streams && slot_stream[si]) ? slot_stream[si] : slot_stream[0];  // (shadows the member)
-  const bool k3s = k3_streams && aux[si][0];
-  hipStream_t ax[3] = {k3s ? aux[si][0] : stream, k3s ? aux[si][1] : stream, k3s ? aux[si][2] : stream};
+  hipStream_t stream = ss.compute;  // (shadows the member)
   // The flat-block finder of batch N+1 (K1: one f64 lane per block, one wave per SIMD, latency bound)
   // runs on its own stream next to the accumulation kernels of batch N.
   static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
@@ -593,11 +599,6 @@ int g1s_diff::submit(int si) {
     hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, Bs), dim3(kClsThreads), 0, stream, g,
                        (const uint8_t *)sl.d_records, qp);
     const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
-    // fork: the six accumulation kernels are independent and latency-bound -> four streams
-    if (k3s) {
-      HIP_TRY(hipEventRecord(ev_fork[si], stream));
-      for (int a = 0; a < 3; ++a) HIP_TRY(hipStreamWaitEvent(aux[si][a], ev_fork[si], 0));
-    }
     // One round of workgroups: as many per frame as stay resident together (occupancy x CUs / batch,
     // a multiple of 8 for the XCD-aware list slices), but never more than 128 areas each (int32 sums).
     auto launch_lag = [&](int K, bool mixed, hipStream_t st) {
@@ -619,16 +620,10 @@ int g1s_diff::submit(int si) {
 #undef G1S_LAG
     };
     launch_lag(0, false, stream);
-    if (ck) launch_lag(ck, false, ax[0]);
+    if (ck) launch_lag(ck, false, stream);
     if (qp.mixed_fast) {
-      launch_lag(0, true, ax[1]);
-      if (ck) launch_lag(ck, true, ax[2]);
-    }
-    if (k3s) {
-      for (int a = 0; a < 3; ++a) {  // join
-        HIP_TRY(hipEventRecord(ev_join[si][a], aux[si][a]));
-        HIP_TRY(hipStreamWaitEvent(stream, ev_join[si][a], 0));
-      }
+      launch_lag(0, true, stream);
+      if (ck) launch_lag(ck, true, stream);
     }
     if (qp.mixed_fast) {
       // <= pg_cap / (chunks * 256) = nblocks / chunks steps per lane; the int32 wave sums need < 520
@@ -654,24 +649,50 @@ int g1s_diff::submit(int si) {
   HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
   HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, ss.copy));
   HIP_TRY(hipEventRecord(sl.done, ss.copy));
-  in_flight.push_back(si);
   stats.launches_flat_features++;
   stats.launches_flat_select++;
   stats.launches_ar_accumulate++;
-  // move to the other slot; if it is still in flight, fold it first
-  const int other = si ^ 1;
-  while (!in_flight.empty() && in_flight.front() == other) {
-    const int rc = drain_one();
-    if (rc && deferred == G1S_OK) deferred = rc;
+  {
+    std::unique_lock<std::mutex> lk(dm);
+    slot_busy[si] = true;
+    in_flight.push_back(si);
+    ++submitted;
+    cv_work.notify_one();
+    // move on to the next slot; wait if the drainer has not freed it yet (back-pressure)
+    cur = (si + 1) % kSlots;
+    cv_free.wait(lk, [&] { return !slot_busy[cur]; });
   }
-  cur = other;
   return G1S_OK;
 }
 
-int g1s_diff::drain_one() {
-  if (in_flight.empty()) return G1S_OK;
-  const int si = in_flight.front();
-  in_flight.pop_front();
+void g1s_diff::drainer_main() {
+  (void)hipSetDevice(device);
+  for (;;) {
+    int si;
+    {
+      std::unique_lock<std::mutex> lk(dm);
+      cv_work.wait(lk, [&] { return drainer_stop || !in_flight.empty(); });
+      if (in_flight.empty()) return;  // stop requested and nothing left
+      si = in_flight.front();
+      in_flight.pop_front();
+    }
+    const int rc = drain_slot(si);
+    {
+      std::lock_guard<std::mutex> lk(dm);
+      if (rc && deferred == G1S_OK) deferred = rc;
+      slot_busy[si] = false;
+      ++drained;
+    }
+    cv_free.notify_all();
+  }
+}
+
+void g1s_diff::wait_drained(uint64_t upto) {
+  std::unique_lock<std::mutex> lk(dm);
+  cv_free.wait(lk, [&] { return drained >= upto; });
+}
+
+int g1s_diff::drain_slot(int si) {
   Slot &sl = slots[si];
   HIP_TRY(hipEventSynchronize(sl.done));
   if (sl.timed) {
@@ -745,18 +766,25 @@ int g1s_diff::drain_one() {
     stats.blocks += L.nblocks;
     stats.flat_blocks += nflat_v[i];
     if (records_only) {
+      std::lock_guard<std::mutex> lk(dm);
       records_out.insert(records_out.end(), rec, rec + L.size);
       records_out_frames++;
     } else if (latest_only) {
+      std::lock_guard<std::mutex> lk(dm);
       latest_out.insert(latest_out.end(), latest_stage.begin() + blob * i, latest_stage.begin() + blob * (i + 1));
       latest_out_frames++;
     } else if (sticky == G1S_OK) {
       rc = fold->push_latest(latest[i]);
       if (rc) {
+        std::lock_guard<std::mutex> lk(dm);
         err = fold->error();
         sticky = rc;
       }
     }
+  }
+  if (latest_only && sl.count) {
+    std::lock_guard<std::mutex> lk(dm);
+    latest_batches.push_back(sl.count);
   }
   if (sl.count) last_record.assign(sl.h_records + L.size * (sl.count - 1), sl.h_records + L.size * sl.count);
   sl.count = 0;
@@ -765,23 +793,27 @@ int g1s_diff::drain_one() {
 }
 
 int g1s_diff::drain_all() {
-  int rc = G1S_OK;
-  while (!in_flight.empty()) {
-    const int r = drain_one();
-    if (r && rc == G1S_OK) rc = r;
+  uint64_t upto;
+  {
+    std::lock_guard<std::mutex> lk(dm);
+    upto = submitted;
   }
-  return rc;
+  wait_drained(upto);
+  return G1S_OK;  // errors of drained batches are in `deferred` / `sticky`
 }
 
 void g1s_diff::release() {
-  for (int i = 0; i < 2; ++i) {
-    if (slot_stream[i]) (void)hipStreamSynchronize(slot_stream[i]);
-    for (int a = 0; a < 3; ++a)
-      if (aux[i][a]) (void)hipStreamSynchronize(aux[i][a]);
+  if (drainer.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(dm);
+      drainer_stop = true;
+    }
+    cv_work.notify_all();
+    drainer.join();  // (it drains whatever was still queued first)
   }
+  if (ss.compute) (void)hipStreamSynchronize(ss.compute);
   if (ss.copy) (void)hipStreamSynchronize(ss.copy);
   if (ss.flat) (void)hipStreamSynchronize(ss.flat);
-  slot_stream[0] = nullptr;  // borrowed
   release_streams(ss);
   for (Slot &sl : slots) {
     if (sl.h_planes && geometry_set) {  // park the buffers for the next generator of this geometry
@@ -810,18 +842,6 @@ void g1s_diff::release() {
     sl = Slot{};
   }
   d_lut = nullptr;  // shared per device
-  for (int i = 0; i < 2; ++i) {
-    if (slot_stream[i]) (void)hipStreamDestroy(slot_stream[i]);
-    slot_stream[i] = nullptr;
-    if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
-    ev_fork[i] = nullptr;
-    for (int a = 0; a < 3; ++a) {
-      if (aux[i][a]) (void)hipStreamDestroy(aux[i][a]);
-      aux[i][a] = nullptr;
-      if (ev_join[i][a]) (void)hipEventDestroy(ev_join[i][a]);
-      ev_join[i][a] = nullptr;
-    }
-  }
   stream = nullptr;
   delete fold;
   fold = nullptr;
@@ -891,20 +911,8 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   g->batch = batch;
   g->device = device;
   make_flat_consts(g->fc);
-  // One stream by default; per-slot and per-kernel streams only for experiments
-  // (G1S_SLOT_STREAMS / G1S_K3_STREAMS): creating streams costs ~0.1-0.2 ms each.
-  const bool want_slot = getenv("G1S_SLOT_STREAMS") != nullptr, want_k3 = getenv("G1S_K3_STREAMS") != nullptr;
   bool streams_ok = acquire_streams(device, g->ss);
-  g->slot_stream[0] = g->ss.compute;
-  if (streams_ok && want_slot)
-    streams_ok = hipStreamCreateWithFlags(&g->slot_stream[1], hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; i < 2 && streams_ok && want_k3; ++i) {
-    streams_ok = hipEventCreateWithFlags(&g->ev_fork[i], hipEventDisableTiming) == hipSuccess;
-    for (int a = 0; a < 3 && streams_ok; ++a)
-      streams_ok = hipStreamCreateWithFlags(&g->aux[i][a], hipStreamNonBlocking) == hipSuccess &&
-                   hipEventCreateWithFlags(&g->ev_join[i][a], hipEventDisableTiming) == hipSuccess;
-  }
-  g->stream = g->slot_stream[0];
+  g->stream = g->ss.compute;
   // the p/255 table is the same for every generator: one device copy per device, kept
   {
     static std::mutex lut_mutex;
@@ -928,14 +936,16 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
     delete g;
     return nullptr;
   }
-  if (!records_only && !latest_only) {
-    g->fold = new NoiseFold(fps_num, fps_den, lag);
-    g->pool = shared_pool();
-  }
+  if (!records_only && !latest_only) g->fold = new NoiseFold(fps_num, fps_den, lag);
+  g->pool = shared_pool();
+  g->drainer = std::thread([g] { g->drainer_main(); });
   return g;
 }
 
+// errors of queued frames surface once, on a later call (the drainer thread records them)
 static int take_deferred(g1s_diff *g) {
+  std::lock_guard<std::mutex> lk(g->dm);
+  if (g->sticky) return g->sticky;
   const int rc = g->deferred;
   g->deferred = G1S_OK;
   return rc;
@@ -944,8 +954,10 @@ static int take_deferred(g1s_diff *g) {
 int g1s_diff_frame(g1s_diff_t *g, const g1s_frame_t *source, const g1s_frame_t *denoised) {
   if (!g) return G1S_ERR_INVALID;
   if (g->finished) return g->fail(G1S_ERR_STATE, "generator already finished");
-  if (g->sticky) return g->sticky;
-  if (g->deferred) return take_deferred(g);
+  {
+    const int pending = take_deferred(g);
+    if (pending) return pending;
+  }
   (void)hipSetDevice(g->device);
   const int rc = g->append(source, denoised);
   if (rc) return rc;
@@ -964,12 +976,10 @@ int g1s_diff_sync(g1s_diff_t *g) {
   if (!g) return G1S_ERR_INVALID;
   (void)hipSetDevice(g->device);
   if (g->geometry_set) {
-    int rc = g->submit(g->cur);
+    const int rc = g->submit(g->cur);
     if (rc) return rc;
-    rc = g->drain_all();
-    if (rc && g->deferred == G1S_OK) g->deferred = rc;
+    (void)g->drain_all();
   }
-  if (g->sticky) return g->sticky;
   return take_deferred(g);
 }
 
@@ -1032,6 +1042,7 @@ int g1s_diff_take_records(g1s_diff_t *g, void *buf, size_t cap_bytes, size_t *n_
   if (!g->records_only) return g->fail(G1S_ERR_STATE, "not a records_only generator");
   const int rc = g1s_diff_sync(g);
   if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g->dm);
   if (n_frames) *n_frames = g->records_out_frames;
   if (g->records_out.size() > cap_bytes) return g->fail(G1S_ERR_CAPACITY, "record buffer too small");
   if (!g->records_out.empty()) std::memcpy(buf, g->records_out.data(), g->records_out.size());
@@ -1046,12 +1057,32 @@ int g1s_diff_take_latest(g1s_diff_t *g, int sync, void *buf, size_t cap_bytes, s
   if (sync) {
     const int rc = g1s_diff_sync(g);
     if (rc) return rc;
+  } else {
+    // everything but the two most recently queued batches has been delivered when this returns
+    uint64_t upto;
+    {
+      std::lock_guard<std::mutex> lk(g->dm);
+      upto = g->submitted >= 2 ? g->submitted - 2 : 0;
+    }
+    g->wait_drained(upto);
   }
-  if (n_frames) *n_frames = g->latest_out_frames;
-  if (g->latest_out.size() > cap_bytes) return g->fail(G1S_ERR_CAPACITY, "latest buffer too small");
-  if (!g->latest_out.empty()) std::memcpy(buf, g->latest_out.data(), g->latest_out.size());
-  g->latest_out.clear();
-  g->latest_out_frames = 0;
+  std::lock_guard<std::mutex> lk(g->dm);
+  // whole batches, in order: all of them after a sync, otherwise exactly those before the two most recent
+  // (so that ranks that run ahead by different amounts still deliver the same batches in the same round)
+  const uint64_t upto_batch = sync ? g->delivered + g->latest_batches.size()
+                                   : std::min<uint64_t>(g->delivered + g->latest_batches.size(),
+                                                        g->submitted >= 2 ? g->submitted - 2 : 0);
+  size_t frames = 0;
+  uint64_t nb = 0;
+  while (g->delivered + nb < upto_batch) frames += g->latest_batches[nb++];
+  const size_t bs = latest_blob_size(g->lag);
+  if (n_frames) *n_frames = frames;
+  if (frames * bs > cap_bytes) return g->fail(G1S_ERR_CAPACITY, "latest buffer too small");
+  if (frames) std::memcpy(buf, g->latest_out.data(), frames * bs);
+  g->latest_out.erase(g->latest_out.begin(), g->latest_out.begin() + frames * bs);
+  g->latest_out_frames -= frames;
+  for (uint64_t i = 0; i < nb; ++i) g->latest_batches.pop_front();
+  g->delivered += nb;
   return G1S_OK;
 }
 

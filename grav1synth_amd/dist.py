@@ -123,14 +123,18 @@ class StreamingShardedDiff:
         blobs = self.generator.take_latest(2 * self.batch, sync=sync)
         per_rank = gather_latest_round(blobs, self._blob, 2 * self.batch, self.dist, self._dev)
         if self._fold is not None:
-            for b in per_rank:  # rank order == global batch order within the round
-                self._fold.push_latest_many(b)
+            # global order: batch by batch, ranks in order within a batch (a round carries one batch of
+            # every rank, the last round up to two)
+            nb = max((len(b) + self.batch - 1) // self.batch for b in per_rank) if per_rank else 0
+            for k in range(nb):
+                for b in per_rank:
+                    self._fold.push_latest_many(b[k * self.batch:(k + 1) * self.batch])
 
     def diff_prepared(self, prepared, sync_torch: bool = True) -> None:
         """Feeds ONE batch (this rank's next batch in the global order)."""
         self.generator.diff_prepared(prepared, sync_torch=sync_torch)
         if self.dist is not None:
-            self._round(sync=False)  # the states of the batch before this one (nothing on the first call)
+            self._round(sync=False)  # the states of the batch two before this one (nothing on the first two calls)
 
     def finish(self) -> Optional[List[GrainTableSegment]]:
         if self.dist is None:

@@ -138,9 +138,10 @@ int g1s_record_init(void *rec, size_t cap_bytes, uint32_t width, uint32_t height
 /* Copies the records of all frames queued so far (frame order) into buf and
  * clears the internal list.  records_only generators only. */
 int g1s_diff_take_records(g1s_diff_t *, void *buf, size_t cap_bytes, size_t *n_frames);
-/* records_only == 2: the latest states (g1s_latest_size() bytes each, frame order) of the
- * frames whose batches are complete (sync = 0: without waiting; a batch is complete at the
- * latest when the next one has been queued) or of all frames queued so far (sync = 1). */
+/* records_only == 2: latest states (g1s_latest_size() bytes each, frame order), whole batches:
+ * sync = 0: exactly the batches queued before the two most recent ones that were not handed out yet
+ * (waits for them if need be; deterministic, so that ranks deliver the same batches in the same
+ * round); sync = 1: everything queued so far. */
 int g1s_diff_take_latest(g1s_diff_t *, int sync, void *buf, size_t cap_bytes, size_t *n_frames);
 size_t g1s_latest_size(uint32_t ar_coeff_lag);
 /* The per-frame half of the fold on the host: record -> latest state.  Thread-safe.  A frame
