@@ -221,12 +221,16 @@ enum {
 };
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 __device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
-// pk / pu / pd: the 32 packed pixels of row yi and of the rows above / below it
+// pk / pu / pd: the 32 packed pixels of row yi and of the rows above / below it (pu, pd are only used
+// for yi = 1 .. 30).  s = this row's share of the 14 block sums.  Sums over shifted copies of a row or
+// of a neighbouring row are taken from the row itself where they telescope:
+//   sum_{x=1..30} p(x+1)^2 + p(x-1)^2 = 2 sum_x p^2 - p0^2 - p1^2 - p30^2 - p31^2,
+//   sum_{x=1..30} p(x+1) - p(x-1)     = p30 + p31 - p0 - p1,
+//   sum_{yi=1..30} q(yi+1) + q(yi-1)  = sum_r q(r) ([r >= 2] + [r <= 29])   (q = interior-column sum of p^2),
+//   sum_{yi=1..30} i0(yi+1) - i0(yi-1) = i0(30) + i0(31) - i0(0) - i0(1).
 __device__ __forceinline__ void row_moments(const uint32_t (&pk)[8], const uint32_t (&pu)[8], const uint32_t (&pd)[8], int yi,
                                             int32_t (&s)[14]) {
-#pragma unroll
-  for (int i = 0; i < 14; ++i) s[i] = 0;
-  uint32_t rowsum = 0, sxu = 0, sax = 0;
+  uint32_t rowsum = 0, sxu = 0, sax = 0, pp = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     rowsum = sad4(pk[k], rowsum);
@@ -234,51 +238,62 @@ __device__ __forceinline__ void row_moments(const uint32_t (&pk)[8], const uint3
     // |xi - 16| for xi = 4k .. 4k+3
     const int a0 = abs(4 * k - 16), a1 = abs(4 * k + 1 - 16), a2 = abs(4 * k + 2 - 16), a3 = abs(4 * k + 3 - 16);
     sax = udot4(pk[k], (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24), sax);
+    pp = udot4(pk[k], pk[k], pp);
   }
+  const uint32_t p0 = pk[0] & 0xffu, p1 = (pk[0] >> 8) & 0xffu, p30 = (pk[7] >> 16) & 0xffu, p31 = pk[7] >> 24;
+  const uint32_t i0 = rowsum - p0 - p31;           // interior columns 1 .. 30
+  const uint32_t q = pp - p0 * p0 - p31 * p31;     // sum of p^2 over them
+  const bool inner = yi >= 1 && yi <= kBlock - 2;
   s[kM_S0] = (int32_t)rowsum;
   s[kM_SXU] = (int32_t)sxu;
   s[kM_SYU] = (int32_t)rowsum * yi;
   s[kM_SAX] = (int32_t)sax;
   s[kM_SAY] = (int32_t)rowsum * abs(yi - 16);
-  if (yi >= 1 && yi <= kBlock - 2) {
-    uint32_t i0 = 0, ixu = 0, ipp = 0, rr = 0, ll = 0, rl = 0, sr = 0, sl = 0, dd = 0, uu = 0, du = 0, sd = 0, su = 0;
-    uint32_t rd = 0, ru = 0, ld = 0, lu = 0;
+  s[kM_I0] = inner ? (int32_t)i0 : 0;
+  s[kM_IXU] = inner ? (int32_t)(sxu - 31u * p31) : 0;
+  s[kM_IYU] = inner ? (int32_t)i0 * yi : 0;
+  s[kM_IPP] = inner ? (int32_t)q : 0;
+  s[kM_DYY] = (int32_t)q * ((yi >= 2 ? 1 : 0) + (yi <= kBlock - 3 ? 1 : 0));
+  s[kM_DY] = yi >= kBlock - 2 ? (int32_t)i0 : (yi <= 1 ? -(int32_t)i0 : 0);
+  s[kM_DXX] = 0;
+  s[kM_DXY] = 0;
+  s[kM_DX] = 0;
+  if (inner) {
+    uint32_t rl = 0, du = 0, rd = 0, ru = 0, ld = 0, lu = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t m = k == 0 ? 0xffffff00u : (k == 7 ? 0x00ffffffu : 0xffffffffu);  // interior columns 1..30
-      const uint32_t pm = pk[k] & m;
-      i0 = sad4(pm, i0);
-      ixu = udot4(pm, 0x03020100u + 0x04040404u * (uint32_t)k, ixu);
-      ipp = udot4(pm, pk[k], ipp);
       // p(xi + 1), p(xi - 1) for xi = 4k .. 4k+3
       const uint32_t pr = __builtin_amdgcn_alignbyte(k < 7 ? pk[k + 1] : 0u, pk[k], 1) & m;
       const uint32_t pl = __builtin_amdgcn_alignbyte(pk[k], k > 0 ? pk[k - 1] : 0u, 3) & m;
-      const uint32_t dn = pd[k] & m, up = pu[k] & m;
-      rr = udot4(pr, pr, rr);
-      ll = udot4(pl, pl, ll);
       rl = udot4(pr, pl, rl);
-      sr = sad4(pr, sr);
-      sl = sad4(pl, sl);
-      dd = udot4(dn, dn, dd);
-      uu = udot4(up, up, uu);
-      du = udot4(dn, up, du);
-      sd = sad4(dn, sd);
-      su = sad4(up, su);
-      rd = udot4(pr, dn, rd);
-      ru = udot4(pr, up, ru);
-      ld = udot4(pl, dn, ld);
-      lu = udot4(pl, up, lu);
+      du = udot4(pd[k] & m, pu[k], du);
+      rd = udot4(pr, pd[k], rd);
+      ru = udot4(pr, pu[k], ru);
+      ld = udot4(pl, pd[k], ld);
+      lu = udot4(pl, pu[k], lu);
     }
-    s[kM_I0] = (int32_t)i0;
-    s[kM_IXU] = (int32_t)ixu;
-    s[kM_IYU] = (int32_t)i0 * yi;
-    s[kM_IPP] = (int32_t)ipp;
-    s[kM_DXX] = (int32_t)(rr + ll - 2u * rl);
-    s[kM_DYY] = (int32_t)(dd + uu - 2u * du);
+    s[kM_DXX] = (int32_t)(2u * pp - p0 * p0 - p1 * p1 - p30 * p30 - p31 * p31 - 2u * rl);
+    s[kM_DYY] -= (int32_t)(2u * du);
     s[kM_DXY] = (int32_t)rd - (int32_t)ru - (int32_t)ld + (int32_t)lu;
-    s[kM_DX] = (int32_t)sr - (int32_t)sl;
-    s[kM_DY] = (int32_t)sd - (int32_t)su;
+    s[kM_DX] = (int32_t)(p30 + p31) - (int32_t)(p0 + p1);
   }
+}
+
+// sums over the two 32-lane halves of a wave, N values at a time (DPP stages batched across the values);
+// totals in lanes 16 .. 31 and 48 .. 63
+template <int N>
+__device__ __forceinline__ void half_sums_dpp(int (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x4E, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x141, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x140, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x142, 0xa, 0xf, false);
 }
 
 // ---------------------------------------------------------------------------------
@@ -459,14 +474,10 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
     }
     int32_t m[14];
     row_moments(pk, pu, pd, yi, m);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-#pragma unroll
-      for (int i = 0; i < 14; ++i) m[i] += __shfl_xor(m[i], o, 32);
-    }
+    half_sums_dpp<14>(m);
     const int bxo = bx0 + b;
     // only blocks that lie inside the plane: the finder replicates edge pixels for the others, K0 does not
-    if (yi == 0 && bxo < g.nbw) {
+    if (yi == kBlock - 1 && bxo < g.nbw) {
       int32_t *out = mom + ((size_t)frame * g.nblocks + (size_t)by * g.nbw + bxo) * kMomInts;
 #pragma unroll
       for (int i = 0; i < 14; ++i) out[i] = m[i];

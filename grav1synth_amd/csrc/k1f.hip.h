@@ -53,12 +53,8 @@ __global__ __launch_bounds__(256) void k1_moments(const FrameTable ft, Geom g, i
   int32_t s[14];
   row_moments(pk, pu, pd, yi, s);
   // sum over the 32 rows of the block
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) {
-#pragma unroll
-    for (int i = 0; i < 14; ++i) s[i] += __shfl_xor(s[i], o, 32);
-  }
-  if (live && yi == 0) {
+  half_sums_dpp<14>(s);
+  if (live && yi == kBlock - 1) {
     int32_t *out = mom + ((size_t)frame * g.nblocks + blk) * kMomInts;
 #pragma unroll
     for (int i = 0; i < 14; ++i) out[i] = s[i];
