@@ -151,6 +151,10 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
+// a.lo * b.lo + a.hi * b.hi + c on packed i16
+__device__ __forceinline__ int pk_dot(uint32_t a, uint32_t b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
 __device__ __forceinline__ int pk_lo(uint32_t a) { return (int)(short)(a & 0xffffu); }
 __device__ __forceinline__ int pk_hi(uint32_t a) { return (int)a >> 16; }
 // running min / max of packed i16 -> does some value not fit int8 (symmetric: |v| > 127) ?
@@ -337,23 +341,24 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
     const int X0 = bx0 * kBlock + seg * 8;
     int sd = 0, sd2 = 0, ls = 0;
     uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0;
+    // a lane takes the rows 2p and 2p + 1 of its segment (the two luma rows under a 4:2:0 chroma row)
+    uint32_t d[2][4];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int row = (tid >> 4) + 16 * k;
+      const int row = 2 * (tid >> 4) + k;
       const int Y = by * kBlock + row;
-      uint32_t hs[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0}, d[4];
+      uint32_t hs[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0};
       if (active) {
         load_narrow<SBPS, 8>(fp.src[0], fp.src_stride[0], g.src_shift, (g.vec_mask & 1) != 0, X0, Y, g.W, g.H, hs);
         load_narrow<DBPS, 8>(fp.den[0], fp.den_stride[0], g.den_shift, (g.vec_mask & 8) != 0, X0, Y, g.W, g.H, hv);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        d[q] = pk_sub(hs[q], hv[q]);
-        mx = pk_max(mx, d[q]);
-        mn = pk_min(mn, d[q]);
-        const int a0 = pk_lo(d[q]), a1 = pk_hi(d[q]);
-        sd += a0 + a1;
-        sd2 += a0 * a0 + a1 * a1;
+        d[k][q] = pk_sub(hs[q], hv[q]);
+        mx = pk_max(mx, d[k][q]);
+        mn = pk_min(mn, d[k][q]);
+        sd = pk_dot(d[k][q], 0x00010001u, sd);
+        sd2 = pk_dot(d[k][q], d[k][q], sd2);
       }
       const uint32_t s_lo = pk_bytes(hs[0], hs[1]), s_hi = pk_bytes(hs[2], hs[3]);  // the 8 source pixels, packed
       ls = (int)__builtin_amdgcn_sad_u8(s_lo, 0u, (uint32_t)ls);
@@ -362,40 +367,35 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
       s_src[row][2 * seg + 1] = s_hi;
       if (active) {
         const size_t o = (size_t)(Y + kPadY) * ps.pitch[0] + kPadX + X0;
-        *reinterpret_cast<uint2 *>(fbase + ps.off_d[0] + o) = make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
+        *reinterpret_cast<uint2 *>(fbase + ps.off_d[0] + o) =
+            make_uint2(pk_bytes(d[k][0], d[k][1]), pk_bytes(d[k][2], d[k][3]));
       }
-      if (chroma) {
-        // L = sum of the (1 << sx) x (1 << sy) luma residuals under a chroma sample; the next
-        // row of the item sits 16 lanes up (same wave: a wave is 4 rows of 16 segments)
+    }
+    if (chroma && active) {
+      // L = sum of the (1 << sx) x (1 << sy) luma residuals under a chroma sample
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (sy && k) break;
+        const int Y = by * kBlock + 2 * (tid >> 4) + k;
+        const int cy = Y >> sy;
         uint32_t v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = sy ? pk_add(d[q], (uint32_t)__shfl_down((int)d[q], 16, 64)) : d[q];
-        const bool store_row = active && (sy == 0 || (row & 1) == 0);
-        const int cy = Y >> sy;
-        uint32_t tmx = 0, tmn = 0;
+        for (int q = 0; q < 4; ++q) v[q] = sy ? pk_add(d[0][q], d[1][q]) : d[k][q];
         if (sx) {
-          int L[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) L[q] = pk_lo(v[q]) + pk_hi(v[q]);
-          const uint32_t p0 = ((uint32_t)L[0] & 0xffffu) | ((uint32_t)L[1] << 16);
-          const uint32_t p1 = ((uint32_t)L[2] & 0xffffu) | ((uint32_t)L[3] << 16);
-          tmx = pk_max(p0, p1);
-          tmn = pk_min(p0, p1);
-          if (store_row)
-            *reinterpret_cast<uint32_t *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + (X0 >> 1)) = pk_bytes(p0, p1);
+          // horizontal pairs: lo + hi of every dword
+          const uint32_t p0 = ((uint32_t)pk_dot(v[0], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[1], 0x00010001u, 0) << 16);
+          const uint32_t p1 = ((uint32_t)pk_dot(v[2], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[3], 0x00010001u, 0) << 16);
+          lmx = pk_max(lmx, pk_max(p0, p1));
+          lmn = pk_min(lmn, pk_min(p0, p1));
+          *reinterpret_cast<uint32_t *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + (X0 >> 1)) = pk_bytes(p0, p1);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            tmx = pk_max(tmx, v[q]);
-            tmn = pk_min(tmn, v[q]);
+            lmx = pk_max(lmx, v[q]);
+            lmn = pk_min(lmn, v[q]);
           }
-          if (store_row)
-            *reinterpret_cast<uint2 *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + X0) =
-                make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
-        }
-        if (store_row) {
-          lmx = pk_max(lmx, tmx);
-          lmn = pk_min(lmn, tmn);
+          *reinterpret_cast<uint2 *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + X0) =
+              make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
         }
       }
     }
@@ -434,9 +434,8 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
         d[q] = pk_sub(hs[q], hv[q]);
         mx = pk_max(mx, d[q]);
         mn = pk_min(mn, d[q]);
-        const int a0 = pk_lo(d[q]), a1 = pk_hi(d[q]);
-        sd += a0 + a1;
-        sd2 += a0 * a0 + a1 * a1;
+        sd = pk_dot(d[q], 0x00010001u, sd);
+        sd2 = pk_dot(d[q], d[q], sd2);
       }
       const size_t o = (size_t)(Y + kPadY) * ps.pitch[1] + kPadX + X0;
       *reinterpret_cast<uint2 *>(fbase + (c == 1 ? ps.off_d[1] : ps.off_d[2]) + o) =
