@@ -546,9 +546,8 @@ int g1s_diff::submit(int si) {
       if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, fstream, ft, g, mom);
       else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, fstream, ft, g, mom);
     }
-    // K0 leaves out blocks that reach over the plane (the finder replicates edge pixels there): literal kernel
     hipLaunchKernelGGL(k1_certify, dim3((g.nblocks + 255) / 256, B), dim3(256), 0, fstream, g, fc, (const int32_t *)mom,
-                       sl.d_records, sl.d_flags, cl, force_literal, fast_ok ? 1 : 0);
+                       sl.d_records, sl.d_flags, cl, force_literal);
     dim3 grid((g.nblocks + 63) / 64, B);
     if (g.src_bps == 1)
       hipLaunchKernelGGL((k1_flat_features<1, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,

@@ -284,6 +284,22 @@ __device__ __forceinline__ void row_moments(const uint32_t (&pk)[8], const uint3
   }
 }
 
+// the bytes of a packed 32-pixel row from column wv (1 .. 31) on := the byte of column wv - 1
+__device__ __forceinline__ void replicate_columns(uint32_t (&p)[8], int wv) {
+  const int lk = (wv - 1) >> 2, lb = (wv - 1) & 3;
+  uint32_t last = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k == lk) last = (p[k] >> (8 * lb)) & 0xffu;
+  const uint32_t fill = last * 0x01010101u;
+  const uint32_t keep = lb == 3 ? 0xffffffffu : ((1u << (8 * (lb + 1))) - 1u);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k > lk) p[k] = fill;
+    else if (k == lk) p[k] = (p[k] & keep) | (fill & ~keep);
+  }
+}
+
 // sums over the two 32-lane halves of a wave, N values at a time (DPP stages batched across the values);
 // totals in lanes 16 .. 31 and 48 .. 63
 template <int N>
@@ -465,17 +481,25 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
   if (mom != nullptr && tid < 128) {
     const int b = tid >> 5, yi = tid & 31;
     uint32_t pk[8], pu[8], pd[8];
+    // the finder's block replicates the last row / column of the plane (extract_block): rows by index
+    // clamp, columns by byte fill
+    const int hv = min(kBlock, g.H - by * kBlock), wv = min(kBlock, g.W - (bx0 + b) * kBlock);
+    const int r0 = min(yi, hv - 1), r1 = min(max(yi - 1, 0), hv - 1), r2 = min(yi + 1, hv - 1);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      pk[k] = s_src[yi][8 * b + k];
-      pu[k] = s_src[max(yi - 1, 0)][8 * b + k];
-      pd[k] = s_src[min(yi + 1, kBlock - 1)][8 * b + k];
+      pk[k] = s_src[r0][8 * b + k];
+      pu[k] = s_src[r1][8 * b + k];
+      pd[k] = s_src[r2][8 * b + k];
+    }
+    if (wv > 0 && wv < kBlock) {
+      replicate_columns(pk, wv);
+      replicate_columns(pu, wv);
+      replicate_columns(pd, wv);
     }
     int32_t m[14];
     row_moments(pk, pu, pd, yi, m);
     half_sums_dpp<14>(m);
     const int bxo = bx0 + b;
-    // only blocks that lie inside the plane: the finder replicates edge pixels for the others, K0 does not
     if (yi == kBlock - 1 && bxo < g.nbw) {
       int32_t *out = mom + ((size_t)frame * g.nblocks + (size_t)by * g.nbw + bxo) * kMomInts;
 #pragma unroll

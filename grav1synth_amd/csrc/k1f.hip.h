@@ -139,15 +139,13 @@ struct CertifyLists {
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k1_certify(Geom g, FlatConsts fc, const int32_t *__restrict__ mom,
                                                   uint8_t *__restrict__ records, uint8_t *__restrict__ flags,
-                                                  CertifyLists cl, int force_literal, int full_blocks_only) {
+                                                  CertifyLists cl, int force_literal) {
   const int frame = blockIdx.y;
   const int blk = (int)blockIdx.x * 256 + (int)threadIdx.x;
   bool certain = false;
   float score_out = 0.0f;
   uint8_t flag_out = 0;
-  // moments from K0 exist only for blocks that lie inside the plane
-  const bool has_moments = !full_blocks_only || ((blk % g.nbw + 1) * kBlock <= g.W && (blk / g.nbw + 1) * kBlock <= g.H);
-  if (blk < g.nblocks && !force_literal && has_moments) {
+  if (blk < g.nblocks && !force_literal) {
     const int32_t *m = mom + ((size_t)frame * g.nblocks + blk) * kMomInts;
     const double S0 = m[kM_S0], SX = (double)m[kM_SXU] - 16.0 * m[kM_S0], SY = (double)m[kM_SYU] - 16.0 * m[kM_S0];
     const double SAX = m[kM_SAX], SAY = m[kM_SAY];
