@@ -122,7 +122,7 @@ Pool *shared_pool() {
 }
 std::mutex g_pool_mutex;  // parallel_for is not re-entrant: one fold batch at a time
 
-constexpr int kSlots = 3;  // batches in flight: one in the kernels, one in D2H + fold, one being filled
+constexpr int kSlots = 4;  // batches in flight: pixel pass + finder, accumulation, D2H + fold, being filled
 
 struct Slot {
   FramePlanes *h_planes = nullptr;  // pinned
@@ -171,6 +171,7 @@ struct StreamSet {
   hipStream_t compute = nullptr, copy = nullptr, flat = nullptr;
   hipEvent_t kernels_done[kSlots] = {};
   hipEvent_t mask_done[kSlots] = {};
+  hipEvent_t pix_done[kSlots] = {};
 };
 std::vector<StreamSet> g_stream_cache;
 bool acquire_streams(int device, StreamSet &out) {
@@ -186,15 +187,17 @@ bool acquire_streams(int device, StreamSet &out) {
   }
   out = StreamSet{};
   out.device = device;
-  // the accumulation chain (many small latency-bound kernels) outranks the pixel pass of the next batch
+  // the side stream (finder chain, window planes, area lists: small latency-bound kernels) outranks the
+  // main stream's big kernels, next to which it runs
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = more urgent
-  bool ok = hipStreamCreateWithPriority(&out.compute, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+  bool ok = hipStreamCreateWithPriority(&out.compute, hipStreamNonBlocking, prio_lo) == hipSuccess &&
             hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_lo) == hipSuccess;
+            hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_hi) == hipSuccess;
   for (int i = 0; i < kSlots && ok; ++i)
     ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&out.pix_done[i], hipEventDisableTiming) == hipSuccess;
   return ok;
 }
 void release_streams(StreamSet &ss) {
@@ -254,6 +257,7 @@ struct g1s_diff {
   SlotKey slot_key{};
   Slot slots[kSlots];
   int cur = 0;
+  int pending = -1;  // slot whose front half is queued and whose back half is not
   // The API thread queues frames and launches batches; the drainer thread waits for a batch's records,
   // runs the fold on them and frees the slot.  Everything below dm is shared between the two.
   std::thread drainer;
@@ -279,7 +283,7 @@ struct g1s_diff {
   int sticky = G1S_OK;  // a fold error kills the generator (the reference `?`-propagates out of main)
   bool finished = false;
   bool timing = false;
-  bool flat_literal = false;  // flat-block finder: literal f64 kernel for every block
+  int flat_literal = 0;  // flat-block finder: literal f64 evaluation of every block (1: lane per block, 2: wave per block)
   g1s_stats_t stats{};
 
   int fail(int code, const std::string &msg) {
@@ -293,7 +297,12 @@ struct g1s_diff {
 
   int set_geometry(const g1s_frame_t *s, const g1s_frame_t *d);
   int append(const g1s_frame_t *s, const g1s_frame_t *d);
-  int submit(int si);
+  int submit(int si);        // front half now; back half now or with the next batch's front half
+  int launch_front(int si);  // zero, pixel pass, flat-block finder, window planes, area lists
+  int launch_back(int si);   // accumulation kernels, records D2H, hand-over to the drainer
+  int flush_pending();
+  Geom batch_geom(const Slot &sl) const;
+  QParams make_qparams(const Slot &sl) const;
   int drain_slot(int si);   // drainer thread
   void drainer_main();
   int drain_all();          // API thread: wait until everything submitted is drained
@@ -467,9 +476,7 @@ int g1s_diff::append(const g1s_frame_t *s, const g1s_frame_t *d) {
   return G1S_OK;
 }
 
-int g1s_diff::submit(int si) {
-  Slot &sl = slots[si];
-  if (sl.count == 0) return G1S_OK;
+Geom g1s_diff::batch_geom(const Slot &sl) const {
   const uint32_t B = sl.count;
   Geom g = geom;
   int fast = 1;
@@ -485,11 +492,61 @@ int g1s_diff::submit(int si) {
     }
   }
   g.vec_mask = vec_mask;
-  hipStream_t stream = ss.compute;  // (shadows the member)
-  // The flat-block finder of batch N+1 (K1: one f64 lane per block, one wave per SIMD, latency bound)
-  // runs on its own stream next to the accumulation kernels of batch N.
+  return g;
+}
+
+// A batch runs in two halves.  Front: zero fills and the pixel pass (K0, HBM bound) on the main stream,
+// then the flat-block finder, the window planes and the area lists -- small latency-bound kernels -- on the
+// side stream.  Back: the accumulation kernels on the main stream, the records D2H, the hand-over to the
+// drainer.  The back half of batch N is queued behind the front half of batch N + 1: the main stream runs
+// K0(N + 1), accumulation(N), K0(N + 2), ... back to back (the big kernels never share the chip, which
+// only stretches them), and the side stream's chain of N + 1 -- a few thousand waves, ~0.1 ms of latency --
+// runs next to accumulation(N) and is long done when accumulation(N + 1) comes up.
+int g1s_diff::submit(int si) {
+  Slot &sl = slots[si];
+  if (sl.count == 0) return G1S_OK;
   static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
+  static const bool no_defer = getenv("G1S_NO_DEFER") != nullptr;     // debugging aid
+  {
+    std::lock_guard<std::mutex> lk(dm);
+    slot_busy[si] = true;  // until the drainer has folded it
+  }
+  int rc = launch_front(si);
+  if (rc) return rc;
+  const int prev = pending;
+  pending = si;
+  if (prev >= 0) {
+    rc = launch_back(prev);
+    if (rc) return rc;
+  }
+  if (one_stream || no_defer || timing || !ss.flat) {
+    rc = flush_pending();
+    if (rc) return rc;
+  }
+  {
+    // move on to the next slot; wait if the drainer has not freed it yet (back-pressure)
+    std::unique_lock<std::mutex> lk(dm);
+    cur = (si + 1) % kSlots;
+    cv_free.wait(lk, [&] { return !slot_busy[cur]; });
+  }
+  return G1S_OK;
+}
+
+int g1s_diff::flush_pending() {
+  if (pending < 0) return G1S_OK;
+  const int si = pending;
+  pending = -1;
+  return launch_back(si);
+}
+
+int g1s_diff::launch_front(int si) {
+  Slot &sl = slots[si];
+  const uint32_t B = sl.count;
+  Geom g = batch_geom(sl);
+  static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
+  hipStream_t stream = ss.compute;                                        // main stream (shadows the member)
   hipStream_t fstream = (one_stream || timing || !ss.flat) ? stream : ss.flat;  // per-kernel timing: one stream
+  hipStream_t pstream = stream;                                           // pixel pass
   FrameTable ft;
   std::memcpy(ft.f, sl.h_planes, sizeof(FramePlanes) * B);
   if (B < (uint32_t)kMaxBatch) std::memset(ft.f + B, 0, sizeof(FramePlanes) * (kMaxBatch - B));
@@ -511,17 +568,18 @@ int g1s_diff::submit(int si) {
     }
     z.ptr[5] = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * (kMomInts + 1);  // literal-list counts
     z.ndw[5] = (uint32_t)batch;
-    hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, fstream, z);
+    hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, pstream, z);
   }
   sl.timed = timing;
-  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], fstream));
+  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], pstream));
   const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   const size_t cls_bytes_q = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   {
     // flat-block features: integer moments + certified evaluation; the literal f64 kernel only for
     // the blocks the certificate leaves open (G1S_K1_LITERAL=1 / g1s_diff_set_flat_finder: for every block)
     static const int env_literal = getenv("G1S_K1_LITERAL") ? atoi(getenv("G1S_K1_LITERAL")) : 0;
-    const int force_literal = (env_literal || flat_literal) ? 1 : 0;
+    const int literal_mode = flat_literal ? flat_literal : env_literal;
+    const int force_literal = literal_mode ? 1 : 0;
     int32_t *mom = sl.d_k1;
     CertifyLists cl;
     cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
@@ -529,74 +587,101 @@ int g1s_diff::submit(int si) {
     if (fast_ok) {
       // K0: one pass over the source / denoised planes -> int8 residual and L planes, block statistics and
       // the finder's moments of the luma source (it needs nothing from the finder: it runs before it)
-      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], fstream));
+      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
       const dim3 gr(8 * ((((g.nbw + 3) / 4) * g.nbh + 7) / 8), 1, B);
       uint8_t *badp = sl.d_defer + cls_bytes_q;
 #define G1S_K0(SB, DB) \
-  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, fstream, ft, g, ps, sl.d_k0, badp, sl.d_records, \
+  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, pstream, ft, g, ps, sl.d_k0, badp, sl.d_records, \
                      force_literal ? (int32_t *)nullptr : mom)
       if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);
       else if (g.src_bps == 1) G1S_K0(1, 2);
       else if (g.den_bps == 1) G1S_K0(2, 1);
       else G1S_K0(2, 2);
 #undef G1S_K0
-      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], fstream));
+      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
     } else if (!force_literal) {
       const dim3 mg((g.nblocks + 7) / 8, B);
-      if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, fstream, ft, g, mom);
-      else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, fstream, ft, g, mom);
+      if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
+      else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, pstream, ft, g, mom);
+    }
+    if (pstream != fstream) {  // the finder chain: on the side stream, behind the pixel pass
+      HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
+      HIP_TRY(hipStreamWaitEvent(fstream, ss.pix_done[si], 0));
     }
     hipLaunchKernelGGL(k1_certify, dim3((g.nblocks + 255) / 256, B), dim3(256), 0, fstream, g, fc, (const int32_t *)mom,
                        sl.d_records, sl.d_flags, cl, force_literal);
-    dim3 grid((g.nblocks + 63) / 64, B);
-    if (g.src_bps == 1)
-      hipLaunchKernelGGL((k1_flat_features<1, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
-                         (const uint32_t *)cl.list, (const uint32_t *)cl.count);
-    else
-      hipLaunchKernelGGL((k1_flat_features<2, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
-                         (const uint32_t *)cl.list, (const uint32_t *)cl.count);
+    if (literal_mode == 1) {  // every block: one lane per block
+      dim3 grid((g.nblocks + 63) / 64, B);
+      if (g.src_bps == 1)
+        hipLaunchKernelGGL((k1_flat_features<1, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
+                           (const uint32_t *)cl.list, (const uint32_t *)cl.count);
+      else
+        hipLaunchKernelGGL((k1_flat_features<2, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
+                           (const uint32_t *)cl.list, (const uint32_t *)cl.count);
+    } else {  // the few blocks the certificate leaves open (mode 2, a test aid: every block): one wave per block
+      dim3 grid(kFbGrid, B);
+      if (g.src_bps == 1)
+        hipLaunchKernelGGL(k1_flat_block<1>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
+                           (const uint32_t *)cl.list, (const uint32_t *)cl.count);
+      else
+        hipLaunchKernelGGL(k1_flat_block<2>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
+                           (const uint32_t *)cl.list, (const uint32_t *)cl.count);
+    }
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
   hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
-  if (fstream != stream) {  // the accumulation chain of this batch starts when its mask is there
-    HIP_TRY(hipEventRecord(ss.mask_done[si], fstream));
-    HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));
+  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
+  if (fast_ok) {
+    // the window bit planes and the area lists need the flat mask: small kernels after K2
+    const QParams qp = make_qparams(sl);
+    const int kinds = g.nplanes == 3 ? 2 : 1;
+    const uint32_t wdw = std::max(ps.wpitch[0], kinds == 2 ? ps.wpitch[1] : 0u) / 4;
+    hipLaunchKernelGGL(k3_windows, dim3((wdw + 63) / 64, 4 * g.nbh, B * kinds), dim3(64), 0, fstream, g, ps, sl.d_k0,
+                       (const uint8_t *)sl.d_records);
+    hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, B), dim3(kClsThreads), 0, fstream, g,
+                       (const uint8_t *)sl.d_records, qp);
   }
-  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], stream));
+  if (fstream != stream) HIP_TRY(hipEventRecord(ss.mask_done[si], fstream));
+  HIP_TRY(hipGetLastError());
+  return G1S_OK;
+}
+
+QParams g1s_diff::make_qparams(const Slot &sl) const {
+  QParams qp;
+  static const bool force_generic = getenv("G1S_MIXED_GENERIC") != nullptr;  // debugging aid
+  qp.mixed_fast = force_generic ? 0 : 1;
+  qp.lagacc = reinterpret_cast<long long *>(sl.d_partials);
+  qp.paracc = qp.lagacc + (size_t)batch * 3 * kQPart;
+  const size_t cls_bytes = ((size_t)geom.nblocks * 2 * batch + 15) & ~size_t(15);
+  qp.cls = sl.d_defer;
+  qp.bad = sl.d_defer + cls_bytes;
+  qp.lists = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes);
+  qp.counts = qp.lists + (size_t)batch * 6 * geom.nblocks;
+  qp.pg_cap = pg_cap;
+  qp.pglist = sl.d_pgl;
+  qp.pgcount = sl.d_pgl + (size_t)batch * 2 * pg_cap;
+  qp.planes = sl.d_k0;
+  qp.ps = ps;
+  return qp;
+}
+
+int g1s_diff::launch_back(int si) {
+  Slot &sl = slots[si];
+  const uint32_t B = sl.count;
+  Geom g = batch_geom(sl);
+  static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
+  hipStream_t stream = ss.compute;
+  const bool side = !(one_stream || sl.timed || !ss.flat);
+  if (side) HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));  // the mask, the window planes, the area lists
+  FrameTable ft;
+  std::memcpy(ft.f, sl.h_planes, sizeof(FramePlanes) * B);
+  if (B < (uint32_t)kMaxBatch) std::memset(ft.f + B, 0, sizeof(FramePlanes) * (kMaxBatch - B));
+  const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   if (fast_ok) {
     // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
     // then the generic int32 kernel on mixed / deferred areas
-    QParams qp;
-    static const bool force_generic = getenv("G1S_MIXED_GENERIC") != nullptr;  // debugging aid
-    qp.mixed_fast = force_generic ? 0 : 1;
-    qp.lagacc = reinterpret_cast<long long *>(sl.d_partials);
-    qp.paracc = qp.lagacc + (size_t)batch * 3 * kQPart;
-    const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
-    qp.cls = sl.d_defer;
-    qp.bad = sl.d_defer + cls_bytes;
-    qp.lists = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes);
-    qp.counts = qp.lists + (size_t)batch * 6 * g.nblocks;
-    qp.pg_cap = pg_cap;
-    qp.pglist = sl.d_pgl;
-    qp.pgcount = sl.d_pgl + (size_t)batch * 2 * pg_cap;
-    qp.planes = sl.d_k0;
-    qp.ps = ps;
-    // The K0 -> K3 chain runs in sub-batches: the int8 planes of one sub-batch (27 MB per 4K frame) should
-    // still be in the 256 MB Infinity Cache when the accumulation kernels read them back.
-    static const int sub_env = getenv("G1S_SUB") ? atoi(getenv("G1S_SUB")) : 0;  // tuning aid
-    const uint32_t sub = sub_env > 0 ? (uint32_t)sub_env : B;
-    for (uint32_t f0 = 0; f0 < B; f0 += sub) {
-    const uint32_t Bs = std::min(sub, B - f0);
-    g.frame0 = (int)f0;
-    {
-      // the window bit planes need the flat mask: a small kernel after K2
-      const int kinds = g.nplanes == 3 ? 2 : 1;
-      const uint32_t wdw = std::max(ps.wpitch[0], kinds == 2 ? ps.wpitch[1] : 0u) / 4;
-      hipLaunchKernelGGL(k3_windows, dim3((wdw + 63) / 64, 4 * g.nbh, Bs * kinds), dim3(64), 0, stream, g, ps, sl.d_k0,
-                         (const uint8_t *)sl.d_records);
-    }
-    hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, Bs), dim3(kClsThreads), 0, stream, g,
-                       (const uint8_t *)sl.d_records, qp);
+    const QParams qp = make_qparams(sl);
+    const uint32_t Bs = B;
     const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
     // One round of workgroups: as many per frame as stay resident together (occupancy x CUs / batch,
     // a multiple of 8 for the XCD-aware list slices), but never more than 128 areas each (int32 sums).
@@ -634,8 +719,6 @@ int g1s_diff::submit(int si) {
     hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, Bs), dim3(256), 0, stream, g, qp, sl.d_records);
     const int chunks = std::min(64, g.nblocks);
     hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, Bs), dim3(256), 0, stream, ft, g, qp, sl.d_records);
-    }
-    g.frame0 = 0;
   } else {
     const int chunks = std::min(kK3Chunks, g.nblocks);
     hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g, sl.d_records,
@@ -653,13 +736,9 @@ int g1s_diff::submit(int si) {
   stats.launches_ar_accumulate++;
   {
     std::unique_lock<std::mutex> lk(dm);
-    slot_busy[si] = true;
     in_flight.push_back(si);
     ++submitted;
     cv_work.notify_one();
-    // move on to the next slot; wait if the drainer has not freed it yet (back-pressure)
-    cur = (si + 1) % kSlots;
-    cv_free.wait(lk, [&] { return !slot_busy[cur]; });
   }
   return G1S_OK;
 }
@@ -975,7 +1054,9 @@ int g1s_diff_sync(g1s_diff_t *g) {
   if (!g) return G1S_ERR_INVALID;
   (void)hipSetDevice(g->device);
   if (g->geometry_set) {
-    const int rc = g->submit(g->cur);
+    int rc = g->submit(g->cur);
+    if (rc) return rc;
+    rc = g->flush_pending();
     if (rc) return rc;
     (void)g->drain_all();
   }
@@ -1197,9 +1278,10 @@ int g1s_diff_get_stats(const g1s_diff_t *g, g1s_stats_t *out) {
   *out = g->stats;
   return G1S_OK;
 }
-int g1s_diff_set_flat_finder(g1s_diff_t *g, int literal_only) {
+int g1s_diff_set_flat_finder(g1s_diff_t *g, int mode) {
   if (!g) return G1S_ERR_INVALID;
-  g->flat_literal = literal_only != 0;
+  if (mode < 0 || mode > 2) return g->fail(G1S_ERR_INVALID, "flat finder mode must be 0, 1 or 2");
+  g->flat_literal = mode;
   return G1S_OK;
 }
 int g1s_diff_set_timing(g1s_diff_t *g, int enable) {

@@ -162,6 +162,35 @@ __device__ __forceinline__ void narrow_row(const RowRaw<BPS> &r, int shift, uint
   }
 }
 
+// The finder's decision from the five interior sums (FlatBlockFinder::run after the loops): the four
+// thresholds -> flag, the sigmoid -> f32 score.
+__device__ __forceinline__ void flat_decide(double Gxx, double Gxy, double Gyy, double var, double mean, const Geom &g,
+                                            uint8_t *__restrict__ records, uint8_t *__restrict__ flags, int frame, int blk) {
+  const double nf = (double)((kBlock - 2) * (kBlock - 2));
+  mean /= nf;
+  Gxx /= nf;
+  Gxy /= nf;
+  Gyy /= nf;
+  var = var / nf - mean * mean;
+  const double trace = Gxx + Gyy;
+  const double det = Gxx * Gyy - Gxy * Gxy;
+  double disc = trace * trace - 4.0 * det;
+  if (!(disc > 0.0)) disc = 0.0;
+  const double sq = sqrt(disc);
+  const double e1 = (trace + sq) / 2.0;
+  const double e2 = (trace - sq) / 2.0;
+  const double norm = e1;
+  const double ratio = e1 / (e2 > 1e-6 ? e2 : 1e-6);
+  const double kTrace = 0.15 / 1024.0, kRatio = 1.25, kNorm = 0.08 / 1024.0, kVar = 0.005 / 1024.0;
+  const bool is_flat = (trace < kTrace) && (ratio < kRatio) && (norm < kNorm) && (var > kVar);
+  double sw = -6682.0 * var + -0.2056 * ratio + 13087.0 * trace + -12434.0 * norm + 2.5694;
+  sw = sw < -25.0 ? -25.0 : (sw > 100.0 ? 100.0 : sw);
+  const float score = (float)(1.0 / (1.0 + exp(-sw)));
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  reinterpret_cast<float *>(rec + g.off_scores)[blk] = var > kVar ? score : 0.0f;
+  flags[(size_t)frame * g.nblocks + blk] = is_flat ? 255 : 0;
+}
+
 // ----------------------------------------------------------------------------
 // K1: flat-block features.  One lane per 32x32 block; every f64 sum runs in the
 // reference's order (k = 0..1023 raster for the plane fit, (yi, xi) raster over
@@ -298,29 +327,97 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom
     grad_row(yi + 1, rb, ra);  // rb: row yi   -> row yi+2
   }
 
-  const double nf = (double)((kBlock - 2) * (kBlock - 2));
-  mean /= nf;
-  Gxx /= nf;
-  Gxy /= nf;
-  Gyy /= nf;
-  var = var / nf - mean * mean;
-  const double trace = Gxx + Gyy;
-  const double det = Gxx * Gyy - Gxy * Gxy;
-  double disc = trace * trace - 4.0 * det;
-  if (!(disc > 0.0)) disc = 0.0;
-  const double sq = sqrt(disc);
-  const double e1 = (trace + sq) / 2.0;
-  const double e2 = (trace - sq) / 2.0;
-  const double norm = e1;
-  const double ratio = e1 / (e2 > 1e-6 ? e2 : 1e-6);
-  const double kTrace = 0.15 / 1024.0, kRatio = 1.25, kNorm = 0.08 / 1024.0, kVar = 0.005 / 1024.0;
-  const bool is_flat = (trace < kTrace) && (ratio < kRatio) && (norm < kNorm) && (var > kVar);
-  double sw = -6682.0 * var + -0.2056 * ratio + 13087.0 * trace + -12434.0 * norm + 2.5694;
-  sw = sw < -25.0 ? -25.0 : (sw > 100.0 ? 100.0 : sw);
-  const float score = (float)(1.0 / (1.0 + exp(-sw)));
-  uint8_t *rec = records + (size_t)frame * g.rec_size;
-  reinterpret_cast<float *>(rec + g.off_scores)[blk] = var > kVar ? score : 0.0f;
-  flags[(size_t)frame * g.nblocks + blk] = is_flat ? 255 : 0;
+  flat_decide(Gxx, Gxy, Gyy, var, mean, g, records, flags, frame, blk);
+}
+
+// ----------------------------------------------------------------------------
+// k1_flat_block<BPS>: the same literal evaluation, one WAVE per listed block (the few blocks the
+// certified path leaves open: a lane-per-block launch of them is one long serial f64 chain per lane,
+// ~0.1 ms whatever their number).  The products / residuals / gradient terms of the 1024 (900)
+// pixels are worked out in parallel and laid down in LDS in raster order; every sum the reference
+// takes sequentially is then one lane adding its array front to back from 0.0 (3 chains for the
+// plane fit, 5 for the gradient sums), so each sum sees the same operands in the same order.
+// grid = (kFbGrid, batch), block = 64; a workgroup strides over the frame's list.
+// ----------------------------------------------------------------------------
+constexpr int kFbGrid = 128;
+constexpr int kFbInner = (kBlock - 2) * (kBlock - 2);
+template <int BPS>
+__global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g, FlatConsts fc,
+                                                    const double *__restrict__ lut_g, uint8_t *__restrict__ records,
+                                                    uint8_t *__restrict__ flags, const uint32_t *__restrict__ list,
+                                                    const uint32_t *__restrict__ count) {
+  __shared__ double lut[256];
+  __shared__ double s_v[kBlock * kBlock];  // pixel / 255, later the residual
+  __shared__ double s_t[5 * kFbInner];     // [3][1024] fit products, then [5][900] gradient terms
+  const int lane = threadIdx.x, frame = blockIdx.y;
+  const int n = (int)count[frame];
+  if ((int)blockIdx.x >= n) return;
+  for (int i = lane; i < 256; i += 64) lut[i] = lut_g[i];
+  const FramePlanes fp = ft.f[frame];
+  for (int it = blockIdx.x; it < n; it += gridDim.x) {
+    const int blk = (int)list[(size_t)frame * g.nblocks + it];
+    const int bx = blk % g.nbw, by = blk / g.nbw;
+    const int ox = bx * kBlock, oy = by * kBlock;
+    __syncthreads();
+    // ---- block(1x1024) and its products with the columns of A ----
+#pragma unroll 4
+    for (int i = lane; i < kBlock * kBlock; i += 64) {
+      const int yi = i >> 5, xi = i & 31;
+      const int p = load_px<BPS>(fp.src[0], fp.src_stride[0], g.src_shift, min(ox + xi, g.W - 1), min(oy + yi, g.H - 1));
+      const double v = lut[p];
+      const double yd = (double)(yi - 16) * 0.0625, xd = (double)(xi - 16) * 0.0625;
+      s_v[i] = v;
+      s_t[i] = v * yd;
+      s_t[kBlock * kBlock + i] = v * xd;
+      s_t[2 * kBlock * kBlock + i] = v;  // v * 1.0
+    }
+    __syncthreads();
+    double sum = 0.0;
+    if (lane < 3) {
+      const double *src = s_t + lane * (kBlock * kBlock);
+#pragma unroll 16
+      for (int i = 0; i < kBlock * kBlock; ++i) sum += src[i];
+    }
+    const double t0 = __shfl(sum, 0, 64), t1 = __shfl(sum, 1, 64), t2 = __shfl(sum, 2, 64);
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    c0 += fc.ata_inv[0] * t0; c0 += fc.ata_inv[1] * t1; c0 += fc.ata_inv[2] * t2;
+    c1 += fc.ata_inv[3] * t0; c1 += fc.ata_inv[4] * t1; c1 += fc.ata_inv[5] * t2;
+    c2 += fc.ata_inv[6] * t0; c2 += fc.ata_inv[7] * t1; c2 += fc.ata_inv[8] * t2;
+    __syncthreads();
+    // ---- residual(yi, xi) = block - (((0 + yd*c0) + xd*c1) + 1*c2), in place ----
+#pragma unroll 4
+    for (int i = lane; i < kBlock * kBlock; i += 64) {
+      const int yi = i >> 5, xi = i & 31;
+      const double yc = 0.0 + ((double)(yi - 16) * 0.0625) * c0;
+      const double xd = (double)(xi - 16) * 0.0625;
+      const double fit = (yc + xd * c1) + c2;
+      s_v[i] = s_v[i] - fit;
+    }
+    __syncthreads();
+    // ---- gradient terms of the 30x30 interior, (yi, xi) raster ----
+    for (int j = lane; j < kFbInner; j += 64) {
+      const int yi = 1 + j / (kBlock - 2), xi = 1 + j % (kBlock - 2);
+      const int o = yi * kBlock + xi;
+      const double cur = s_v[o];
+      const double gx = (s_v[o + 1] - s_v[o - 1]) * 0.5;
+      const double gy = (s_v[o + kBlock] - s_v[o - kBlock]) * 0.5;
+      s_t[j] = gx * gx;
+      s_t[kFbInner + j] = gx * gy;
+      s_t[2 * kFbInner + j] = gy * gy;
+      s_t[3 * kFbInner + j] = cur;
+      s_t[4 * kFbInner + j] = cur * cur;
+    }
+    __syncthreads();
+    sum = 0.0;
+    if (lane < 5) {
+      const double *src = s_t + lane * kFbInner;
+#pragma unroll 12
+      for (int j = 0; j < kFbInner; ++j) sum += src[j];
+    }
+    const double Gxx = __shfl(sum, 0, 64), Gxy = __shfl(sum, 1, 64), Gyy = __shfl(sum, 2, 64);
+    const double mean = __shfl(sum, 3, 64), var = __shfl(sum, 4, 64);
+    if (lane == 0) flat_decide(Gxx, Gxy, Gyy, var, mean, g, records, flags, frame, blk);
+  }
 }
 
 // ----------------------------------------------------------------------------

@@ -255,9 +255,10 @@ class DiffGenerator:
     def set_timing(self, enable: bool) -> None:
         self._L.g1s_diff_set_timing(self._h, int(enable))
 
-    def set_flat_finder(self, literal_only: bool) -> None:
-        """False (default): certified fast path; True: the literal f64 kernel for every block."""
-        self._L.g1s_diff_set_flat_finder(self._h, int(literal_only))
+    def set_flat_finder(self, mode) -> None:
+        """0 / False (default): certified fast path; 1 / True: the literal f64 evaluation of every block,
+        one lane per block; 2: of every block, one wave per block."""
+        self._check(self._L.g1s_diff_set_flat_finder(self._h, int(mode)))
 
     def stats(self) -> G1SStats:
         st = G1SStats()

@@ -183,10 +183,11 @@ typedef struct {
 int g1s_diff_get_stats(const g1s_diff_t *, g1s_stats_t *out);
 /* Enable per-kernel HIP-event timing (off by default: events serialise batches). */
 int g1s_diff_set_timing(g1s_diff_t *, int enable);
-/* Flat-block finder: 0 (default) = integer moments + certified evaluation, literal f64 kernel only for
- * the blocks the certificate leaves open; 1 = literal kernel for every block (the two must agree bit
- * for bit: tests/test_gpu_parity.py).  Takes effect from the next batch. */
-int g1s_diff_set_flat_finder(g1s_diff_t *, int literal_only);
+/* Flat-block finder: 0 (default) = integer moments + certified evaluation, literal f64 evaluation (one
+ * wave per block) only for the blocks the certificate leaves open; 1 = literal evaluation of every
+ * block, one lane per block; 2 = of every block, one wave per block (all three must agree bit for
+ * bit: tests/test_gpu_parity.py).  Takes effect from the next batch. */
+int g1s_diff_set_flat_finder(g1s_diff_t *, int mode);
 
 /* ---- introspection of the most recently *completed* frame (parity tests) ---- */
 /* Copies the frame's record (layout: g1s_record_* accessors below). */

@@ -124,13 +124,13 @@ def test_latest_only_generator_streams_the_fold():
 @pytest.mark.parametrize("bd,w,h", [(8, 1920, 1080), (10, 2048, 1152), (12, 1280, 736)])
 def test_certified_flat_finder_equals_literal_kernel(bd, w, h):
     """The flat-block finder's fast path (integer moments + certified evaluation, literal kernel for the
-    blocks it cannot decide) must give the literal kernel's mask bytes and f32 score bits for EVERY
+    blocks it cannot decide) and the wave-per-block literal kernel must give the lane-per-block literal kernel's mask bytes and f32 score bits for EVERY
     block: tens of thousands of blocks here, textured and flat, on top of the oracle cases above."""
     spec = SynthSpec(w, h, bd)
     res = []
-    for literal in (False, True):
+    for mode in (0, 1, 2):
         g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=4)
-        g.set_flat_finder(literal)
+        g.set_flat_finder(mode)
         g.set_timing(True)
         masks, scores = [], []
         for k in range(4):
@@ -143,13 +143,14 @@ def test_certified_flat_finder_equals_literal_kernel(bd, w, h):
         st = g.stats()
         res.append((masks, scores, st.literal_blocks, st.blocks))
         g.close()
-    (m0, s0, lit0, nb0), (m1, s1, lit1, nb1) = res
-    for a, b in zip(m0, m1):
-        assert np.array_equal(a, b)
-    for a, b in zip(s0, s1):
-        assert np.array_equal(a, b)
-    assert lit1 == nb1          # literal mode: every block through the literal kernel
-    assert lit0 < nb0 // 20     # fast path: only the undecidable few
+    (m0, s0, lit0, nb0), (m1, s1, lit1, nb1), (m2, s2, lit2, nb2) = res
+    for other_m, other_s in ((m0, s0), (m2, s2)):
+        for a, b in zip(other_m, m1):
+            assert np.array_equal(a, b)
+        for a, b in zip(other_s, s1):
+            assert np.array_equal(a, b)
+    assert lit1 == nb1 and lit2 == nb2   # literal modes: every block through a literal kernel
+    assert lit0 < nb0 // 100             # fast path: only the undecidable few
 
 
 def test_scene_cut_emits_two_segments():
