@@ -99,6 +99,21 @@ class G1SStats(C.Structure):
     ]
 
 
+class G1SY4MInfo(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("bit_depth", C.c_uint32),
+        ("xdec", C.c_uint32),
+        ("ydec", C.c_uint32),
+        ("nplanes", C.c_uint32),
+        ("fps_num", C.c_int64),
+        ("fps_den", C.c_int64),
+    ]
+
+
+NEXT_FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(G1SFrame))
+
 # every symbol include/g1s_diff.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("g1s_diff_new", C.c_void_p, [C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.POINTER(G1SOpts)]),
@@ -135,6 +150,15 @@ SYMBOLS = [
                                       C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
     ("g1s_record_block_stats", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint32)),
                                           C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_uint32))]),
+    ("g1s_diff_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    ("g1s_y4m_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("g1s_y4m_get_info", C.c_int, [C.c_void_p, C.POINTER(G1SY4MInfo)]),
+    ("g1s_y4m_next", C.c_int, [C.c_void_p, C.POINTER(G1SFrame)]),
+    ("g1s_y4m_last_error", C.c_char_p, [C.c_void_p]),
+    ("g1s_y4m_close", None, [C.c_void_p]),
+    ("g1s_diff_y4m_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(G1SOpts),
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
 ]
 
 _lib = None

@@ -1,0 +1,338 @@
+// ingest.cpp -- the caller side of the diff path: the frame-pair loop of `grav1synth diff`
+// (reference: src/main.rs:414-531, get_filtered_frame_pair at :615-629) over pull-model frame
+// sources, and a YUV4MPEG2 source that stands where the reference's libav BitstreamReader
+// (src/reader.rs:37-212) stands: raw planar frames from a file into PINNED host memory, read
+// ahead by a thread per file, so that file IO, the H2D copies of g1s_diff_frame and the kernels
+// of earlier frames overlap.
+//
+// Plain C ABI (include/g1s_diff.h).  No pixel arithmetic happens here.
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/g1s_diff.h"
+
+namespace {
+
+void set_err(char *err, size_t cap, const std::string &msg) {
+  if (!err || !cap) return;
+  std::snprintf(err, cap, "%s", msg.c_str());
+}
+
+struct PinnedBuf {
+  uint8_t *p = nullptr;
+  bool pinned = false;
+  void alloc(size_t n) {
+    // pinned when a HIP device is there (DMA straight out of it); plain memory otherwise, so that
+    // the reader itself also works on a machine without a GPU (header / frame-count tools, tests)
+    void *q = nullptr;
+    if (hipHostMalloc(&q, n, hipHostMallocDefault) == hipSuccess && q) {
+      p = static_cast<uint8_t *>(q);
+      pinned = true;
+    } else {
+      (void)hipGetLastError();
+      p = static_cast<uint8_t *>(std::malloc(n));
+      pinned = false;
+    }
+  }
+  void release() {
+    if (!p) return;
+    if (pinned) (void)hipHostFree(p);
+    else std::free(p);
+    p = nullptr;
+  }
+};
+
+constexpr int kRing = 4;  // frames read ahead per file
+
+}  // namespace
+
+struct g1s_y4m {
+  FILE *f = nullptr;
+  g1s_y4m_info_t info{};
+  size_t plane_bytes[3] = {0, 0, 0}, plane_off[3] = {0, 0, 0}, frame_bytes = 0;
+  size_t row_bytes[3] = {0, 0, 0};
+  PinnedBuf ring[kRing];
+  // reader thread -> consumer
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<int> ready;  // ring indices holding a frame
+  int free_slots = kRing;
+  int held = -1;          // ring index lent to the consumer by the last g1s_y4m_next
+  bool eof = false, stop = false, failed = false;
+  std::string error;
+  uint64_t frames_read = 0;
+
+  bool read_frame_into(uint8_t *dst) {
+    // "FRAME" [ params ] '\n'
+    char line[256];
+    int c = std::fgetc(f);
+    if (c == EOF) return false;  // clean end of stream
+    std::ungetc(c, f);
+    if (!std::fgets(line, sizeof line, f) || std::strncmp(line, "FRAME", 5) != 0) {
+      failed = true;
+      error = "y4m: FRAME marker expected at frame " + std::to_string(frames_read);
+      return false;
+    }
+    if (std::fread(dst, 1, frame_bytes, f) != frame_bytes) {
+      failed = true;
+      error = "y4m: truncated frame " + std::to_string(frames_read);
+      return false;
+    }
+    return true;
+  }
+
+  void reader_main() {
+    int next = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || free_slots > 0; });
+        if (stop) return;
+        --free_slots;
+      }
+      const bool ok = read_frame_into(ring[next].p);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (ok) {
+          ready.push_back(next);
+          ++frames_read;
+        } else {
+          eof = true;
+        }
+      }
+      cv.notify_all();
+      if (!ok) return;
+      next = (next + 1) % kRing;
+    }
+  }
+};
+
+extern "C" {
+
+g1s_y4m_t *g1s_y4m_open(const char *path, char *err, size_t errcap) {
+  if (!path) {
+    set_err(err, errcap, "y4m: null path");
+    return nullptr;
+  }
+  FILE *f = std::fopen(path, "rb");
+  if (!f) {
+    set_err(err, errcap, std::string("y4m: cannot open ") + path);
+    return nullptr;
+  }
+  char hdr[1024];
+  if (!std::fgets(hdr, sizeof hdr, f) || std::strncmp(hdr, "YUV4MPEG2", 9) != 0) {
+    std::fclose(f);
+    set_err(err, errcap, std::string("y4m: not a YUV4MPEG2 stream: ") + path);
+    return nullptr;
+  }
+  g1s_y4m_info_t info{};
+  info.fps_num = 25;  // the format's defaults when a field is absent
+  info.fps_den = 1;
+  info.bit_depth = 8;
+  info.xdec = 1;
+  info.ydec = 1;
+  info.nplanes = 3;
+  std::string cs = "420";
+  for (char *tok = std::strtok(hdr + 9, " \n\r"); tok; tok = std::strtok(nullptr, " \n\r")) {
+    switch (tok[0]) {
+      case 'W': info.width = (uint32_t)std::strtoul(tok + 1, nullptr, 10); break;
+      case 'H': info.height = (uint32_t)std::strtoul(tok + 1, nullptr, 10); break;
+      case 'F': {
+        long long n = 0, d = 0;
+        if (std::sscanf(tok + 1, "%lld:%lld", &n, &d) == 2 && n > 0 && d > 0) {
+          info.fps_num = n;
+          info.fps_den = d;
+        }
+        break;
+      }
+      case 'C': cs = tok + 1; break;
+      default: break;  // interlacing, aspect, comments: not needed by the estimator
+    }
+  }
+  // colour space tag -> subsampling and depth: C420jpeg / C420mpeg2 / C420paldv / C420 / C422 /
+  // C444 / Cmono, with an optional p9..p16 depth suffix (the pixel formats src/reader.rs:51-85 maps)
+  std::string base = cs;
+  const size_t pp = cs.find('p', 3);
+  if (cs.compare(0, 4, "mono") == 0) {
+    info.nplanes = 1;
+    info.xdec = info.ydec = 0;
+    if (cs.size() > 4) info.bit_depth = (uint32_t)std::strtoul(cs.c_str() + 4, nullptr, 10);
+  } else {
+    if (pp != std::string::npos && pp + 1 < cs.size() && cs[pp + 1] >= '0' && cs[pp + 1] <= '9') {
+      info.bit_depth = (uint32_t)std::strtoul(cs.c_str() + pp + 1, nullptr, 10);
+      base = cs.substr(0, pp);
+    }
+    if (base.compare(0, 3, "420") == 0) info.xdec = 1, info.ydec = 1;
+    else if (base.compare(0, 3, "422") == 0) info.xdec = 1, info.ydec = 0;
+    else if (base.compare(0, 3, "444") == 0) info.xdec = 0, info.ydec = 0;
+    else {
+      std::fclose(f);
+      set_err(err, errcap, "y4m: unsupported colour space C" + cs);
+      return nullptr;
+    }
+  }
+  if (info.width == 0 || info.height == 0 || info.bit_depth < 8 || info.bit_depth > 16) {
+    std::fclose(f);
+    set_err(err, errcap, "y4m: bad header (size or bit depth)");
+    return nullptr;
+  }
+  g1s_y4m *y = new g1s_y4m;
+  y->f = f;
+  y->info = info;
+  const size_t bps = info.bit_depth > 8 ? 2 : 1;
+  size_t off = 0;
+  for (uint32_t c = 0; c < info.nplanes; ++c) {
+    // chroma planes: ceil(width / 2^xdec) x ceil(height / 2^ydec) samples in the file
+    const size_t fw = c ? (info.width + (1u << info.xdec) - 1) >> info.xdec : info.width;
+    const size_t fh = c ? (info.height + (1u << info.ydec) - 1) >> info.ydec : info.height;
+    y->row_bytes[c] = fw * bps;
+    y->plane_bytes[c] = fw * fh * bps;
+    y->plane_off[c] = off;
+    off += y->plane_bytes[c];
+  }
+  y->frame_bytes = off;
+  for (auto &b : y->ring) {
+    b.alloc(y->frame_bytes);
+    if (!b.p) {
+      set_err(err, errcap, "y4m: out of memory");
+      g1s_y4m_close(y);
+      return nullptr;
+    }
+  }
+  y->th = std::thread([y] { y->reader_main(); });
+  return y;
+}
+
+int g1s_y4m_get_info(const g1s_y4m_t *y, g1s_y4m_info_t *out) {
+  if (!y || !out) return G1S_ERR_INVALID;
+  *out = y->info;
+  return G1S_OK;
+}
+
+int g1s_y4m_next(void *user, g1s_frame_t *out) {
+  g1s_y4m *y = static_cast<g1s_y4m *>(user);
+  if (!y || !out) return G1S_ERR_INVALID;
+  int idx;
+  {
+    std::unique_lock<std::mutex> lk(y->m);
+    if (y->held >= 0) {  // the frame lent by the previous call goes back to the reader
+      y->held = -1;
+      ++y->free_slots;
+      y->cv.notify_all();
+    }
+    y->cv.wait(lk, [&] { return !y->ready.empty() || y->eof; });
+    if (y->ready.empty()) return y->failed ? G1S_ERR_INVALID : 0;  // 0: end of stream
+    idx = y->ready.front();
+    y->ready.pop_front();
+    y->held = idx;
+  }
+  std::memset(out, 0, sizeof *out);
+  out->width = y->info.width;
+  out->height = y->info.height;
+  out->bytes_per_sample = y->info.bit_depth > 8 ? 2 : 1;
+  out->xdec = (uint8_t)y->info.xdec;
+  out->ydec = (uint8_t)y->info.ydec;
+  out->nplanes = (uint8_t)y->info.nplanes;
+  for (uint32_t c = 0; c < y->info.nplanes; ++c) {
+    out->data[c] = y->ring[idx].p + y->plane_off[c];
+    out->stride_bytes[c] = y->row_bytes[c];
+  }
+  out->on_device = 0;
+  return 1;
+}
+
+const char *g1s_y4m_last_error(const g1s_y4m_t *y) { return y ? y->error.c_str() : ""; }
+
+void g1s_y4m_close(g1s_y4m_t *y) {
+  if (!y) return;
+  {
+    std::lock_guard<std::mutex> lk(y->m);
+    y->stop = true;
+  }
+  y->cv.notify_all();
+  if (y->th.joinable()) y->th.join();
+  for (auto &b : y->ring) b.release();
+  if (y->f) std::fclose(y->f);
+  delete y;
+}
+
+int g1s_diff_run(g1s_diff_t *g, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
+                 void *denoised_user, uint64_t *frames_out, int *unequal_out) {
+  if (!g || !source || !denoised) return G1S_ERR_INVALID;
+  uint64_t frames = 0;
+  int unequal = 0;
+  for (;;) {
+    // get_filtered_frame_pair (src/main.rs:615-629): one frame from each reader, source first
+    g1s_frame_t s, d;
+    const int rs = source(source_user, &s);
+    const int rd = denoised(denoised_user, &d);
+    if (rs < 0) return rs;
+    if (rd < 0) return rd;
+    if (rs == 0 && rd == 0) break;  // (None, None)
+    if (rs == 0 || rd == 0) {       // "Videos did not have equal frame counts. Resulting grain table may
+      unequal = 1;                  //  not be as expected." -- a warning, then the loop ends (src/main.rs:449-455)
+      break;
+    }
+    const int rc = g1s_diff_frame(g, &s, &d);  // `?`: the first error ends the command
+    if (rc) return rc;
+    ++frames;
+  }
+  if (frames_out) *frames_out = frames;
+  if (unequal_out) *unequal_out = unequal;
+  return G1S_OK;
+}
+
+int g1s_diff_y4m_files(const char *source_path, const char *denoised_path, const char *out_tbl_path,
+                       const g1s_opts_t *opts, uint64_t *frames_out, int *unequal_out, char *err, size_t errcap) {
+  g1s_y4m_t *ys = g1s_y4m_open(source_path, err, errcap);
+  if (!ys) return G1S_ERR_INVALID;
+  g1s_y4m_t *yd = g1s_y4m_open(denoised_path, err, errcap);
+  if (!yd) {
+    g1s_y4m_close(ys);
+    return G1S_ERR_INVALID;
+  }
+  int rc = G1S_OK;
+  g1s_diff_t *g = nullptr;
+  std::vector<g1s_segment_t> segs(64);
+  size_t n = 0;
+  // the frame rate and the bit depths come from the readers (src/main.rs:414-427)
+  g = g1s_diff_new(ys->info.fps_num, ys->info.fps_den, ys->info.bit_depth, yd->info.bit_depth, opts);
+  if (!g) {
+    set_err(err, errcap, g1s_last_global_error());
+    rc = G1S_ERR_NO_DEVICE;
+    goto done;
+  }
+  rc = g1s_diff_run(g, g1s_y4m_next, ys, g1s_y4m_next, yd, frames_out, unequal_out);
+  if (rc) {
+    const char *e = g1s_diff_last_error(g);
+    set_err(err, errcap, (e && *e) ? e : (ys->failed ? ys->error : yd->error));
+    goto done;
+  }
+  rc = g1s_diff_finish(g, segs.data(), segs.size(), &n);
+  if (rc == G1S_ERR_CAPACITY) {
+    set_err(err, errcap, "more than 64 grain table segments");
+    goto done;
+  }
+  if (rc) {
+    set_err(err, errcap, g1s_diff_last_error(g));
+    goto done;
+  }
+  rc = g1s_write_tbl(out_tbl_path, segs.data(), n);
+  if (rc) set_err(err, errcap, std::string("cannot write ") + out_tbl_path);
+done:
+  if (g) g1s_diff_free(g);
+  g1s_y4m_close(ys);
+  g1s_y4m_close(yd);
+  return rc;
+}
+
+}  // extern "C"

@@ -202,6 +202,41 @@ int g1s_record_ar_sums(const void *rec, uint32_t c, const int64_t **S, const int
 int g1s_record_block_stats(const void *rec, uint32_t c, const uint32_t **luma_sum,
                            const int32_t **sum_d, const uint32_t **sum_d2);
 
+/* ---- the caller of the path: `grav1synth diff`'s frame-pair loop and a raw-video frame source ---- */
+/* A frame source == BitstreamReader::get_frame (src/reader.rs:122-170) as the diff loop uses it:
+ * returns 1 and fills *out (host or device planes, valid until the next call on this source),
+ * 0 at end of stream (`None`), a negative G1S_ERR_* on failure (`Err`, `?`-propagated). */
+typedef int (*g1s_next_frame_fn)(void *user, g1s_frame_t *out);
+/* The loop of Commands::Diff (src/main.rs:432-521) with get_filtered_frame_pair (src/main.rs:615-629):
+ * one frame from each source (source first), diff_frame on the pair, until a source ends.
+ * Both ended together: normal end.  Only one ended: *unequal = 1 -- the reference warns "Videos did
+ * not have equal frame counts. Resulting grain table may not be as expected." and stops there too.
+ * The first error ends the loop and is returned.  g1s_diff_finish() is left to the caller
+ * (src/main.rs:524).  *frames = pairs handed to diff_frame. */
+int g1s_diff_run(g1s_diff_t *, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
+                 void *denoised_user, uint64_t *frames, int *unequal);
+
+/* YUV4MPEG2 frame source: stands where the libav reader stands in the reference (what reaches the
+ * estimator is the same planar Y,U,V u8 / little-endian u16 frame, src/reader.rs:172-212).  Frames
+ * are read ahead by a thread into pinned host memory (a ring of 4), so file IO, the H2D copies of
+ * g1s_diff_frame and the kernels of earlier frames overlap.  Colour spaces: C420* / C422 / C444 /
+ * Cmono with an optional p9..p16 depth suffix (8-, 10-, 12-bit 4:2:0 / 4:2:2 / 4:4:4 are what
+ * src/reader.rs:51-85 accepts). */
+typedef struct g1s_y4m g1s_y4m_t;
+typedef struct {
+  uint32_t width, height, bit_depth, xdec, ydec, nplanes;
+  int64_t fps_num, fps_den;
+} g1s_y4m_info_t;
+g1s_y4m_t *g1s_y4m_open(const char *path, char *err, size_t errcap); /* NULL on failure, reason in err */
+int g1s_y4m_get_info(const g1s_y4m_t *, g1s_y4m_info_t *out);
+int g1s_y4m_next(void *y4m, g1s_frame_t *out); /* a g1s_next_frame_fn; user = the g1s_y4m_t* */
+const char *g1s_y4m_last_error(const g1s_y4m_t *);
+void g1s_y4m_close(g1s_y4m_t *);
+/* `grav1synth diff SOURCE DENOISED -o OUT` for two .y4m files (src/main.rs:414-531): frame rate from
+ * the source, bit depths from each file, the loop above, finish, "filmgrn1" table to out_tbl. */
+int g1s_diff_y4m_files(const char *source, const char *denoised, const char *out_tbl, const g1s_opts_t *opts,
+                       uint64_t *frames, int *unequal, char *err, size_t errcap);
+
 #ifdef __cplusplus
 }
 #endif

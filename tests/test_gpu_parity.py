@@ -253,3 +253,52 @@ def test_large_residuals_take_the_deferred_path(bd, xdec, ydec):
                 S2, Sb2, n2 = r.ar_sums(c)
                 assert n == n2 and np.array_equal(S, S2) and np.array_equal(Sb, Sb2), f"plane {c}"
     assert format_tbl(g.finish()) == ofmt(o.finish())
+
+
+@pytest.mark.parametrize("spec,nframes", [(SynthSpec(320, 200, 10), 5), (SynthSpec(288, 160, 8, xdec=0, ydec=0), 4)],
+                         ids=["10b420", "8b444"])
+def test_y4m_files_give_the_table_of_the_in_memory_path_and_of_the_oracle(tmp_path, spec, nframes):
+    """`grav1synth diff SOURCE DENOISED -o OUT` (src/main.rs:414-531) through g1s_diff_y4m_files: pinned
+    read-ahead reader, frame-pair loop, finish, table -- same bytes as feeding the frames by hand and as
+    the oracle."""
+    from grav1synth_amd.ingest import diff_y4m_files, write_y4m
+
+    pairs = [make_pair(spec, k, device="cpu") for k in range(nframes)]
+    fps = Fraction(30000, 1001)
+    write_y4m(str(tmp_path / "src.y4m"), [s for s, _ in pairs], spec.bit_depth, spec.xdec, spec.ydec, fps)
+    write_y4m(str(tmp_path / "den.y4m"), [d for _, d in pairs], spec.bit_depth, spec.xdec, spec.ydec, fps)
+    out = tmp_path / "out.tbl"
+    frames, unequal = diff_y4m_files(str(tmp_path / "src.y4m"), str(tmp_path / "den.y4m"), str(out), batch_frames=2)
+    assert (frames, unequal) == (nframes, False)
+    g = DiffGenerator(fps, spec.bit_depth, spec.bit_depth)
+    for s, d in pairs:
+        g.diff_frame(s, d, spec.xdec, spec.ydec)
+    by_hand = format_tbl(g.finish())
+    g.close()
+    assert out.read_bytes() == by_hand
+    oracle_tbl, _ = oracle_run(spec, list(range(nframes)), 3, True, fps=fps)
+    assert by_hand == oracle_tbl
+
+
+def test_y4m_unequal_frame_counts_stop_at_the_shorter_file(tmp_path):
+    """The reference warns and stops when only one reader ends (src/main.rs:449-455): the table then covers
+    the common prefix."""
+    from grav1synth_amd.ingest import diff_y4m_files, write_y4m
+
+    spec = SynthSpec(320, 192, 8)
+    pairs = [make_pair(spec, k, device="cpu") for k in range(4)]
+    write_y4m(str(tmp_path / "src.y4m"), [s for s, _ in pairs], 8, 1, 1)
+    write_y4m(str(tmp_path / "den.y4m"), [d for _, d in pairs[:3]], 8, 1, 1)
+    out = tmp_path / "out.tbl"
+    frames, unequal = diff_y4m_files(str(tmp_path / "src.y4m"), str(tmp_path / "den.y4m"), str(out))
+    assert (frames, unequal) == (3, True)
+    g = DiffGenerator(Fraction(24, 1), 8, 8)
+    for s, d in pairs[:3]:
+        g.diff_frame(s, d, 1, 1)
+    assert out.read_bytes() == format_tbl(g.finish())
+    g.close()
+    # geometry mismatch between the two files: diff_frame's error ends the command
+    other = SynthSpec(352, 192, 8)
+    write_y4m(str(tmp_path / "den2.y4m"), [make_pair(other, 0, device="cpu")[1]], 8, 1, 1)
+    with pytest.raises(RuntimeError, match="dimensions do not match"):
+        diff_y4m_files(str(tmp_path / "src.y4m"), str(tmp_path / "den2.y4m"), str(out))
