@@ -41,9 +41,11 @@ WORKLOADS = {
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="frame pairs per rank per step (one video chunk per step)")
+    ap.add_argument("--cycles", type=int, default=4,
+                    help="a step feeds the resident frames this many times over: one job of frames x cycles frame pairs")
     ap.add_argument("--batch", type=int, default=32, help="frames per kernel launch group (<= 32)")
     ap.add_argument("--workload", default="4k10", choices=sorted(WORKLOADS))
     ap.add_argument("--flat", action="store_true", help="all-flat stress variant (no textured region)")
@@ -85,6 +87,7 @@ def main() -> None:
     W, H, bd, xdec, ydec, lag, chroma, bpp = WORKLOADS[args.workload]
     spec = SynthSpec(W, H, bd, xdec, ydec, textured=not args.flat)
     F = args.frames
+    FJ = F * args.cycles  # frame pairs of one step (job)
     fps = Fraction(24, 1)
 
     # ---- synthetic frame pairs, resident in HBM before any timed region ----
@@ -114,13 +117,15 @@ def main() -> None:
             sd = StreamingShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
                                       batch_frames=B, group=dist)
             sd.generator.set_timing(timing)
-            for pb in prepared_batches:
-                sd.diff_prepared(pb, sync_torch=False)
+            for _ in range(args.cycles):
+                for pb in prepared_batches:
+                    sd.diff_prepared(pb, sync_torch=False)
         else:
             sd = ShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
                              batch_frames=args.batch, group=None)
             sd.generator.set_timing(timing)
-            sd.diff_prepared(prepared, W, H, nplanes, sync_torch=False)
+            for _ in range(args.cycles):
+                sd.diff_prepared(prepared, W, H, nplanes, sync_torch=False)
         segs = sd.finish()  # (exchange +) ordered fold; rank 0 holds the table
         st = sd.generator.stats()
         if segs is not None:
@@ -138,8 +143,11 @@ def main() -> None:
         one_step(False)
     barrier()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         one_step(False)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -157,7 +165,7 @@ def main() -> None:
     }
     dom = max(kernels, key=lambda k: kernels[k][0])
     dom_ms, dom_launches = kernels[dom]
-    frames_per_launch = F / max(dom_launches, 1)
+    frames_per_launch = FJ / max(dom_launches, 1)
     alg_bytes_per_launch = bpp * W * H * frames_per_launch
     avg_launch_ms = dom_ms / max(dom_launches, 1)
     achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
@@ -170,7 +178,7 @@ def main() -> None:
         except Exception:
             traffic = None
 
-    total_px = float(W) * H * F * args.steps * world
+    total_px = float(W) * H * F * args.cycles * args.steps * world
     value = total_px / elapsed / 1e6
     out = {
         "metric": "diff Mpixels/s (luma pixels of frame pairs fully processed: flat-block finder + AR accumulation + block stats + ordered fold)",
@@ -180,6 +188,7 @@ def main() -> None:
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "step_ms": [round(x, 3) for x in step_ms],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -187,7 +196,8 @@ def main() -> None:
         "data": "synthetic (deterministic integer generator, grav1synth_amd/synth.py), device-resident",
         "config": {
             "workload": f"diff {W}x{H} {bd}-bit {'4:2:0' if (xdec, ydec) == (1, 1) else '4:4:4' if (xdec, ydec) == (0, 0) else '4:2:2'}, ar_coeff_lag={lag}, {'chroma' if chroma else 'luma-only'} ({args.workload}{', all-flat' if args.flat else ''})",
-            "frames_per_rank_per_step": F,
+            "frames_per_rank_per_step": FJ,
+            "resident_frames_per_rank": F,
             "batch_frames": args.batch,
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
@@ -204,14 +214,14 @@ def main() -> None:
             "traffic": traffic,
             "avg_launch_ms": avg_launch_ms,
             "alg_bytes_per_launch": alg_bytes_per_launch,
-            "all_kernels_ms_per_frame": {k: v[0] / F for k, v in kernels.items()},
-            "host_fold_ms_per_frame": st.ms_host_fold / F,
+            "all_kernels_ms_per_frame": {k: v[0] / FJ for k, v in kernels.items()},
+            "host_fold_ms_per_frame": st.ms_host_fold / FJ,
             # inside k3_ar_accumulate: K0, the one pass over the source / denoised planes (the HBM-streaming kernel)
             "k0_residual": {
-                "ms_per_frame": st.ms_residual / F,
-                "achieved": (bpp * W * H * F / (st.ms_residual * 1e-3) / 1e9) if st.ms_residual > 0 else None,
+                "ms_per_frame": st.ms_residual / FJ,
+                "achieved": (bpp * W * H * FJ / (st.ms_residual * 1e-3) / 1e9) if st.ms_residual > 0 else None,
                 "unit": "GB/s",
-                "frac": (bpp * W * H * F / (st.ms_residual * 1e-3) / 1e9 / HBM_PEAK_GBS) if st.ms_residual > 0 else None,
+                "frac": (bpp * W * H * FJ / (st.ms_residual * 1e-3) / 1e9 / HBM_PEAK_GBS) if st.ms_residual > 0 else None,
             },
         },
     }
