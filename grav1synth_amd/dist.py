@@ -110,6 +110,7 @@ class StreamingShardedDiff:
                                        records_only=2 if group is not None else False)
         self._blob = 0
         self._fold = None
+        self._queue: List[np.ndarray] = []  # this rank's delivered, not yet exchanged batches
         if group is not None:
             from .diff import latest_size
             self._blob = latest_size(ar_coeff_lag)
@@ -119,27 +120,39 @@ class StreamingShardedDiff:
         if torch.cuda.is_available():
             self._dev = torch.device("cuda", device if device >= 0 else torch.cuda.current_device())
 
-    def _round(self, sync: bool) -> None:
-        blobs = self.generator.take_latest(2 * self.batch, sync=sync)
-        per_rank = gather_latest_round(blobs, self._blob, 2 * self.batch, self.dist, self._dev)
+    # batches that can still be inside a generator when the last frame has been queued: being filled,
+    # pixel pass queued, accumulation queued, draining (csrc/engine.hip, kSlots)
+    PIPELINE_BATCHES = 4
+
+    def _exchange_one(self) -> None:
+        """One fixed-size round: the next undelivered batch of every rank (possibly none)."""
+        mine = self._queue.pop(0) if self._queue else np.zeros((0, self._blob), dtype=np.uint8)
+        per_rank = gather_latest_round(mine, self._blob, self.batch, self.dist, self._dev)
         if self._fold is not None:
-            # global order: batch by batch, ranks in order within a batch (a round carries one batch of
-            # every rank, the last round up to two)
-            nb = max((len(b) + self.batch - 1) // self.batch for b in per_rank) if per_rank else 0
-            for k in range(nb):
-                for b in per_rank:
-                    self._fold.push_latest_many(b[k * self.batch:(k + 1) * self.batch])
+            for b in per_rank:  # global order: batch by batch, ranks in order within a batch
+                self._fold.push_latest_many(b)
+
+    def _collect(self, sync: bool) -> None:
+        blobs = self.generator.take_latest(self.PIPELINE_BATCHES * self.batch, sync=sync)
+        for k in range(0, len(blobs), self.batch):
+            self._queue.append(blobs[k:k + self.batch])
 
     def diff_prepared(self, prepared, sync_torch: bool = True) -> None:
         """Feeds ONE batch (this rank's next batch in the global order)."""
         self.generator.diff_prepared(prepared, sync_torch=sync_torch)
         if self.dist is not None:
-            self._round(sync=False)  # the states of the batch two before this one (nothing on the first two calls)
+            # the states of an earlier batch (which one is a function of the call sequence only, so every
+            # rank contributes the same batch index; nothing on the first calls)
+            self._collect(sync=False)
+            self._exchange_one()
 
     def finish(self) -> Optional[List[GrainTableSegment]]:
         if self.dist is None:
             return self.generator.finish()
-        self._round(sync=True)
+        self._collect(sync=True)
+        for _ in range(self.PIPELINE_BATCHES):
+            self._exchange_one()
+        assert not self._queue
         if self._fold is None:
             return None
         segs = self._fold.finish()
