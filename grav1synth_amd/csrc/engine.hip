@@ -68,24 +68,28 @@ class Pool {
       fn_ = &fn;
       n_ = n;
       next_.store(0);
-      done_ = 0;
+      done_.store(0);
       ++epoch_;
     }
     cv_.notify_all();
     work();
     std::unique_lock<std::mutex> lk(m_);
-    cv_done_.wait(lk, [this] { return done_ == n_; });
+    cv_done_.wait(lk, [this] { return done_.load() == n_; });
     fn_ = nullptr;
   }
 
  private:
   void work() {
+    int mine = 0;
     for (;;) {
       const int i = next_.fetch_add(1);
       if (i >= n_) break;
       (*fn_)(i);
-      std::lock_guard<std::mutex> lk(m_);
-      if (++done_ == n_) cv_done_.notify_all();
+      ++mine;
+    }
+    if (mine && done_.fetch_add(mine) + mine == n_) {
+      std::lock_guard<std::mutex> lk(m_);  // (the waiter checks under this lock: no lost wake-up)
+      cv_done_.notify_all();
     }
   }
   void loop() {
@@ -105,7 +109,8 @@ class Pool {
   std::condition_variable cv_, cv_done_;
   const std::function<void(int)> *fn_ = nullptr;
   std::atomic<int> next_{0};
-  int n_ = 0, done_ = 0;
+  int n_ = 0;
+  std::atomic<int> done_{0};
   uint64_t epoch_ = 0;
   bool stop_ = false;
 };
@@ -851,13 +856,23 @@ int g1s_diff::drain_slot(int si) {
       std::lock_guard<std::mutex> lk(dm);
       latest_out.insert(latest_out.end(), latest_stage.begin() + blob * i, latest_stage.begin() + blob * (i + 1));
       latest_out_frames++;
-    } else if (sticky == G1S_OK) {
-      rc = fold->push_latest(latest[i]);
-      if (rc) {
-        std::lock_guard<std::mutex> lk(dm);
-        err = fold->error();
-        sticky = rc;
+    }
+  }
+  if (!records_only && !latest_only && sticky == G1S_OK && sl.count) {
+    // the ordered merge of the batch: combined-model solves in parallel, tests and commits in order
+    const NoiseFold::ParallelFor pfor = [&](int m, const std::function<void(int)> &fn) {
+      if (pool) {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        pool->parallel_for(m, fn);
+      } else {
+        for (int i = 0; i < m; ++i) fn(i);
       }
+    };
+    rc = fold->push_latest_many(latest.data(), sl.count, pfor);
+    if (rc) {
+      std::lock_guard<std::mutex> lk(dm);
+      err = fold->error();
+      sticky = rc;
     }
   }
   if (latest_only && sl.count) {
@@ -1226,19 +1241,48 @@ int g1s_fold_push_many(g1s_fold_t *f, const void *records, size_t stride_bytes, 
 int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, size_t n) {
   if (!f || (!blobs && n)) return G1S_ERR_INVALID;
   if (f->finished) return G1S_ERR_STATE;
-  if (f->latest.empty()) f->latest.resize(1);
+  if (!f->pool) f->pool = shared_pool();
+  constexpr size_t kChunk = 256;  // frames parsed and merged per pass (bounds the staging memory)
+  if (n > kChunk) {
+    for (size_t o = 0; o < n; o += kChunk) {
+      const int rc = g1s_fold_push_latest(f, (const uint8_t *)blobs + o * stride_bytes, stride_bytes, std::min(kChunk, n - o));
+      if (rc) return rc;
+    }
+    return G1S_OK;
+  }
+  if (f->latest.size() < n) f->latest.resize(n);
   const uint8_t *base = (const uint8_t *)blobs;
+  const NoiseFold::ParallelFor pfor = [&](int m, const std::function<void(int)> &fn) {
+    if (f->pool && m > 1) {
+      std::lock_guard<std::mutex> lk(g_pool_mutex);
+      f->pool->parallel_for(m, fn);
+    } else {
+      for (int i = 0; i < m; ++i) fn(i);
+    }
+  };
+  std::vector<int> prc(n, G1S_OK);
+  {
+    const int T = (int)std::min<size_t>(n, 8);
+    pfor(T, [&](int t) {
+      for (size_t i = n * t / T; i < n * (t + 1) / T; ++i)
+        prc[i] = latest_from_blob(base + i * stride_bytes, stride_bytes, f->lag, f->latest[i]);
+    });
+  }
+  size_t good = n;
   for (size_t i = 0; i < n; ++i) {
-    int rc = latest_from_blob(base + i * stride_bytes, stride_bytes, f->lag, f->latest[0]);
-    if (rc) {
-      f->err = "bad latest blob";
-      return rc;
+    if (prc[i]) {
+      good = i;
+      break;
     }
-    rc = f->fold.push_latest(f->latest[0]);
-    if (rc) {
-      f->err = f->fold.error();
-      return rc;
-    }
+  }
+  const int rc = f->fold.push_latest_many(f->latest.data(), good, pfor);  // (the frames before a bad blob still count)
+  if (rc) {
+    f->err = f->fold.error();
+    return rc;
+  }
+  if (good < n) {
+    f->err = "bad latest blob";
+    return prc[good];
   }
   return G1S_OK;
 }

@@ -29,25 +29,28 @@ __attribute__((target_clones("avx2", "default"))) bool gauss_solve(int n, double
   // one row at a time" pivoting.  Columns left of the pivot column are never read again
   // (pivoting looks at column k, back substitution at columns >= i), so the row operations
   // run over columns >= k only: every value that is used is bit for bit the reference's.
+  // Rows are swapped by pointer: the same values meet in the same operations, nothing is moved.
+  double *R[kMaxN];
+  for (int i = 0; i < n; ++i) R[i] = A + i * n;
   for (int k = 0; k < n - 1; ++k) {
     for (int i = n - 1; i > k; --i) {
-      double *lo = A + (i - 1) * n, *hi = A + i * n;
-      if (std::fabs(lo[k]) < std::fabs(hi[k])) {
-        for (int j = k; j < n; ++j) std::swap(lo[j], hi[j]);
+      if (std::fabs(R[i - 1][k]) < std::fabs(R[i][k])) {
+        std::swap(R[i - 1], R[i]);
         std::swap(b[i], b[i - 1]);
       }
     }
-    const double *pivot = A + k * n;
+    const double *__restrict pivot = R[k];
+    if (std::fabs(pivot[k]) < kTiny) return false;
+    const double pk = pivot[k], bk = b[k];
     for (int i = k; i < n - 1; ++i) {
-      if (std::fabs(pivot[k]) < kTiny) return false;
-      double *row = A + (i + 1) * n;
-      const double c = row[k] / pivot[k];
+      double *__restrict row = R[i + 1];
+      const double c = row[k] / pk;
       for (int j = k + 1; j < n; ++j) row[j] -= c * pivot[j];
-      b[i + 1] -= c * b[k];
+      b[i + 1] -= c * bk;
     }
   }
   for (int i = n - 1; i >= 0; --i) {
-    const double *row = A + i * n;
+    const double *row = R[i];
     if (std::fabs(row[i]) < kTiny) return false;
     double c = 0;
     for (int j = i + 1; j <= n - 1; ++j) c += row[j] * x[j];
@@ -74,6 +77,7 @@ void LinearSystem::add(const LinearSystem &o) {
   }
 }
 void LinearSystem::assign(const LinearSystem &o) {
+  n = o.n;
   A = o.A;
   b = o.b;
   x = o.x;
@@ -526,6 +530,91 @@ int NoiseFold::push_latest(FrameLatest &fl) {
     prev_timestamp_ = cur;
   }
   frame_count_ += 1;
+  return G1S_OK;
+}
+
+int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pfor) {
+  constexpr size_t kWindow = 64;
+  if (snap_.size() < kWindow) {
+    snap_.resize(kWindow);
+    snap_ok_.resize(kWindow);
+  }
+  size_t i = 0;
+  while (i < n) {
+    // ---- prefix sums of the luma systems over a window of frames (no segment cut assumed) ----
+    size_t W = std::min(kWindow, n - i);
+    for (size_t j = 0; j < W; ++j) {
+      if (fl[i + j].status != G1S_OK) {  // an error frame ends the window; it is reported when reached
+        W = j;
+        break;
+      }
+      PlaneState &s = snap_[j];
+      const PlaneState &prev = j ? snap_[j - 1] : combined_[0];
+      const PlaneState &lat = fl[i + j].st[0];
+      s.ar.assign(prev.ar);
+      s.strength.eq.assign(prev.strength.eq);
+      s.strength.num_equations = prev.strength.num_equations;
+      s.strength.total = prev.strength.total;
+      s.num_observations = prev.num_observations + lat.num_observations;
+      s.ar.add(lat.ar);
+      s.strength.add(lat.strength);
+      s.strength.apply_regularisation_to_b();  // (the first half of StrengthSolver::solve)
+    }
+    if (W == 0) {
+      err_ = fl[i].err;
+      return fl[i].status;
+    }
+    // ---- the solves, independent of each other ----
+    const std::function<void(int)> solve_one = [&](int j) {
+      const bool a = ar_solve(snap_[j], false);
+      const bool b = snap_[j].strength.solve_x_only();
+      snap_ok_[j] = (uint8_t)((a ? 1 : 0) | (b ? 2 : 0));
+    };
+    if (pfor && W > 1) {
+      // a few tasks of several solves each: a solve is ~3 us, waking a thread costs about as much
+      const int T = (int)std::min<size_t>(W, 8);
+      const std::function<void(int)> range = [&](int t) {
+        for (size_t j = W * t / T; j < W * (t + 1) / T; ++j) solve_one((int)j);
+      };
+      pfor(T, range);
+    } else {
+      for (size_t j = 0; j < W; ++j) solve_one((int)j);
+    }
+    // ---- in order: the is_different() tests, commits, segment cuts ----
+    size_t done = W;
+    for (size_t j = 0; j < W; ++j) {
+      FrameLatest &f = fl[i + j];
+      for (int c = 0; c < 3; ++c) std::swap(latest_[c], f.st[c]);
+      if (combined_[0].strength.num_equations > 0 && is_different()) {
+        const uint64_t cur = frame_count_ * 10000000ULL * (uint64_t)fps_den_ / (uint64_t)fps_num_;
+        table_.push_back(grain_parameters(prev_timestamp_, cur));
+        save_latest();
+        prev_timestamp_ = cur;
+        frame_count_ += 1;
+        done = j + 1;  // the states behind the cut were built on a combined model that is gone
+        break;
+      }
+      if (!(snap_ok_[j] & 1)) {
+        set_error(err_, "Solving combined noise equation system failed %d!", 0);
+        return G1S_ERR_SOLVE;
+      }
+      if (!(snap_ok_[j] & 2)) {
+        set_error(err_, "Solving combined noise strength failed!");
+        return G1S_ERR_SOLVE;
+      }
+      std::swap(combined_[0], snap_[j]);
+      for (int c = 1; c < (int)f.nplanes; ++c) {
+        PlaneState &com = combined_[c];
+        com.num_observations += latest_[c].num_observations;
+        com.ar.add(latest_[c].ar);
+        com.strength.add(latest_[c].strength);
+        com.strength.apply_regularisation_to_b();
+        chroma_dirty_ = true;
+      }
+      frame_count_ += 1;
+    }
+    i += done;
+  }
   return G1S_OK;
 }
 

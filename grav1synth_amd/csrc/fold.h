@@ -8,6 +8,7 @@
 // product's own implementation; the test oracle under oracle/ is separate.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -90,6 +91,15 @@ class NoiseFold {
   int push(const uint8_t *rec, size_t size);
   // The sequential half: merge one frame's latest state (frame order!).
   int push_latest(FrameLatest &fl);
+  // The same for n frames in order, with the solves of the combined luma systems taken out of the
+  // serial chain: as long as no frame starts a new segment, the combined (A, b) after frame j are
+  // prefix sums of the frames' systems -- cheap, sequential -- and their solves are independent of
+  // each other, so a window of them runs through `pfor` (runs fn(i) for i in [0, n), any order, any
+  // threads; empty = serial); the is_different() tests then run in order on the solved states, and
+  // a segment cut discards the speculative states behind it.  Every solve sees exactly the operands
+  // push_latest() would give it: results are identical bit for bit.
+  using ParallelFor = std::function<void(int, const std::function<void(int)> &)>;
+  int push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pfor);
   void finish(std::vector<g1s_segment_t> &out);
   const std::string &error() const { return err_; }
   uint64_t frames() const { return frame_count_; }
@@ -109,6 +119,8 @@ class NoiseFold {
   uint64_t frame_count_ = 0, prev_timestamp_ = 0;
   std::vector<g1s_segment_t> table_;
   std::string err_;
+  std::vector<PlaneState> snap_;  // push_latest_many: speculative combined luma states
+  std::vector<uint8_t> snap_ok_;
 };
 
 long format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap);

@@ -129,8 +129,10 @@ class StreamingShardedDiff:
         mine = self._queue.pop(0) if self._queue else np.zeros((0, self._blob), dtype=np.uint8)
         per_rank = gather_latest_round(mine, self._blob, self.batch, self.dist, self._dev)
         if self._fold is not None:
-            for b in per_rank:  # global order: batch by batch, ranks in order within a batch
-                self._fold.push_latest_many(b)
+            # global order: batch by batch, ranks in order within a batch; one call merges the whole round
+            blobs = [b for b in per_rank if len(b)]
+            if blobs:
+                self._fold.push_latest_many(np.concatenate(blobs) if len(blobs) > 1 else blobs[0])
 
     def _collect(self, sync: bool) -> None:
         blobs = self.generator.take_latest(self.PIPELINE_BATCHES * self.batch, sync=sync)

@@ -118,3 +118,38 @@ def test_tbl_round_trip_of_diff_output_and_parser_errors():
         parse_tbl(b"filmgrn2\n")
     with pytest.raises(TblError):
         parse_tbl(tbl.replace(b"\tcY", b"\tcY 1"))  # coefficient count no longer 2*lag*(lag+1)
+
+
+def test_batched_merge_equals_frame_by_frame_merge_across_segment_cuts():
+    """g1s_fold_push_latest merges a batch with the combined-model solves taken out of the serial chain
+    (speculative prefix sums, discarded behind a segment cut): same table as one frame at a time, as the
+    record path (sequential push) and as the oracle, with cuts inside a batch."""
+    from grav1synth_amd.diff import latest_from_records
+
+    a = SynthSpec(320, 192, 8)
+    b = SynthSpec(320, 192, 8, gain_scale=3)
+    specs = [a, a, a, b, b, b, b, a, a, b, a, a]
+    fps = Fraction(30000, 1001)
+    recs = []
+    tbl, segs = oracle_run(a, range(len(specs)), fps=fps, specs_per_frame=specs,
+                           collect=lambda o, k: recs.append(record_from_oracle(o, a, 3, 3).buf.copy()))
+    assert len(segs) >= 3
+    recs = np.stack(recs)
+    blobs = latest_from_records(recs, 3)
+    tables = []
+    for mode in ("all_at_once", "one_by_one", "records", "uneven"):
+        fold = RecordFold(fps, 3)
+        if mode == "all_at_once":
+            fold.push_latest_many(blobs)
+        elif mode == "one_by_one":
+            for k in range(len(blobs)):
+                fold.push_latest_many(blobs[k:k + 1])
+        elif mode == "records":
+            fold.push_many(recs)
+        else:
+            fold.push_latest_many(blobs[:5])
+            fold.push_latest_many(blobs[5:6])
+            fold.push_latest_many(blobs[6:])
+        tables.append(format_tbl(fold.finish()))
+        fold.close()
+    assert all(t == tbl for t in tables)
