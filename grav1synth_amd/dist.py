@@ -10,6 +10,8 @@ integers, so the result does not depend on the number of ranks.
 """
 from __future__ import annotations
 
+import queue
+import threading
 from fractions import Fraction
 from typing import List, Optional
 
@@ -60,12 +62,18 @@ def fold_records(per_rank: List[np.ndarray], fps, ar_coeff_lag: int = 3) -> List
     return segs
 
 
+_GATHER_TO_ROOT_OK = True  # falls back to an all-gather if the backend refuses a rooted gather
+
+
 def gather_latest_round(blobs: np.ndarray, blob_size: int, max_frames: int, dist,
-                        device: Optional[torch.device] = None) -> List[np.ndarray]:
+                        device: Optional[torch.device] = None) -> Optional[List[np.ndarray]]:
     """One round of the streaming exchange: every rank contributes the latest states of ONE batch
-    ([n_r, blob_size], n_r <= max_frames; fixed-size message: [count | blobs]).  Returns the per-rank
-    arrays in rank order on every rank."""
+    ([n_r, blob_size], n_r <= max_frames; fixed-size message: [count | blobs]).  Only rank 0 merges, so
+    the round is a gather to rank 0 (RCCL: send/recv over xGMI; 1/N of an all-gather's traffic).
+    Returns the per-rank arrays in rank order on rank 0, None on the other ranks."""
+    global _GATHER_TO_ROOT_OK
     world = dist.get_world_size()
+    rank = dist.get_rank()
     backend = dist.get_backend()
     dev = device if (backend == "nccl" and device is not None) else torch.device("cpu")
     n_local = int(blobs.shape[0])
@@ -74,14 +82,26 @@ def gather_latest_round(blobs: np.ndarray, blob_size: int, max_frames: int, dist
     if n_local:
         msg[16 : 16 + n_local * blob_size] = torch.from_numpy(np.ascontiguousarray(blobs).reshape(-1))
     msg = msg.to(dev)
-    if backend == "nccl":  # RCCL: one flat all-gather over xGMI
-        out = torch.empty((world, msg.numel()), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, msg)
-        host = out.cpu().numpy()
-    else:  # gloo (CPU tests, shared-GPU smoke test)
-        parts = [torch.empty_like(msg) for _ in range(world)]
-        dist.all_gather(parts, msg)
-        host = torch.stack(parts).numpy()
+    host = None
+    if _GATHER_TO_ROOT_OK:
+        try:
+            parts = [torch.empty_like(msg) for _ in range(world)] if rank == 0 else None
+            dist.gather(msg, gather_list=parts, dst=0)
+            if rank == 0:
+                host = torch.stack(parts).cpu().numpy()
+        except (RuntimeError, NotImplementedError):  # raised on every rank alike, before any traffic
+            _GATHER_TO_ROOT_OK = False
+    if not _GATHER_TO_ROOT_OK:
+        if backend == "nccl":
+            out = torch.empty((world, msg.numel()), dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(out, msg)
+            host = out.cpu().numpy() if rank == 0 else None
+        else:
+            parts = [torch.empty_like(msg) for _ in range(world)]
+            dist.all_gather(parts, msg)
+            host = torch.stack(parts).numpy() if rank == 0 else None
+    if host is None:
+        return None
     res = []
     for r in range(world):
         n_r = int(host[r, :8].view(np.int64)[0])
@@ -94,7 +114,7 @@ class StreamingShardedDiff:
     (global batch j goes to rank j % N), every rank runs the kernels AND the per-frame half of the
     fold on its batches, and after each batch ONE small all-gather (a latest state is ~27 KB a frame)
     brings the round's states to rank 0, which merges them in global frame order while the GPUs are
-    already on the next batch.  The ordered merge (~8 us a frame) is all that stays serial.
+    already on the next batch.  The ordered merge (3-5 us a frame, on its own thread) is all that stays serial.
 
     Every rank must feed the same number of batches of `batch_frames` frames (the last may be short)."""
 
@@ -116,6 +136,10 @@ class StreamingShardedDiff:
             self._blob = latest_size(ar_coeff_lag)
             if group.get_rank() == 0:
                 self._fold = RecordFold(fps, ar_coeff_lag)
+                self._merge_q = queue.Queue()
+                self._merge_err = None
+                self._merger = threading.Thread(target=self._merge_main, daemon=True)
+                self._merger.start()
         self._dev = None
         if torch.cuda.is_available():
             self._dev = torch.device("cuda", device if device >= 0 else torch.cuda.current_device())
@@ -129,10 +153,22 @@ class StreamingShardedDiff:
         mine = self._queue.pop(0) if self._queue else np.zeros((0, self._blob), dtype=np.uint8)
         per_rank = gather_latest_round(mine, self._blob, self.batch, self.dist, self._dev)
         if self._fold is not None:
-            # global order: batch by batch, ranks in order within a batch; one call merges the whole round
+            # global order: batch by batch, ranks in order within a batch; the merge itself runs on a
+            # thread of its own (the C call drops the GIL): this thread goes back to feeding its GPU
             blobs = [b for b in per_rank if len(b)]
             if blobs:
-                self._fold.push_latest_many(np.concatenate(blobs) if len(blobs) > 1 else blobs[0])
+                self._merge_q.put(np.concatenate(blobs) if len(blobs) > 1 else blobs[0])
+
+    def _merge_main(self) -> None:
+        while True:
+            item = self._merge_q.get()
+            if item is None:
+                return
+            if self._merge_err is None:
+                try:
+                    self._fold.push_latest_many(item)
+                except Exception as e:  # surfaces in finish()
+                    self._merge_err = e
 
     def _collect(self, sync: bool) -> None:
         blobs = self.generator.take_latest(self.PIPELINE_BATCHES * self.batch, sync=sync)
@@ -157,12 +193,22 @@ class StreamingShardedDiff:
         assert not self._queue
         if self._fold is None:
             return None
+        self._stop_merger()
+        if self._merge_err is not None:
+            raise self._merge_err
         segs = self._fold.finish()
         self._fold.close()
         self._fold = None
         return segs
 
+    def _stop_merger(self) -> None:
+        if getattr(self, "_merger", None) is not None:
+            self._merge_q.put(None)
+            self._merger.join()
+            self._merger = None
+
     def close(self) -> None:
+        self._stop_merger()
         self.generator.close()
         if self._fold is not None:
             self._fold.close()
