@@ -334,6 +334,50 @@ struct TileRegs {
   }
 };
 
+// ---------------------------------------------------------------------------------
+// TileT: the luma d tile ROW-INTERLEAVED.  Dword (rq, x) of the LDS tile = the samples of column x
+// in the four rows 4 rq .. 4 rq + 3, one per byte (x = -8 .. 39 at dword index 0 .. 47, rq = 0 .. 8:
+// rows 0 .. 35, row 35 never used).  A lane then owns 4 columns x 4 rows: the operands of a horizontal
+// lag are simply other registers, the operands of a vertical lag dy are ONE v_alignbyte per column over
+// this row quad and the next -- 48 alignbytes per 184 dot4 where the row-major tile needs 144, and 2.5
+// LDS dwords per sample instead of 4.5.  The transposition (8 v_perm per 4 x 4 bytes) is done once per
+// area by the 27 lanes that stage the tile: lane = (row quad, 16-byte segment), four rows of it.
+// ---------------------------------------------------------------------------------
+struct TileT {
+  static constexpr int NQ = 9, SEG = 3, UNITS = NQ * SEG, ROW_DW = 48, BYTES = NQ * ROW_DW * 4;
+  u32x4 r[4];
+  __device__ __forceinline__ void fetch(const uint8_t *fbase, const PlaneSet &ps, int lane, int bx, int by) {
+    const int rq = lane / SEG, sg = lane - rq * SEG;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 4 * rq + k;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (lane < UNITS && y <= kBlock + kQLag - 1) {
+        gptr_u8 p = as_global(fbase) + ps.off_d[0] + (size_t)(by * kBlock + y + kPadY) * ps.pitch[0] + (size_t)(bx * kBlock + 16 * sg);
+        v = *(gptr_u4)p;
+      }
+      r[k] = v;
+    }
+  }
+  __device__ __forceinline__ void store(uint8_t *lds, int lane) const {
+    if (lane >= UNITS) return;
+    const int rq = lane / SEG, sg = lane - rq * SEG;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(lds + (rq * ROW_DW + 16 * sg) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t a = r[0][j], b = r[1][j], c = r[2][j], d = r[3][j];
+      const uint32_t ab_lo = __builtin_amdgcn_perm(b, a, 0x05010400u), ab_hi = __builtin_amdgcn_perm(b, a, 0x07030602u);
+      const uint32_t cd_lo = __builtin_amdgcn_perm(d, c, 0x05010400u), cd_hi = __builtin_amdgcn_perm(d, c, 0x07030602u);
+      u32x4 o;
+      o.x = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);  // column 4 j    : rows 0 .. 3
+      o.y = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);  // column 4 j + 1
+      o.z = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+      o.w = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+      dst[j] = o;
+    }
+  }
+};
+
 // Group classification from window bytes: w32 points at the dword of x = 4g - 8 in row 0 of
 // the group, rows are `pitch_dw` dwords apart; the group's own samples are dword +2.
 // FULL / EMPTY are decided on the bytes x-3 .. x+6 of rows 0..3 (a superset of what the 24
@@ -375,7 +419,8 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
   // partial-group coordinates of this wave; normally flushed ONCE, by the whole workgroup at the
   // end (every flush is a returning atomic on the one counter of the (frame, kind) list)
   constexpr int PGBUF = MIXED ? (S::NG < 256 ? 256 : 2 * S::NG) : 1;
-  __shared__ __attribute__((aligned(16))) uint8_t lds_all[kLagWaves][Tile::BYTES];
+  constexpr bool TRANSPOSED = KIND == 0 && !MIXED;  // row-interleaved tile (TileT)
+  __shared__ __attribute__((aligned(16))) uint8_t lds_all[kLagWaves][TRANSPOSED ? TileT::BYTES : Tile::BYTES];
   __shared__ uint32_t s_pg_all[kLagWaves][PGBUF];
   __shared__ int red[kLagWaves][kQPart + 1];
   __shared__ uint32_t s_pgn[kLagWaves];
@@ -410,12 +455,56 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
     pgn = 0;
   };
 
-  Tile tr;
   int li, li_end;
   list_slice(slice, nslices, nlist, li, li_end);
   auto entry_at = [&](int pos) -> uint32_t {
     return pos < li_end ? (uint32_t)__builtin_amdgcn_readfirstlane((int)list[pos]) : kEntryNone;
   };
+  if constexpr (TRANSPOSED) {
+    TileT tt;
+    uint32_t e_cur = entry_at(li), e_nxt = entry_at(li + 1);
+    if (e_cur != kEntryNone) tt.fetch(fbase, qp.ps, lane, (int)(e_cur & 0xffffu), (int)(e_cur >> 16));
+    const int rq = lane >> 3, cg = lane & 7;
+    for (; e_cur != kEntryNone; e_cur = e_nxt, e_nxt = entry_at(li + 1)) {
+      __builtin_amdgcn_wave_barrier();
+      tt.store(lds, lane);  // in order after the reads of the previous area
+      __builtin_amdgcn_wave_barrier();
+      ++li;
+      if (e_nxt != kEntryNone) tt.fetch(fbase, qp.ps, lane, (int)(e_nxt & 0xffffu), (int)(e_nxt >> 16));
+      ++nobs;
+      // columns x0 - 8 .. x0 + 11 (x0 = 4 cg) of this row quad (T) and of the next (N)
+      const u32x4 *tq = reinterpret_cast<const u32x4 *>(lds + (rq * TileT::ROW_DW + 4 * cg) * 4);
+      const u32x4 *nq = tq + TileT::ROW_DW / 4;
+      uint32_t T[20], N[20];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const u32x4 a = tq[k], b = nq[k];
+        T[4 * k] = a.x, T[4 * k + 1] = a.y, T[4 * k + 2] = a.z, T[4 * k + 3] = a.w;
+        N[4 * k] = b.x, N[4 * k + 1] = b.y, N[4 * k + 2] = b.z, N[4 * k + 3] = b.w;
+      }
+      // own columns: T[8 + c], c = 0 .. 3
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int dx = 0; dx <= 6; ++dx) acc[dx] = sdot4((int)T[8 + c], (int)T[8 + c + dx], acc[dx]);
+      }
+#pragma unroll
+      for (int dy = 1; dy <= 3; ++dy) {
+        uint32_t Sv[16];  // rows + dy of columns x0 - 6 .. x0 + 9
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Sv[i] = alignbyte(N[2 + i], T[2 + i], dy);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int dx = -6; dx <= 6; ++dx) {
+            const int a = 7 + (dy - 1) * 13 + dx + 6;
+            acc[a] = sdot4((int)T[8 + c], (int)Sv[6 + c + dx], acc[a]);
+          }
+        }
+      }
+    }
+  } else {
+  Tile tr;
   uint32_t e_cur = entry_at(li), e_nxt = entry_at(li + 1);
   if (e_cur != kEntryNone) tr.fetch(fbase, qp.ps, lane, pl, (int)(e_cur & 0xffffu), (int)(e_cur >> 16));
 
@@ -502,6 +591,7 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
         al[25] = sdot4((int)Lm, (int)c0, al[25]);
       }
     }
+  }
   }
   if (MIXED && lane == 0) s_pgn[wave] = pgn;
 
