@@ -378,6 +378,42 @@ struct TileT {
   }
 };
 
+// The luma window tile next to a TileT: row-major bytes 0xFF / 0x00, rows 0 .. BH+2, the column layout
+// of TileRegs (sample x at byte 8 + x, pitch 3 G dwords); 105 items of 16 samples, loaded as 16 bits.
+struct WTileT {
+  static constexpr int ROWS = kBlock + kQLag, SEG = 3, ITEMS = ROWS * SEG, PITCH = 3 * (kBlock / 4) * 4;
+  static constexpr int BYTES = ROWS * PITCH;
+  uint32_t bits[2];
+  __device__ __forceinline__ void fetch(const uint8_t *fbase, const PlaneSet &ps, int lane, int bx, int by) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int it = lane + 64 * k;
+      const int y = it / SEG, sg = it - y * SEG;
+      uint32_t v = 0;
+      if (it < ITEMS) {
+        gptr_u8 p = as_global(fbase) + ps.off_w[0] + (size_t)(by * kBlock + y + kPadY) * ps.wpitch[0] +
+                    (size_t)((bx * kBlock + 16 * sg) >> 3);
+        v = *(const G1S_GLOBAL uint16_t *)p;
+      }
+      bits[k] = v;
+    }
+  }
+  __device__ __forceinline__ void store(uint8_t *lds, int lane) const {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int it = lane + 64 * k;
+      const int y = it / SEG, sg = it - y * SEG;
+      const uint32_t b16 = bits[k];
+      u32x4 v;
+      v.x = expand_bits4(b16 & 15u);
+      v.y = expand_bits4((b16 >> 4) & 15u);
+      v.z = expand_bits4((b16 >> 8) & 15u);
+      v.w = expand_bits4((b16 >> 12) & 15u);
+      if (it < ITEMS) *reinterpret_cast<u32x4 *>(lds + y * PITCH + 16 * sg) = v;
+    }
+  }
+};
+
 // Group classification from window bytes: w32 points at the dword of x = 4g - 8 in row 0 of
 // the group, rows are `pitch_dw` dwords apart; the group's own samples are dword +2.
 // FULL / EMPTY are decided on the bytes x-3 .. x+6 of rows 0..3 (a superset of what the 24
@@ -419,8 +455,8 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
   // partial-group coordinates of this wave; normally flushed ONCE, by the whole workgroup at the
   // end (every flush is a returning atomic on the one counter of the (frame, kind) list)
   constexpr int PGBUF = MIXED ? (S::NG < 256 ? 256 : 2 * S::NG) : 1;
-  constexpr bool TRANSPOSED = KIND == 0 && !MIXED;  // row-interleaved tile (TileT)
-  __shared__ __attribute__((aligned(16))) uint8_t lds_all[kLagWaves][TRANSPOSED ? TileT::BYTES : Tile::BYTES];
+  constexpr bool TRANSPOSED = KIND == 0;  // luma: row-interleaved tile (TileT)
+  __shared__ __attribute__((aligned(16))) uint8_t lds_all[kLagWaves][TRANSPOSED ? TileT::BYTES + (MIXED ? WTileT::BYTES : 0) : Tile::BYTES];
   __shared__ uint32_t s_pg_all[kLagWaves][PGBUF];
   __shared__ int red[kLagWaves][kQPart + 1];
   __shared__ uint32_t s_pgn[kLagWaves];
@@ -462,16 +498,54 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
   };
   if constexpr (TRANSPOSED) {
     TileT tt;
+    WTileT wt;
     uint32_t e_cur = entry_at(li), e_nxt = entry_at(li + 1);
-    if (e_cur != kEntryNone) tt.fetch(fbase, qp.ps, lane, (int)(e_cur & 0xffffu), (int)(e_cur >> 16));
+    if (e_cur != kEntryNone) {
+      tt.fetch(fbase, qp.ps, lane, (int)(e_cur & 0xffffu), (int)(e_cur >> 16));
+      if (MIXED) wt.fetch(fbase, qp.ps, lane, (int)(e_cur & 0xffffu), (int)(e_cur >> 16));
+    }
     const int rq = lane >> 3, cg = lane & 7;
     for (; e_cur != kEntryNone; e_cur = e_nxt, e_nxt = entry_at(li + 1)) {
       __builtin_amdgcn_wave_barrier();
       tt.store(lds, lane);  // in order after the reads of the previous area
+      if (MIXED) wt.store(lds + TileT::BYTES, lane);
       __builtin_amdgcn_wave_barrier();
+      const int bx = (int)(e_cur & 0xffffu), by = (int)(e_cur >> 16);
       ++li;
-      if (e_nxt != kEntryNone) tt.fetch(fbase, qp.ps, lane, (int)(e_nxt & 0xffffu), (int)(e_nxt >> 16));
-      ++nobs;
+      if (e_nxt != kEntryNone) {
+        tt.fetch(fbase, qp.ps, lane, (int)(e_nxt & 0xffffu), (int)(e_nxt >> 16));
+        if (MIXED) wt.fetch(fbase, qp.ps, lane, (int)(e_nxt & 0xffffu), (int)(e_nxt >> 16));
+      }
+      if (!MIXED) ++nobs;
+      if (MIXED && pgn + S::NG > (uint32_t)PGBUF) pg_flush();
+      // the lane's four groups: rows 4 rq + r of group column cg.  FULL groups enter the lag sums (their
+      // byte of the row-interleaved operand stays), PARTIAL ones are listed, nobs counts window samples.
+      uint32_t M = 0xffffffffu;
+      if (MIXED) {
+        constexpr int WP = WTileT::PITCH / 4;
+        const uint32_t *wb = reinterpret_cast<const uint32_t *>(lds + TileT::BYTES) + (4 * rq) * WP + cg;
+        uint32_t ra[7], ro[7];
+#pragma unroll
+        for (int y = 0; y < 7; ++y) {
+          const uint32_t q1 = wb[y * WP + 1], q2 = wb[y * WP + 2], q3 = wb[y * WP + 3];
+          ra[y] = (q1 | 0x000000ffu) & q2 & (q3 | 0xff000000u);
+          ro[y] = (q1 & 0xffffff00u) | q2 | (q3 & 0x00ffffffu);
+          if (y < 4) nobs = sdot4((int)(q2 & 0x01010101u), 0x01010101, nobs);
+        }
+        M = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool full = (ra[r] & ra[r + 1] & ra[r + 2] & ra[r + 3]) == 0xffffffffu;
+          const bool empty = (ro[r] | ro[r + 1] | ro[r + 2] | ro[r + 3]) == 0u;
+          if (full) M |= 0xffu << (8 * r);
+          const bool part = !full && !empty;
+          const unsigned long long bal = __ballot(part);
+          if (part)
+            s_pg[pgn + __popcll(bal & ((1ull << lane) - 1ull))] =
+                (uint32_t)(bx * S::G + cg) | ((uint32_t)(by * S::BH + 4 * rq + r) << 16);
+          pgn += (uint32_t)__popcll(bal);
+        }
+      }
       // columns x0 - 8 .. x0 + 11 (x0 = 4 cg) of this row quad (T) and of the next (N)
       const u32x4 *tq = reinterpret_cast<const u32x4 *>(lds + (rq * TileT::ROW_DW + 4 * cg) * 4);
       const u32x4 *nq = tq + TileT::ROW_DW / 4;
@@ -483,10 +557,13 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
         N[4 * k] = b.x, N[4 * k + 1] = b.y, N[4 * k + 2] = b.z, N[4 * k + 3] = b.w;
       }
       // own columns: T[8 + c], c = 0 .. 3
+      uint32_t D[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) D[c] = T[8 + c] & M;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int dx = 0; dx <= 6; ++dx) acc[dx] = sdot4((int)T[8 + c], (int)T[8 + c + dx], acc[dx]);
+        for (int dx = 0; dx <= 6; ++dx) acc[dx] = sdot4((int)D[c], (int)T[8 + c + dx], acc[dx]);
       }
 #pragma unroll
       for (int dy = 1; dy <= 3; ++dy) {
@@ -498,7 +575,7 @@ __global__ __launch_bounds__(64 * kLagWaves) void k3_lag(Geom g, QParams qp) {
 #pragma unroll
           for (int dx = -6; dx <= 6; ++dx) {
             const int a = 7 + (dy - 1) * 13 + dx + 6;
-            acc[a] = sdot4((int)T[8 + c], (int)Sv[6 + c + dx], acc[a]);
+            acc[a] = sdot4((int)D[c], (int)Sv[6 + c + dx], acc[a]);
           }
         }
       }
