@@ -694,8 +694,15 @@ int g1s_diff::launch_back(int si) {
       const int resident = lag_resident_blocks(K, mixed);
       static const int lag_div = getenv("G1S_LAG_DIV") ? std::max(1, atoi(getenv("G1S_LAG_DIV"))) : 1;  // tuning aid
       // (measured: the INT kernels are better off with half a round of longer-lived waves)
-      int chunks = std::max(8, (resident / (lag_div * (mixed ? 1 : 2)) / (int)Bs) & ~7);
-      chunks = std::max(chunks, ((g.nblocks + 127) / 128 + 7) & ~7);
+      // (measured: the row-major INT kernels (chroma) are better off with half a round of longer-lived waves)
+      static const int lag_round = getenv("G1S_LAG_ROUND") ? std::max(1, atoi(getenv("G1S_LAG_ROUND"))) : 1;  // tuning aid
+      const int half = (!mixed && K != 0) ? 2 : 1;
+      int chunks = std::max(8, (resident * lag_round / (lag_div * half) / (int)Bs) & ~7);
+      // int32 sums: <= 128 areas per list slice; a workgroup walks 4 slices (chroma: 2, two waves to a slice)
+      const int slices_per_wg = K ? 2 : 4;
+      // (measured: the chroma MIX kernel wants twice the minimum: shorter slices, more waves in flight)
+      const int per_wg = 128 * slices_per_wg / ((K != 0 && mixed) ? 2 : 1);
+      chunks = std::max(chunks, ((g.nblocks + per_wg - 1) / per_wg + 7) & ~7);
       const dim3 gr(chunks, 1, Bs);
 #define G1S_LAG(KK)                                                                                  \
   if (mixed)                                                                                         \
