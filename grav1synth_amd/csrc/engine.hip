@@ -724,8 +724,8 @@ int g1s_diff::launch_back(int si) {
     if (qp.mixed_fast) {
       // <= pg_cap / (chunks * 256) = nblocks / chunks steps per lane; the int32 wave sums need < 520
       static const int dense_env = getenv("G1S_DENSE_CHUNKS") ? atoi(getenv("G1S_DENSE_CHUNKS")) : 0;  // tuning aid
-      int chunks = std::max(std::max(8, std::min(16, g.nblocks / 512)), (g.nblocks + 255) / 256);
-      if (dense_env > 0) chunks = std::max(dense_env, (g.nblocks + 255) / 256);
+      int chunks = std::max(std::max(8, std::min(16, g.nblocks / 512)), (g.nblocks + 511) / 512);
+      if (dense_env > 0) chunks = std::max(dense_env, (g.nblocks + 511) / 512);
       hipLaunchKernelGGL(k3_partial_dense, dim3(chunks, Bs * g.nplanes), dim3(256), 0, stream, g, qp);
     }
     hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, Bs), dim3(256), 0, stream, g, qp, sl.d_records);
