@@ -139,6 +139,9 @@ SYMBOLS = [
     ("g1s_fold_last_error", C.c_char_p, [C.c_void_p]),
     ("g1s_format_tbl", C.c_long, [C.POINTER(G1SSegment), C.c_size_t, C.c_char_p, C.c_size_t]),
     ("g1s_write_tbl", C.c_int, [C.c_char_p, C.POINTER(G1SSegment), C.c_size_t]),
+    ("g1s_parse_tbl", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(G1SSegment), C.c_size_t, C.POINTER(C.c_size_t),
+                                C.c_char_p, C.c_size_t]),
+    ("g1s_tbl_segment_for", C.c_long, [C.POINTER(G1SSegment), C.c_size_t, C.c_uint64]),
     ("g1s_diff_get_stats", C.c_int, [C.c_void_p, C.POINTER(G1SStats)]),
     ("g1s_diff_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("g1s_diff_set_flat_finder", C.c_int, [C.c_void_p, C.c_int]),

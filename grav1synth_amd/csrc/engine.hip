@@ -1313,6 +1313,30 @@ const char *g1s_fold_last_error(const g1s_fold_t *f) { return f ? f->err.c_str()
 long g1s_format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap) {
   return format_tbl(segs, n, buf, cap);
 }
+int g1s_parse_tbl(const char *text, size_t len, g1s_segment_t *out, size_t cap, size_t *n_out, char *err, size_t errcap) {
+  if (!text && len) return G1S_ERR_INVALID;
+  std::vector<g1s_segment_t> segs;
+  std::string msg;
+  const int rc = parse_tbl(text, len, segs, msg);
+  if (rc) {
+    if (err && errcap) snprintf(err, errcap, "%s", msg.c_str());
+    return rc;
+  }
+  if (n_out) *n_out = segs.size();
+  if (segs.size() > cap) return G1S_ERR_CAPACITY;
+  if (!segs.empty()) std::memcpy(out, segs.data(), sizeof(g1s_segment_t) * segs.size());
+  return G1S_OK;
+}
+long g1s_tbl_segment_for(g1s_segment_t *segs, size_t n, uint64_t packet_ts) {
+  if (!segs) return -1;
+  for (size_t i = 0; i < n; ++i) {
+    if (segs[i].start_time <= packet_ts && packet_ts < segs[i].end_time) {
+      segs[i].random_seed = (uint16_t)(segs[i].random_seed + 10956u);  // DEFAULT_GRAIN_SEED, wrapping
+      return (long)i;
+    }
+  }
+  return -1;
+}
 int g1s_write_tbl(const char *path, const g1s_segment_t *segs, size_t n) {
   std::vector<char> buf(1024 + 2048 * n);
   const long k = format_tbl(segs, n, buf.data(), buf.size());

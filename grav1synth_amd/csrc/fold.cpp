@@ -762,4 +762,157 @@ long format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap) {
   return (long)s.size();
 }
 
+// The reader of the same text (av1_grain::parse_grain_table as `apply` uses it, src/main.rs:228-241):
+// header line, then per segment the E line and the seven tagged lines in any order.
+int parse_tbl(const char *text, size_t len, std::vector<g1s_segment_t> &out, std::string &err) {
+  out.clear();
+  std::vector<std::string> lines;
+  {
+    std::string cur;
+    for (size_t i = 0; i < len; ++i) {
+      if (text[i] == '\n') {
+        lines.push_back(cur);
+        cur.clear();
+      } else if (text[i] != '\r') {
+        cur.push_back(text[i]);
+      }
+    }
+    if (!cur.empty()) lines.push_back(cur);
+  }
+  auto blank = [](const std::string &l) { return l.find_first_not_of(" \t") == std::string::npos; };
+  auto fields = [](const std::string &l, std::string &tag, std::vector<long long> &v) -> bool {
+    tag.clear();
+    v.clear();
+    size_t i = 0;
+    auto skip = [&] { while (i < l.size() && (l[i] == ' ' || l[i] == '\t')) ++i; };
+    skip();
+    while (i < l.size() && l[i] != ' ' && l[i] != '\t') tag.push_back(l[i++]);
+    for (;;) {
+      skip();
+      if (i >= l.size()) return true;
+      char *end = nullptr;
+      const long long x = std::strtoll(l.c_str() + i, &end, 10);
+      if (end == l.c_str() + i) return false;  // not a number
+      v.push_back(x);
+      i = (size_t)(end - l.c_str());
+    }
+  };
+  size_t li = 0;
+  while (li < lines.size() && blank(lines[li])) ++li;
+  {
+    std::string tag;
+    std::vector<long long> v;
+    if (li >= lines.size() || !fields(lines[li], tag, v) || tag != "filmgrn1" || !v.empty()) {
+      err = "missing filmgrn1 header";
+      return G1S_ERR_INVALID;
+    }
+    ++li;
+  }
+  char msg[160];
+  while (li < lines.size()) {
+    if (blank(lines[li])) {
+      ++li;
+      continue;
+    }
+    std::string tag;
+    std::vector<long long> e;
+    if (!fields(lines[li], tag, e) || tag != "E") {
+      snprintf(msg, sizeof msg, "line %zu: expected an E line", li + 1);
+      err = msg;
+      return G1S_ERR_INVALID;
+    }
+    if (e.size() != 5) {
+      snprintf(msg, sizeof msg, "line %zu: E line needs 5 fields", li + 1);
+      err = msg;
+      return G1S_ERR_INVALID;
+    }
+    if (e[2] != 1 || e[4] != 1) {
+      snprintf(msg, sizeof msg, "line %zu: apply_grain/update_parameters must be 1", li + 1);
+      err = msg;
+      return G1S_ERR_INVALID;
+    }
+    g1s_segment_t g;
+    std::memset(&g, 0, sizeof g);
+    g.start_time = (uint64_t)e[0];
+    g.end_time = (uint64_t)e[1];
+    g.random_seed = (uint16_t)e[3];
+    std::vector<long long> body[7];
+    bool have[7] = {false, false, false, false, false, false, false};
+    static const char *const kTags[7] = {"p", "sY", "sCb", "sCr", "cY", "cCb", "cCr"};
+    for (int k = 1; k <= 7; ++k) {
+      std::vector<long long> v;
+      if (li + k >= lines.size() || blank(lines[li + k]) || !fields(lines[li + k], tag, v)) {
+        err = "truncated segment";
+        return G1S_ERR_INVALID;
+      }
+      for (int t = 0; t < 7; ++t) {
+        if (tag == kTags[t]) {
+          body[t] = v;
+          have[t] = true;
+        }
+      }
+    }
+    li += 8;
+    for (int t = 0; t < 7; ++t) {
+      if (!have[t]) {
+        snprintf(msg, sizeof msg, "segment starting at %llu: missing %s line", (unsigned long long)g.start_time, kTags[t]);
+        err = msg;
+        return G1S_ERR_INVALID;
+      }
+    }
+    const std::vector<long long> &p = body[0];
+    if (p.size() != 12) {
+      err = "p line needs 12 fields";
+      return G1S_ERR_INVALID;
+    }
+    if (p[0] < 0 || p[0] > 3) {
+      err = "ar_coeff_lag out of range";
+      return G1S_ERR_INVALID;
+    }
+    g.ar_coeff_lag = (uint8_t)p[0];
+    g.ar_coeff_shift = (uint8_t)p[1];
+    g.grain_scale_shift = (uint8_t)p[2];
+    g.scaling_shift = (uint8_t)p[3];
+    g.chroma_scaling_from_luma = p[4] != 0;
+    g.overlap_flag = p[5] != 0;
+    g.cb_mult = (uint8_t)p[6];
+    g.cb_luma_mult = (uint8_t)p[7];
+    g.cb_offset = (uint16_t)p[8];
+    g.cr_mult = (uint8_t)p[9];
+    g.cr_luma_mult = (uint8_t)p[10];
+    g.cr_offset = (uint16_t)p[11];
+    auto points = [&](int t, size_t cap, uint8_t(*dst)[2], uint8_t &n_out) -> bool {
+      const std::vector<long long> &v = body[t];
+      if (v.empty() || v[0] < 0 || (size_t)v[0] > cap || v.size() != 1 + 2 * (size_t)v[0]) {
+        err = std::string(kTags[t]) + ": bad point count";
+        return false;
+      }
+      n_out = (uint8_t)v[0];
+      for (size_t j = 0; j < (size_t)v[0]; ++j) {
+        dst[j][0] = (uint8_t)v[1 + 2 * j];
+        dst[j][1] = (uint8_t)v[2 + 2 * j];
+      }
+      return true;
+    };
+    if (!points(1, G1S_NUM_Y_POINTS, g.scaling_points_y, g.num_y_points) ||
+        !points(2, G1S_NUM_UV_POINTS, g.scaling_points_cb, g.num_cb_points) ||
+        !points(3, G1S_NUM_UV_POINTS, g.scaling_points_cr, g.num_cr_points))
+      return G1S_ERR_INVALID;
+    const size_t ncoef = 2 * (size_t)g.ar_coeff_lag * (g.ar_coeff_lag + 1);  // src/parser/grain.rs:40-44
+    if (body[4].size() != ncoef || body[5].size() != ncoef + 1 || body[6].size() != ncoef + 1) {
+      err = "coefficient count does not match ar_coeff_lag";
+      return G1S_ERR_INVALID;
+    }
+    g.num_y_coeffs = (uint8_t)ncoef;
+    g.num_uv_coeffs = (uint8_t)(ncoef + 1);
+    for (size_t j = 0; j < ncoef; ++j) g.ar_coeffs_y[j] = (int8_t)body[4][j];
+    for (size_t j = 0; j < ncoef + 1; ++j) {
+      g.ar_coeffs_cb[j] = (int8_t)body[5][j];
+      g.ar_coeffs_cr[j] = (int8_t)body[6][j];
+    }
+    out.push_back(g);
+  }
+  return G1S_OK;
+}
+
 }  // namespace g1s

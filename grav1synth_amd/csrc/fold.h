@@ -124,5 +124,6 @@ class NoiseFold {
 };
 
 long format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap);
+int parse_tbl(const char *text, size_t len, std::vector<g1s_segment_t> &out, std::string &err);
 
 }  // namespace g1s

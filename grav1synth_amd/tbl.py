@@ -83,3 +83,46 @@ def parse_tbl(data: bytes) -> List[GrainTableSegment]:
             cr_mult=p[9], cr_luma_mult=p[10], cr_offset=p[11],
             chroma_scaling_from_luma=bool(p[4]), grain_scale_shift=p[2], overlap_flag=bool(p[5])))
     return segs
+
+
+def parse_tbl_native(data: bytes) -> List[GrainTableSegment]:
+    """The same through the library's C parser (g1s_parse_tbl)."""
+    import ctypes as C
+
+    from . import _lib
+    from ._lib import G1SSegment
+
+    L = _lib.lib()
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(256)
+    cap = 64
+    while True:
+        buf = (G1SSegment * cap)()
+        rc = L.g1s_parse_tbl(data, len(data), buf, cap, C.byref(n), err, len(err))
+        if rc == -8:  # G1S_ERR_CAPACITY: *n_out holds the count
+            cap = n.value
+            continue
+        if rc:
+            raise TblError(err.value.decode() or f"g1s_parse_tbl failed ({rc})")
+        return [GrainTableSegment.from_c(buf[i]) for i in range(n.value)]
+
+
+class GrainTable:
+    """Segments + the lookup `apply` does per frame (src/parser/frame.rs:617-633): the first segment with
+    start_time <= ts < end_time; every hit advances that segment's seed by DEFAULT_GRAIN_SEED (wrapping)."""
+
+    def __init__(self, segments: List[GrainTableSegment]):
+        import ctypes as C
+
+        from ._lib import G1SSegment
+
+        self._n = len(segments)
+        self._buf = (G1SSegment * max(self._n, 1))()
+        for i, s in enumerate(segments):
+            self._buf[i] = s.to_c()
+
+    def segment_for(self, packet_ts: int):
+        from . import _lib
+
+        i = _lib.lib().g1s_tbl_segment_for(self._buf, self._n, int(packet_ts))
+        return None if i < 0 else GrainTableSegment.from_c(self._buf[i])

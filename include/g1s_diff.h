@@ -168,6 +168,13 @@ const char *g1s_fold_last_error(const g1s_fold_t *);
 /* Returns the number of bytes written (no NUL), or G1S_ERR_CAPACITY. */
 long g1s_format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap);
 int g1s_write_tbl(const char *path, const g1s_segment_t *segs, size_t n);
+/* The reader of the same text: av1_grain::parse_grain_table as `apply` calls it (src/main.rs:228-241).
+ * *n_out = number of segments (also when cap is too small: G1S_ERR_CAPACITY); reason of a failure in err. */
+int g1s_parse_tbl(const char *text, size_t len, g1s_segment_t *out, size_t cap, size_t *n_out, char *err, size_t errcap);
+/* The segment `apply` stamps on a frame with presentation time packet_ts (src/parser/frame.rs:617-633): the
+ * first one with start_time <= ts < end_time, or -1.  Like the reference, every hit advances that segment's
+ * random_seed by DEFAULT_GRAIN_SEED (wrapping) before it is used. */
+long g1s_tbl_segment_for(g1s_segment_t *segs, size_t n, uint64_t packet_ts);
 
 /* ---- measurement hooks (bench.py) ---- */
 typedef struct {

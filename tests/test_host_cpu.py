@@ -153,3 +153,38 @@ def test_batched_merge_equals_frame_by_frame_merge_across_segment_cuts():
         tables.append(format_tbl(fold.finish()))
         fold.close()
     assert all(t == tbl for t in tables)
+
+
+def test_native_tbl_reader_round_trips_and_matches_the_python_reader():
+    """N1: the consumer side of diff's output.  g1s_parse_tbl must read what g1s_format_tbl and the reference
+    write (tests/golden/*.tbl incl. the reference's own sample table), agree with the Python reader, and
+    reject what it rejects; g1s_tbl_segment_for is `apply`'s per-frame lookup (src/parser/frame.rs:617-633)."""
+    import glob
+    import os
+
+    from grav1synth_amd.tbl import GrainTable, TblError, parse_tbl, parse_tbl_native
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.tbl")))
+    assert len(files) >= 5
+    for f in files:
+        data = open(f, "rb").read()
+        a, b = parse_tbl(data), parse_tbl_native(data)
+        assert a == b and len(a) >= 1
+        assert format_tbl(b) == data          # writer(reader(x)) == x, byte for byte
+    for bad in (b"", b"filmgrn2\n", b"filmgrn1\nX 0 1 1 1 1\n", b"filmgrn1\nE 0 1 1 1\n", b"filmgrn1\nE 0 1 0 1 1\n",
+                b"filmgrn1\nE 0 9 1 7 1\n\tp 3 7 0 11 0 1 128 192 256 128 192 256\n"):
+        with pytest.raises(TblError):
+            parse_tbl_native(bad)
+        with pytest.raises((TblError, ValueError)):
+            parse_tbl(bad)
+    data = open(os.path.join(os.path.dirname(__file__), "golden", "oracle_scenecut_30000_1001.tbl"), "rb").read()
+    segs = parse_tbl_native(data)
+    assert len(segs) >= 2
+    t = GrainTable(segs)
+    first = t.segment_for(0)
+    assert first.start_time == 0 and first.random_seed == (segs[0].random_seed + 10956) & 0xffff
+    again = t.segment_for(segs[0].end_time - 1)
+    assert again.start_time == 0 and again.random_seed == (segs[0].random_seed + 2 * 10956) & 0xffff
+    second = t.segment_for(segs[0].end_time)
+    assert second.start_time == segs[1].start_time and second.random_seed == (segs[1].random_seed + 10956) & 0xffff
+    assert GrainTable(segs[:1]).segment_for(segs[0].end_time) is None
