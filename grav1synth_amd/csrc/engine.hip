@@ -717,9 +717,28 @@ int g1s_diff::launch_back(int si) {
     };
     launch_lag(0, false, stream);
     if (ck) launch_lag(ck, false, stream);
+    // The tail of the accumulation -- the partial-group kernel, the reducer, the generic kernel (G1S_TAIL=2:
+    // the MIX lag kernels as well) -- runs on the copy stream, i.e. next to the pixel pass of the batch after
+    // next: its gathers and LDS traffic mix well with K0's streaming, unlike the dot4-bound lag kernels.
+    static const int tail_env = getenv("G1S_TAIL") ? atoi(getenv("G1S_TAIL")) : 1;  // tuning aid
+    const int tail = side ? tail_env : 0;
+    auto to_tail = [&]() -> int {
+      HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
+      HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
+      stream = ss.copy;
+      return G1S_OK;
+    };
+    if (tail == 2) {
+      const int rc = to_tail();
+      if (rc) return rc;
+    }
     if (qp.mixed_fast) {
       launch_lag(0, true, stream);
       if (ck) launch_lag(ck, true, stream);
+    }
+    if (tail == 1) {
+      const int rc = to_tail();
+      if (rc) return rc;
     }
     if (qp.mixed_fast) {
       // <= pg_cap / (chunks * 256) = nblocks / chunks steps per lane; the int32 wave sums need < 520
