@@ -373,8 +373,8 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     frame_bytes += ((pw * d->bytes_per_sample + 15) & ~size_t(15)) * ph;
   }
   size_t partial_bytes = 0, k0_bytes = 0, pgl_bytes = 0;
-  if (lag == kQLag) {
-    partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart);
+  {  // the lag-structured path serves every lag (1 and 2 through lag-3 tiles and a scratch lag-3 system)
+    partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart + kAr3);
     const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
     // [cls][bad][lists u32 x6 per frame][counts]
     defer_bytes = 2 * cls_bytes + sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 8);
@@ -560,10 +560,10 @@ int g1s_diff::launch_front(int si) {
     ZeroJob z{};
     z.ptr[0] = reinterpret_cast<uint32_t *>(sl.d_records);
     z.ndw[0] = (uint32_t)(L.size * B / 4);
-    if ((int)lag == kQLag) {
+    {
       const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
       z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_partials);
-      z.ndw[1] = (uint32_t)(sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart) / 4);
+      z.ndw[1] = (uint32_t)(sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart + ((int)lag == kQLag ? 0 : kAr3)) / 4);
       z.ptr[2] = reinterpret_cast<uint32_t *>(sl.d_defer + cls_bytes);  // bad flags
       z.ndw[2] = (uint32_t)(cls_bytes / 4);
       z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes) + (size_t)batch * 6 * g.nblocks;  // list counts
@@ -577,7 +577,7 @@ int g1s_diff::launch_front(int si) {
   }
   sl.timed = timing;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], pstream));
-  const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
+  const bool fast_ok = !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   const size_t cls_bytes_q = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   {
     // flat-block features: integer moments + certified evaluation; the literal f64 kernel only for
@@ -657,6 +657,7 @@ QParams g1s_diff::make_qparams(const Slot &sl) const {
   qp.mixed_fast = force_generic ? 0 : 1;
   qp.lagacc = reinterpret_cast<long long *>(sl.d_partials);
   qp.paracc = qp.lagacc + (size_t)batch * 3 * kQPart;
+  qp.ar3 = (int)lag == kQLag ? nullptr : qp.paracc + (size_t)batch * 3 * kPPart;
   const size_t cls_bytes = ((size_t)geom.nblocks * 2 * batch + 15) & ~size_t(15);
   qp.cls = sl.d_defer;
   qp.bad = sl.d_defer + cls_bytes;
@@ -681,7 +682,7 @@ int g1s_diff::launch_back(int si) {
   FrameTable ft;
   std::memcpy(ft.f, sl.h_planes, sizeof(FramePlanes) * B);
   if (B < (uint32_t)kMaxBatch) std::memset(ft.f + B, 0, sizeof(FramePlanes) * (kMaxBatch - B));
-  const bool fast_ok = (int)lag == kQLag && !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
+  const bool fast_ok = !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   if (fast_ok) {
     // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
     // then the generic int32 kernel on mixed / deferred areas
@@ -750,6 +751,7 @@ int g1s_diff::launch_back(int si) {
     hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, Bs), dim3(256), 0, stream, g, qp, sl.d_records);
     const int chunks = std::min(64, g.nblocks);
     hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, Bs), dim3(256), 0, stream, ft, g, qp, sl.d_records);
+    if (qp.ar3) hipLaunchKernelGGL(k3q_compact, dim3(g.nplanes, Bs), dim3(256), 0, stream, g, qp, sl.d_records);
   } else {
     const int chunks = std::min(kK3Chunks, g.nblocks);
     hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g, sl.d_records,
@@ -806,7 +808,7 @@ int g1s_diff::drain_slot(int si) {
   HIP_TRY(hipEventSynchronize(sl.done));
   if (sl.timed) {
     float ms = 0;
-    const bool k0_timed = (int)lag == kQLag && !(geom.nplanes == 3 && geom.xdec == 0 && geom.ydec == 1);
+    const bool k0_timed = !(geom.nplanes == 3 && geom.xdec == 0 && geom.ydec == 1);
     float ms_k0 = 0;
     if (k0_timed) HIP_TRY(hipEventElapsedTime(&ms_k0, sl.ev[5], sl.ev[4]));
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));

@@ -91,24 +91,26 @@ __device__ __forceinline__ int wave_sum(int v) {
 struct Win {
   int flat, xs, xe, ys, ye;
 };
+// (lag = the AR lag of the generator: the border a window keeps from a non-flat neighbour and from the right
+//  plane edge; the lag-structured kernels run lag 1 and 2 with lag-3 tiles and these narrower borders)
 __device__ __forceinline__ Win block_window(const uint8_t *mask, int nbw, int nbh, int bx, int by, int bw, int bh,
-                                            int pw, int ph) {
+                                            int pw, int ph, int lag) {
   Win w{0, 0, 0, 0, 0};
   if (bx < 0 || by < 0 || bx >= nbw || by >= nbh) return w;
   if (!mask[by * nbw + bx]) return w;
   w.flat = 1;
-  w.ys = (by > 0 && mask[(by - 1) * nbw + bx]) ? 0 : kQLag;
-  w.xs = (bx > 0 && mask[by * nbw + bx - 1]) ? 0 : kQLag;
+  w.ys = (by > 0 && mask[(by - 1) * nbw + bx]) ? 0 : lag;
+  w.xs = (bx > 0 && mask[by * nbw + bx - 1]) ? 0 : lag;
   w.ye = min(ph - by * bh, bh);
-  w.xe = min(pw - bx * bw - kQLag, (bx + 1 < nbw && mask[by * nbw + bx + 1]) ? bw : (bw - kQLag));
+  w.xe = min(pw - bx * bw - lag, (bx + 1 < nbw && mask[by * nbw + bx + 1]) ? bw : (bw - lag));
   if (w.xe <= w.xs || w.ye <= w.ys) w.flat = 0;  // empty window
   return w;
 }
 __device__ __forceinline__ int window_at(const uint8_t *mask, int nbw, int nbh, int bw, int bh, int pw, int ph, int X,
-                                         int Y) {
+                                         int Y, int lag) {
   if (X < 0 || Y < 0 || X >= pw || Y >= ph) return 0;
   const int bx = X / bw, by = Y / bh;
-  const Win w = block_window(mask, nbw, nbh, bx, by, bw, bh, pw, ph);
+  const Win w = block_window(mask, nbw, nbh, bx, by, bw, bh, pw, ph, lag);
   const int lx = X - bx * bw, ly = Y - by * bh;
   return w.flat && lx >= w.xs && lx < w.xe && ly >= w.ys && ly < w.ye;
 }
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(64) void k3_windows(Geom g, PlaneSet ps, uint8_t *_
   for (int t = 0; t < 3; ++t) {
     const int bx = b_first + t;
     if (bx > b_last) continue;
-    const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph);
+    const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph, g.lag);
     if (!w.flat) continue;
     const int lo = max(bx * bw + w.xs - x_first, 0), hi = min(bx * bw + w.xe - x_first, 32);
     if (hi > lo) colbits[t] = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
@@ -558,14 +560,15 @@ __global__ __launch_bounds__(64) void k3_windows(Geom g, PlaneSet ps, uint8_t *_
 // k_zero: every per-batch zero fill in ONE launch (records, accumulators, flags, counters);
 // separate memset nodes each cost a dispatch gap in the launch chain.
 // ---------------------------------------------------------------------------------
+constexpr int kZeroBufs = 7;
 struct ZeroJob {
-  uint32_t *ptr[6];
-  uint32_t ndw[6];  // dwords
+  uint32_t *ptr[kZeroBufs];
+  uint32_t ndw[kZeroBufs];  // dwords
 };
 __global__ __launch_bounds__(256) void k_zero(ZeroJob z) {
   const uint32_t stride = gridDim.x * 256u;
 #pragma unroll
-  for (int r = 0; r < 6; ++r) {
+  for (int r = 0; r < kZeroBufs; ++r) {
     uint32_t *p = z.ptr[r];
     const uint32_t n = z.ndw[r];
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) p[i] = 0u;

@@ -55,7 +55,11 @@ constexpr int kPPart = 324;
 constexpr int kPSub = kPPart / kPParts;
 __host__ __device__ constexpr bool p_in_part(int part, int i) { return ((i < 12 ? i : 23 - i) % kPParts) == part; }
 
+// ar3: lag 1 / 2 generators: the lag-3 systems [frame][3][kAr3] the kernels fill (the record holds the lag's own,
+// smaller system: k3q_compact picks it out); nullptr for lag 3 (the kernels write the record directly)
+constexpr int kAr3 = (kQN + 1) * (kQN + 1) + (kQN + 1) + 1 + 3;  // S 25x25, Sb 25, nobs (+ pad)
 struct QParams {
+  long long *ar3;
   int mixed_fast;    // 1: MIX areas by k3_lag<true> + k3_partial_dense; 0: by k3q_generic (debug)
   long long *lagacc;   // [batch][3][kQPart]  int64 sums of all lag-kernel workgroups (zeroed per batch)
   long long *paracc;   // [batch][3][kPPart]  int64 sums of all k3_partial_dense workgroups (zeroed per batch)
@@ -164,10 +168,10 @@ __global__ __launch_bounds__(kClsThreads) void k3_classify(Geom g, const uint8_t
           Win w{0, 0, 0, 0, 0};
           if (m[1 + dby][2 + dbx]) {
             w.flat = 1;
-            w.ys = m[dby][2 + dbx] ? 0 : kQLag;
-            w.xs = m[1 + dby][1 + dbx] ? 0 : kQLag;
+            w.ys = m[dby][2 + dbx] ? 0 : g.lag;
+            w.xs = m[1 + dby][1 + dbx] ? 0 : g.lag;
             w.ye = min(ph - By * bh, bh);
-            w.xe = min(pw - Bx * bw - kQLag, m[1 + dby][3 + dbx] ? bw : (bw - kQLag));
+            w.xe = min(pw - Bx * bw - g.lag, m[1 + dby][3 + dbx] ? bw : (bw - g.lag));
             if (w.xe <= w.xs || w.ye <= w.ys) w.flat = 0;
           }
           const int rx0 = max(AX0, Bx * bw), rx1 = min(AX1, Bx * bw + bw);
@@ -1004,7 +1008,8 @@ __global__ __launch_bounds__(256) void k3q_generic(const FrameTable ft, Geom g, 
       om[s] = tile_off(0, 0);
     }
   }
-  unsigned long long *ar = reinterpret_cast<unsigned long long *>(rec + g.off_ar[c]);
+  unsigned long long *ar = qp.ar3 ? reinterpret_cast<unsigned long long *>(qp.ar3) + ((size_t)frame * 3 + c) * kAr3
+                                  : reinterpret_cast<unsigned long long *>(rec + g.off_ar[c]);
   const uint8_t *sp = fp.src[c], *dp = fp.den[c];
   const uint32_t sst = fp.src_stride[c], dst = fp.den_stride[c];
 
@@ -1020,7 +1025,7 @@ __global__ __launch_bounds__(256) void k3q_generic(const FrameTable ft, Geom g, 
       if (X >= 0 && X < pw && Y >= 0 && Y < ph) {
         const int s = load_px_rt(sp, sst, g.src_bps, g.src_shift, X, Y);
         d = s - load_px_rt(dp, dst, g.den_bps, g.den_shift, X, Y);
-        wv = window_at(mask, g.nbw, g.nbh, bw, bh, pw, ph, X, Y);
+        wv = window_at(mask, g.nbw, g.nbh, bw, bh, pw, ph, X, Y, g.lag);
         if (tx >= 6 && tx < 6 + bw && ty >= 3 && ty < 3 + bh) {  // block proper
           s_d += d;
           s_d2 += d * d;
@@ -1099,7 +1104,7 @@ __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *_
   const bool chroma = c > 0;
   const int nc = kQN + (chroma ? 1 : 0);
   uint8_t *rec = records + (size_t)frame * g.rec_size;
-  long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
+  long long *ar = qp.ar3 ? qp.ar3 + ((size_t)frame * 3 + c) * kAr3 : reinterpret_cast<long long *>(rec + g.off_ar[c]);
   const long long *lag = qp.lagacc + ((size_t)frame * 3 + c) * kQPart;
   const long long *par = qp.paracc + ((size_t)frame * 3 + c) * kPPart;
   for (int p = threadIdx.x; p < kQN * kQN; p += 256) {
@@ -1127,6 +1132,32 @@ __global__ __launch_bounds__(256) void k3q_reduce(Geom g, QParams qp, uint8_t *_
     ar[nc * nc + kQN] += lag[kNumLags + 25];   // Sb[L]
   }
   if (threadIdx.x == 64) ar[nc * nc + nc] += lag[kQPart - 1];
+}
+
+// ---------------------------------------------------------------------------------
+// k3q_compact (lag 1 / 2): the lag's own system out of the lag-3 one.  The lag-L neighbourhood is a subset
+// of the lag-3 neighbourhood and, with the windows built for lag L (block_window), entry (a, b) of the lag-L
+// normal equations IS entry (i3(a), i3(b)) of the lag-3 ones: same samples, same products.
+// grid = (nplanes, batch), block = 256.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int lag3_index(int a, int lag, int n) {  // coefficient a of lag `lag` (n of them) -> lag-3 index
+  if (a >= n) return kQN;                                            // the chroma luma regressor
+  const int row = 2 * lag + 1;
+  const int y = a / row - lag, x = a % row - lag;                    // raster over (-lag..0, -lag..lag), causal part
+  return (y + kQLag) * 7 + (x + kQLag);
+}
+__global__ __launch_bounds__(256) void k3q_compact(Geom g, QParams qp, uint8_t *__restrict__ records) {
+  const int c = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;
+  const int nc = g.n + (c > 0), nc3 = kQN + (c > 0);
+  long long *dst = reinterpret_cast<long long *>(records + (size_t)frame * g.rec_size + g.off_ar[c]);
+  const long long *src = qp.ar3 + ((size_t)frame * 3 + c) * kAr3;
+  for (int p = threadIdx.x; p < nc * nc; p += 256) {
+    const int a = p / nc, b = p % nc;
+    if (b < a) continue;  // (the host mirrors the upper triangle)
+    dst[a * nc + b] = src[lag3_index(a, g.lag, g.n) * nc3 + lag3_index(b, g.lag, g.n)];
+  }
+  if (threadIdx.x < nc) dst[nc * nc + threadIdx.x] = src[nc3 * nc3 + lag3_index(threadIdx.x, g.lag, g.n)];
+  if (threadIdx.x == 64) dst[nc * nc + nc] = src[nc3 * nc3 + nc3];
 }
 
 }  // namespace g1s

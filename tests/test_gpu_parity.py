@@ -34,6 +34,12 @@ CASES = [
     (SynthSpec(64, 64, 8), 3, True, 2, True),              # 2 x 2 blocks: every area touches the frame edge
     (SynthSpec(512, 40, 8, textured=False), 3, True, 2, True),   # a 1.25-block-high strip
     (SynthSpec(288, 160, 8, xdec=0, ydec=0), 3, True, 2, True),  # 4:4:4 8-bit
+    # lag 1 / 2 run through the lag-3 tiles with their own (narrower) window borders
+    (SynthSpec(326, 198, 8), 2, True, 2, True),            # odd sizes, chroma
+    (SynthSpec(320, 200, 10), 1, True, 2, False),          # partial bottom block row, host frames
+    (SynthSpec(256, 160, 10, xdec=0, ydec=0), 2, True, 2, True),   # 4:4:4
+    (SynthSpec(320, 192, 10, xdec=1, ydec=0), 1, False, 2, True),  # 4:2:2 source, luma only
+    (SynthSpec(64, 64, 8), 2, True, 2, True),              # every area touches the frame edge
 ]
 
 
@@ -222,17 +228,17 @@ def test_errors_match_reference_behaviour():
     assert e.value.code == -7
 
 
-@pytest.mark.parametrize("bd,xdec,ydec", [(8, 1, 1), (10, 0, 0)])
-def test_large_residuals_take_the_deferred_path(bd, xdec, ydec):
+@pytest.mark.parametrize("bd,xdec,ydec,lag", [(8, 1, 1, 3), (10, 0, 0, 3), (8, 1, 1, 2), (10, 1, 0, 1)])
+def test_large_residuals_take_the_deferred_path(bd, xdec, ydec, lag):
     """|src - den| > 127 does not fit the int8 dot4 path: those blocks must be
     handled by the generic kernel with identical integer sums."""
     spec = SynthSpec(320, 192, bd, xdec=xdec, ydec=ydec)
     up = bd - 8
-    o_args = (24, 1, bd, bd, 3, True)
+    o_args = (24, 1, bd, bd, lag, True)
     from tests.oracle_binding import OracleDiff, format_tbl as ofmt
 
     o = OracleDiff(*o_args)
-    g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=2)
+    g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=2, ar_coeff_lag=lag)
     rng = np.random.default_rng(7)
     for k in range(2):
         s, d = np_pair(spec, k)
