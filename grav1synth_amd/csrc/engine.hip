@@ -173,10 +173,11 @@ std::vector<CachedSlot> g_slot_cache;
 // and one event per slot, and hands them back when it is freed.
 struct StreamSet {
   int device = -1;
-  hipStream_t compute = nullptr, copy = nullptr, flat = nullptr;
+  hipStream_t compute = nullptr, copy = nullptr, flat = nullptr, upload = nullptr;
   hipEvent_t kernels_done[kSlots] = {};
   hipEvent_t mask_done[kSlots] = {};
   hipEvent_t pix_done[kSlots] = {};
+  hipEvent_t table_done[kSlots] = {};
 };
 std::vector<StreamSet> g_stream_cache;
 bool acquire_streams(int device, StreamSet &out) {
@@ -198,11 +199,13 @@ bool acquire_streams(int device, StreamSet &out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = more urgent
   bool ok = hipStreamCreateWithPriority(&out.compute, hipStreamNonBlocking, prio_lo) == hipSuccess &&
             hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_hi) == hipSuccess;
+            hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+            hipStreamCreateWithFlags(&out.upload, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < kSlots && ok; ++i)
     ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&out.pix_done[i], hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&out.pix_done[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&out.table_done[i], hipEventDisableTiming) == hipSuccess;
   return ok;
 }
 void release_streams(StreamSet &ss) {
@@ -247,6 +250,7 @@ struct g1s_diff {
   bool luma_only, records_only;
   bool latest_only = false;  // keep the per-frame latest states (blobs) instead of folding them here
   uint32_t batch;
+  bool batch_auto = false;  // no batch size asked for: sized to the frames at the first frame pair
   int device = 0;
   hipStream_t stream = nullptr;       // == ss.compute
   StreamSet ss;                       // borrowed from the process-wide cache
@@ -339,6 +343,12 @@ static void make_flat_consts(FlatConsts &fc) {
 
 int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   shape = *s;
+  if (batch_auto) {
+    // about 265 Mpixels a launch group (32 4K frames): the per-launch costs of the small kernels are the same
+    // for small frames, so they get more frames per launch (1080p: 128)
+    const uint64_t px = (uint64_t)s->width * s->height;
+    batch = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(kDefaultBatch, (265000000ull + px / 2) / std::max<uint64_t>(px, 1)));
+  }
   const uint32_t np = luma_only ? 1u : (uint32_t)s->nplanes;
   L = make_layout(s->width, s->height, np, lag);
   Geom &g = geom;
@@ -552,9 +562,18 @@ int g1s_diff::launch_front(int si) {
   hipStream_t stream = ss.compute;                                        // main stream (shadows the member)
   hipStream_t fstream = (one_stream || timing || !ss.flat) ? stream : ss.flat;  // per-kernel timing: one stream
   hipStream_t pstream = stream;                                           // pixel pass
+  // the frame table: pinned host copy -> device, on the upload stream (idle: done long before the main
+  // stream gets here); per-kernel timing / one-stream mode: in line
   FrameTable ft;
-  std::memcpy(ft.f, sl.h_planes, sizeof(FramePlanes) * B);
-  if (B < (uint32_t)kMaxBatch) std::memset(ft.f + B, 0, sizeof(FramePlanes) * (kMaxBatch - B));
+  ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);
+  {
+    hipStream_t up = (fstream == stream || !ss.upload) ? stream : ss.upload;
+    HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, up));
+    if (up != stream) {
+      HIP_TRY(hipEventRecord(ss.table_done[si], up));
+      HIP_TRY(hipStreamWaitEvent(stream, ss.table_done[si], 0));
+    }
+  }
   {
     // all per-batch zero fills in one launch: records, lag / masked accumulators, bad flags + list counters
     ZeroJob z{};
@@ -680,8 +699,7 @@ int g1s_diff::launch_back(int si) {
   const bool side = !(one_stream || sl.timed || !ss.flat);
   if (side) HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));  // the mask, the window planes, the area lists
   FrameTable ft;
-  std::memcpy(ft.f, sl.h_planes, sizeof(FramePlanes) * B);
-  if (B < (uint32_t)kMaxBatch) std::memset(ft.f + B, 0, sizeof(FramePlanes) * (kMaxBatch - B));
+  ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);  // (uploaded by the front half)
   const bool fast_ok = !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   if (fast_ok) {
     // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
@@ -935,6 +953,7 @@ void g1s_diff::release() {
   if (ss.compute) (void)hipStreamSynchronize(ss.compute);
   if (ss.copy) (void)hipStreamSynchronize(ss.copy);
   if (ss.flat) (void)hipStreamSynchronize(ss.flat);
+  if (ss.upload) (void)hipStreamSynchronize(ss.upload);
   release_streams(ss);
   for (Slot &sl : slots) {
     if (sl.h_planes && geometry_set) {  // park the buffers for the next generator of this geometry
@@ -987,6 +1006,7 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
     return nullptr;
   }
   uint32_t lag = 3, batch = kDefaultBatch;
+  bool batch_auto = true;
   bool luma_only = false, records_only = false, latest_only = false;
   int device = -1;
   if (opts) {
@@ -995,7 +1015,10 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
       return nullptr;
     }
     if (opts->ar_coeff_lag) lag = opts->ar_coeff_lag;
-    if (opts->batch_frames) batch = std::min<uint32_t>(opts->batch_frames, (uint32_t)kMaxBatch);
+    if (opts->batch_frames) {
+      batch = std::min<uint32_t>(opts->batch_frames, (uint32_t)kMaxBatch);
+      batch_auto = false;
+    }
     luma_only = opts->luma_only != 0;
     records_only = opts->records_only == 1;
     latest_only = opts->records_only == 2;
@@ -1030,6 +1053,7 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   g->records_only = records_only;
   g->latest_only = latest_only;
   g->batch = batch;
+  g->batch_auto = batch_auto;
   g->device = device;
   make_flat_consts(g->fc);
   bool streams_ok = acquire_streams(device, g->ss);

@@ -29,10 +29,11 @@ struct FramePlanes {
   uint32_t den_stride[3];
 };
 
-// The frame table of a batch travels in the kernel arguments (no H2D copy in the launch chain).
-constexpr int kMaxBatch = 32;
+// The frame table of a batch lives in device memory (72 bytes a frame pair); it is uploaded on a stream of
+// its own when the batch is queued, long before the main stream gets to the batch: no copy in the launch chain.
+constexpr int kMaxBatch = 256;
 struct FrameTable {
-  FramePlanes f[kMaxBatch];
+  const FramePlanes *f;
 };
 
 struct Geom {
