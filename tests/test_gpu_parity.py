@@ -40,6 +40,7 @@ CASES = [
     (SynthSpec(256, 160, 10, xdec=0, ydec=0), 2, True, 2, True),   # 4:4:4
     (SynthSpec(320, 192, 10, xdec=1, ydec=0), 1, False, 2, True),  # 4:2:2 source, luma only
     (SynthSpec(64, 64, 8), 2, True, 2, True),              # every area touches the frame edge
+    (SynthSpec(3840, 2160, 10), 3, True, 1, True),         # the bench workload at full size, one frame pair
 ]
 
 
@@ -100,6 +101,26 @@ def test_batched_equals_unbatched_and_oracle():
         s, d = make_pair(spec, k, device="cuda")
         g.diff_frame(s, d, spec.xdec, spec.ydec)
     assert format_tbl(g.finish()) == tbl
+
+
+def test_full_size_batching_and_pipeline_depth_do_not_change_the_records():
+    """4K 10-bit 4:2:0 (BASELINE configs[2]): the per-frame records must not depend on how frames are grouped
+    into launches (1, 3 or 5 per batch: the last batches ragged), nor on where in the four-slot pipeline a
+    frame sits -- a size-independent property checked at the full size."""
+    spec = SynthSpec(3840, 2160, 10)
+    pairs = [make_pair(spec, k, device="cuda") for k in range(7)]
+    ref = None
+    for bf in (1, 3, 5):
+        g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=bf, records_only=True)
+        for s, d in pairs:
+            g.diff_frame(s, d, 1, 1)
+        recs, n = g.take_records(spec.width, spec.height, 3, len(pairs))
+        g.close()
+        assert n == len(pairs)
+        if ref is None:
+            ref = recs.copy()
+        else:
+            assert np.array_equal(ref, recs), f"batch_frames={bf}"
 
 
 def test_latest_only_generator_streams_the_fold():
