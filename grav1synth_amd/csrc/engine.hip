@@ -660,8 +660,11 @@ int g1s_diff::launch_front(int si) {
     const QParams qp = make_qparams(sl);
     const int kinds = g.nplanes == 3 ? 2 : 1;
     const uint32_t wdw = std::max(ps.wpitch[0], kinds == 2 ? ps.wpitch[1] : 0u) / 4;
-    hipLaunchKernelGGL(k3_windows, dim3((wdw + 63) / 64, 4 * g.nbh, B * kinds), dim3(64), 0, fstream, g, ps, sl.d_k0,
-                       (const uint8_t *)sl.d_records);
+    // one workgroup per block row and dword column: the kernel runs off the critical path, next to the lag kernels,
+    // so the fewest instructions win (measured: split 1 / 2 / 4 = +1.0 / +0.7 / 0 %)
+    constexpr int kWinSplit = 1;
+    hipLaunchKernelGGL(k3_windows, dim3((wdw + 63) / 64, kWinSplit * g.nbh, B * kinds), dim3(64), 0, fstream, g, ps, sl.d_k0,
+                       (const uint8_t *)sl.d_records, kWinSplit);
     hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, B), dim3(kClsThreads), 0, fstream, g,
                        (const uint8_t *)sl.d_records, qp);
   }

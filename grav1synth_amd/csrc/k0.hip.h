@@ -513,19 +513,20 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
 // ---------------------------------------------------------------------------------
 // k3_windows: the window bit planes w1[kind] from the flat mask (after K2).  Lane = one aligned
 // dword column j of a block row by: bits 32 j .. 32 j + 31 = samples 32 j - 8 .. 32 j + 23, which
-// belong to up to three blocks; their windows are worked out once and written for a quarter of
+// belong to up to three blocks; their windows are worked out once and written for 1 / split of
 // the block's rows.  Every dword of the sample rows is written (zeros where no window is); the
 // padding rows stay zero from the allocation.
-// grid = (ceil(dwords per bit row / 64), 4 * nbh, batch * kinds), block = 64.
+// grid = (ceil(dwords per bit row / 64), split * nbh, batch * kinds), block = 64; split = 1, 2 or 4 workgroups
+// per block row.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k3_windows(Geom g, PlaneSet ps, uint8_t *__restrict__ planes,
-                                                 const uint8_t *__restrict__ records) {
+                                                 const uint8_t *__restrict__ records, int kWinSplit) {
   const int kinds = g.nplanes == 3 ? 2 : 1;
   const int frame = g.frame0 + (int)blockIdx.z / kinds, kind = (int)blockIdx.z % kinds;
   const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
   const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
   const int j = (int)blockIdx.x * 64 + (int)threadIdx.x;  // dword of the bit row
-  const int by = (int)blockIdx.y >> 2, quarter = (int)blockIdx.y & 3;
+  const int by = (int)blockIdx.y / kWinSplit, part = (int)blockIdx.y % kWinSplit;
   const uint32_t wpitch = ps.wpitch[kind];
   if (j * 4 >= (int)wpitch) return;
   const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
@@ -545,10 +546,10 @@ __global__ __launch_bounds__(64) void k3_windows(Geom g, PlaneSet ps, uint8_t *_
     ys[t] = w.ys;
     ye[t] = w.ye;
   }
-  const int rows = bh >> 2;
+  const int rows = bh / kWinSplit;
   uint8_t *dst = planes + (size_t)frame * ps.frame_bytes + ps.off_w[kind] + 4 * (size_t)j;
   for (int r = 0; r < rows; ++r) {
-    const int ly = quarter * rows + r;
+    const int ly = part * rows + r;
     uint32_t bits = 0;
 #pragma unroll
     for (int t = 0; t < 3; ++t) bits |= (ly >= ys[t] && ly < ye[t]) ? colbits[t] : 0u;
