@@ -226,7 +226,8 @@ int g1s_diff_run(g1s_diff_t *, g1s_next_frame_fn source, void *source_user, g1s_
 
 /* YUV4MPEG2 frame source: stands where the libav reader stands in the reference (what reaches the
  * estimator is the same planar Y,U,V u8 / little-endian u16 frame, src/reader.rs:172-212).  Frames
- * are read ahead by a thread into pinned host memory (a ring of 4), so file IO, the H2D copies of
+ * are read ahead by a thread (big frames: four positional reads at a time) into pinned host memory (a ring
+ * of 4), so file IO, the H2D copies of
  * g1s_diff_frame and the kernels of earlier frames overlap.  Colour spaces: C420* / C422 / C444 /
  * Cmono with an optional p9..p16 depth suffix (8-, 10-, 12-bit 4:2:0 / 4:2:2 / 4:4:4 are what
  * src/reader.rs:51-85 accepts). */

@@ -26,11 +26,12 @@ def _frames(n, w, h, bd, xdec, ydec, nplanes, seed=7):
 @pytest.mark.parametrize("bd,xdec,ydec,nplanes,w,h", [
     (8, 1, 1, 3, 64, 48), (10, 1, 1, 3, 50, 38), (12, 1, 0, 3, 48, 32), (10, 0, 0, 3, 33, 17),
     (8, 0, 0, 1, 40, 24), (8, 1, 1, 3, 35, 27),   # odd sizes: the file holds ceil(w/2) x ceil(h/2) chroma
+    (10, 1, 1, 3, 2048, 1024),                     # 6 MB frames: the parallel positional-read path
 ])
 def test_reader_returns_the_written_planes(tmp_path, bd, xdec, ydec, nplanes, w, h):
-    frames = _frames(9, w, h, bd, xdec, ydec, nplanes)   # more than the read-ahead ring holds
+    frames = _frames(9 if w < 1000 else 6, w, h, bd, xdec, ydec, nplanes)   # more than the read-ahead ring holds
     path = tmp_path / "a.y4m"
-    assert write_y4m(str(path), frames, bd, xdec, ydec, Fraction(30000, 1001)) == 9
+    assert write_y4m(str(path), frames, bd, xdec, ydec, Fraction(30000, 1001)) == len(frames)
     r = Y4MReader(str(path))
     d = r.details
     assert (d.width, d.height, d.bit_depth, d.nplanes) == (w, h, bd, nplanes)
@@ -75,5 +76,15 @@ def test_malformed_files_are_reported(tmp_path):
     p.write_bytes(b"YUV4MPEG2 W16 H8 F24:1 C420\nFRAME\n" + bytes(100))
     r = Y4MReader(str(p))
     with pytest.raises(ValueError, match="truncated frame 0"):
+        r.get_frame()
+    r.close()
+    # the same on the big-frame (positional read) path: second frame cut short
+    big = _frames(2, 2048, 1024, 10, 1, 1, 3)
+    write_y4m(str(p), big, 10, 1, 1)
+    data = p.read_bytes()
+    p.write_bytes(data[:-1000])
+    r = Y4MReader(str(p))
+    assert r.get_frame() is not None
+    with pytest.raises(ValueError, match="truncated frame 1"):
         r.get_frame()
     r.close()
