@@ -168,9 +168,14 @@ struct CachedSlot {
 std::mutex g_cache_mutex;
 std::vector<CachedSlot> g_slot_cache;
 
-// Streams and their events are process-wide too (0.1-0.2 ms to create each): a generator
-// borrows a compute stream, a copy stream (records D2H overlaps the next batch's kernels)
-// and one event per slot, and hands them back when it is freed.
+// Streams and their events are process-wide too (0.1-0.2 ms to create each); a generator borrows a set and
+// hands it back when it is freed:
+//   compute  main stream: pixel pass (K0) and the four lag kernels of alternating batches, back to back
+//   flat     side stream (high priority): finder chain, window planes, area lists of a batch, next to the
+//            lag kernels of the batch before
+//   copy     tail of the accumulation (partial-group kernel, reducer, generic kernel) next to the pixel pass
+//            of the batch after next, then the records D2H
+//   upload   the frame tables (72 bytes a frame pair), ahead of everything
 struct StreamSet {
   int device = -1;
   hipStream_t compute = nullptr, copy = nullptr, flat = nullptr, upload = nullptr;
@@ -780,7 +785,7 @@ int g1s_diff::launch_back(int si) {
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[3], stream));
   HIP_TRY(hipGetLastError());
-  // records D2H on the copy stream: the compute stream goes straight on to the next batch
+  // records D2H on the copy stream (behind the tail kernels): the main stream goes straight on to the next batch
   HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
   HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
   HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, ss.copy));
