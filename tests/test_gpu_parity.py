@@ -329,3 +329,43 @@ def test_y4m_unequal_frame_counts_stop_at_the_shorter_file(tmp_path):
     write_y4m(str(tmp_path / "den2.y4m"), [make_pair(other, 0, device="cpu")[1]], 8, 1, 1)
     with pytest.raises(RuntimeError, match="dimensions do not match"):
         diff_y4m_files(str(tmp_path / "src.y4m"), str(tmp_path / "den2.y4m"), str(out))
+
+
+def test_tuning_switches_do_not_change_results():
+    """The environment switches of DESIGN.md (stream layout, launch sizes, finder modes, generic MIX path) are read
+    once per process, so each runs in its own interpreter; records and table must equal the default run's."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import hashlib, sys\n"
+        "from fractions import Fraction\n"
+        "from grav1synth_amd.diff import DiffGenerator, format_tbl\n"
+        "from grav1synth_amd.synth import SynthSpec, make_pair\n"
+        "spec = SynthSpec(352, 208, 10)\n"
+        "h = hashlib.sha256()\n"
+        "g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=2, records_only=True)\n"
+        "for k in range(5):\n"
+        "    s, d = make_pair(spec, k, device='cuda'); g.diff_frame(s, d, 1, 1)\n"
+        "recs, n = g.take_records(spec.width, spec.height, 3, 5); g.close(); h.update(recs.tobytes())\n"
+        "g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=2)\n"
+        "for k in range(5):\n"
+        "    s, d = make_pair(spec, k, device='cuda'); g.diff_frame(s, d, 1, 1)\n"
+        "h.update(format_tbl(g.finish())); g.close(); print(h.hexdigest())\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.strip().splitlines()[-1]
+
+    ref = run({})
+    assert len(ref) == 64
+    for extra in ({"G1S_ONE_STREAM": "1"}, {"G1S_NO_DEFER": "1"}, {"G1S_TAIL": "0"}, {"G1S_TAIL": "2"},
+                  {"G1S_K1_LITERAL": "1"}, {"G1S_K1_LITERAL": "2"}, {"G1S_MIXED_GENERIC": "1"},
+                  {"G1S_LAG_DIV": "2", "G1S_LAG_ROUND": "2", "G1S_DENSE_CHUNKS": "48"}, {"G1S_FOLD_THREADS": "1"}):
+        assert run(extra) == ref, extra
