@@ -126,6 +126,19 @@ Pool *shared_pool() {
   return p;
 }
 std::mutex g_pool_mutex;  // parallel_for is not re-entrant: one fold batch at a time
+// The ordered merge of exchanged latest states (rank 0 of a frame-shard job) has a small pool of its own:
+// on that rank the shared pool is busy half of the time with the per-frame half of the rank's own batches,
+// and a merge that waits for it falls behind the eight GPUs it serves.
+Pool *merge_pool() {
+  static Pool *p = [] {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("G1S_FOLD_THREADS")) hw = (unsigned)atoi(e);
+    const unsigned n = std::min(8u, hw / 4);
+    return n > 1 ? new Pool(n - 1) : nullptr;
+  }();
+  return p;
+}
+std::mutex g_merge_pool_mutex;
 
 constexpr int kSlots = 4;  // batches in flight: pixel pass + finder, accumulation, D2H + fold, being filled
 
@@ -1301,7 +1314,7 @@ int g1s_fold_push_many(g1s_fold_t *f, const void *records, size_t stride_bytes, 
 int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, size_t n) {
   if (!f || (!blobs && n)) return G1S_ERR_INVALID;
   if (f->finished) return G1S_ERR_STATE;
-  if (!f->pool) f->pool = shared_pool();
+  Pool *mp = merge_pool();
   constexpr size_t kChunk = 256;  // frames parsed and merged per pass (bounds the staging memory)
   if (n > kChunk) {
     for (size_t o = 0; o < n; o += kChunk) {
@@ -1313,9 +1326,9 @@ int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, 
   if (f->latest.size() < n) f->latest.resize(n);
   const uint8_t *base = (const uint8_t *)blobs;
   const NoiseFold::ParallelFor pfor = [&](int m, const std::function<void(int)> &fn) {
-    if (f->pool && m > 1) {
-      std::lock_guard<std::mutex> lk(g_pool_mutex);
-      f->pool->parallel_for(m, fn);
+    if (mp && m > 1) {
+      std::lock_guard<std::mutex> lk(g_merge_pool_mutex);
+      mp->parallel_for(m, fn);
     } else {
       for (int i = 0; i < m; ++i) fn(i);
     }

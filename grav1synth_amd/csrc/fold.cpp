@@ -22,6 +22,13 @@ inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (v >
 inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 }  // namespace
 
+// (this file also passes through the device compiler, which knows no x86 function multiversioning)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define G1S_HOST_CLONES
+#else
+#define G1S_HOST_CLONES __attribute__((target_clones("avx2", "default")))
+#endif
+
 // ---------------------------------------------------------------- solver ---
 // (clones: the row operations are elementwise, AVX2 does four at a time with the same roundings)
 __attribute__((target_clones("avx2", "default"))) bool gauss_solve(int n, double *A, double *b, double *x) {
@@ -70,11 +77,23 @@ void LinearSystem::clear() {
   std::fill(b.begin(), b.end(), 0.0);
   std::fill(x.begin(), x.end(), 0.0);
 }
+// (clones: elementwise, AVX2 does four at a time with the same roundings)
+G1S_HOST_CLONES void add_into(double *__restrict dst, const double *__restrict src, int n) {
+  for (int i = 0; i < n; ++i) dst[i] += src[i];
+}
+G1S_HOST_CLONES void sum_into(double *__restrict dst, const double *__restrict a,
+                                                                        const double *__restrict b, int n) {
+  for (int i = 0; i < n; ++i) dst[i] = a[i] + b[i];
+}
 void LinearSystem::add(const LinearSystem &o) {
-  for (int i = 0; i < n; ++i) {
-    for (int j = 0; j < n; ++j) A[i * n + j] += o.A[i * n + j];
-    b[i] += o.b[i];
-  }
+  add_into(A.data(), o.A.data(), n * n);
+  add_into(b.data(), o.b.data(), n);
+}
+// this = a + b (elementwise on A and b; x is left alone): one pass instead of assign + add
+void LinearSystem::set_sum(const LinearSystem &a, const LinearSystem &bb) {
+  if (n != a.n) resize(a.n);
+  sum_into(A.data(), a.A.data(), bb.A.data(), n * n);
+  sum_into(b.data(), a.b.data(), bb.b.data(), n);
 }
 void LinearSystem::assign(const LinearSystem &o) {
   n = o.n;
@@ -551,13 +570,11 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       PlaneState &s = snap_[j];
       const PlaneState &prev = j ? snap_[j - 1] : combined_[0];
       const PlaneState &lat = fl[i + j].st[0];
-      s.ar.assign(prev.ar);
-      s.strength.eq.assign(prev.strength.eq);
-      s.strength.num_equations = prev.strength.num_equations;
-      s.strength.total = prev.strength.total;
+      s.ar.set_sum(prev.ar, lat.ar);
+      s.strength.eq.set_sum(prev.strength.eq, lat.strength.eq);
+      s.strength.num_equations = prev.strength.num_equations + lat.strength.num_equations;
+      s.strength.total = prev.strength.total + lat.strength.total;
       s.num_observations = prev.num_observations + lat.num_observations;
-      s.ar.add(lat.ar);
-      s.strength.add(lat.strength);
       s.strength.apply_regularisation_to_b();  // (the first half of StrengthSolver::solve)
     }
     if (W == 0) {

@@ -27,6 +27,7 @@ struct LinearSystem {
   void resize(int n_);
   void clear();
   void add(const LinearSystem &o);
+  void set_sum(const LinearSystem &a, const LinearSystem &b);
   void assign(const LinearSystem &o);
   bool solve();  // works on copies of A and b; writes x
 };
