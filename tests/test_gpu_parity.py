@@ -369,3 +369,39 @@ def test_tuning_switches_do_not_change_results():
                   {"G1S_K1_LITERAL": "1"}, {"G1S_K1_LITERAL": "2"}, {"G1S_MIXED_GENERIC": "1"},
                   {"G1S_LAG_DIV": "2", "G1S_LAG_ROUND": "2", "G1S_DENSE_CHUNKS": "48"}, {"G1S_FOLD_THREADS": "1"}):
         assert run(extra) == ref, extra
+
+
+def test_streaming_shards_over_rccl_with_one_rank():
+    """The frame-shard exchange on the real backend ("nccl" = RCCL), world size 1 (two ranks on one device are
+    refused by RCCL; the 2-rank logic is covered over gloo in tests/test_dist_cpu.py): device-side message,
+    rooted gather, merge thread -- the table must equal the plain generator's."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from fractions import Fraction\n"
+        "from grav1synth_amd.diff import DiffGenerator, format_tbl\n"
+        "from grav1synth_amd.dist import StreamingShardedDiff\n"
+        "from grav1synth_amd.synth import SynthSpec, make_pair\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "spec = SynthSpec(352, 208, 10)\n"
+        "pairs = [make_pair(spec, k, device='cuda') for k in range(11)]\n"
+        "sd = StreamingShardedDiff(Fraction(24, 1), 10, 10, device=0, batch_frames=2, group=dist)\n"
+        "for i in range(0, 11, 2):\n"
+        "    sd.diff_prepared(DiffGenerator.prepare_frames(pairs[i:i + 2], 1, 1))\n"
+        "a = format_tbl(sd.finish()); sd.close()\n"
+        "g = DiffGenerator(Fraction(24, 1), 10, 10)\n"
+        "for s, d in pairs: g.diff_frame(s, d, 1, 1)\n"
+        "b = format_tbl(g.finish()); g.close()\n"
+        "dist.destroy_process_group()\n"
+        "assert a == b and len(a) > 100\n"
+        "print('RCCL_OK')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
