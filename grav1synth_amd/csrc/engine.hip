@@ -287,7 +287,16 @@ struct g1s_diff {
   int pending = -1;  // slot whose front half is queued and whose back half is not
   // The API thread queues frames and launches batches; the drainer thread waits for a batch's records,
   // runs the fold on them and frees the slot.  Everything below dm is shared between the two.
-  std::thread drainer;
+  std::thread drainer;  // waits for a batch's records, runs the per-frame half of the fold on the pool
+  std::thread folder;   // the ordered half (merge in frame order), then frees the slot
+  std::deque<int> fold_q;  // batches whose per-frame half is done
+  std::condition_variable cv_fold;
+  bool folder_stop = false;
+  std::vector<FrameLatest> latest_s[kSlots];  // per slot: two batches are in the fold at a time
+  std::vector<uint32_t> nflat_s[kSlots];
+  std::vector<uint8_t> stage_s[kSlots];
+  double ms_fold_front = 0, ms_fold_back = 0;  // (one writer each)
+  bool front_failed[kSlots] = {};               // a HIP error in the front stage: the batch is not folded
   std::mutex dm;
   std::condition_variable cv_work, cv_free;
   std::deque<int> in_flight;       // submitted, not yet picked up by the drainer
@@ -296,7 +305,6 @@ struct g1s_diff {
   bool drainer_stop = false;
   NoiseFold *fold = nullptr;
   Pool *pool = nullptr;
-  std::vector<FrameLatest> latest;  // one per frame of a batch, reused
   std::vector<uint8_t> records_out;
   size_t records_out_frames = 0;
   std::vector<uint8_t> latest_out;  // latest_only: blobs of the drained frames, in frame order
@@ -304,7 +312,6 @@ struct g1s_diff {
   std::deque<uint32_t> latest_batches;  // frames per drained, not yet delivered batch
   uint64_t delivered = 0;               // batches handed out by g1s_diff_take_latest
   std::vector<uint8_t> last_record;
-  std::vector<uint8_t> latest_stage;
   std::string err;
   int deferred = G1S_OK;
   int sticky = G1S_OK;  // a fold error kills the generator (the reference `?`-propagates out of main)
@@ -330,8 +337,10 @@ struct g1s_diff {
   int flush_pending();
   Geom batch_geom(const Slot &sl) const;
   QParams make_qparams(const Slot &sl) const;
-  int drain_slot(int si);   // drainer thread
+  int drain_front(int si);  // drainer thread
+  int drain_back(int si);   // folder thread
   void drainer_main();
+  void folder_main();
   int drain_all();          // API thread: wait until everything submitted is drained
   void wait_drained(uint64_t upto);
   void release();
@@ -826,7 +835,28 @@ void g1s_diff::drainer_main() {
       si = in_flight.front();
       in_flight.pop_front();
     }
-    const int rc = drain_slot(si);
+    const int rc = drain_front(si);
+    {
+      std::lock_guard<std::mutex> lk(dm);
+      if (rc && deferred == G1S_OK) deferred = rc;
+      front_failed[si] = rc != G1S_OK;
+      fold_q.push_back(si);
+    }
+    cv_fold.notify_one();
+  }
+}
+
+void g1s_diff::folder_main() {
+  for (;;) {
+    int si;
+    {
+      std::unique_lock<std::mutex> lk(dm);
+      cv_fold.wait(lk, [&] { return folder_stop || !fold_q.empty(); });
+      if (fold_q.empty()) return;  // stop requested and nothing left
+      si = fold_q.front();
+      fold_q.pop_front();
+    }
+    const int rc = drain_back(si);
     {
       std::lock_guard<std::mutex> lk(dm);
       if (rc && deferred == G1S_OK) deferred = rc;
@@ -842,8 +872,11 @@ void g1s_diff::wait_drained(uint64_t upto) {
   cv_free.wait(lk, [&] { return drained >= upto; });
 }
 
-int g1s_diff::drain_slot(int si) {
+int g1s_diff::drain_front(int si) {
   Slot &sl = slots[si];
+  std::vector<FrameLatest> &latest = latest_s[si];
+  std::vector<uint32_t> &nflat_v = nflat_s[si];
+  std::vector<uint8_t> &latest_stage = stage_s[si];
   HIP_TRY(hipEventSynchronize(sl.done));
   if (sl.timed) {
     float ms = 0;
@@ -867,9 +900,8 @@ int g1s_diff::drain_slot(int si) {
     }
   }
   const auto t0 = std::chrono::steady_clock::now();
-  int rc = G1S_OK;
   if (latest.size() < sl.count) latest.resize(sl.count);
-  std::vector<uint32_t> nflat_v(sl.count, 0);
+  nflat_v.assign(sl.count, 0);
   // ---- per-frame half, concurrent: header, symmetric mirror, latest noise state ----
   const size_t blob = latest_only ? latest_blob_size(lag) : 0;
   if (latest_only) latest_stage.resize(blob * sl.count);
@@ -909,7 +941,23 @@ int g1s_diff::drain_slot(int si) {
   } else {
     for (uint32_t i = 0; i < sl.count; ++i) per_frame((int)i);
   }
-  // ---- ordered half, serial ----
+  ms_fold_front += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return G1S_OK;
+}
+
+// ---- ordered half, serial in frame order; runs next to the per-frame half of the following batch ----
+int g1s_diff::drain_back(int si) {
+  Slot &sl = slots[si];
+  std::vector<FrameLatest> &latest = latest_s[si];
+  const std::vector<uint32_t> &nflat_v = nflat_s[si];
+  const std::vector<uint8_t> &latest_stage = stage_s[si];
+  const size_t blob = latest_only ? latest_blob_size(lag) : 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = G1S_OK;
+  if (front_failed[si]) {
+    sl.count = 0;
+    return G1S_OK;  // (the error is already in `deferred`)
+  }
   for (uint32_t i = 0; i < sl.count; ++i) {
     uint8_t *rec = sl.h_records + L.size * i;
     stats.frames++;
@@ -927,10 +975,11 @@ int g1s_diff::drain_slot(int si) {
   }
   if (!records_only && !latest_only && sticky == G1S_OK && sl.count) {
     // the ordered merge of the batch: combined-model solves in parallel, tests and commits in order
+    Pool *mp = merge_pool();  // (the shared pool is busy with the next batch's per-frame half)
     const NoiseFold::ParallelFor pfor = [&](int m, const std::function<void(int)> &fn) {
-      if (pool) {
-        std::lock_guard<std::mutex> lk(g_pool_mutex);
-        pool->parallel_for(m, fn);
+      if (mp) {
+        std::lock_guard<std::mutex> lk(g_merge_pool_mutex);
+        mp->parallel_for(m, fn);
       } else {
         for (int i = 0; i < m; ++i) fn(i);
       }
@@ -948,7 +997,7 @@ int g1s_diff::drain_slot(int si) {
   }
   if (sl.count) last_record.assign(sl.h_records + L.size * (sl.count - 1), sl.h_records + L.size * sl.count);
   sl.count = 0;
-  stats.ms_host_fold += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ms_fold_back += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return rc;
 }
 
@@ -970,6 +1019,14 @@ void g1s_diff::release() {
     }
     cv_work.notify_all();
     drainer.join();  // (it drains whatever was still queued first)
+  }
+  if (folder.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(dm);
+      folder_stop = true;
+    }
+    cv_fold.notify_all();
+    folder.join();
   }
   if (ss.compute) (void)hipStreamSynchronize(ss.compute);
   if (ss.copy) (void)hipStreamSynchronize(ss.copy);
@@ -1105,6 +1162,7 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   if (!records_only && !latest_only) g->fold = new NoiseFold(fps_num, fps_den, lag);
   g->pool = shared_pool();
   g->drainer = std::thread([g] { g->drainer_main(); });
+  g->folder = std::thread([g] { g->folder_main(); });
   return g;
 }
 
@@ -1417,6 +1475,7 @@ int g1s_write_tbl(const char *path, const g1s_segment_t *segs, size_t n) {
 int g1s_diff_get_stats(const g1s_diff_t *g, g1s_stats_t *out) {
   if (!g || !out) return G1S_ERR_INVALID;
   *out = g->stats;
+  out->ms_host_fold = g->ms_fold_front + g->ms_fold_back;  // (the two stages overlap across batches)
   return G1S_OK;
 }
 int g1s_diff_set_flat_finder(g1s_diff_t *g, int mode) {
