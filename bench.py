@@ -109,9 +109,10 @@ def main() -> None:
 
     stats_total = None
     last_tbl = None
+    window_samples = None  # per plane, of the last frame of the timed-kernels step
 
     def one_step(timing: bool):
-        nonlocal stats_total, last_tbl
+        nonlocal stats_total, last_tbl, window_samples
         if world > 1:
             # streaming frame shards: per batch one small all-gather of latest states, rank 0 merges in order
             sd = StreamingShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
@@ -130,6 +131,12 @@ def main() -> None:
         st = sd.generator.stats()
         if segs is not None:
             last_tbl = format_tbl(segs)
+        if timing:
+            try:
+                r = sd.generator.last_record()
+                window_samples = [int(r.ar_sums(c)[2]) for c in range(nplanes)]
+            except Exception:
+                window_samples = None
         sd.close()
         return st
 
@@ -180,6 +187,13 @@ def main() -> None:
 
     total_px = float(W) * H * F * args.cycles * args.steps * world
     value = total_px / elapsed / 1e6
+    valu = None
+    if window_samples and lag == 3:
+        macs = window_samples[0] * 324 + sum(window_samples[1:]) * 350
+        fps_all = value * 1e6 / (W * H)
+        valu = {"window_samples_per_frame": window_samples, "gmac_per_frame": macs / 1e9,
+                "achieved_tmac_s": macs * fps_all / world / 1e12, "dot4_peak_tmac_s": 133.0,
+                "frac": macs * fps_all / world / 1e12 / 133.0}
     out = {
         "metric": "diff Mpixels/s (luma pixels of frame pairs fully processed: flat-block finder + AR accumulation + block stats + ordered fold)",
         "value": value,
@@ -216,6 +230,10 @@ def main() -> None:
             "alg_bytes_per_launch": alg_bytes_per_launch,
             "all_kernels_ms_per_frame": {k: v[0] / FJ for k, v in kernels.items()},
             "host_fold_ms_per_frame": st.ms_host_fold / FJ,
+            # SURVEY 8(d), caveat H1: the accumulation is VALU work.  Algorithmic MACs of a frame = window samples x
+            # (324 luma / 350 chroma: unique products + right-hand sides of add_block_observations); the kernels execute
+            # about a sixth of them (46 lag sums instead of 324 products on full groups).  Peak = measured v_dot4 rate.
+            "valu_algorithmic": valu,
             # inside k3_ar_accumulate: K0, the one pass over the source / denoised planes (the HBM-streaming kernel)
             "k0_residual": {
                 "ms_per_frame": st.ms_residual / FJ,
