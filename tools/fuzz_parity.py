@@ -49,9 +49,20 @@ for k in range(n // 4):
     try:
         o = OracleDiff(30000, 1001, sbd, dbd, lag, True)
         g = DiffGenerator(Fraction(30000, 1001), sbd, dbd, ar_coeff_lag=lag, batch_frames=bf)
+        damage = rng.random() < 0.35   # outliers |src - den| > 127: the deferred exact path
+        cut = rng.randint(1, nf - 1) if rng.random() < 0.35 else nf   # noise gain changes there: a new segment
+        ss2 = SynthSpec(w, h, sbd, xdec=xd, ydec=yd, textured=ss.textured, gain_scale=3)
         for f in range(nf):
-            s, _ = np_pair(ss, f)
+            s, _ = np_pair(ss if f < cut else ss2, f)
             _, d = np_pair(ds, f)
+            if damage:
+                nr = np.random.default_rng(rng.randint(0, 1 << 30))
+                d = [p.copy() for p in d]
+                for c in range(len(d)):
+                    hh, ww = d[c].shape
+                    for _ in range(nr.integers(1, 10)):
+                        y, x = int(nr.integers(0, hh)), int(nr.integers(0, ww))
+                        d[c][y, x] = 0 if (int(s[c][y, x]) >> (sbd - 8)) > 140 else ((255 << (dbd - 8)))
             o.diff_frame(s, d, xd, yd)
             g.diff_frame(Frame(s, xd, yd), Frame(d, xd, yd))
         a, b = format_tbl(g.finish()), oracle_tbl(o.finish())
