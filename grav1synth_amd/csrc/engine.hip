@@ -632,6 +632,7 @@ int g1s_diff::launch_front(int si) {
     const int literal_mode = flat_literal ? flat_literal : env_literal;
     const int force_literal = literal_mode ? 1 : 0;
     int32_t *mom = sl.d_k1;
+    bool pix_recorded = false;
     CertifyLists cl;
     cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
     cl.count = cl.list + (size_t)g.nblocks * batch;
@@ -641,22 +642,38 @@ int g1s_diff::launch_front(int si) {
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
       const dim3 gr(8 * ((((g.nbw + 3) / 4) * g.nbh + 7) / 8), 1, B);
       uint8_t *badp = sl.d_defer + cls_bytes_q;
-#define G1S_K0(SB, DB) \
-  hipLaunchKernelGGL((k0_residual<SB, DB>), gr, dim3(256), 0, pstream, ft, g, ps, sl.d_k0, badp, sl.d_records, \
+#define G1S_K0P(SB, DB, P) \
+  hipLaunchKernelGGL((k0_residual<SB, DB, P>), gr, dim3(256), 0, pstream, ft, g, ps, sl.d_k0, badp, sl.d_records, \
                      force_literal ? (int32_t *)nullptr : mom)
-      if (g.src_bps == 1 && g.den_bps == 1) G1S_K0(1, 1);
-      else if (g.src_bps == 1) G1S_K0(1, 2);
-      else if (g.den_bps == 1) G1S_K0(2, 1);
-      else G1S_K0(2, 2);
+#define G1S_K0(P)                                                  \
+  do {                                                             \
+    if (g.src_bps == 1 && g.den_bps == 1) G1S_K0P(1, 1, P);        \
+    else if (g.src_bps == 1) G1S_K0P(1, 2, P);                     \
+    else if (g.den_bps == 1) G1S_K0P(2, 1, P);                     \
+    else G1S_K0P(2, 2, P);                                         \
+  } while (0)
+      // With a side stream and chroma planes the pass runs as two launches, luma half first: the finder chain
+      // needs only that one and starts next to the chroma half (bandwidth bound) instead of spending its
+      // whole length next to the VALU-bound lag kernels.
+      static const bool k0_split_env = getenv("G1S_K0_ONE") == nullptr;  // tuning aid
+      if (pstream != fstream && g.nplanes == 3 && k0_split_env) {
+        G1S_K0(1);
+        HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
+        pix_recorded = true;
+        G1S_K0(2);
+      } else {
+        G1S_K0(0);
+      }
 #undef G1S_K0
+#undef G1S_K0P
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
     } else if (!force_literal) {
       const dim3 mg((g.nblocks + 7) / 8, B);
       if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
       else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, pstream, ft, g, mom);
     }
-    if (pstream != fstream) {  // the finder chain: on the side stream, behind the pixel pass
-      HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
+    if (pstream != fstream) {  // the finder chain: on the side stream, behind the pixel pass (its luma half)
+      if (!pix_recorded) HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
       HIP_TRY(hipStreamWaitEvent(fstream, ss.pix_done[si], 0));
     }
     hipLaunchKernelGGL(k1_certify, dim3((g.nblocks + 255) / 256, B), dim3(256), 0, fstream, g, fc, (const int32_t *)mom,

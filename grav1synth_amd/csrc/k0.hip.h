@@ -328,7 +328,9 @@ __device__ __forceinline__ void half_sums_dpp(int (&v)[N]) {
 // of the four blocks is also kept in LDS; 128 lanes (block, row) then take the flat-block finder's
 // moments from it.
 // ---------------------------------------------------------------------------------
-template <int SBPS, int DBPS>
+// PART: 0 = everything; 1 = the luma half (residual, L plane, statistics, finder moments); 2 = the chroma half.
+// The engine runs the halves as two launches so that the finder chain can start after the first.
+template <int SBPS, int DBPS, int PART = 0>
 __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, PlaneSet ps,
                                                    uint8_t *__restrict__ planes, uint8_t *__restrict__ bad,
                                                    uint8_t *__restrict__ records, int32_t *__restrict__ mom) {
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
   __syncthreads();
 
   // ------------------------------- luma -------------------------------
-  {
+  if constexpr (PART != 2) {
     const int seg = tid & 15, b = seg >> 2;
     const bool active = bx0 + b < g.nbw;
     const int X0 = bx0 * kBlock + seg * 8;
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
     }
   }
   // ------------------------------- chroma -------------------------------
-  if (chroma) {
+  if (PART != 1 && chroma) {
     const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
     const int segs = (4 * bw) >> 3, spb = bw >> 3;  // 8-sample segments per region row / per block
     const int ipp = segs * bh;                       // items per component: 128, 256 or 512
@@ -466,13 +468,15 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
   __syncthreads();
   if (tid < 4 && bx0 + tid < g.nbw) {
     const int blk = by * g.nbw + bx0 + tid;
-    if (s_bad[0][tid]) bad[(size_t)frame * 2 * g.nblocks + blk] = 1;
-    if (chroma && s_bad[1][tid]) bad[((size_t)frame * 2 + 1) * g.nblocks + blk] = 1;
+    if (PART != 2 && s_bad[0][tid]) bad[(size_t)frame * 2 * g.nblocks + blk] = 1;
+    if (chroma && s_bad[1][tid]) bad[((size_t)frame * 2 + 1) * g.nblocks + blk] = 1;  // (either half may raise it)
     // noise statistics of every block (the fold reads those of the flat blocks)
-    reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = s_sum[0][tid][0];
-    reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)s_sum[0][tid][1];
-    reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)s_sum[0][tid][2];
-    if (chroma) {
+    if (PART != 2) {
+      reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = s_sum[0][tid][0];
+      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)s_sum[0][tid][1];
+      reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)s_sum[0][tid][2];
+    }
+    if (PART != 1 && chroma) {
       reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = s_sum[1][tid][0];
       reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)s_sum[1][tid][1];
       reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = s_sum[2][tid][0];
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, 
     }
   }
   // ---- flat-block finder moments of the four luma source blocks (k1f.hip.h), from the LDS copy ----
-  if (mom != nullptr && tid < 128) {
+  if (PART != 2 && mom != nullptr && tid < 128) {
     const int b = tid >> 5, yi = tid & 31;
     uint32_t pk[8], pu[8], pd[8];
     // the finder's block replicates the last row / column of the plane (extract_block): rows by index

@@ -366,7 +366,7 @@ def test_tuning_switches_do_not_change_results():
 
     ref = run({})
     assert len(ref) == 64
-    for extra in ({"G1S_ONE_STREAM": "1"}, {"G1S_NO_DEFER": "1"}, {"G1S_TAIL": "0"}, {"G1S_TAIL": "2"},
+    for extra in ({"G1S_ONE_STREAM": "1"}, {"G1S_NO_DEFER": "1"}, {"G1S_K0_ONE": "1"}, {"G1S_TAIL": "0"}, {"G1S_TAIL": "2"},
                   {"G1S_K1_LITERAL": "1"}, {"G1S_K1_LITERAL": "2"}, {"G1S_MIXED_GENERIC": "1"},
                   {"G1S_LAG_DIV": "2", "G1S_LAG_ROUND": "2", "G1S_DENSE_CHUNKS": "48"}, {"G1S_FOLD_THREADS": "1"}):
         assert run(extra) == ref, extra
