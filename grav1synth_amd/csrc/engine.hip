@@ -593,14 +593,8 @@ int g1s_diff::launch_front(int si) {
   // stream gets here); per-kernel timing / one-stream mode: in line
   FrameTable ft;
   ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);
-  {
-    hipStream_t up = (fstream == stream || !ss.upload) ? stream : ss.upload;
-    HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, up));
-    if (up != stream) {
-      HIP_TRY(hipEventRecord(ss.table_done[si], up));
-      HIP_TRY(hipStreamWaitEvent(stream, ss.table_done[si], 0));
-    }
-  }
+  hipStream_t up = (fstream == stream || !ss.upload) ? stream : ss.upload;
+  HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, up));
   {
     // all per-batch zero fills in one launch: records, lag / masked accumulators, bad flags + list counters
     ZeroJob z{};
@@ -619,7 +613,13 @@ int g1s_diff::launch_front(int si) {
     }
     z.ptr[5] = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * (kMomInts + 1);  // literal-list counts
     z.ndw[5] = (uint32_t)batch;
-    hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, pstream, z);
+    // (on the upload stream too: the slot is free, its buffers can be zeroed while the main stream is still busy
+    //  with earlier batches)
+    hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, up, z);
+  }
+  if (up != stream) {
+    HIP_TRY(hipEventRecord(ss.table_done[si], up));
+    HIP_TRY(hipStreamWaitEvent(stream, ss.table_done[si], 0));
   }
   sl.timed = timing;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], pstream));
