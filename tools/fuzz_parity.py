@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_parity.py [N] [SEED] -- random geometries / depths / subsamplings / lags through the oracle comparison
+"""tools/fuzz_parity.py [N] [SEED] [WMAX HMAX] -- random geometries / depths / subsamplings / lags through the oracle comparison
 of tests/test_gpu_parity.py (records and table, bit for bit).  Prints the failing specs, if any."""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,10 +8,11 @@ from tests import test_gpu_parity as T
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+WMAX, HMAX = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (420, 300)
 bad = 0
 t0 = time.time()
 for k in range(n):
-    w, h = rng.randint(66, 420), rng.randint(66, 300)
+    w, h = rng.randint(66, WMAX), rng.randint(66, HMAX)
     bd = rng.choice([8, 10, 12])
     xd, yd = rng.choice([(1, 1), (1, 1), (1, 0), (0, 0)])
     lag = rng.choice([3, 3, 2, 1])
@@ -39,7 +40,7 @@ from tests.oracle_binding import OracleDiff, format_tbl as oracle_tbl
 bad2 = 0
 t0 = time.time()
 for k in range(n // 4):
-    w, h = rng.randint(66, 420), rng.randint(66, 300)
+    w, h = rng.randint(66, WMAX), rng.randint(66, HMAX)
     sbd, dbd = rng.choice([(8, 8), (10, 10), (10, 8), (8, 10), (12, 10)])
     xd, yd = rng.choice([(1, 1), (1, 0), (0, 0)])
     lag = rng.choice([3, 3, 2, 1])
