@@ -41,6 +41,7 @@ CASES = [
     (SynthSpec(320, 192, 10, xdec=1, ydec=0), 1, False, 2, True),  # 4:2:2 source, luma only
     (SynthSpec(64, 64, 8), 2, True, 2, True),              # every area touches the frame edge
     (SynthSpec(3840, 2160, 10), 3, True, 1, True),         # the bench workload at full size, one frame pair
+    (SynthSpec(320, 192, 8, xdec=0, ydec=1), 3, True, 2, True),   # 4:4:0 (not a format the reference reads): generic kernel
 ]
 
 
