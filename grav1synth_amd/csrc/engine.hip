@@ -6,6 +6,7 @@
 // batch k+1 while the host folds batch k in frame order (fold.cpp).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -24,6 +25,7 @@
 #include "kernels.hip.h"
 #include "k1f.hip.h"
 #include "k3q.hip.h"
+#include "k3m.hip.h"
 #include "record.h"
 
 using namespace g1s;
@@ -34,6 +36,22 @@ thread_local std::string g_global_error;
 
 constexpr uint32_t kDefaultBatch = 32;
 constexpr int kK3Chunks = 48;
+
+// The AR accumulation runs on the matrix cores (k3m.hip.h) unless G1S_K3=dot4 asks for the lag-structured
+// v_dot4 kernels of round 1 (k3q.hip.h; kept so that the two can be compared bit for bit).
+bool use_mfma() {
+  static const bool v = [] {
+    const char *e = getenv("G1S_K3");
+    return !(e && std::strcmp(e, "dot4") == 0);
+  }();
+  return v;
+}
+constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per CU
+// workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
+int m_wgs_per_frame(int nunits, int B) {
+  const int gmin = (nunits + kMMaxUnits - 1) / kMMaxUnits;
+  return std::max(gmin, (kMTargetWgs + B - 1) / std::max(B, 1));
+}
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -153,6 +171,8 @@ struct Slot {
   uint8_t *d_k0 = nullptr;         // K0 int8 planes [batch] x PlaneSet::frame_bytes
   int32_t *d_k1 = nullptr;         // flat-block fast path: moments [batch][nblocks][16], literal list [batch][nblocks], counts [batch]
   uint32_t *d_pgl = nullptr;       // partial-group lists [batch][2][pg_cap] + counts [batch][2]
+  uint8_t *d_mu = nullptr;         // MFMA path: unit lists [batch][nunits], unit counts, deferred-block flags
+  long long *d_mpart = nullptr;    // MFMA path: partial systems of the accumulation workgroups
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
   hipEvent_t done = nullptr;
@@ -166,11 +186,12 @@ struct Slot {
 // (one per video, or one per bench step) reuse them.
 struct SlotKey {
   int device;
-  size_t planes, records, flags, partials, defer, stage, k0, pgl;
+  size_t planes, records, flags, partials, defer, stage, k0, pgl, mu, mpart;
   int W, H, xdec, ydec, nplanes;  // the zeroed padding of the K0 planes depends on the exact geometry
   bool operator==(const SlotKey &o) const {
     return device == o.device && planes == o.planes && records == o.records && flags == o.flags &&
-           partials == o.partials && defer == o.defer && stage == o.stage && k0 == o.k0 && pgl == o.pgl &&
+           partials == o.partials && defer == o.defer && stage == o.stage && k0 == o.k0 && pgl == o.pgl && mu == o.mu &&
+           mpart == o.mpart &&
            W == o.W && H == o.H && xdec == o.xdec && ydec == o.ydec && nplanes == o.nplanes;
   }
 };
@@ -281,6 +302,9 @@ struct g1s_diff {
   size_t defer_bytes = 0;
   PlaneSet ps{};
   uint32_t pg_cap = 0;
+  int m_nunits = 0;          // MFMA path: chunks per frame
+  size_t m_only_bytes = 0;   // ... deferred-block flags [batch][2][nblocks], 16-byte rounded
+  MParams make_mparams(const Slot &sl) const;
   SlotKey slot_key{};
   Slot slots[kSlots];
   int cur = 0;
@@ -420,8 +444,14 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     pg_cap = (uint32_t)g.nblocks * 256u;
     pgl_bytes = sizeof(uint32_t) * ((size_t)batch * 2 * pg_cap + (size_t)batch * 2);
   }
+  m_nunits = ((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * g.nbh;
+  m_only_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
+  // [units][unit counts][any-deferred flags][deferred-block flags]
+  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits + 2 * (size_t)batch) + m_only_bytes;
+  const size_t mpart_bytes = sizeof(long long) * 3 * kMRec *
+                             ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits) + kMTargetWgs + batch);
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
-                     partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes,
+                     partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes, mpart_bytes,
                      g.W, g.H, g.xdec, g.ydec, g.nplanes};
   for (Slot &sl : slots) {
     {
@@ -449,6 +479,8 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
       HIP_TRY(hipMalloc((void **)&sl.d_k0, k0_bytes));
       HIP_TRY(hipMemset(sl.d_k0, 0, k0_bytes));  // the padding of the w8 planes stays zero for good
       HIP_TRY(hipMalloc((void **)&sl.d_pgl, pgl_bytes));
+      HIP_TRY(hipMalloc((void **)&sl.d_mu, mu_bytes));
+      HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes));
     }
     HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
@@ -600,7 +632,15 @@ int g1s_diff::launch_front(int si) {
     ZeroJob z{};
     z.ptr[0] = reinterpret_cast<uint32_t *>(sl.d_records);
     z.ndw[0] = (uint32_t)(L.size * B / 4);
-    {
+    if (use_mfma()) {
+      const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
+      z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits;  // unit counts, any-deferred flags
+      z.ndw[1] = 2 * (uint32_t)batch;
+      z.ptr[2] = reinterpret_cast<uint32_t *>(sl.d_defer + cls_bytes);  // bad flags
+      z.ndw[2] = (uint32_t)(cls_bytes / 4);
+      z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits + 2 * (size_t)batch;  // deferred-block flags
+      z.ndw[3] = (uint32_t)(m_only_bytes / 4);
+    } else {
       const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
       z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_partials);
       z.ndw[1] = (uint32_t)(sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart + ((int)lag == kQLag ? 0 : kAr3)) / 4);
@@ -699,7 +739,11 @@ int g1s_diff::launch_front(int si) {
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
   hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
-  if (fast_ok) {
+  if (fast_ok && use_mfma()) {
+    // the unit lists (chunks with a flat block) need the flat mask
+    const MParams mp = make_mparams(sl);
+    hipLaunchKernelGGL(k3m_units, dim3((m_nunits + 255) / 256, B), dim3(256), 0, fstream, g, (const uint8_t *)sl.d_records, mp);
+  } else if (fast_ok) {
     // the window bit planes and the area lists need the flat mask: small kernels after K2
     const QParams qp = make_qparams(sl);
     const int kinds = g.nplanes == 3 ? 2 : 1;
@@ -737,6 +781,21 @@ QParams g1s_diff::make_qparams(const Slot &sl) const {
   return qp;
 }
 
+MParams g1s_diff::make_mparams(const Slot &sl) const {
+  MParams mp;
+  const size_t cls_bytes = ((size_t)geom.nblocks * 2 * batch + 15) & ~size_t(15);
+  mp.planes = sl.d_k0;
+  mp.ps = ps;
+  mp.bad = sl.d_defer + cls_bytes;
+  mp.units = reinterpret_cast<uint32_t *>(sl.d_mu);
+  mp.unit_count = mp.units + (size_t)batch * m_nunits;
+  mp.only_any = mp.unit_count + batch;
+  mp.only = reinterpret_cast<uint8_t *>(mp.only_any + batch);
+  mp.partials = sl.d_mpart;
+  mp.nunits = m_nunits;
+  return mp;
+}
+
 int g1s_diff::launch_back(int si) {
   Slot &sl = slots[si];
   const uint32_t B = sl.count;
@@ -748,7 +807,21 @@ int g1s_diff::launch_back(int si) {
   FrameTable ft;
   ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);  // (uploaded by the front half)
   const bool fast_ok = !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
-  if (fast_ok) {
+  if (fast_ok && use_mfma()) {
+    // exact int8 SYRK on the matrix cores over the flat blocks' windows, one partial system per workgroup,
+    // the reducer, then the exact int32 kernel for the few blocks next to a residual outside int8
+    const MParams mp = make_mparams(sl);
+    const int G = m_wgs_per_frame(m_nunits, (int)B);
+    const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = kBlock >> g.ydec;
+    const size_t lds = m_lds_bytes(cbw, cbh);
+    const dim3 gr(G, 1, B);
+    if (cbw == 0) hipLaunchKernelGGL(k3m_accumulate<0>, gr, dim3(256), lds, stream, g, mp, (const uint8_t *)sl.d_records);
+    else if (cbw == 16) hipLaunchKernelGGL(k3m_accumulate<16>, gr, dim3(256), lds, stream, g, mp, (const uint8_t *)sl.d_records);
+    else hipLaunchKernelGGL(k3m_accumulate<32>, gr, dim3(256), lds, stream, g, mp, (const uint8_t *)sl.d_records);
+    hipLaunchKernelGGL(k3m_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, mp, G, sl.d_records);
+    hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
+                       sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
+  } else if (fast_ok) {
     // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
     // then the generic int32 kernel on mixed / deferred areas
     const QParams qp = make_qparams(sl);
@@ -1070,6 +1143,8 @@ void g1s_diff::release() {
     if (sl.d_defer) (void)hipFree(sl.d_defer);
     if (sl.d_k0) (void)hipFree(sl.d_k0);
     if (sl.d_pgl) (void)hipFree(sl.d_pgl);
+    if (sl.d_mu) (void)hipFree(sl.d_mu);
+    if (sl.d_mpart) (void)hipFree(sl.d_mpart);
     if (sl.d_stage) (void)hipFree(sl.d_stage);
     if (sl.done) (void)hipEventDestroy(sl.done);
     for (auto &e : sl.ev)
