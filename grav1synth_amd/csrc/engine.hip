@@ -447,7 +447,7 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   m_nunits = ((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * g.nbh;
   m_only_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   // [units][unit counts][any-deferred flags][deferred-block flags]
-  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits + 2 * (size_t)batch) + m_only_bytes;
+  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 2 * (size_t)batch) + m_only_bytes;
   const size_t mpart_bytes = sizeof(long long) * 3 * kMRec *
                              ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits) + kMTargetWgs + batch);
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
@@ -634,11 +634,11 @@ int g1s_diff::launch_front(int si) {
     z.ndw[0] = (uint32_t)(L.size * B / 4);
     if (use_mfma()) {
       const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
-      z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits;  // unit counts, any-deferred flags
+      z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords;  // unit counts, any-deferred flags
       z.ndw[1] = 2 * (uint32_t)batch;
       z.ptr[2] = reinterpret_cast<uint32_t *>(sl.d_defer + cls_bytes);  // bad flags
       z.ndw[2] = (uint32_t)(cls_bytes / 4);
-      z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits + 2 * (size_t)batch;  // deferred-block flags
+      z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords + 2 * (size_t)batch;  // deferred-block flags
       z.ndw[3] = (uint32_t)(m_only_bytes / 4);
     } else {
       const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
@@ -788,7 +788,7 @@ MParams g1s_diff::make_mparams(const Slot &sl) const {
   mp.ps = ps;
   mp.bad = sl.d_defer + cls_bytes;
   mp.units = reinterpret_cast<uint32_t *>(sl.d_mu);
-  mp.unit_count = mp.units + (size_t)batch * m_nunits;
+  mp.unit_count = mp.units + (size_t)batch * m_nunits * kMUnitDwords;
   mp.only_any = mp.unit_count + batch;
   mp.only = reinterpret_cast<uint8_t *>(mp.only_any + batch);
   mp.partials = sl.d_mpart;
@@ -812,12 +812,22 @@ int g1s_diff::launch_back(int si) {
     // the reducer, then the exact int32 kernel for the few blocks next to a residual outside int8
     const MParams mp = make_mparams(sl);
     const int G = m_wgs_per_frame(m_nunits, (int)B);
-    const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = kBlock >> g.ydec;
-    const size_t lds = m_lds_bytes(cbw, cbh);
+    const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = g.nplanes == 3 ? (kBlock >> g.ydec) : 0;
+    const size_t lds = (size_t)m_lds_bytes(cbw, cbh);
     const dim3 gr(G, 1, B);
-    if (cbw == 0) hipLaunchKernelGGL(k3m_accumulate<0>, gr, dim3(256), lds, stream, g, mp, (const uint8_t *)sl.d_records);
-    else if (cbw == 16) hipLaunchKernelGGL(k3m_accumulate<16>, gr, dim3(256), lds, stream, g, mp, (const uint8_t *)sl.d_records);
-    else hipLaunchKernelGGL(k3m_accumulate<32>, gr, dim3(256), lds, stream, g, mp, (const uint8_t *)sl.d_records);
+#define G1S_M(CW, CH)                                                                                          \
+  do {                                                                                                         \
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3m_accumulate<CW, CH>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, m_lds_bytes(CW, CH)); \
+    (void)attr_rc;                                                                                             \
+    hipLaunchKernelGGL((k3m_accumulate<CW, CH>), gr, dim3(256), lds, stream, g, mp);                            \
+  } while (0)
+    if (cbw == 0) G1S_M(0, 0);
+    else if (cbw == 16 && cbh == 16) G1S_M(16, 16);
+    else if (cbw == 16) G1S_M(16, 32);
+    else if (cbh == 32) G1S_M(32, 32);
+    else G1S_M(32, 16);
+#undef G1S_M
     hipLaunchKernelGGL(k3m_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, mp, G, sl.d_records);
     hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                        sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);

@@ -17,14 +17,19 @@
 // hold the rows a in {0, 1} (+ L) and a in {2, 3}: 16 distinct slots each.
 //
 // Work unit = 4 horizontally adjacent blocks of one block row (a `chunk`) holding at least one flat
-// block, compacted per frame by k3m_units.  A workgroup walks a contiguous slice of one frame's list,
-// keeps the 32x32 int32 accumulators of the three planes in registers, and writes ONE partial system
-// per plane at the end (k3m_reduce adds them into the record).  Blocks whose tile touches a residual
-// outside int8 (K0 `bad` flags) are left to the exact int32 kernel (k3_ar_generic, `only` list).
-// Any lag 1..3 (the lag-L neighbourhood and window border; rows of other neighbours are ignored).
+// block, listed per frame by k3m_units together with the observation windows of its blocks.  A
+// workgroup walks a contiguous slice of one frame's list: the rows of the NEXT unit are requested into
+// registers before the current unit's tiles are multiplied (no load latency in the loop), the tiles of
+// all planes are staged together (two barriers per unit), the 32x32 int32 accumulators stay in
+// registers (two for luma: dependent MFMAs on one accumulator wait for each other), and ONE partial
+// system per plane is written at the end (k3m_reduce adds them into the record).  Blocks whose tile
+// touches a residual outside int8 (K0 `bad` flags) are left to the exact int32 kernel (k3_ar_generic,
+// `only` list).  Any lag 1..3 (the lag-L neighbourhood and window border; the other matrix rows are ignored).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "k0.hip.h"
 #include "kernels.hip.h"
@@ -37,6 +42,7 @@ typedef int v16i32 __attribute__((ext_vector_type(16)));
 constexpr int kMCopies = 7;
 constexpr int kMRec = 656;        // int64 entries of one partial system (>= 25 * 25 + 25 + 1)
 constexpr int kMUnitBlocks = 4;   // blocks per unit
+constexpr int kMUnitDwords = 8;   // list entry: [0] chunk | block row << 12 | flat bits << 24, [1..4] 8 x u16 windows
 constexpr int kMMaxUnits = 120;   // units per workgroup: 120 * 4 blocks * 8 steps * 32 samples * 127^2 < 2^31
 
 struct MParams {
@@ -45,22 +51,24 @@ struct MParams {
   const uint8_t *bad;     // [batch][2][nblocks]  K0: a residual (kind 1: or L) outside int8
   uint8_t *only;          // [batch][2][nblocks]  flat blocks left to k3_ar_generic (zeroed per batch)
   uint32_t *only_any;     // [batch]
-  uint32_t *units;        // [batch][nunits]  chunk | block row << 12 | flat bits << 24
+  uint32_t *units;        // [batch][nunits][kMUnitDwords]
   uint32_t *unit_count;   // [batch]  (zeroed per batch)
   long long *partials;    // [batch][G][3][kMRec]
   int nunits;             // chunks per frame = ceil(nbw / 4) * nbh
 };
 
-// tile geometry of a plane kind: block BW x bh, chunk of 4 blocks
+// tile geometry of a plane kind: block BW x BH, chunk of 4 blocks
 __host__ __device__ constexpr int m_pitch(int BW) { return 4 * BW + 16; }
-__host__ __device__ constexpr int m_copy_stride(int BW, int bh) {
+__host__ __device__ constexpr int m_copy_stride(int BW, int BH) {
   // >= rows * pitch, in 16-byte slots == 2 (mod 16)
-  int slots = ((bh + 3) * m_pitch(BW) + 15) / 16;
+  int slots = ((BH + 3) * m_pitch(BW) + 15) / 16;
   while ((slots & 15) != 2) ++slots;
   return slots * 16;
 }
-__host__ __device__ constexpr int m_tile_bytes(int BW, int bh, bool with_l) {
-  return kMCopies * m_copy_stride(BW, bh) + (with_l ? bh * m_pitch(BW) : 0);
+__host__ __device__ constexpr int m_tile_bytes(int BW, int BH) { return kMCopies * m_copy_stride(BW, BH); }
+// LDS map of a workgroup: [luma tile][Cb tile][Cr tile][L tile]
+__host__ __device__ constexpr int m_lds_bytes(int CBW, int CBH) {
+  return m_tile_bytes(32, kBlock) + (CBW ? 2 * m_tile_bytes(CBW, CBH) + CBH * m_pitch(CBW) : 0);
 }
 
 // ---- matrix row i (0..31) -> what it holds ------------------------------------------
@@ -104,8 +112,23 @@ __device__ __forceinline__ int m_rec_index(int i, int lag, int n, bool chroma) {
   return (lag - a) * (2 * lag + 1) + (cx + lag);
 }
 
+// ---- per-block window of a unit, 16 bits: xe | ye << 6 | (ys != 0) << 13 | (xs != 0) << 14 | go << 15 ----
+struct MWin {
+  int go, xs, xe, ys, ye;
+};
+__device__ __forceinline__ MWin m_unpack(uint32_t w, int lag) {
+  MWin r;
+  r.go = (int)((w >> 15) & 1u);
+  r.xe = (int)(w & 63u);
+  r.ye = (int)((w >> 6) & 63u);
+  r.ys = (w >> 13) & 1u ? lag : 0;
+  r.xs = (w >> 14) & 1u ? lag : 0;
+  return r;
+}
+
 // ---------------------------------------------------------------------------------
-// k3m_units: per frame, the chunks with a flat block.  grid = (ceil(nunits / 256), batch), block = 256;
+// k3m_units: per frame, the chunks with a flat block, the windows of their blocks per plane kind, and
+// which of them go to the exact kernel instead.  grid = (ceil(nunits / 256), batch), block = 256;
 // one atomic per wave.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restrict__ records, MParams mp) {
@@ -130,25 +153,46 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(&mp.unit_count[frame], (uint32_t)__popcll(vote));
   base = __shfl(base, 0, 64);
-  if (bits) {
-    const uint32_t pos = base + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
-    mp.units[(size_t)frame * mp.nunits + pos] = (uint32_t)ci | ((uint32_t)by << 12) | (bits << 24);
+  if (!bits) return;
+  const uint32_t pos = base + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
+  const bool chroma = g.nplanes == 3;
+  uint32_t win[2 * kMUnitBlocks];
+#pragma unroll
+  for (int t = 0; t < 2 * kMUnitBlocks; ++t) {
+    const int kind = t / kMUnitBlocks, b = t % kMUnitBlocks, bx = kMUnitBlocks * ci + b;
+    win[t] = 0;
+    if (!((bits >> b) & 1u) || (kind && !chroma)) continue;
+    const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
+    const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
+    const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph, g.lag);
+    if (!w.flat) continue;
+    // the tile reaches into the left / right / upper neighbours
+    const uint8_t *bad = mp.bad + ((size_t)frame * 2 + kind) * g.nblocks;
+    bool defer = false;
+    for (int dy = -1; dy <= 0; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int x = bx + dx, y = by + dy;
+        if (x >= 0 && x < g.nbw && y >= 0 && bad[y * g.nbw + x]) defer = true;
+      }
+    if (defer) {
+      mp.only[((size_t)frame * 2 + kind) * g.nblocks + by * g.nbw + bx] = 1;
+      mp.only_any[frame] = 1u;
+    } else {
+      win[t] = (uint32_t)w.xe | ((uint32_t)w.ye << 6) | (w.ys ? 1u << 13 : 0u) | (w.xs ? 1u << 14 : 0u) | (1u << 15);
+    }
   }
+  uint32_t *e = mp.units + ((size_t)frame * mp.nunits + pos) * kMUnitDwords;
+  *reinterpret_cast<uint4 *>(e) = make_uint4((uint32_t)ci | ((uint32_t)by << 12) | (bits << 24), win[0] | (win[1] << 16),
+                                             win[2] | (win[3] << 16), win[4] | (win[5] << 16));
+  *reinterpret_cast<uint4 *>(e + 4) = make_uint4(win[6] | (win[7] << 16), 0u, 0u, 0u);
 }
-
-// ---------------------------------------------------------------------------------
-// per-unit block info (one thread per (kind, block) writes it, everybody reads it)
-// ---------------------------------------------------------------------------------
-struct MBlockInfo {
-  int go;  // flat, window not empty, not deferred
-  int xs, xe, ys, ye;
-};
 
 __device__ __forceinline__ uint32_t m_bytemask(int k) { return k >= 4 ? 0xffffffffu : ((1u << (8 * k)) - 1u); }
 
 // 7 shifted copies of one row word (8 samples) -> LDS.  d0, d1: the word; prev1: the dword before it,
 // next0: the dword after it.
-__device__ __forceinline__ void m_write_copies(uint8_t *dst, int CS, uint32_t prev1, uint32_t d0, uint32_t d1, uint32_t next0) {
+__device__ __forceinline__ void m_write_copies(uint8_t *dst, int CS, uint32_t prev1, uint32_t d0, uint32_t d1, uint32_t next0,
+                                               uint2 cm) {
 #pragma unroll
   for (int cxp = 0; cxp < kMCopies; ++cxp) {
     const int cx = cxp - 3;
@@ -163,193 +207,216 @@ __device__ __forceinline__ void m_write_copies(uint8_t *dst, int CS, uint32_t pr
       w0 = __builtin_amdgcn_alignbyte(d1, d0, cx);
       w1 = __builtin_amdgcn_alignbyte(next0, d1, cx);
     }
-    *reinterpret_cast<uint2 *>(dst + cxp * CS) = make_uint2(w0, w1);
+    *reinterpret_cast<uint2 *>(dst + cxp * CS) = make_uint2(w0 & cm.x, w1 & cm.y);
   }
 }
 
-// stage the d8 tile of the unit (rows -3 .. bh-1, samples -8 .. 4 BW + 7 of the chunk) as 7 shifted copies
-template <int BW>
-__device__ __forceinline__ void m_stage_plane(uint8_t *tile, const uint8_t *__restrict__ plane, uint32_t pitch, int bx0, int by,
-                                              int bh, int CS, int wave, int lane) {
-  constexpr int P = m_pitch(BW), WPR = P / 8, RPP = 64 / WPR;
-  const int rows = bh + 3;
-  const int lr = lane / WPR, wd = lane - lr * WPR;
-  for (int r0 = wave * RPP; r0 < rows; r0 += 4 * RPP) {
-    const int row = r0 + lr;
-    const bool active = lr < RPP && row < rows;
+// ---- the rows of one plane tile (rows -3 .. BH-1, samples -8 .. 4 BW + 7 of the chunk): a wave moves
+// 64 / WPR rows a round, a lane one 8-sample word; ROUNDS rounds cover the tile ----
+template <int BW, int BH>
+struct MTile {
+  static constexpr int P = m_pitch(BW), WPR = P / 8, RPP = 64 / WPR, ROWS = BH + 3;
+  static constexpr int ROUNDS = (ROWS + 4 * RPP - 1) / (4 * RPP);
+  static constexpr int CS = m_copy_stride(BW, BH);
+  uint2 w[ROUNDS];
+
+  __device__ __forceinline__ void load(const uint8_t *__restrict__ plane, uint32_t pitch, int bx0, int by, int wave, int lane) {
+    const int lr = lane / WPR, wd = lane - lr * WPR;
     const uint32_t col = (uint32_t)(bx0 * BW + 8 * wd);
-    uint2 D = make_uint2(0u, 0u);
-    if (active && col + 8u <= pitch) D = *reinterpret_cast<const uint2 *>(plane + (size_t)(by * bh + row) * pitch + col);
-    const uint32_t prev1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)D.y, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    const uint32_t next0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)D.x, 0x130, 0xf, 0xf, false);  // wave_shl:1
-    if (active && wd >= 1 && wd <= WPR - 2) m_write_copies(tile + row * P + 8 * (wd - 1), CS, prev1, D.x, D.y, next0);
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+      const int row = (4 * k + wave) * RPP + lr;
+      w[k] = make_uint2(0u, 0u);
+      if (lr < RPP && row < ROWS && col + 8u <= pitch)
+        w[k] = *reinterpret_cast<const uint2 *>(plane + (size_t)(by * BH + row) * pitch + col);
+    }
   }
+  // cm: the window columns of the word's block as a byte mask (0: block not processed, nothing is written:
+  // byte x of a copy row is only ever read as the operand of sample x)
+  __device__ __forceinline__ void store(uint8_t *tile, int wave, int lane, uint2 cm) const {
+    const int lr = lane / WPR, wd = lane - lr * WPR;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+      const int row = (4 * k + wave) * RPP + lr;
+      const uint32_t prev1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k].y, 0x138, 0xf, 0xf, false);  // wave_shr:1
+      const uint32_t next0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k].x, 0x130, 0xf, 0xf, false);  // wave_shl:1
+      if (lr < RPP && row < ROWS && wd >= 1 && wd <= WPR - 2 && (cm.x | cm.y))
+        m_write_copies(tile + row * P + 8 * (wd - 1), CS, prev1, w[k].x, w[k].y, next0, cm);
+    }
+  }
+};
+
+// byte mask of the 8 samples xb .. xb + 7 of a block under its window columns [xs, xe)
+__device__ __forceinline__ uint2 m_colmask8(const MWin &bi, int xb) {
+  if (!bi.go) return make_uint2(0u, 0u);
+  const int lo = min(max(bi.xs - xb, 0), 8), hi = min(max(bi.xe - xb, 0), 8);
+  const unsigned long long mh = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
+  const unsigned long long ml = lo >= 8 ? ~0ull : ((1ull << (8 * lo)) - 1ull);
+  const unsigned long long m = mh & ~ml;
+  return make_uint2((uint32_t)m, (uint32_t)(m >> 32));
 }
 
-// the block's share of S: acc += V V^T over this wave's rows of the window
-template <int BW>
-__device__ __forceinline__ void m_block(v16i32 &acc, const uint8_t *tile, int addr, const MBlockInfo &bi, int bh, int wave, int h) {
-  constexpr int P = m_pitch(BW);
-  const int xh = BW == 32 ? 16 * h : 0;
-  const int lo = min(max(bi.xs - xh, 0), 16), hi = min(max(bi.xe - xh, 0), 16);
-  v4i32 m;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int l = min(max(lo - 4 * q, 0), 4), u = min(max(hi - 4 * q, 0), 4);
-    m[q] = u > l ? (int)(m_bytemask(u) & ~m_bytemask(l)) : 0;
-  }
-  const bool full = bi.xs == 0 && bi.xe == BW;
-  if constexpr (BW == 32) {
-    const int rpw = bh >> 2;
-    const int y0 = max(bi.ys, wave * rpw), y1 = min(bi.ye, (wave + 1) * rpw);
-    if (full) {
-      for (int y = y0; y < y1; ++y) {
-        const v4i32 v = *reinterpret_cast<const v4i32 *>(tile + addr + y * P);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v, v, acc, 0, 0, 0);
-      }
-    } else {
-      for (int y = y0; y < y1; ++y) {
-        const v4i32 v = *reinterpret_cast<const v4i32 *>(tile + addr + y * P) & m;
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v, v, acc, 0, 0, 0);
-      }
-    }
-  } else {
-    const int spw = bh >> 3;  // steps (row pairs) per wave
-    for (int s = wave * spw; s < (wave + 1) * spw; ++s) {
-      const int ya = 2 * s;
-      if (ya + 1 < bi.ys || ya >= bi.ye) continue;
-      v4i32 v = *reinterpret_cast<const v4i32 *>(tile + addr + ya * P);
-      if (ya < bi.ys || ya + 1 >= bi.ye) {
-        const bool ok = ya + h >= bi.ys && ya + h < bi.ye;
-        const v4i32 z = {0, 0, 0, 0};
-        v = ok ? (v & m) : z;
-      } else if (!full) {
-        v &= m;
-      }
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v, v, acc, 0, 0, 0);
-    }
+__device__ __forceinline__ v4i32 m_lds16(const uint8_t *smem, int a) { return *reinterpret_cast<const v4i32 *>(smem + a); }
+
+// A luma-shaped block's share of S (blocks 32 wide: a step is one row): acc += V V^T over this wave's rows
+// of the window rows [ys, ye) (the window columns are already zeroed in the tile).  Two accumulators
+// alternate (dependent MFMAs wait for each other), the operands of the next pair of rows are read while
+// this pair is multiplied.  ONE code path: the register allocator copies accumulators at every merge of
+// two paths that both multiply.
+// na rows from addr_a into accA, nb <= na rows from addr_b into accB, `stride` bytes from row to row
+__device__ __forceinline__ void m_rows32(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int addr_a, int addr_b, int stride, int na,
+                                         int nb) {
+  if (na <= 0) return;
+  const v4i32 z = {0, 0, 0, 0};
+  v4i32 va = m_lds16(smem, addr_a), vb = z;
+  if (nb > 0) vb = m_lds16(smem, addr_b);
+  for (int k = 0; k < na; ++k) {
+    v4i32 xa = z, xb = z;
+    addr_a += stride;
+    addr_b += stride;
+    if (k + 1 < na) xa = m_lds16(smem, addr_a);
+    if (k + 1 < nb) xb = m_lds16(smem, addr_b);
+    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va, va, accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb, vb, accB, 0, 0, 0);  // (an odd tail multiplies zeros)
+    va = xa;
+    vb = xb;
   }
 }
-
-// one plane of one unit: stage, accumulate
-template <int BW>
-__device__ __forceinline__ void m_plane_pass(v16i32 &acc, long long &nobs, uint8_t *tile, const MBlockInfo *info, int c,
-                                             const MParams &mp, const uint8_t *fplanes, int bx0, int by, int bh, bool with_l,
-                                             int lag_base, int wave, int lane) {
-  constexpr int P = m_pitch(BW);
-  const int CS = m_copy_stride(BW, bh);
-  const int kind = c > 0 ? 1 : 0;
-  __syncthreads();  // the previous plane's reads are done
-  m_stage_plane<BW>(tile, fplanes + mp.ps.off_d[c], mp.ps.pitch[kind], bx0, by, bh, CS, wave, lane);
-  if (with_l && c == 1) {
-    // L tile (no halo): rows 0 .. bh-1, samples 0 .. 4 BW - 1
-    constexpr int WL = 4 * BW / 8;
-    uint8_t *lt = tile + kMCopies * CS;
-    for (int idx = threadIdx.x; idx < bh * WL; idx += 256) {
-      const int row = idx / WL, wd = idx - row * WL;
-      const uint32_t col = (uint32_t)(bx0 * BW + 8 * wd);
-      uint2 D = make_uint2(0u, 0u);
-      if (col + 8u <= mp.ps.lpitch) D = *reinterpret_cast<const uint2 *>(fplanes + mp.ps.off_l + (size_t)(by * bh + row) * mp.ps.lpitch + col);
-      *reinterpret_cast<uint2 *>(lt + row * P + 8 * wd) = D;
-    }
-  }
-  __syncthreads();
-  const int h = lane >> 5;
-#pragma unroll
-  for (int b = 0; b < kMUnitBlocks; ++b) {
-    const MBlockInfo bi = info[kind * kMUnitBlocks + b];
-    if (!bi.go) continue;
-    m_block<BW>(acc, tile, lag_base + BW * b, bi, bh, wave, h);
-    if (threadIdx.x == 0) nobs += (long long)(bi.xe - bi.xs) * (bi.ye - bi.ys);
+// Blocks 16 wide: a step is two rows, one per lane half; both chroma planes in one loop (two accumulators).
+template <int BH>
+__device__ __forceinline__ void m_block16x2(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int addr_a, int addr_b, int ys, int ye,
+                                            int wave, int h) {
+  constexpr int P = m_pitch(16), SPW = BH / 8;  // steps (row pairs) per wave
+  const int s0 = max(ys >> 1, wave * SPW), s1 = min((ye + 1) >> 1, wave * SPW + SPW);
+  for (int s = s0; s < s1; ++s) {
+    const int yl = 2 * s + h;  // this lane half's row
+    const int ok = (yl >= ys && yl < ye) ? -1 : 0;
+    const v4i32 va = m_lds16(smem, addr_a + 2 * s * P) & ok, vb = m_lds16(smem, addr_b + 2 * s * P) & ok;
+    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va, va, accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb, vb, accB, 0, 0, 0);
   }
 }
 
 // ---------------------------------------------------------------------------------
-// k3m_accumulate<CBW>: CBW = chroma block width (32 >> xdec; 0 = luma only).
-// grid = (G, 1, batch), block = 256, dynamic LDS = max tile bytes (see m_lds_bytes).
+// k3m_accumulate<CBW, CBH>: chroma block 32 >> xdec by 32 >> ydec (0, 0: luma only).
+// grid = (G, 1, batch), block = 256, dynamic LDS = m_lds_bytes(CBW, CBH).
 // ---------------------------------------------------------------------------------
-template <int CBW>
-__global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp, const uint8_t *__restrict__ records) {
+template <int CBW, int CBH>
+__global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t m_smem[];
-  __shared__ MBlockInfo s_info[2 * kMUnitBlocks];
-  uint8_t *tile = m_smem;
+  constexpr bool CH = CBW != 0;
+  constexpr int CW_ = CH ? CBW : 16, CH_ = CH ? CBH : 16;  // (dummy chroma tile types for the luma-only kernel)
+  using LT = MTile<32, kBlock>;
+  using CT = MTile<CW_, CH_>;
+  uint8_t *tile_y = m_smem;
+  uint8_t *tile_cb = m_smem + m_tile_bytes(32, kBlock);
+  uint8_t *tile_cr = tile_cb + m_tile_bytes(CW_, CH_);
+  uint8_t *tile_l = tile_cr + m_tile_bytes(CW_, CH_);
+
   const int frame = g.frame0 + (int)blockIdx.z;
   const int G = gridDim.x, wg = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t cnt = mp.unit_count[frame];
   const uint32_t u0 = (uint32_t)((unsigned long long)cnt * wg / G), u1 = (uint32_t)((unsigned long long)cnt * (wg + 1) / G);
-  const uint32_t *units = mp.units + (size_t)frame * mp.nunits;
-  const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
+  const uint32_t *units = mp.units + (size_t)frame * mp.nunits * kMUnitDwords;
   const uint8_t *fplanes = mp.planes + (size_t)frame * mp.ps.frame_bytes;
-  const bool chroma = CBW != 0 && g.nplanes == 3;
-  const int cbh = kBlock >> g.ydec;
 
   // this lane's operand address inside a tile, per plane kind
   const int i = lane & 31, h = lane >> 5;
   int ea, ecxp, esp;
   m_entry(i, ea, ecxp, esp);
-  int base_luma, base_chroma = 0;
-  {
-    constexpr int P = m_pitch(32);
-    const int CS = m_copy_stride(32, kBlock);
-    const bool plain = esp == 0;
-    base_luma = (plain ? ecxp : 3) * CS + (3 - (plain ? ea : 0)) * P + 16 * h;
-  }
-  if constexpr (CBW != 0) {
-    constexpr int P = m_pitch(CBW);
-    const int CS = m_copy_stride(CBW, cbh);
-    const bool plain = esp == 0;
-    const int hoff = CBW == 32 ? 16 * h : h * P;
-    base_chroma = esp == 1 ? kMCopies * CS + hoff : (plain ? ecxp : 3) * CS + (3 - (plain ? ea : 0)) * P + hoff;
-  }
+  const bool plain = esp == 0;
+  const int base_luma = (plain ? ecxp : 3) * LT::CS + (3 - (plain ? ea : 0)) * LT::P + 16 * h;
+  const int hoff_c = CW_ == 32 ? 16 * h : h * CT::P;
+  // (the L tile sits behind the two chroma tiles: relative to the Cb / Cr tile it is at a different distance)
+  const int base_chroma = (plain ? ecxp : 3) * CT::CS + (3 - (plain ? ea : 0)) * CT::P + hoff_c;
+  // (the L row of the matrix reads the L tile: no halo, no copies)
+  const int off_l = m_tile_bytes(32, kBlock) + 2 * m_tile_bytes(CW_, CH_) + hoff_c;
+  const int addr_cb = esp == 1 ? off_l : m_tile_bytes(32, kBlock) + base_chroma;
+  const int addr_cr = esp == 1 ? off_l : m_tile_bytes(32, kBlock) + m_tile_bytes(CW_, CH_) + base_chroma;
 
-  v16i32 acc0, acc1, acc2;
+  v16i32 accY0, accY1, accCb, accCr;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = 0;
-  long long nobs0 = 0, nobs1 = 0, nobs2 = 0;
+  for (int r = 0; r < 16; ++r) accY0[r] = accY1[r] = accCb[r] = accCr[r] = 0;
+  long long nobs0 = 0, nobs1 = 0;
+
+  // ---- the rows of a unit, requested one unit ahead ----
+  LT py;
+  CT pcb, pcr;
+  uint2 pl[(CH_ * (4 * CW_ / 8) + 255) / 256];
+  constexpr int WL = 4 * CW_ / 8, LROUNDS = (CH_ * WL + 255) / 256;
+  uint4 ent0 = make_uint4(0, 0, 0, 0);
+  uint32_t ent4 = 0;
+  auto request = [&](uint32_t u) {
+    const uint32_t *e = units + (size_t)u * kMUnitDwords;
+    ent0 = *reinterpret_cast<const uint4 *>(e);
+    ent4 = e[4];
+    const int bx0 = kMUnitBlocks * (int)(ent0.x & 0xfffu), by = (int)((ent0.x >> 12) & 0xfffu);
+    py.load(fplanes + mp.ps.off_d[0], mp.ps.pitch[0], bx0, by, wave, lane);
+    if constexpr (CH) {
+      pcb.load(fplanes + mp.ps.off_d[1], mp.ps.pitch[1], bx0, by, wave, lane);
+      pcr.load(fplanes + mp.ps.off_d[2], mp.ps.pitch[1], bx0, by, wave, lane);
+#pragma unroll
+      for (int k = 0; k < LROUNDS; ++k) {
+        const int idx = tid + 256 * k, row = idx / WL, wd = idx - row * WL;
+        const uint32_t col = (uint32_t)(bx0 * CW_ + 8 * wd);
+        pl[k] = make_uint2(0u, 0u);
+        if (row < CH_ && col + 8u <= mp.ps.lpitch)
+          pl[k] = *reinterpret_cast<const uint2 *>(fplanes + mp.ps.off_l + (size_t)(by * CH_ + row) * mp.ps.lpitch + col);
+      }
+    }
+  };
+  if (u0 < u1) request(u0);
 
   for (uint32_t u = u0; u < u1; ++u) {
-    const uint32_t e = units[u];
-    const int ci = (int)(e & 0xfffu), by = (int)((e >> 12) & 0xfffu);
-    const int bx0 = kMUnitBlocks * ci;
-    __syncthreads();  // s_info of the previous unit is no longer read
-    if (tid < 2 * kMUnitBlocks) {
-      const int kind = tid / kMUnitBlocks, b = tid % kMUnitBlocks;
-      MBlockInfo bi{0, 0, 0, 0, 0};
-      const int bx = bx0 + b;
-      if ((kind == 0 || chroma) && ((e >> (24 + b)) & 1u)) {
-        const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? cbh : kBlock;
-        const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
-        const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph, g.lag);
-        if (w.flat) {
-          // the tile reaches into the left / right / upper neighbours
-          const uint8_t *bad = mp.bad + ((size_t)frame * 2 + kind) * g.nblocks;
-          bool defer = false;
-          for (int dy = -1; dy <= 0; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-              const int x = bx + dx, y = by + dy;
-              if (x >= 0 && x < g.nbw && y >= 0 && bad[y * g.nbw + x]) defer = true;
-            }
-          if (defer) {
-            mp.only[((size_t)frame * 2 + kind) * g.nblocks + by * g.nbw + bx] = 1;
-            mp.only_any[frame] = 1u;
-          } else {
-            bi.go = 1;
-            bi.xs = w.xs;
-            bi.xe = w.xe;
-            bi.ys = w.ys;
-            bi.ye = w.ye;
-          }
-        }
-      }
-      s_info[tid] = bi;
+    const uint4 e0 = ent0;
+    const uint32_t e4 = ent4;
+    __syncthreads();  // the previous unit's tiles are no longer read
+    const uint32_t wins[8] = {e0.y & 0xffffu, e0.y >> 16, e0.z & 0xffffu, e0.z >> 16, e0.w & 0xffffu, e0.w >> 16, e4 & 0xffffu, e4 >> 16};
+    {
+      // the window columns of the block under this lane's word, as a byte mask
+      const int xw = 8 * (lane % LT::WPR - 1), bq = (xw >> 5) & 3;
+      const uint32_t wsel = bq == 0 ? wins[0] : (bq == 1 ? wins[1] : (bq == 2 ? wins[2] : wins[3]));
+      py.store(tile_y, wave, lane, m_colmask8(m_unpack(wsel, g.lag), xw - 32 * bq));
     }
-    // (m_plane_pass opens with a barrier)
-    m_plane_pass<32>(acc0, nobs0, tile, s_info, 0, mp, fplanes, bx0, by, kBlock, false, base_luma, wave, lane);
-    if constexpr (CBW != 0) {
-      if (chroma) {
-        m_plane_pass<CBW>(acc1, nobs1, tile, s_info, 1, mp, fplanes, bx0, by, cbh, true, base_chroma, wave, lane);
-        m_plane_pass<CBW>(acc2, nobs2, tile, s_info, 2, mp, fplanes, bx0, by, cbh, true, base_chroma, wave, lane);
+    if constexpr (CH) {
+      const int xw = 8 * (lane % CT::WPR - 1), bq = (xw / CW_) & 3;
+      const uint32_t wsel = bq == 0 ? wins[4] : (bq == 1 ? wins[5] : (bq == 2 ? wins[6] : wins[7]));
+      const uint2 cm = m_colmask8(m_unpack(wsel, g.lag), xw - CW_ * bq);
+      pcb.store(tile_cb, wave, lane, cm);
+      pcr.store(tile_cr, wave, lane, cm);
+#pragma unroll
+      for (int k = 0; k < LROUNDS; ++k) {
+        const int idx = tid + 256 * k, row = idx / WL, wd = idx - row * WL;
+        const int bl = (8 * wd / CW_) & 3;
+        const uint32_t wl = bl == 0 ? wins[4] : (bl == 1 ? wins[5] : (bl == 2 ? wins[6] : wins[7]));
+        const uint2 lm = m_colmask8(m_unpack(wl, g.lag), 8 * wd - CW_ * bl);
+        if (row < CH_) *reinterpret_cast<uint2 *>(tile_l + row * CT::P + 8 * wd) = make_uint2(pl[k].x & lm.x, pl[k].y & lm.y);
+      }
+    }
+    if (u + 1 < u1) request(u + 1);
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < kMUnitBlocks; ++b) {
+      const MWin wy = m_unpack(wins[b], g.lag);
+      if (wy.go) {
+        // even rows of this wave's share into one accumulator, odd rows into the other
+        const int y0 = max(wy.ys, wave * (kBlock / 4)), n = min(wy.ye, (wave + 1) * (kBlock / 4)) - y0;
+        const int a0 = base_luma + 32 * b + y0 * LT::P;
+        m_rows32(accY0, accY1, m_smem, a0, a0 + LT::P, 2 * LT::P, (n + 1) >> 1, n >> 1);
+        if (tid == 0) nobs0 += (long long)(wy.xe - wy.xs) * (wy.ye - wy.ys);
+      }
+      if constexpr (CH) {
+        const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
+        if (wc.go) {
+          if constexpr (CW_ == 32) {
+            const int y0 = max(wc.ys, wave * (CH_ / 4)), n = min(wc.ye, (wave + 1) * (CH_ / 4)) - y0;
+            m_rows32(accCb, accCr, m_smem, addr_cb + CW_ * b + y0 * CT::P, addr_cr + CW_ * b + y0 * CT::P, CT::P, n, n);
+          } else {
+            m_block16x2<CH_>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, wc.ys, wc.ye, wave, h);
+          }
+          if (tid == 0) nobs1 += (long long)(wc.xe - wc.xs) * (wc.ye - wc.ys);
+        }
       }
     }
   }
@@ -376,21 +443,15 @@ __global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp, const 
     }
     if (tid == 0 && nobs) atomicAdd(reinterpret_cast<unsigned long long *>(&s_S[c * kMRec + nc * nc + nc]), (unsigned long long)nobs);
   };
-  flush(acc0, 0, nobs0);
-  if (chroma) {
-    flush(acc1, 1, nobs1);
-    flush(acc2, 2, nobs2);
+  flush(accY0, 0, nobs0);
+  flush(accY1, 0, 0);
+  if (CH) {
+    flush(accCb, 1, nobs1);
+    flush(accCr, 2, nobs1);
   }
   __syncthreads();
   long long *out = mp.partials + ((size_t)frame * G + wg) * 3 * kMRec;
   for (int k = tid; k < 3 * kMRec; k += 256) out[k] = s_S[k];
-}
-
-inline size_t m_lds_bytes(int cbw, int cbh) {
-  size_t b = (size_t)m_tile_bytes(32, kBlock, false);
-  if (cbw == 32) b = std::max(b, (size_t)m_tile_bytes(32, cbh, true));
-  if (cbw == 16) b = std::max(b, (size_t)m_tile_bytes(16, cbh, true));
-  return std::max(b, sizeof(long long) * 3 * kMRec);
 }
 
 // ---------------------------------------------------------------------------------
