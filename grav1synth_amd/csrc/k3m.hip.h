@@ -66,10 +66,12 @@ __host__ __device__ constexpr int m_copy_stride(int BW, int BH) {
   return slots * 16;
 }
 __host__ __device__ constexpr int m_tile_bytes(int BW, int BH) { return kMCopies * m_copy_stride(BW, BH); }
-// LDS map of a workgroup: [luma tile][Cb tile][Cr tile][L tile]
-__host__ __device__ constexpr int m_lds_bytes(int CBW, int CBH) {
+// LDS map of a workgroup: [luma tile][Cb tile][Cr tile][L tile][zero block]
+__host__ __device__ constexpr int m_lds_tiles(int CBW, int CBH) {
   return m_tile_bytes(32, kBlock) + (CBW ? 2 * m_tile_bytes(CBW, CBH) + CBH * m_pitch(CBW) : 0);
 }
+// ... followed by a block of 16 zero bytes (the operand of rows outside a window)
+__host__ __device__ constexpr int m_lds_bytes(int CBW, int CBH) { return m_lds_tiles(CBW, CBH) + 16; }
 
 // ---- matrix row i (0..31) -> what it holds ------------------------------------------
 // order inside the two b128 lane groups
@@ -219,29 +221,37 @@ struct MTile {
   static constexpr int ROUNDS = (ROWS + 4 * RPP - 1) / (4 * RPP);
   static constexpr int CS = m_copy_stride(BW, BH);
   uint2 w[ROUNDS];
+  uint32_t off[ROUNDS];  // byte offset of the lane's word of round k from the unit's first tile row in the plane
+  int lrow[ROUNDS];      // its LDS offset inside a copy + 8 (-1: the lane has no word in this round)
+  int wd;                // word of the row: 0 and WPR - 1 are the halo words
 
-  __device__ __forceinline__ void load(const uint8_t *__restrict__ plane, uint32_t pitch, int bx0, int by, int wave, int lane) {
-    const int lr = lane / WPR, wd = lane - lr * WPR;
-    const uint32_t col = (uint32_t)(bx0 * BW + 8 * wd);
+  __device__ __forceinline__ void init(uint32_t pitch, int wave, int lane) {
+    const int lr = lane / WPR;
+    wd = lane - lr * WPR;
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k) {
       const int row = (4 * k + wave) * RPP + lr;
+      const bool ok = lr < RPP && row < ROWS;
+      off[k] = ok ? (uint32_t)row * pitch + 8u * (uint32_t)wd : 0u;
+      lrow[k] = ok ? row * P + 8 * wd : -1;
+    }
+  }
+  // base: the plane at (first tile row, first sample of the chunk - 8) -- uniform; colok: the word lies inside the plane row
+  __device__ __forceinline__ void load(const uint8_t *__restrict__ base, bool colok) {
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
       w[k] = make_uint2(0u, 0u);
-      if (lr < RPP && row < ROWS && col + 8u <= pitch)
-        w[k] = *reinterpret_cast<const uint2 *>(plane + (size_t)(by * BH + row) * pitch + col);
+      if (lrow[k] >= 0 && colok) w[k] = *reinterpret_cast<const uint2 *>(base + off[k]);
     }
   }
   // cm: the window columns of the word's block as a byte mask (0: block not processed, nothing is written:
   // byte x of a copy row is only ever read as the operand of sample x)
-  __device__ __forceinline__ void store(uint8_t *tile, int wave, int lane, uint2 cm) const {
-    const int lr = lane / WPR, wd = lane - lr * WPR;
+  __device__ __forceinline__ void store(uint8_t *tile, uint2 cm) const {
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k) {
-      const int row = (4 * k + wave) * RPP + lr;
       const uint32_t prev1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k].y, 0x138, 0xf, 0xf, false);  // wave_shr:1
       const uint32_t next0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k].x, 0x130, 0xf, 0xf, false);  // wave_shl:1
-      if (lr < RPP && row < ROWS && wd >= 1 && wd <= WPR - 2 && (cm.x | cm.y))
-        m_write_copies(tile + row * P + 8 * (wd - 1), CS, prev1, w[k].x, w[k].y, next0, cm);
+      if (lrow[k] >= 0 && wd >= 1 && wd <= WPR - 2 && (cm.x | cm.y)) m_write_copies(tile + lrow[k] - 8, CS, prev1, w[k].x, w[k].y, next0, cm);
     }
   }
 };
@@ -263,35 +273,44 @@ __device__ __forceinline__ v4i32 m_lds16(const uint8_t *smem, int a) { return *r
 // alternate (dependent MFMAs wait for each other), the operands of the next pair of rows are read while
 // this pair is multiplied.  ONE code path: the register allocator copies accumulators at every merge of
 // two paths that both multiply.
-// na rows from addr_a into accA, nb <= na rows from addr_b into accB, `stride` bytes from row to row
-__device__ __forceinline__ void m_rows32(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int addr_a, int addr_b, int stride, int na,
-                                         int nb) {
-  if (na <= 0) return;
-  const v4i32 z = {0, 0, 0, 0};
-  v4i32 va = m_lds16(smem, addr_a), vb = z;
-  if (nb > 0) vb = m_lds16(smem, addr_b);
-  for (int k = 0; k < na; ++k) {
-    v4i32 xa = z, xb = z;
-    addr_a += stride;
-    addr_b += stride;
-    if (k + 1 < na) xa = m_lds16(smem, addr_a);
-    if (k + 1 < nb) xb = m_lds16(smem, addr_b);
-    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va, va, accA, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb, vb, accB, 0, 0, 0);  // (an odd tail multiplies zeros)
-    va = xa;
-    vb = xb;
+// The multiplies of a block run over ALL of the wave's rows, unrolled, on ONE code path (the register
+// allocator copies accumulators at every merge of two paths that both multiply): a row outside the window
+// rows [ys, ye) reads the zero block at LDS offset `zoff` instead of its tile row (3 of 32 rows when the block
+// above is not flat).
+// R rows from a0 + j * P: even j into accA, odd j into accB (a luma-shaped block, two accumulators: dependent
+// MFMAs wait for each other)
+template <int R, int P>
+__device__ __forceinline__ void m_rows_alt(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int y0, int ys, int ye, int zoff) {
+  v4i32 v[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) v[j] = m_lds16(smem, (y0 + j >= ys && y0 + j < ye) ? a0 + j * P : zoff);
+#pragma unroll
+  for (int j = 0; j < R; j += 2) {
+    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j], v[j], accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j + 1], v[j + 1], accB, 0, 0, 0);
   }
 }
-// Blocks 16 wide: a step is two rows, one per lane half; both chroma planes in one loop (two accumulators).
-template <int BH>
-__device__ __forceinline__ void m_block16x2(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int addr_a, int addr_b, int ys, int ye,
-                                            int wave, int h) {
-  constexpr int P = m_pitch(16), SPW = BH / 8;  // steps (row pairs) per wave
-  const int s0 = max(ys >> 1, wave * SPW), s1 = min((ye + 1) >> 1, wave * SPW + SPW);
-  for (int s = s0; s < s1; ++s) {
-    const int yl = 2 * s + h;  // this lane half's row
-    const int ok = (yl >= ys && yl < ye) ? -1 : 0;
-    const v4i32 va = m_lds16(smem, addr_a + 2 * s * P) & ok, vb = m_lds16(smem, addr_b + 2 * s * P) & ok;
+// R rows of two planes: plane A from a0 into accA, plane B from b0 into accB (chroma blocks 32 wide)
+template <int R, int P>
+__device__ __forceinline__ void m_rows_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, int y0, int ys, int ye,
+                                           int zoff) {
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const bool ok = y0 + j >= ys && y0 + j < ye;
+    const v4i32 va = m_lds16(smem, ok ? a0 + j * P : zoff), vb = m_lds16(smem, ok ? b0 + j * P : zoff);
+    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va, va, accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb, vb, accB, 0, 0, 0);
+  }
+}
+// S steps of two planes, blocks 16 wide: a step is two rows, one per lane half (h)
+template <int S, int P>
+__device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, int s0, int ys, int ye,
+                                            int h, int zoff) {
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const int yl = 2 * (s0 + j) + h;  // this lane half's row
+    const bool ok = yl >= ys && yl < ye;
+    const v4i32 va = m_lds16(smem, ok ? a0 + 2 * j * P : zoff), vb = m_lds16(smem, ok ? b0 + 2 * j * P : zoff);
     accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va, va, accA, 0, 0, 0);
     accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb, vb, accB, 0, 0, 0);
   }
@@ -341,10 +360,15 @@ __global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp) {
   long long nobs0 = 0, nobs1 = 0;
 
   // ---- the rows of a unit, requested one unit ahead ----
+  constexpr int ZOFF = m_lds_tiles(CBW, CBH);
+  if (tid < 4) reinterpret_cast<uint32_t *>(m_smem + ZOFF)[tid] = 0u;
   LT py;
   CT pcb, pcr;
-  uint2 pl[(CH_ * (4 * CW_ / 8) + 255) / 256];
+  py.init(mp.ps.pitch[0], wave, lane);
+  pcb.init(mp.ps.pitch[1], wave, lane);
+  pcr.init(mp.ps.pitch[1], wave, lane);
   constexpr int WL = 4 * CW_ / 8, LROUNDS = (CH_ * WL + 255) / 256;
+  uint2 pl[LROUNDS];
   uint4 ent0 = make_uint4(0, 0, 0, 0);
   uint32_t ent4 = 0;
   auto request = [&](uint32_t u) {
@@ -352,17 +376,20 @@ __global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp) {
     ent0 = *reinterpret_cast<const uint4 *>(e);
     ent4 = e[4];
     const int bx0 = kMUnitBlocks * (int)(ent0.x & 0xfffu), by = (int)((ent0.x >> 12) & 0xfffu);
-    py.load(fplanes + mp.ps.off_d[0], mp.ps.pitch[0], bx0, by, wave, lane);
+    py.load(fplanes + mp.ps.off_d[0] + (size_t)(by * kBlock) * mp.ps.pitch[0] + bx0 * 32,
+            (uint32_t)(bx0 * 32 + 8 * py.wd + 8) <= mp.ps.pitch[0]);
     if constexpr (CH) {
-      pcb.load(fplanes + mp.ps.off_d[1], mp.ps.pitch[1], bx0, by, wave, lane);
-      pcr.load(fplanes + mp.ps.off_d[2], mp.ps.pitch[1], bx0, by, wave, lane);
+      const size_t co = (size_t)(by * CH_) * mp.ps.pitch[1] + bx0 * CW_;
+      const bool cok = (uint32_t)(bx0 * CW_ + 8 * pcb.wd + 8) <= mp.ps.pitch[1];
+      pcb.load(fplanes + mp.ps.off_d[1] + co, cok);
+      pcr.load(fplanes + mp.ps.off_d[2] + co, cok);
+      const uint8_t *lb = fplanes + mp.ps.off_l + (size_t)(by * CH_) * mp.ps.lpitch + bx0 * CW_;
 #pragma unroll
       for (int k = 0; k < LROUNDS; ++k) {
         const int idx = tid + 256 * k, row = idx / WL, wd = idx - row * WL;
-        const uint32_t col = (uint32_t)(bx0 * CW_ + 8 * wd);
         pl[k] = make_uint2(0u, 0u);
-        if (row < CH_ && col + 8u <= mp.ps.lpitch)
-          pl[k] = *reinterpret_cast<const uint2 *>(fplanes + mp.ps.off_l + (size_t)(by * CH_ + row) * mp.ps.lpitch + col);
+        if (row < CH_ && (uint32_t)(bx0 * CW_ + 8 * wd + 8) <= mp.ps.lpitch)
+          pl[k] = *reinterpret_cast<const uint2 *>(lb + (uint32_t)row * mp.ps.lpitch + 8u * (uint32_t)wd);
       }
     }
   };
@@ -375,16 +402,16 @@ __global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp) {
     const uint32_t wins[8] = {e0.y & 0xffffu, e0.y >> 16, e0.z & 0xffffu, e0.z >> 16, e0.w & 0xffffu, e0.w >> 16, e4 & 0xffffu, e4 >> 16};
     {
       // the window columns of the block under this lane's word, as a byte mask
-      const int xw = 8 * (lane % LT::WPR - 1), bq = (xw >> 5) & 3;
+      const int xw = 8 * (py.wd - 1), bq = (xw >> 5) & 3;
       const uint32_t wsel = bq == 0 ? wins[0] : (bq == 1 ? wins[1] : (bq == 2 ? wins[2] : wins[3]));
-      py.store(tile_y, wave, lane, m_colmask8(m_unpack(wsel, g.lag), xw - 32 * bq));
+      py.store(tile_y, m_colmask8(m_unpack(wsel, g.lag), xw - 32 * bq));
     }
     if constexpr (CH) {
-      const int xw = 8 * (lane % CT::WPR - 1), bq = (xw / CW_) & 3;
+      const int xw = 8 * (pcb.wd - 1), bq = (xw / CW_) & 3;
       const uint32_t wsel = bq == 0 ? wins[4] : (bq == 1 ? wins[5] : (bq == 2 ? wins[6] : wins[7]));
       const uint2 cm = m_colmask8(m_unpack(wsel, g.lag), xw - CW_ * bq);
-      pcb.store(tile_cb, wave, lane, cm);
-      pcr.store(tile_cr, wave, lane, cm);
+      pcb.store(tile_cb, cm);
+      pcr.store(tile_cr, cm);
 #pragma unroll
       for (int k = 0; k < LROUNDS; ++k) {
         const int idx = tid + 256 * k, row = idx / WL, wd = idx - row * WL;
@@ -400,20 +427,21 @@ __global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp) {
     for (int b = 0; b < kMUnitBlocks; ++b) {
       const MWin wy = m_unpack(wins[b], g.lag);
       if (wy.go) {
-        // even rows of this wave's share into one accumulator, odd rows into the other
-        const int y0 = max(wy.ys, wave * (kBlock / 4)), n = min(wy.ye, (wave + 1) * (kBlock / 4)) - y0;
-        const int a0 = base_luma + 32 * b + y0 * LT::P;
-        m_rows32(accY0, accY1, m_smem, a0, a0 + LT::P, 2 * LT::P, (n + 1) >> 1, n >> 1);
+        constexpr int RPW = kBlock / 4;
+        m_rows_alt<RPW, LT::P>(accY0, accY1, m_smem, base_luma + 32 * b + wave * RPW * LT::P, wave * RPW, wy.ys, wy.ye, ZOFF);
         if (tid == 0) nobs0 += (long long)(wy.xe - wy.xs) * (wy.ye - wy.ys);
       }
       if constexpr (CH) {
         const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
         if (wc.go) {
           if constexpr (CW_ == 32) {
-            const int y0 = max(wc.ys, wave * (CH_ / 4)), n = min(wc.ye, (wave + 1) * (CH_ / 4)) - y0;
-            m_rows32(accCb, accCr, m_smem, addr_cb + CW_ * b + y0 * CT::P, addr_cr + CW_ * b + y0 * CT::P, CT::P, n, n);
+            constexpr int RPW = CH_ / 4;
+            const int o = CW_ * b + wave * RPW * CT::P;
+            m_rows_two<RPW, CT::P>(accCb, accCr, m_smem, addr_cb + o, addr_cr + o, wave * RPW, wc.ys, wc.ye, ZOFF);
           } else {
-            m_block16x2<CH_>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, wc.ys, wc.ye, wave, h);
+            constexpr int SPW = CH_ / 8;
+            const int o = CW_ * b + 2 * wave * SPW * CT::P;
+            m_steps_two<SPW, CT::P>(accCb, accCr, m_smem, addr_cb + o, addr_cr + o, wave * SPW, wc.ys, wc.ye, h, ZOFF);
           }
           if (tid == 0) nobs1 += (long long)(wc.xe - wc.xs) * (wc.ye - wc.ys);
         }
