@@ -66,9 +66,22 @@ __host__ __device__ constexpr int m_copy_stride(int BW, int BH) {
   return slots * 16;
 }
 __host__ __device__ constexpr int m_tile_bytes(int BW, int BH) { return kMCopies * m_copy_stride(BW, BH); }
-// LDS map of a workgroup: [luma tile][Cb tile][Cr tile][L tile][zero block]
+// LDS map of a workgroup: [luma tile][Cb tile][Cr tile][pad][L tile][zero block].  The pad puts the L tile on a
+// 16-byte slot (mod 16) that none of the rows read together with it (a in {0, 1}) uses, in the Cb and in the Cr tile.
+__host__ __device__ constexpr bool m_l_slot_free(int rel, int p) {
+  for (int a = 0; a < 2; ++a)
+    for (int cxp = 0; cxp < (a == 0 ? 4 : 7); ++cxp)
+      if (((2 * cxp + p * (3 - a) - rel) & 15) == 0) return false;
+  return true;
+}
+__host__ __device__ constexpr int m_l_pad(int CBW, int CBH) {
+  const int T = m_tile_bytes(CBW, CBH) / 16, p = m_pitch(CBW) / 16;
+  for (int pad = 0; pad < 16; ++pad)
+    if (m_l_slot_free(2 * T + pad, p) && m_l_slot_free(T + pad, p)) return 16 * pad;
+  return 0;
+}
 __host__ __device__ constexpr int m_lds_tiles(int CBW, int CBH) {
-  return m_tile_bytes(32, kBlock) + (CBW ? 2 * m_tile_bytes(CBW, CBH) + CBH * m_pitch(CBW) : 0);
+  return m_tile_bytes(32, kBlock) + (CBW ? 2 * m_tile_bytes(CBW, CBH) + m_l_pad(CBW, CBH) + CBH * m_pitch(CBW) : 0);
 }
 // ... followed by a block of 16 zero bytes (the operand of rows outside a window)
 __host__ __device__ constexpr int m_lds_bytes(int CBW, int CBH) { return m_lds_tiles(CBW, CBH) + 16; }
@@ -99,7 +112,7 @@ __device__ __forceinline__ void m_entry(int i, int &a, int &cxp, int &special) {
   } else {
     if (k < 7) { a = 2; cxp = k; }
     else if (k < 14) { a = 3; cxp = k - 7; }
-    else special = 2;
+    else { special = 2; a = 2; cxp = 0; }  // (a spare row reads what another row of its group reads: a broadcast)
   }
 }
 // index in the record's (nc+1)-vector: 0..n-1 neighbours, n = L (chroma), nc = the sample; -1 = not part of it
@@ -284,6 +297,7 @@ __device__ __forceinline__ void m_rows_alt(v16i32 &accA, v16i32 &accB, const uin
   v4i32 v[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) v[j] = m_lds16(smem, (y0 + j >= ys && y0 + j < ye) ? a0 + j * P : zoff);
+  __builtin_amdgcn_sched_barrier(0);  // all reads in flight before the first multiply (the scheduler would keep one ahead)
 #pragma unroll
   for (int j = 0; j < R; j += 2) {
     accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j], v[j], accA, 0, 0, 0);
@@ -294,25 +308,41 @@ __device__ __forceinline__ void m_rows_alt(v16i32 &accA, v16i32 &accB, const uin
 template <int R, int P>
 __device__ __forceinline__ void m_rows_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, int y0, int ys, int ye,
                                            int zoff) {
+  constexpr int H = R > 4 ? 4 : R;  // rows per batch of reads
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const bool ok = y0 + j >= ys && y0 + j < ye;
-    const v4i32 va = m_lds16(smem, ok ? a0 + j * P : zoff), vb = m_lds16(smem, ok ? b0 + j * P : zoff);
-    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va, va, accA, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb, vb, accB, 0, 0, 0);
+  for (int j0 = 0; j0 < R; j0 += H) {
+    v4i32 va[H], vb[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const bool ok = y0 + j0 + j >= ys && y0 + j0 + j < ye;
+      va[j] = m_lds16(smem, ok ? a0 + (j0 + j) * P : zoff);
+      vb[j] = m_lds16(smem, ok ? b0 + (j0 + j) * P : zoff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[j], va[j], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb[j], vb[j], accB, 0, 0, 0);
+    }
   }
 }
 // S steps of two planes, blocks 16 wide: a step is two rows, one per lane half (h)
 template <int S, int P>
 __device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, int s0, int ys, int ye,
                                             int h, int zoff) {
+  v4i32 va[S], vb[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) {
     const int yl = 2 * (s0 + j) + h;  // this lane half's row
     const bool ok = yl >= ys && yl < ye;
-    const v4i32 va = m_lds16(smem, ok ? a0 + 2 * j * P : zoff), vb = m_lds16(smem, ok ? b0 + 2 * j * P : zoff);
-    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va, va, accA, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb, vb, accB, 0, 0, 0);
+    va[j] = m_lds16(smem, ok ? a0 + 2 * j * P : zoff);
+    vb[j] = m_lds16(smem, ok ? b0 + 2 * j * P : zoff);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[j], va[j], accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb[j], vb[j], accB, 0, 0, 0);
   }
 }
 
@@ -330,7 +360,7 @@ __global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp) {
   uint8_t *tile_y = m_smem;
   uint8_t *tile_cb = m_smem + m_tile_bytes(32, kBlock);
   uint8_t *tile_cr = tile_cb + m_tile_bytes(CW_, CH_);
-  uint8_t *tile_l = tile_cr + m_tile_bytes(CW_, CH_);
+  uint8_t *tile_l = tile_cr + m_tile_bytes(CW_, CH_) + m_l_pad(CW_, CH_);
 
   const int frame = g.frame0 + (int)blockIdx.z;
   const int G = gridDim.x, wg = blockIdx.x;
@@ -344,13 +374,12 @@ __global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp) {
   const int i = lane & 31, h = lane >> 5;
   int ea, ecxp, esp;
   m_entry(i, ea, ecxp, esp);
-  const bool plain = esp == 0;
-  const int base_luma = (plain ? ecxp : 3) * LT::CS + (3 - (plain ? ea : 0)) * LT::P + 16 * h;
+  const int base_luma = ecxp * LT::CS + (3 - ea) * LT::P + 16 * h;
   const int hoff_c = CW_ == 32 ? 16 * h : h * CT::P;
   // (the L tile sits behind the two chroma tiles: relative to the Cb / Cr tile it is at a different distance)
-  const int base_chroma = (plain ? ecxp : 3) * CT::CS + (3 - (plain ? ea : 0)) * CT::P + hoff_c;
+  const int base_chroma = ecxp * CT::CS + (3 - ea) * CT::P + hoff_c;
   // (the L row of the matrix reads the L tile: no halo, no copies)
-  const int off_l = m_tile_bytes(32, kBlock) + 2 * m_tile_bytes(CW_, CH_) + hoff_c;
+  const int off_l = m_tile_bytes(32, kBlock) + 2 * m_tile_bytes(CW_, CH_) + m_l_pad(CW_, CH_) + hoff_c;
   const int addr_cb = esp == 1 ? off_l : m_tile_bytes(32, kBlock) + base_chroma;
   const int addr_cr = esp == 1 ? off_l : m_tile_bytes(32, kBlock) + m_tile_bytes(CW_, CH_) + base_chroma;
 
