@@ -26,6 +26,7 @@
 #include "k1f.hip.h"
 #include "k3q.hip.h"
 #include "k3m.hip.h"
+#include "k3f.hip.h"
 #include "record.h"
 
 using namespace g1s;
@@ -37,8 +38,9 @@ thread_local std::string g_global_error;
 constexpr uint32_t kDefaultBatch = 32;
 constexpr int kK3Chunks = 48;
 
-// The AR accumulation runs on the matrix cores (k3m.hip.h) unless G1S_K3=dot4 asks for the lag-structured
-// v_dot4 kernels of round 1 (k3q.hip.h; kept so that the two can be compared bit for bit).
+// The AR accumulation runs fused with the residual pass on the matrix cores (k3f.hip.h) unless G1S_K3=dot4 asks
+// for round 1's chain -- K0 pixel pass, int8 planes, lag-structured v_dot4 kernels (k0.hip.h, k3q.hip.h) -- which is
+// kept so that the two can be compared bit for bit.
 bool use_mfma() {
   static const bool v = [] {
     const char *e = getenv("G1S_K3");
@@ -46,7 +48,7 @@ bool use_mfma() {
   }();
   return v;
 }
-constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per CU
+constexpr int kMTargetWgs = 768;  // accumulation workgroups per launch: 3 per CU, one round
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
 int m_wgs_per_frame(int nunits, int B) {
   const int gmin = (nunits + kMMaxUnits - 1) / kMMaxUnits;
@@ -434,7 +436,7 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     frame_bytes += ((pw * d->bytes_per_sample + 15) & ~size_t(15)) * ph;
   }
   size_t partial_bytes = 0, k0_bytes = 0, pgl_bytes = 0;
-  {  // the lag-structured path serves every lag (1 and 2 through lag-3 tiles and a scratch lag-3 system)
+  if (!use_mfma()) {  // the lag-structured path serves every lag (1 and 2 through lag-3 tiles and a scratch lag-3 system)
     partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart + kAr3);
     const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
     // [cls][bad][lists u32 x6 per frame][counts]
@@ -479,6 +481,7 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
       HIP_TRY(hipMalloc((void **)&sl.d_k0, k0_bytes));
       HIP_TRY(hipMemset(sl.d_k0, 0, k0_bytes));  // the padding of the w8 planes stays zero for good
       HIP_TRY(hipMalloc((void **)&sl.d_pgl, pgl_bytes));
+    } else {
       HIP_TRY(hipMalloc((void **)&sl.d_mu, mu_bytes));
       HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes));
     }
@@ -633,11 +636,8 @@ int g1s_diff::launch_front(int si) {
     z.ptr[0] = reinterpret_cast<uint32_t *>(sl.d_records);
     z.ndw[0] = (uint32_t)(L.size * B / 4);
     if (use_mfma()) {
-      const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
       z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords;  // unit counts, any-deferred flags
       z.ndw[1] = 2 * (uint32_t)batch;
-      z.ptr[2] = reinterpret_cast<uint32_t *>(sl.d_defer + cls_bytes);  // bad flags
-      z.ndw[2] = (uint32_t)(cls_bytes / 4);
       z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords + 2 * (size_t)batch;  // deferred-block flags
       z.ndw[3] = (uint32_t)(m_only_bytes / 4);
     } else {
@@ -663,7 +663,8 @@ int g1s_diff::launch_front(int si) {
   }
   sl.timed = timing;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], pstream));
-  const bool fast_ok = !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
+  // (the fused pass serves every format; round 1's chain has no structured path for 4:4:0)
+  const bool fast_ok = use_mfma() || !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
   const size_t cls_bytes_q = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   {
     // flat-block features: integer moments + certified evaluation; the literal f64 kernel only for
@@ -676,7 +677,16 @@ int g1s_diff::launch_front(int si) {
     CertifyLists cl;
     cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
     cl.count = cl.list + (size_t)g.nblocks * batch;
-    if (fast_ok) {
+    if (use_mfma()) {
+      // the finder's moments of the luma source: the only pass over pixels that are not in a flat block's tile
+      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
+      if (!force_literal) {
+        const dim3 mg((g.nblocks + 7) / 8, B);
+        if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
+        else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, pstream, ft, g, mom);
+      }
+      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
+    } else if (fast_ok) {
       // K0: one pass over the source / denoised planes -> int8 residual and L planes, block statistics and
       // the finder's moments of the luma source (it needs nothing from the finder: it runs before it)
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
@@ -783,10 +793,7 @@ QParams g1s_diff::make_qparams(const Slot &sl) const {
 
 MParams g1s_diff::make_mparams(const Slot &sl) const {
   MParams mp;
-  const size_t cls_bytes = ((size_t)geom.nblocks * 2 * batch + 15) & ~size_t(15);
-  mp.planes = sl.d_k0;
-  mp.ps = ps;
-  mp.bad = sl.d_defer + cls_bytes;
+  mp.bad = nullptr;  // (the fused pass finds the residuals outside int8 itself)
   mp.units = reinterpret_cast<uint32_t *>(sl.d_mu);
   mp.unit_count = mp.units + (size_t)batch * m_nunits * kMUnitDwords;
   mp.only_any = mp.unit_count + batch;
@@ -806,28 +813,38 @@ int g1s_diff::launch_back(int si) {
   if (side) HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));  // the mask, the window planes, the area lists
   FrameTable ft;
   ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);  // (uploaded by the front half)
-  const bool fast_ok = !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
-  if (fast_ok && use_mfma()) {
-    // exact int8 SYRK on the matrix cores over the flat blocks' windows, one partial system per workgroup,
-    // the reducer, then the exact int32 kernel for the few blocks next to a residual outside int8
+  const bool fast_ok = use_mfma() || !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
+  if (use_mfma()) {
+    // the fused pass: planes of the flat blocks' tiles -> residuals, block statistics, exact int8 SYRK on the matrix
+    // cores, one partial system per workgroup; the reducer; then the exact int32 kernel for the few blocks next to a
+    // residual outside int8
     const MParams mp = make_mparams(sl);
+    FParams fq;
+    fq.ft = ft;
+    fq.records = sl.d_records;
+    fq.only = mp.only;
+    fq.only_any = mp.only_any;
+    fq.units = mp.units;
+    fq.unit_count = mp.unit_count;
+    fq.partials = mp.partials;
+    fq.nunits = m_nunits;
     const int G = m_wgs_per_frame(m_nunits, (int)B);
     const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = g.nplanes == 3 ? (kBlock >> g.ydec) : 0;
     const size_t lds = (size_t)m_lds_bytes(cbw, cbh);
     const dim3 gr(G, 1, B);
-#define G1S_M(CW, CH)                                                                                          \
-  do {                                                                                                         \
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3m_accumulate<CW, CH>), \
+#define G1S_F(CW, CH)                                                                                         \
+  do {                                                                                                        \
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, m_lds_bytes(CW, CH)); \
-    (void)attr_rc;                                                                                             \
-    hipLaunchKernelGGL((k3m_accumulate<CW, CH>), gr, dim3(256), lds, stream, g, mp);                            \
+    (void)attr_rc;                                                                                            \
+    hipLaunchKernelGGL((k3f_fused<CW, CH>), gr, dim3(kFThreads), lds, stream, g, fq);                          \
   } while (0)
-    if (cbw == 0) G1S_M(0, 0);
-    else if (cbw == 16 && cbh == 16) G1S_M(16, 16);
-    else if (cbw == 16) G1S_M(16, 32);
-    else if (cbh == 32) G1S_M(32, 32);
-    else G1S_M(32, 16);
-#undef G1S_M
+    if (cbw == 0) G1S_F(0, 0);
+    else if (cbw == 16 && cbh == 16) G1S_F(16, 16);
+    else if (cbw == 16) G1S_F(16, 32);
+    else if (cbh == 32) G1S_F(32, 32);
+    else G1S_F(32, 16);
+#undef G1S_F
     hipLaunchKernelGGL(k3m_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, mp, G, sl.d_records);
     hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                        sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
@@ -980,16 +997,22 @@ int g1s_diff::drain_front(int si) {
   HIP_TRY(hipEventSynchronize(sl.done));
   if (sl.timed) {
     float ms = 0;
-    const bool k0_timed = !(geom.nplanes == 3 && geom.xdec == 0 && geom.ydec == 1);
-    float ms_k0 = 0;
+    const bool k0_timed = use_mfma() || !(geom.nplanes == 3 && geom.xdec == 0 && geom.ydec == 1);
+    float ms_k0 = 0;  // round 1's chain: K0 (counted with the accumulation); fused pass: the finder's moments pass
     if (k0_timed) HIP_TRY(hipEventElapsedTime(&ms_k0, sl.ev[5], sl.ev[4]));
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
-    stats.ms_flat_features += ms - ms_k0;  // (K0 sits between the finder's launches)
+    if (use_mfma()) {
+      stats.ms_flat_features += ms;
+      stats.ms_residual += ms_k0;
+      ms_k0 = 0;
+    } else {
+      stats.ms_flat_features += ms - ms_k0;  // (K0 sits between the finder's launches)
+    }
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
     stats.ms_flat_select += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
     stats.ms_ar_accumulate += ms + ms_k0;
-    stats.ms_residual += ms_k0;
+    if (!use_mfma()) stats.ms_residual += ms_k0;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
     stats.ms_total_gpu += ms;
     {

@@ -16,20 +16,15 @@
 // and the two 16-lane groups a b128 read is served in, {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31},
 // hold the rows a in {0, 1} (+ L) and a in {2, 3}: 16 distinct slots each.
 //
-// Work unit = 4 horizontally adjacent blocks of one block row (a `chunk`) holding at least one flat
-// block, listed per frame by k3m_units together with the observation windows of its blocks.  A
-// workgroup walks a contiguous slice of one frame's list: the rows of the NEXT unit are requested into
-// registers before the current unit's tiles are multiplied (no load latency in the loop), the tiles of
-// all planes are staged together (two barriers per unit), the 32x32 int32 accumulators stay in
-// registers (two for luma: dependent MFMAs on one accumulator wait for each other), and ONE partial
-// system per plane is written at the end (k3m_reduce adds them into the record).  Blocks whose tile
-// touches a residual outside int8 (K0 `bad` flags) are left to the exact int32 kernel (k3_ar_generic,
-// `only` list).  Any lag 1..3 (the lag-L neighbourhood and window border; the other matrix rows are ignored).
+// Work unit = kMUnitBlocks horizontally adjacent blocks of one block row (a `chunk`) holding at least one
+// flat block, listed per frame by k3m_units together with the observation windows of its blocks.  This
+// file holds the scheme's shared parts (matrix row map, tile geometry, the copy writer, the multiply
+// loops, the unit lists, the reducer); the kernel that stages the tiles straight from the source /
+// denoised planes and multiplies them is k3f.hip.h.  Any lag 1..3 (the lag-L neighbourhood and window
+// border; the other matrix rows are ignored).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#include <algorithm>
 
 #include "k0.hip.h"
 #include "kernels.hip.h"
@@ -41,14 +36,12 @@ typedef int v16i32 __attribute__((ext_vector_type(16)));
 
 constexpr int kMCopies = 7;
 constexpr int kMRec = 656;        // int64 entries of one partial system (>= 25 * 25 + 25 + 1)
-constexpr int kMUnitBlocks = 4;   // blocks per unit
-constexpr int kMUnitDwords = 8;   // list entry: [0] chunk | block row << 12 | flat bits << 24, [1..4] 8 x u16 windows
-constexpr int kMMaxUnits = 120;   // units per workgroup: 120 * 4 blocks * 8 steps * 32 samples * 127^2 < 2^31
+constexpr int kMUnitBlocks = 2;   // blocks per unit
+constexpr int kMUnitDwords = 4;   // list entry: [0] chunk | block row << 12 | flat bits << 24, [1..2] 4 x u16 windows (luma, chroma)
+constexpr int kMMaxUnits = 240;   // units per workgroup: 240 * 2 blocks * 8 steps * 32 samples * 127^2 < 2^31
 
 struct MParams {
-  const uint8_t *planes;  // K0 planes [batch] x ps.frame_bytes
-  PlaneSet ps;
-  const uint8_t *bad;     // [batch][2][nblocks]  K0: a residual (kind 1: or L) outside int8
+  const uint8_t *bad;     // [batch][2][nblocks]  residual (kind 1: or L) outside int8, when a pixel pass has flagged them; or null
   uint8_t *only;          // [batch][2][nblocks]  flat blocks left to k3_ar_generic (zeroed per batch)
   uint32_t *only_any;     // [batch]
   uint32_t *units;        // [batch][nunits][kMUnitDwords]
@@ -57,8 +50,8 @@ struct MParams {
   int nunits;             // chunks per frame = ceil(nbw / 4) * nbh
 };
 
-// tile geometry of a plane kind: block BW x BH, chunk of 4 blocks
-__host__ __device__ constexpr int m_pitch(int BW) { return 4 * BW + 16; }
+// tile geometry of a plane kind: block BW x BH, chunk of kMUnitBlocks blocks (pitch / 16 must be odd)
+__host__ __device__ constexpr int m_pitch(int BW) { return kMUnitBlocks * BW + 16; }
 __host__ __device__ constexpr int m_copy_stride(int BW, int BH) {
   // >= rows * pitch, in 16-byte slots == 2 (mod 16)
   int slots = ((BH + 3) * m_pitch(BW) + 15) / 16;
@@ -182,13 +175,16 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
     const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph, g.lag);
     if (!w.flat) continue;
     // the tile reaches into the left / right / upper neighbours
-    const uint8_t *bad = mp.bad + ((size_t)frame * 2 + kind) * g.nblocks;
+    // (the fused pass, k3f.hip.h, finds the residuals outside int8 itself: no flags here)
     bool defer = false;
-    for (int dy = -1; dy <= 0; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int x = bx + dx, y = by + dy;
-        if (x >= 0 && x < g.nbw && y >= 0 && bad[y * g.nbw + x]) defer = true;
-      }
+    if (mp.bad) {
+      const uint8_t *bad = mp.bad + ((size_t)frame * 2 + kind) * g.nblocks;
+      for (int dy = -1; dy <= 0; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int x = bx + dx, y = by + dy;
+          if (x >= 0 && x < g.nbw && y >= 0 && bad[y * g.nbw + x]) defer = true;
+        }
+    }
     if (defer) {
       mp.only[((size_t)frame * 2 + kind) * g.nblocks + by * g.nbw + bx] = 1;
       mp.only_any[frame] = 1u;
@@ -196,10 +192,10 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
       win[t] = (uint32_t)w.xe | ((uint32_t)w.ye << 6) | (w.ys ? 1u << 13 : 0u) | (w.xs ? 1u << 14 : 0u) | (1u << 15);
     }
   }
+  static_assert(kMUnitBlocks == 2 && kMUnitDwords == 4, "list entry layout");
   uint32_t *e = mp.units + ((size_t)frame * mp.nunits + pos) * kMUnitDwords;
   *reinterpret_cast<uint4 *>(e) = make_uint4((uint32_t)ci | ((uint32_t)by << 12) | (bits << 24), win[0] | (win[1] << 16),
-                                             win[2] | (win[3] << 16), win[4] | (win[5] << 16));
-  *reinterpret_cast<uint4 *>(e + 4) = make_uint4(win[6] | (win[7] << 16), 0u, 0u, 0u);
+                                             win[2] | (win[3] << 16), 0u);
 }
 
 __device__ __forceinline__ uint32_t m_bytemask(int k) { return k >= 4 ? 0xffffffffu : ((1u << (8 * k)) - 1u); }
@@ -226,49 +222,6 @@ __device__ __forceinline__ void m_write_copies(uint8_t *dst, int CS, uint32_t pr
   }
 }
 
-// ---- the rows of one plane tile (rows -3 .. BH-1, samples -8 .. 4 BW + 7 of the chunk): a wave moves
-// 64 / WPR rows a round, a lane one 8-sample word; ROUNDS rounds cover the tile ----
-template <int BW, int BH>
-struct MTile {
-  static constexpr int P = m_pitch(BW), WPR = P / 8, RPP = 64 / WPR, ROWS = BH + 3;
-  static constexpr int ROUNDS = (ROWS + 4 * RPP - 1) / (4 * RPP);
-  static constexpr int CS = m_copy_stride(BW, BH);
-  uint2 w[ROUNDS];
-  uint32_t off[ROUNDS];  // byte offset of the lane's word of round k from the unit's first tile row in the plane
-  int lrow[ROUNDS];      // its LDS offset inside a copy + 8 (-1: the lane has no word in this round)
-  int wd;                // word of the row: 0 and WPR - 1 are the halo words
-
-  __device__ __forceinline__ void init(uint32_t pitch, int wave, int lane) {
-    const int lr = lane / WPR;
-    wd = lane - lr * WPR;
-#pragma unroll
-    for (int k = 0; k < ROUNDS; ++k) {
-      const int row = (4 * k + wave) * RPP + lr;
-      const bool ok = lr < RPP && row < ROWS;
-      off[k] = ok ? (uint32_t)row * pitch + 8u * (uint32_t)wd : 0u;
-      lrow[k] = ok ? row * P + 8 * wd : -1;
-    }
-  }
-  // base: the plane at (first tile row, first sample of the chunk - 8) -- uniform; colok: the word lies inside the plane row
-  __device__ __forceinline__ void load(const uint8_t *__restrict__ base, bool colok) {
-#pragma unroll
-    for (int k = 0; k < ROUNDS; ++k) {
-      w[k] = make_uint2(0u, 0u);
-      if (lrow[k] >= 0 && colok) w[k] = *reinterpret_cast<const uint2 *>(base + off[k]);
-    }
-  }
-  // cm: the window columns of the word's block as a byte mask (0: block not processed, nothing is written:
-  // byte x of a copy row is only ever read as the operand of sample x)
-  __device__ __forceinline__ void store(uint8_t *tile, uint2 cm) const {
-#pragma unroll
-    for (int k = 0; k < ROUNDS; ++k) {
-      const uint32_t prev1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k].y, 0x138, 0xf, 0xf, false);  // wave_shr:1
-      const uint32_t next0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k].x, 0x130, 0xf, 0xf, false);  // wave_shl:1
-      if (lrow[k] >= 0 && wd >= 1 && wd <= WPR - 2 && (cm.x | cm.y)) m_write_copies(tile + lrow[k] - 8, CS, prev1, w[k].x, w[k].y, next0, cm);
-    }
-  }
-};
-
 // byte mask of the 8 samples xb .. xb + 7 of a block under its window columns [xs, xe)
 __device__ __forceinline__ uint2 m_colmask8(const MWin &bi, int xb) {
   if (!bi.go) return make_uint2(0u, 0u);
@@ -289,20 +242,17 @@ __device__ __forceinline__ v4i32 m_lds16(const uint8_t *smem, int a) { return *r
 // The multiplies of a block run over ALL of the wave's rows, unrolled, on ONE code path (the register
 // allocator copies accumulators at every merge of two paths that both multiply): a row outside the window
 // rows [ys, ye) reads the zero block at LDS offset `zoff` instead of its tile row (3 of 32 rows when the block
-// above is not flat).
-// R rows from a0 + j * P: even j into accA, odd j into accB (a luma-shaped block, two accumulators: dependent
-// MFMAs wait for each other)
+// above is not flat).  One accumulator per plane: dependent v_mfma_i32_32x32x32_i8 issue at the pipe rate
+// (tools/mfma_chain_probe.hip).
+// R rows from a0 + j * P into one accumulator
 template <int R, int P>
-__device__ __forceinline__ void m_rows_alt(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int y0, int ys, int ye, int zoff) {
+__device__ __forceinline__ void m_rows_one(v16i32 &acc, const uint8_t *smem, int a0, int y0, int ys, int ye, int zoff) {
   v4i32 v[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) v[j] = m_lds16(smem, (y0 + j >= ys && y0 + j < ye) ? a0 + j * P : zoff);
-  __builtin_amdgcn_sched_barrier(0);  // all reads in flight before the first multiply (the scheduler would keep one ahead)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int j = 0; j < R; j += 2) {
-    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j], v[j], accA, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j + 1], v[j + 1], accB, 0, 0, 0);
-  }
+  for (int j = 0; j < R; ++j) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j], v[j], acc, 0, 0, 0);
 }
 // R rows of two planes: plane A from a0 into accA, plane B from b0 into accB (chroma blocks 32 wide)
 template <int R, int P>
@@ -344,171 +294,6 @@ __device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const ui
     accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[j], va[j], accA, 0, 0, 0);
     accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb[j], vb[j], accB, 0, 0, 0);
   }
-}
-
-// ---------------------------------------------------------------------------------
-// k3m_accumulate<CBW, CBH>: chroma block 32 >> xdec by 32 >> ydec (0, 0: luma only).
-// grid = (G, 1, batch), block = 256, dynamic LDS = m_lds_bytes(CBW, CBH).
-// ---------------------------------------------------------------------------------
-template <int CBW, int CBH>
-__global__ __launch_bounds__(256) void k3m_accumulate(Geom g, MParams mp) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t m_smem[];
-  constexpr bool CH = CBW != 0;
-  constexpr int CW_ = CH ? CBW : 16, CH_ = CH ? CBH : 16;  // (dummy chroma tile types for the luma-only kernel)
-  using LT = MTile<32, kBlock>;
-  using CT = MTile<CW_, CH_>;
-  uint8_t *tile_y = m_smem;
-  uint8_t *tile_cb = m_smem + m_tile_bytes(32, kBlock);
-  uint8_t *tile_cr = tile_cb + m_tile_bytes(CW_, CH_);
-  uint8_t *tile_l = tile_cr + m_tile_bytes(CW_, CH_) + m_l_pad(CW_, CH_);
-
-  const int frame = g.frame0 + (int)blockIdx.z;
-  const int G = gridDim.x, wg = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t cnt = mp.unit_count[frame];
-  const uint32_t u0 = (uint32_t)((unsigned long long)cnt * wg / G), u1 = (uint32_t)((unsigned long long)cnt * (wg + 1) / G);
-  const uint32_t *units = mp.units + (size_t)frame * mp.nunits * kMUnitDwords;
-  const uint8_t *fplanes = mp.planes + (size_t)frame * mp.ps.frame_bytes;
-
-  // this lane's operand address inside a tile, per plane kind
-  const int i = lane & 31, h = lane >> 5;
-  int ea, ecxp, esp;
-  m_entry(i, ea, ecxp, esp);
-  const int base_luma = ecxp * LT::CS + (3 - ea) * LT::P + 16 * h;
-  const int hoff_c = CW_ == 32 ? 16 * h : h * CT::P;
-  // (the L tile sits behind the two chroma tiles: relative to the Cb / Cr tile it is at a different distance)
-  const int base_chroma = ecxp * CT::CS + (3 - ea) * CT::P + hoff_c;
-  // (the L row of the matrix reads the L tile: no halo, no copies)
-  const int off_l = m_tile_bytes(32, kBlock) + 2 * m_tile_bytes(CW_, CH_) + m_l_pad(CW_, CH_) + hoff_c;
-  const int addr_cb = esp == 1 ? off_l : m_tile_bytes(32, kBlock) + base_chroma;
-  const int addr_cr = esp == 1 ? off_l : m_tile_bytes(32, kBlock) + m_tile_bytes(CW_, CH_) + base_chroma;
-
-  v16i32 accY0, accY1, accCb, accCr;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accY0[r] = accY1[r] = accCb[r] = accCr[r] = 0;
-  long long nobs0 = 0, nobs1 = 0;
-
-  // ---- the rows of a unit, requested one unit ahead ----
-  constexpr int ZOFF = m_lds_tiles(CBW, CBH);
-  if (tid < 4) reinterpret_cast<uint32_t *>(m_smem + ZOFF)[tid] = 0u;
-  LT py;
-  CT pcb, pcr;
-  py.init(mp.ps.pitch[0], wave, lane);
-  pcb.init(mp.ps.pitch[1], wave, lane);
-  pcr.init(mp.ps.pitch[1], wave, lane);
-  constexpr int WL = 4 * CW_ / 8, LROUNDS = (CH_ * WL + 255) / 256;
-  uint2 pl[LROUNDS];
-  uint4 ent0 = make_uint4(0, 0, 0, 0);
-  uint32_t ent4 = 0;
-  auto request = [&](uint32_t u) {
-    const uint32_t *e = units + (size_t)u * kMUnitDwords;
-    ent0 = *reinterpret_cast<const uint4 *>(e);
-    ent4 = e[4];
-    const int bx0 = kMUnitBlocks * (int)(ent0.x & 0xfffu), by = (int)((ent0.x >> 12) & 0xfffu);
-    py.load(fplanes + mp.ps.off_d[0] + (size_t)(by * kBlock) * mp.ps.pitch[0] + bx0 * 32,
-            (uint32_t)(bx0 * 32 + 8 * py.wd + 8) <= mp.ps.pitch[0]);
-    if constexpr (CH) {
-      const size_t co = (size_t)(by * CH_) * mp.ps.pitch[1] + bx0 * CW_;
-      const bool cok = (uint32_t)(bx0 * CW_ + 8 * pcb.wd + 8) <= mp.ps.pitch[1];
-      pcb.load(fplanes + mp.ps.off_d[1] + co, cok);
-      pcr.load(fplanes + mp.ps.off_d[2] + co, cok);
-      const uint8_t *lb = fplanes + mp.ps.off_l + (size_t)(by * CH_) * mp.ps.lpitch + bx0 * CW_;
-#pragma unroll
-      for (int k = 0; k < LROUNDS; ++k) {
-        const int idx = tid + 256 * k, row = idx / WL, wd = idx - row * WL;
-        pl[k] = make_uint2(0u, 0u);
-        if (row < CH_ && (uint32_t)(bx0 * CW_ + 8 * wd + 8) <= mp.ps.lpitch)
-          pl[k] = *reinterpret_cast<const uint2 *>(lb + (uint32_t)row * mp.ps.lpitch + 8u * (uint32_t)wd);
-      }
-    }
-  };
-  if (u0 < u1) request(u0);
-
-  for (uint32_t u = u0; u < u1; ++u) {
-    const uint4 e0 = ent0;
-    const uint32_t e4 = ent4;
-    __syncthreads();  // the previous unit's tiles are no longer read
-    const uint32_t wins[8] = {e0.y & 0xffffu, e0.y >> 16, e0.z & 0xffffu, e0.z >> 16, e0.w & 0xffffu, e0.w >> 16, e4 & 0xffffu, e4 >> 16};
-    {
-      // the window columns of the block under this lane's word, as a byte mask
-      const int xw = 8 * (py.wd - 1), bq = (xw >> 5) & 3;
-      const uint32_t wsel = bq == 0 ? wins[0] : (bq == 1 ? wins[1] : (bq == 2 ? wins[2] : wins[3]));
-      py.store(tile_y, m_colmask8(m_unpack(wsel, g.lag), xw - 32 * bq));
-    }
-    if constexpr (CH) {
-      const int xw = 8 * (pcb.wd - 1), bq = (xw / CW_) & 3;
-      const uint32_t wsel = bq == 0 ? wins[4] : (bq == 1 ? wins[5] : (bq == 2 ? wins[6] : wins[7]));
-      const uint2 cm = m_colmask8(m_unpack(wsel, g.lag), xw - CW_ * bq);
-      pcb.store(tile_cb, cm);
-      pcr.store(tile_cr, cm);
-#pragma unroll
-      for (int k = 0; k < LROUNDS; ++k) {
-        const int idx = tid + 256 * k, row = idx / WL, wd = idx - row * WL;
-        const int bl = (8 * wd / CW_) & 3;
-        const uint32_t wl = bl == 0 ? wins[4] : (bl == 1 ? wins[5] : (bl == 2 ? wins[6] : wins[7]));
-        const uint2 lm = m_colmask8(m_unpack(wl, g.lag), 8 * wd - CW_ * bl);
-        if (row < CH_) *reinterpret_cast<uint2 *>(tile_l + row * CT::P + 8 * wd) = make_uint2(pl[k].x & lm.x, pl[k].y & lm.y);
-      }
-    }
-    if (u + 1 < u1) request(u + 1);
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < kMUnitBlocks; ++b) {
-      const MWin wy = m_unpack(wins[b], g.lag);
-      if (wy.go) {
-        constexpr int RPW = kBlock / 4;
-        m_rows_alt<RPW, LT::P>(accY0, accY1, m_smem, base_luma + 32 * b + wave * RPW * LT::P, wave * RPW, wy.ys, wy.ye, ZOFF);
-        if (tid == 0) nobs0 += (long long)(wy.xe - wy.xs) * (wy.ye - wy.ys);
-      }
-      if constexpr (CH) {
-        const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
-        if (wc.go) {
-          if constexpr (CW_ == 32) {
-            constexpr int RPW = CH_ / 4;
-            const int o = CW_ * b + wave * RPW * CT::P;
-            m_rows_two<RPW, CT::P>(accCb, accCr, m_smem, addr_cb + o, addr_cr + o, wave * RPW, wc.ys, wc.ye, ZOFF);
-          } else {
-            constexpr int SPW = CH_ / 8;
-            const int o = CW_ * b + 2 * wave * SPW * CT::P;
-            m_steps_two<SPW, CT::P>(accCb, accCr, m_smem, addr_cb + o, addr_cr + o, wave * SPW, wc.ys, wc.ye, h, ZOFF);
-          }
-          if (tid == 0) nobs1 += (long long)(wc.xe - wc.xs) * (wc.ye - wc.ys);
-        }
-      }
-    }
-  }
-
-  // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
-  long long *s_S = reinterpret_cast<long long *>(m_smem);
-  __syncthreads();
-  for (int k = tid; k < 3 * kMRec; k += 256) s_S[k] = 0;
-  __syncthreads();
-  auto flush = [&](const v16i32 &acc, int c, long long nobs) {
-    const bool ch = c > 0;
-    const int nc = g.n + (ch ? 1 : 0);
-    const int ec = m_rec_index(i, g.lag, g.n, ch);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int er = m_rec_index(row, g.lag, g.n, ch);
-      if (er < 0 || ec < 0 || er == nc) continue;
-      int idx = -1;
-      if (ec == nc) idx = nc * nc + er;
-      else if (er <= ec) idx = er * nc + ec;
-      if (idx >= 0 && acc[r] != 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(&s_S[c * kMRec + idx]), (unsigned long long)(long long)acc[r]);
-    }
-    if (tid == 0 && nobs) atomicAdd(reinterpret_cast<unsigned long long *>(&s_S[c * kMRec + nc * nc + nc]), (unsigned long long)nobs);
-  };
-  flush(accY0, 0, nobs0);
-  flush(accY1, 0, 0);
-  if (CH) {
-    flush(accCb, 1, nobs1);
-    flush(accCr, 2, nobs1);
-  }
-  __syncthreads();
-  long long *out = mp.partials + ((size_t)frame * G + wg) * 3 * kMRec;
-  for (int k = tid; k < 3 * kMRec; k += 256) out[k] = s_S[k];
 }
 
 // ---------------------------------------------------------------------------------
