@@ -449,7 +449,9 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   m_nunits = ((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * g.nbh;
   m_only_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   // [units][unit counts][any-deferred flags][deferred-block flags]
-  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 2 * (size_t)batch) + m_only_bytes;
+  // ... [per-unit statistics records]
+  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 2 * (size_t)batch) + m_only_bytes +
+                          sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
   const size_t mpart_bytes = sizeof(long long) * 3 * kMRec *
                              ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits) + kMTargetWgs + batch);
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
@@ -821,31 +823,38 @@ int g1s_diff::launch_back(int si) {
     const MParams mp = make_mparams(sl);
     FParams fq;
     fq.ft = ft;
-    fq.records = sl.d_records;
-    fq.only = mp.only;
-    fq.only_any = mp.only_any;
     fq.units = mp.units;
     fq.unit_count = mp.unit_count;
     fq.partials = mp.partials;
+    fq.ustats = reinterpret_cast<int32_t *>(mp.only + m_only_bytes);
     fq.nunits = m_nunits;
     const int G = m_wgs_per_frame(m_nunits, (int)B);
     const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = g.nplanes == 3 ? (kBlock >> g.ydec) : 0;
     const size_t lds = (size_t)m_lds_bytes(cbw, cbh);
     const dim3 gr(G, 1, B);
-#define G1S_F(CW, CH)                                                                                         \
-  do {                                                                                                        \
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH>), \
+    const int bpsm = g.src_bps == g.den_bps ? g.src_bps : 0;  // bytes per sample at compile time unless the depths are mixed
+#define G1S_F(CW, CH, BP)                                                                                         \
+  do {                                                                                                            \
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, BP>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, m_lds_bytes(CW, CH)); \
-    (void)attr_rc;                                                                                            \
-    hipLaunchKernelGGL((k3f_fused<CW, CH>), gr, dim3(kFThreads), lds, stream, g, fq);                          \
+    (void)attr_rc;                                                                                                \
+    hipLaunchKernelGGL((k3f_fused<CW, CH, BP>), gr, dim3(kFThreads), lds, stream, g, fq);                          \
   } while (0)
-    if (cbw == 0) G1S_F(0, 0);
-    else if (cbw == 16 && cbh == 16) G1S_F(16, 16);
-    else if (cbw == 16) G1S_F(16, 32);
-    else if (cbh == 32) G1S_F(32, 32);
-    else G1S_F(32, 16);
+#define G1S_FS(CW, CH)             \
+  do {                             \
+    if (bpsm == 2) G1S_F(CW, CH, 2); \
+    else if (bpsm == 1) G1S_F(CW, CH, 1); \
+    else G1S_F(CW, CH, 0);         \
+  } while (0)
+    if (cbw == 0) G1S_FS(0, 0);
+    else if (cbw == 16 && cbh == 16) G1S_FS(16, 16);
+    else if (cbw == 16) G1S_FS(16, 32);
+    else if (cbh == 32) G1S_FS(32, 32);
+    else G1S_FS(32, 16);
+#undef G1S_FS
 #undef G1S_F
-    hipLaunchKernelGGL(k3m_reduce, dim3(g.nplanes, B), dim3(256), 0, stream, g, mp, G, sl.d_records);
+    hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G, (const int32_t *)fq.ustats,
+                       sl.d_records);
     hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                        sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
   } else if (fast_ok) {

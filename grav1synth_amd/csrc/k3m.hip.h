@@ -234,37 +234,37 @@ __device__ __forceinline__ uint2 m_colmask8(const MWin &bi, int xb) {
 
 __device__ __forceinline__ v4i32 m_lds16(const uint8_t *smem, int a) { return *reinterpret_cast<const v4i32 *>(smem + a); }
 
-// A luma-shaped block's share of S (blocks 32 wide: a step is one row): acc += V V^T over this wave's rows
-// of the window rows [ys, ye) (the window columns are already zeroed in the tile).  Two accumulators
-// alternate (dependent MFMAs wait for each other), the operands of the next pair of rows are read while
-// this pair is multiplied.  ONE code path: the register allocator copies accumulators at every merge of
-// two paths that both multiply.
+// rows [ys, ye) of a block as a bit mask (bit y = row y), ye <= 32
+__device__ __forceinline__ uint32_t m_rowmask(int ys, int ye) {
+  return (uint32_t)(((1ull << ye) - 1ull) & ~((1ull << ys) - 1ull));
+}
+
 // The multiplies of a block run over ALL of the wave's rows, unrolled, on ONE code path (the register
 // allocator copies accumulators at every merge of two paths that both multiply): a row outside the window
-// rows [ys, ye) reads the zero block at LDS offset `zoff` instead of its tile row (3 of 32 rows when the block
-// above is not flat).  One accumulator per plane: dependent v_mfma_i32_32x32x32_i8 issue at the pipe rate
-// (tools/mfma_chain_probe.hip).
+// rows (bit clear in `rm`, whose bit 0 is the wave's first row) reads the zero block at LDS offset `zoff`
+// instead of its tile row (3 of 32 rows when the block above is not flat).  One accumulator per plane:
+// dependent v_mfma_i32_32x32x32_i8 issue at the pipe rate (tools/mfma_chain_probe.hip).  All reads of a
+// block are issued before its first multiply.
 // R rows from a0 + j * P into one accumulator
 template <int R, int P>
-__device__ __forceinline__ void m_rows_one(v16i32 &acc, const uint8_t *smem, int a0, int y0, int ys, int ye, int zoff) {
+__device__ __forceinline__ void m_rows_one(v16i32 &acc, const uint8_t *smem, int a0, uint32_t rm, int zoff) {
   v4i32 v[R];
 #pragma unroll
-  for (int j = 0; j < R; ++j) v[j] = m_lds16(smem, (y0 + j >= ys && y0 + j < ye) ? a0 + j * P : zoff);
+  for (int j = 0; j < R; ++j) v[j] = m_lds16(smem, ((rm >> j) & 1u) ? a0 + j * P : zoff);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < R; ++j) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j], v[j], acc, 0, 0, 0);
 }
 // R rows of two planes: plane A from a0 into accA, plane B from b0 into accB (chroma blocks 32 wide)
 template <int R, int P>
-__device__ __forceinline__ void m_rows_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, int y0, int ys, int ye,
-                                           int zoff) {
+__device__ __forceinline__ void m_rows_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, uint32_t rm, int zoff) {
   constexpr int H = R > 4 ? 4 : R;  // rows per batch of reads
 #pragma unroll
   for (int j0 = 0; j0 < R; j0 += H) {
     v4i32 va[H], vb[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const bool ok = y0 + j0 + j >= ys && y0 + j0 + j < ye;
+      const bool ok = ((rm >> (j0 + j)) & 1u) != 0;
       va[j] = m_lds16(smem, ok ? a0 + (j0 + j) * P : zoff);
       vb[j] = m_lds16(smem, ok ? b0 + (j0 + j) * P : zoff);
     }
@@ -276,15 +276,14 @@ __device__ __forceinline__ void m_rows_two(v16i32 &accA, v16i32 &accB, const uin
     }
   }
 }
-// S steps of two planes, blocks 16 wide: a step is two rows, one per lane half (h)
+// S steps of two planes, blocks 16 wide: a step is two rows, one per lane half; rml = the row mask shifted so
+// that bit 2 j is this lane's row of step j
 template <int S, int P>
-__device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, int s0, int ys, int ye,
-                                            int h, int zoff) {
+__device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, uint32_t rml, int zoff) {
   v4i32 va[S], vb[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) {
-    const int yl = 2 * (s0 + j) + h;  // this lane half's row
-    const bool ok = yl >= ys && yl < ye;
+    const bool ok = ((rml >> (2 * j)) & 1u) != 0;
     va[j] = m_lds16(smem, ok ? a0 + 2 * j * P : zoff);
     vb[j] = m_lds16(smem, ok ? b0 + 2 * j * P : zoff);
   }
@@ -297,17 +296,76 @@ __device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const ui
 }
 
 // ---------------------------------------------------------------------------------
-// k3m_reduce: the G partial systems of a (frame, plane) -> record.  grid = (nplanes, batch), block = 256.
+// k3m_finish: what the accumulation workgroups left behind -> the frame's record.
+//   x < nplanes:  the G partial systems of plane x, summed, + nobs of the blocks that were multiplied;
+//   x >= nplanes: the per-unit statistics records (kMStatInts ints a unit: per block sum d, sum d^2, sum src8 of
+//                 luma, sum d, sum d^2 of Cb and Cr; then the deferral bits kind * 2 + block) -> block statistics
+//                 of the flat blocks, `only` flags of the deferred ones.
+// grid = (nplanes + kMFinishWgs, batch), block = 256.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k3m_reduce(Geom g, MParams mp, int G, uint8_t *__restrict__ records) {
-  const int c = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;
-  const int nc = g.n + (c > 0);
-  long long *ar = reinterpret_cast<long long *>(records + (size_t)frame * g.rec_size + g.off_ar[c]);
-  const long long *p = mp.partials + (size_t)frame * G * 3 * kMRec + (size_t)c * kMRec;
-  for (int k = threadIdx.x; k < nc * nc + nc + 1; k += 256) {
-    long long s = 0;
-    for (int w = 0; w < G; ++w) s += p[(size_t)w * 3 * kMRec + k];
-    ar[k] += s;
+constexpr int kMStatInts = 16, kMFinishWgs = 4;
+__global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, const int32_t *__restrict__ ustats,
+                                                  uint8_t *__restrict__ records) {
+  const int frame = g.frame0 + (int)blockIdx.y;
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  const uint32_t cnt = mp.unit_count[frame];
+  const uint32_t *units = mp.units + (size_t)frame * mp.nunits * kMUnitDwords;
+  const int32_t *us = ustats + (size_t)frame * mp.nunits * kMStatInts;
+  if ((int)blockIdx.x < g.nplanes) {
+    const int c = blockIdx.x, nc = g.n + (c > 0);
+    long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
+    const long long *p = mp.partials + (size_t)frame * G * 3 * kMRec + (size_t)c * kMRec;
+    for (int k = threadIdx.x; k < nc * nc + nc; k += 256) {
+      long long s = 0;
+      for (int w = 0; w < G; ++w) s += p[(size_t)w * 3 * kMRec + k];
+      ar[k] += s;
+    }
+    // observations: the windows of the blocks that were multiplied (go and not deferred)
+    __shared__ long long s_n[4];
+    long long n = 0;
+    for (uint32_t u = threadIdx.x; u < cnt; u += 256) {
+      const uint32_t wz = units[(size_t)u * kMUnitDwords + (c > 0 ? 2 : 1)];
+      const uint32_t defer = (uint32_t)us[(size_t)u * kMStatInts + 14] >> (c > 0 ? kMUnitBlocks : 0);
+#pragma unroll
+      for (int b = 0; b < kMUnitBlocks; ++b) {
+        const MWin w = m_unpack((wz >> (16 * b)) & 0xffffu, g.lag);
+        if (w.go && !((defer >> b) & 1u)) n += (long long)(w.xe - w.xs) * (w.ye - w.ys);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) ar[nc * nc + nc] += s_n[0] + s_n[1] + s_n[2] + s_n[3];
+    return;
+  }
+  const int part = (int)blockIdx.x - g.nplanes;
+  const bool chroma = g.nplanes == 3;
+  for (uint32_t u = part * 256 + threadIdx.x; u < cnt; u += kMFinishWgs * 256) {
+    const uint32_t e0 = units[(size_t)u * kMUnitDwords];
+    const int bx0 = kMUnitBlocks * (int)(e0 & 0xfffu), by = (int)((e0 >> 12) & 0xfffu);
+    const int32_t *r = us + (size_t)u * kMStatInts;
+    const uint32_t defer = (uint32_t)r[14];
+#pragma unroll
+    for (int b = 0; b < kMUnitBlocks; ++b) {
+      if (!((e0 >> (24 + b)) & 1u)) continue;
+      const int blk = by * g.nbw + bx0 + b;
+      reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = r[7 * b + 0];
+      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)r[7 * b + 1];
+      reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)r[7 * b + 2];
+      if (chroma) {
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = r[7 * b + 3];
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)r[7 * b + 4];
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = r[7 * b + 5];
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)r[7 * b + 6];
+      }
+#pragma unroll
+      for (int kind = 0; kind < 2; ++kind)
+        if ((defer >> (kind * kMUnitBlocks + b)) & 1u) {
+          mp.only[((size_t)frame * 2 + kind) * g.nblocks + blk] = 1;
+          mp.only_any[frame] = 1u;
+        }
+    }
   }
 }
 
