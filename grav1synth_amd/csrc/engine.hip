@@ -52,7 +52,7 @@ constexpr int kMTargetWgs = 768;  // accumulation workgroups per launch: 3 per C
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
 int m_wgs_per_frame(int nunits, int B) {
   const int gmin = (nunits + kMMaxUnits - 1) / kMMaxUnits;
-  return std::max(gmin, (kMTargetWgs + B - 1) / std::max(B, 1));
+  return (std::max(gmin, (kMTargetWgs + B - 1) / std::max(B, 1)) + 7) & ~7;  // (a multiple of 8: workgroup b of a frame on XCD b % 8)
 }
 
 #define HIP_TRY(expr)                                                                      \
@@ -453,7 +453,7 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 2 * (size_t)batch) + m_only_bytes +
                           sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
   const size_t mpart_bytes = sizeof(long long) * 3 * kMRec *
-                             ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits) + kMTargetWgs + batch);
+                             ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits + 8) + kMTargetWgs + batch);
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
                      partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes, mpart_bytes,
                      g.W, g.H, g.xdec, g.ydec, g.nplanes};

@@ -142,7 +142,12 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
   const int G = gridDim.x, wg = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t cnt = fpar.unit_count[frame];
-  const uint32_t u0 = (uint32_t)((unsigned long long)cnt * wg / G), u1 = (uint32_t)((unsigned long long)cnt * (wg + 1) / G);
+  // Workgroup b runs on XCD b % 8 (observed; speed only).  An XCD owns a contiguous eighth of the frame's unit list and
+  // deals it round-robin to its workgroups of this frame: horizontally adjacent units -- which share the 128-byte lines
+  // their halo columns sit in -- are then read at about the same time through the same L2.
+  const int xcd = wg & 7, jx = wg >> 3, nx = (G + 7 - xcd) >> 3;  // this workgroup's rank among the nx of its XCD
+  const uint32_t c0 = (uint32_t)((unsigned long long)cnt * xcd / 8), c1 = (uint32_t)((unsigned long long)cnt * (xcd + 1) / 8);
+  const uint32_t u0 = c0 + (uint32_t)jx, u1 = c1, ustep = (uint32_t)nx;
   const uint32_t *units = fpar.units + (size_t)frame * fpar.nunits * kMUnitDwords;
   int32_t *ustats = fpar.ustats + (size_t)frame * fpar.nunits * kMStatInts;
   const FramePlanes fp = fpar.ft.f[frame];
@@ -253,9 +258,9 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
   };
   if (u0 < u1) request(u0);
 
-  for (uint32_t u = u0; u < u1; ++u) {
+  for (uint32_t u = u0; u < u1; u += ustep) {
     const uint4 e0 = ent;
-    const int par = (int)(u & 1u);
+    const int par = (int)(((u - u0) / ustep) & 1u);
     const uint32_t wins[4] = {e0.y & 0xffffu, e0.y >> 16, e0.z & 0xffffu, e0.z >> 16};  // luma block 0, 1; chroma block 0, 1
     __syncthreads();  // the previous unit's tiles are no longer read
     // ------------------------------- staging: luma -------------------------------
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
       }
       if (c && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][1][0], wd, CW_ / 8);
     }
-    if (u + 1 < u1) request(u + 1);
+    if (u + ustep < u1) request(u + ustep);
     __syncthreads();
     // ------------------------------- multiply -------------------------------
     uint32_t defer = 0;
