@@ -829,6 +829,14 @@ int g1s_diff::launch_back(int si) {
     fq.ustats = reinterpret_cast<int32_t *>(mp.only + m_only_bytes);
     fq.nunits = m_nunits;
     const int G = m_wgs_per_frame(m_nunits, (int)B);
+    // profiling aid: G1S_F_PHASES=1 prints, per batch, the cycles the accumulation waves spent in each phase
+    static const bool phases = getenv("G1S_F_PHASES") != nullptr;
+    static long long *d_phase = nullptr;
+    fq.phase_cycles = nullptr;
+    if (phases) {
+      if (!d_phase) (void)hipMalloc((void **)&d_phase, sizeof(long long) * 6 * kFWaves * 4096);
+      if ((size_t)G * B <= 4096) fq.phase_cycles = d_phase;
+    }
     const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = g.nplanes == 3 ? (kBlock >> g.ydec) : 0;
     const size_t lds = (size_t)m_lds_bytes(cbw, cbh);
     const dim3 gr(G, 1, B);
@@ -855,6 +863,18 @@ int g1s_diff::launch_back(int si) {
 #undef G1S_F
     hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G, (const int32_t *)fq.ustats,
                        sl.d_records);
+    if (fq.phase_cycles) {
+      std::vector<long long> hc((size_t)G * B * kFWaves * 6);
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpy(hc.data(), d_phase, hc.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      double tot[kFWaves][6] = {};
+      for (size_t w = 0; w < (size_t)G * B; ++w)
+        for (int v = 0; v < kFWaves; ++v)
+          for (int k = 0; k < 6; ++k) tot[v][k] += (double)hc[(w * kFWaves + v) * 6 + k];
+      for (int v = 0; v < kFWaves; ++v)
+        fprintf(stderr, "k3f phases, wave %d: copies %.0f  barrier %.0f  multiply %.0f  barrier %.0f  wait for words %.0f  residuals %.0f  (mean cycles per workgroup)\n",
+                v, tot[v][0] / (G * B), tot[v][1] / (G * B), tot[v][2] / (G * B), tot[v][3] / (G * B), tot[v][4] / (G * B), tot[v][5] / (G * B));
+    }
     hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                        sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
   } else if (fast_ok) {

@@ -29,6 +29,9 @@
 namespace g1s {
 
 constexpr int kFWaves = 4, kFThreads = 64 * kFWaves;
+#ifndef G1S_F_OCC
+#define G1S_F_OCC 3  // waves per SIMD the fused kernel is compiled for (3 workgroups to a CU)
+#endif
 
 struct FParams {
   FrameTable ft;
@@ -37,6 +40,7 @@ struct FParams {
   long long *partials;    // [batch][G][3][kMRec]
   int32_t *ustats;        // [batch][nunits][kMStatInts]  per-unit block statistics + deferral bits (k3m_finish)
   int nunits;
+  long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][6] cycles: tile copies, barrier, multiply, barrier, wait for the words, residuals + requests; or null
 };
 
 // BPS: bytes per sample known at compile time (1, 2), or 0: given at run time (mixed depths)
@@ -92,6 +96,8 @@ __device__ __forceinline__ u32x4 f_load_slow(const uint8_t *plane, uint32_t stri
   return u32x4{w[0], w[1], w[2], w[3]};
 }
 
+constexpr int kFBiasY = 16 * 255, kFBiasC = 8 * 255;  // bias of a lane's sum of residuals: two rows / one row of 8 samples
+
 // blocks whose tile holds word wd of a row (WB words to a block; the tile reaches one word into its neighbours)
 __device__ __forceinline__ void f_flag_blocks(int *flags, int wd, int WB) {
   const int b = wd / WB;
@@ -114,7 +120,8 @@ struct FShape {
   // chroma tiles: rows -3 .. CBH-1
   static constexpr int PC = m_pitch(CW_), WC = PC / 8, CSC = m_copy_stride(CW_, CH_);
   static constexpr int RC = CH_ + 3, RPW = 64 / WC;             // tile rows per plane / rows per wave and round
-  static constexpr int CROUNDS = CH ? (2 * RC + kFWaves * RPW - 1) / (kFWaves * RPW) : 0;
+  // waves 0, 1 take Cb, waves 2, 3 Cr (the plane is uniform in a wave: scalar base addresses)
+  static constexpr int CROUNDS = CH ? (RC + 2 * RPW - 1) / (2 * RPW) : 0;
 };
 
 __device__ __forceinline__ void f_residual(const uint32_t (&hs)[4], const uint32_t (&hv)[4], uint32_t (&d16)[4], uint32_t &mx, uint32_t &mn) {
@@ -127,7 +134,7 @@ __device__ __forceinline__ void f_residual(const uint32_t (&hs)[4], const uint32
 }
 
 template <int CBW, int CBH, int BPS>
-__global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) {
+__global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParams fpar) {
   extern __shared__ __attribute__((aligned(16))) uint8_t m_smem[];
   using SH = FShape<CBW, CBH>;
   constexpr bool CH = SH::CH;
@@ -135,7 +142,9 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
   constexpr int ZOFF = m_lds_tiles(CBW, CBH);
   constexpr int OFF_CB = m_tile_bytes(32, kBlock), OFF_CR = OFF_CB + m_tile_bytes(CW_, CH_);
   constexpr int OFF_L = OFF_CR + m_tile_bytes(CW_, CH_) + m_l_pad(CW_, CH_);
-  __shared__ int s_sum[2][kMStatInts];  // [unit parity][block * 7 + {luma: sum d, sum d^2, sum src8; Cb: sum d, sum d^2; Cr: ...}]
+  // block statistics, ONE 64-bit LDS atomic a lane (they all hit the same few words): [unit parity][plane][block]
+  //   sum d^2 << 37 | sum src8 << 19 | sum (d + bias): every contributing lane adds its bias, their number is fixed
+  __shared__ unsigned long long s_sum[2][3][kMUnitBlocks];
   __shared__ int s_bad[2][2][kMUnitBlocks];  // [unit parity][kind][block]
 
   const int frame = g.frame0 + (int)blockIdx.z;
@@ -172,24 +181,18 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
   const int ypair = wave * SH::PPJ + ypl;
   const bool yon = wave < kFWaves - 1 && ypl < SH::PPJ && ypair < SH::PAIRS;
   const int ytr0 = yon ? 2 * ypair - 1 : -9;
-  uint32_t yso[2], ydo[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    yso[r] = (uint32_t)max(ytr0 + r, 0) * fp.src_stride[0] + (uint32_t)(8 * ywd * sbps);
-    ydo[r] = (uint32_t)max(ytr0 + r, 0) * fp.den_stride[0] + (uint32_t)(8 * ywd * dbps);
-  }
-  // chroma: round k, tile row index rr = (4 k + wave) * RPW + lane / WC over the two planes' RC rows each
+  // chroma: waves 0, 1 stage Cb, waves 2, 3 Cr; round k, tile row (2 k + (wave & 1)) * RPW + lane / WC
   const int cwd = lane % SH::WC;
-  int cpl[NCR], ctr[NCR];  // plane (1, 2; 0: idle), tile row
-  uint32_t cso[NCR], cdo[NCR];
+  const int cplane = 1 + (wave >> 1);
+  const uint8_t *c_src = cplane == 2 ? fp.src[2] : fp.src[1], *c_den = cplane == 2 ? fp.den[2] : fp.den[1];
+  const uint32_t c_sst = cplane == 2 ? fp.src_stride[2] : fp.src_stride[1], c_dst = cplane == 2 ? fp.den_stride[2] : fp.den_stride[1];
+  int cpl[NCR], ctr[NCR];  // plane (1, 2; 0: the lane is idle in this round), tile row
 #pragma unroll
   for (int k = 0; k < CROUNDS; ++k) {
-    const int rr = (kFWaves * k + wave) * SH::RPW + lane / SH::WC;
-    const bool on = lane / SH::WC < SH::RPW && rr < 2 * SH::RC;
-    cpl[k] = on ? 1 + rr / SH::RC : 0;
-    ctr[k] = on ? rr % SH::RC : 0;
-    cso[k] = (uint32_t)ctr[k] * (cpl[k] == 2 ? fp.src_stride[2] : fp.src_stride[1]) + (uint32_t)(8 * cwd * sbps);
-    cdo[k] = (uint32_t)ctr[k] * (cpl[k] == 2 ? fp.den_stride[2] : fp.den_stride[1]) + (uint32_t)(8 * cwd * dbps);
+    const int rr = (2 * k + (wave & 1)) * SH::RPW + lane / SH::WC;
+    const bool on = lane / SH::WC < SH::RPW && rr < SH::RC;
+    cpl[k] = on ? cplane : 0;
+    ctr[k] = on ? rr : 0;
   }
   // planes whose rows are 16-byte aligned take the vector loads; a chunk that reaches over the right plane edge
   // inside a word (W % 8 != 0) and unaligned planes go sample by sample
@@ -199,17 +202,28 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
 #pragma unroll
   for (int r = 0; r < 16; ++r) accY[r] = accCb[r] = accCr[r] = 0;
 
+  // ---- this workgroup's units: list positions u0 + k * ustep, their entries parked in LDS ----
+  __shared__ uint4 s_ent[kMMaxUnits];
+  const int nmine = u1 > u0 ? (int)((u1 - u0 + ustep - 1) / ustep) : 0;  // (<= kMMaxUnits: the host sizes G for it)
+  if (tid < nmine) s_ent[tid] = *reinterpret_cast<const uint4 *>(units + (size_t)(u0 + (uint32_t)tid * ustep) * kMUnitDwords);
   if (tid < 4) reinterpret_cast<uint32_t *>(m_smem + ZOFF)[tid] = 0u;
-  if (tid < 2 * kMStatInts) (&s_sum[0][0])[tid] = 0;
+  if (tid < 2 * 3 * kMUnitBlocks) (&s_sum[0][0][0])[tid] = 0ull;
   if (tid < 2 * 2 * kMUnitBlocks) (&s_bad[0][0][0])[tid] = 0;
+  __syncthreads();
 
-  // ---- the words of a unit, requested one unit ahead ----
-  u32x4 ys_[2], yd_[2];  // luma: two rows, source and denoised
-  u32x4 cs_[NCR], cd_[NCR];  // chroma: one row a round
-  uint4 ent = make_uint4(0, 0, 0, 0);
-  auto request = [&](uint32_t u) {
-    ent = *reinterpret_cast<const uint4 *>(units + (size_t)u * kMUnitDwords);
-    const int bx0 = kMUnitBlocks * (int)(ent.x & 0xfffu), by = (int)((ent.x >> 12) & 0xfffu);
+  // ---- software pipeline over the units k = 0 .. nmine - 1 ----
+  //   request(k)  the plane words of unit k -> raw registers (global loads, no wait)
+  //   phase A(k)  raw words -> residual words Dy / Dc, L words, block statistics and out-of-int8 flags (LDS atomics, parity k & 1)
+  //   phase B(k)  residual words -> the 7 shifted tile copies in LDS (needs the tiles free: after barrier 1)
+  //   multiply(k) after barrier 2
+  // Iteration k runs B(k), multiply(k), A(k + 1), request(k + 2): A's arithmetic issues behind the wave's own MFMAs,
+  // and a request has a whole iteration to land.
+  u32x4 ys_[2], yd_[2];      // luma raw words: two rows, source and denoised
+  u32x4 cs_[NCR], cd_[NCR];  // chroma raw words: one row a round
+  uint32_t Dy[2][2], Lw[2][2], Dc[NCR][2];  // residual bytes of the luma rows / L bytes / residual bytes of the chroma rows
+  auto request = [&](int k) {
+    const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
+    const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
     const int X0y = bx0 * 32 - 8, Y0y = by * kBlock - 3, X0c = bx0 * CW_ - 8, Y0c = by * CH_ - 3;
     const bool slow = !vec_all || ((g.W & 7) != 0 && X0y + SH::PY > g.W) || (CH && (cpw & 7) != 0 && X0c + SH::PC > cpw);
     if (__builtin_expect(slow, 0)) {
@@ -219,12 +233,10 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
         yd_[r] = f_load_slow(fp.den[0], fp.den_stride[0], dbps, X0y + 8 * ywd, ytr0 + r >= 0 ? Y0y + ytr0 + r : -1, g.W, g.H);
       }
 #pragma unroll
-      for (int k = 0; k < CROUNDS; ++k) {
-        const int c = cpl[k];
-        cs_[k] = f_load_slow(c == 2 ? fp.src[2] : fp.src[1], c == 2 ? fp.src_stride[2] : fp.src_stride[1], sbps, X0c + 8 * cwd,
-                             c ? Y0c + ctr[k] : -1, cpw, cph);
-        cd_[k] = f_load_slow(c == 2 ? fp.den[2] : fp.den[1], c == 2 ? fp.den_stride[2] : fp.den_stride[1], dbps, X0c + 8 * cwd,
-                             c ? Y0c + ctr[k] : -1, cpw, cph);
+      for (int q = 0; q < CROUNDS; ++q) {
+        const int c = cpl[q];
+        cs_[q] = f_load_slow(c_src, c_sst, sbps, X0c + 8 * cwd, c ? Y0c + ctr[q] : -1, cpw, cph);
+        cd_[q] = f_load_slow(c_den, c_dst, dbps, X0c + 8 * cwd, c ? Y0c + ctr[q] : -1, cpw, cph);
       }
       return;
     }
@@ -232,45 +244,51 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
       // (pointers to the unit's origin: not dereferenced where the origin lies outside the plane)
       const uint8_t *sb = fp.src[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.src_stride[0] + (ptrdiff_t)X0y * sbps);
       const uint8_t *db = fp.den[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.den_stride[0] + (ptrdiff_t)X0y * dbps);
+#ifdef G1S_DBG_NOHALO
+      const bool xok = X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W && ywd >= 1 && ywd <= SH::WY - 2;
+#else
       const bool xok = X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W;
+#endif
+      // (the lane's offsets from the unit's origin are worked out here from values the optimiser cannot see through:
+      //  hoisted out of the unit loop they would cost two registers a load -- and a spill, whose reload from scratch
+      //  waits for every load in flight)
+      int l_tr = ytr0, l_wd = ywd;
+      asm volatile("" : "+v"(l_tr), "+v"(l_wd));
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int Y = Y0y + ytr0 + r;
         const bool ok = xok && ytr0 + r >= 0 && Y >= 0 && Y < g.H;
-        ys_[r] = f_load<BPS>(sb, yso[r], g.src_bps, ok);
-        yd_[r] = f_load<BPS>(db, ydo[r], g.den_bps, ok);
+        ys_[r] = f_load<BPS>(sb, (uint32_t)max(l_tr + r, 0) * fp.src_stride[0] + (uint32_t)(8 * l_wd * sbps), g.src_bps, ok);
+        yd_[r] = f_load<BPS>(db, (uint32_t)max(l_tr + r, 0) * fp.den_stride[0] + (uint32_t)(8 * l_wd * dbps), g.den_bps, ok);
       }
     }
     if constexpr (CH) {
-      const ptrdiff_t o1s = (ptrdiff_t)Y0c * (ptrdiff_t)fp.src_stride[1] + (ptrdiff_t)X0c * sbps;
-      const ptrdiff_t o2s = (ptrdiff_t)Y0c * (ptrdiff_t)fp.src_stride[2] + (ptrdiff_t)X0c * sbps;
-      const ptrdiff_t o1d = (ptrdiff_t)Y0c * (ptrdiff_t)fp.den_stride[1] + (ptrdiff_t)X0c * dbps;
-      const ptrdiff_t o2d = (ptrdiff_t)Y0c * (ptrdiff_t)fp.den_stride[2] + (ptrdiff_t)X0c * dbps;
+      const uint8_t *sb = c_src + ((ptrdiff_t)Y0c * (ptrdiff_t)c_sst + (ptrdiff_t)X0c * sbps);
+      const uint8_t *db = c_den + ((ptrdiff_t)Y0c * (ptrdiff_t)c_dst + (ptrdiff_t)X0c * dbps);
+#ifdef G1S_DBG_NOHALO
+      const bool xok = X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw && cwd >= 1 && cwd <= SH::WC - 2;
+#else
       const bool xok = X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw;
+#endif
+      int l_wd = cwd;
+      asm volatile("" : "+v"(l_wd));
 #pragma unroll
-      for (int k = 0; k < CROUNDS; ++k) {
-        const int c = cpl[k], Y = Y0c + ctr[k];
-        const bool ok = xok && c != 0 && Y >= 0 && Y < cph;
-        cs_[k] = f_load<BPS>(c == 2 ? fp.src[2] + o2s : fp.src[1] + o1s, cso[k], g.src_bps, ok);
-        cd_[k] = f_load<BPS>(c == 2 ? fp.den[2] + o2d : fp.den[1] + o1d, cdo[k], g.den_bps, ok);
+      for (int q = 0; q < CROUNDS; ++q) {
+        const int Y = Y0c + ctr[q];
+        const bool ok = xok && cpl[q] != 0 && Y >= 0 && Y < cph;
+        int l_tr = ctr[q];
+        asm volatile("" : "+v"(l_tr));
+        cs_[q] = f_load<BPS>(sb, (uint32_t)l_tr * c_sst + (uint32_t)(8 * l_wd * sbps), g.src_bps, ok);
+        cd_[q] = f_load<BPS>(db, (uint32_t)l_tr * c_dst + (uint32_t)(8 * l_wd * dbps), g.den_bps, ok);
       }
     }
   };
-  if (u0 < u1) request(u0);
-
-  for (uint32_t u = u0; u < u1; u += ustep) {
-    const uint4 e0 = ent;
-    const int par = (int)(((u - u0) / ustep) & 1u);
-    const uint32_t wins[4] = {e0.y & 0xffffu, e0.y >> 16, e0.z & 0xffffu, e0.z >> 16};  // luma block 0, 1; chroma block 0, 1
-    __syncthreads();  // the previous unit's tiles are no longer read
-    // ------------------------------- staging: luma -------------------------------
+  const bool y_interior = ywd >= 1 && ywd <= SH::WY - 2, c_interior = cwd >= 1 && cwd <= SH::WC - 2;
+  const int y_xw = 8 * (ywd - 1), y_bq = (y_xw >> 5) & 1;     // luma word: first sample of the chunk, block
+  const int c_xw = 8 * (cwd - 1), c_bq = (c_xw / CW_) & 1;   // chroma word
+  auto phase_a = [&](int par) {
+    // ---- luma: residuals of the two rows, their statistics, L ----
     if (wave < kFWaves - 1) {
-      const int wd = ywd;
-      const bool interior = wd >= 1 && wd <= SH::WY - 2;
-      const int xw = 8 * (wd - 1), bq = (xw >> 5) & 1;  // sample of the chunk, block
-      const uint2 cm = interior ? m_colmask8(m_unpack(bq ? wins[1] : wins[0], g.lag), xw - 32 * bq) : make_uint2(0u, 0u);
-      uint2 lm = make_uint2(0u, 0u);
-      if (CH && interior) lm = m_colmask8(m_unpack(bq ? wins[3] : wins[2], g.lag), (xw >> sx) - CW_ * bq);  // the co-located chroma block's window
       uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0, keep16[4] = {0, 0, 0, 0};
       int sd = 0, sd2 = 0, ls = 0;
 #pragma unroll
@@ -280,24 +298,20 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
         f_narrow<BPS>(ys_[r], g.src_bps, g.src_shift, hs);
         f_narrow<BPS>(yd_[r], g.den_bps, g.den_shift, hv);
         f_residual(hs, hv, d16, mx, mn);
-        if (tr >= 3 && interior) {  // the block proper: its statistics
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            sd = pk_dot(d16[q], 0x00010001u, sd);
-            sd2 = pk_dot(d16[q], d16[q], sd2);
-          }
+        Dy[r][0] = pk_bytes(d16[0], d16[1]);
+        Dy[r][1] = pk_bytes(d16[2], d16[3]);
+        if (tr >= 3 && y_interior) {  // the block proper: its statistics (int8 arithmetic: a block that holds a residual outside
+                                      // int8 is redone by the exact kernel, statistics included)
+          sd = __builtin_amdgcn_sdot4((int)Dy[r][0], 0x01010101, sd, false);
+          sd = __builtin_amdgcn_sdot4((int)Dy[r][1], 0x01010101, sd, false);
+          sd2 = __builtin_amdgcn_sdot4((int)Dy[r][0], (int)Dy[r][0], sd2, false);
+          sd2 = __builtin_amdgcn_sdot4((int)Dy[r][1], (int)Dy[r][1], sd2, false);
           ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[0], hs[1]), 0u, (uint32_t)ls);
           ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[2], hs[3]), 0u, (uint32_t)ls);
         }
-        const uint32_t D0 = pk_bytes(d16[0], d16[1]), D1 = pk_bytes(d16[2], d16[3]);
-        const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)D1, 0x138, 0xf, 0xf, true);  // wave_shr:1
-        const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)D0, 0x130, 0xf, 0xf, true);  // wave_shl:1
-        if (tr >= 0 && (cm.x | cm.y)) m_write_copies(m_smem + tr * SH::PY + xw, SH::CSY, prev1, D0, D1, next0, cm);
-        // ---- the chroma regressor L from the luma residuals (chroma resolution) ----
         if constexpr (CH) {
           uint32_t v[4] = {0, 0, 0, 0};
           bool have = false;
-          int cy = 0;
           if (sy) {
             if (r == 0) {
 #pragma unroll
@@ -306,108 +320,186 @@ __global__ __launch_bounds__(kFThreads, 3) void k3f_fused(Geom g, FParams fpar) 
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = pk_add(keep16[q], d16[q]);
               have = tr >= 4;  // tile rows tr - 1, tr = block rows 2 cy, 2 cy + 1
-              cy = (tr - 4) >> 1;
             }
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = d16[q];
             have = tr >= 3;
-            cy = tr - 3;
           }
-          if (have && (lm.x | lm.y)) {
-            const int xc = xw >> sx;  // first chroma sample under the word
+          Lw[r][0] = Lw[r][1] = 0;
+          if (have) {
             if (sx) {
               const uint32_t p0 = ((uint32_t)pk_dot(v[0], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[1], 0x00010001u, 0) << 16);
               const uint32_t p1 = ((uint32_t)pk_dot(v[2], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[3], 0x00010001u, 0) << 16);
               lmx = pk_max(lmx, pk_max(p0, p1));
               lmn = pk_min(lmn, pk_min(p0, p1));
-              *reinterpret_cast<uint32_t *>(m_smem + OFF_L + cy * SH::PC + xc) = pk_bytes(p0, p1) & lm.x;
+              Lw[r][0] = pk_bytes(p0, p1);
             } else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 lmx = pk_max(lmx, v[q]);
                 lmn = pk_min(lmn, v[q]);
               }
-              *reinterpret_cast<uint2 *>(m_smem + OFF_L + cy * SH::PC + xc) = make_uint2(pk_bytes(v[0], v[1]) & lm.x, pk_bytes(v[2], v[3]) & lm.y);
+              Lw[r][0] = pk_bytes(v[0], v[1]);
+              Lw[r][1] = pk_bytes(v[2], v[3]);
             }
           }
         }
       }
-      if (interior && (sd | sd2 | ls)) {
-        atomicAdd(&s_sum[par][7 * bq + 0], sd);
-        atomicAdd(&s_sum[par][7 * bq + 1], sd2);
-        atomicAdd(&s_sum[par][7 * bq + 2], ls);
-      }
-      if (yon && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][0][0], wd, 4);
-      if (CH && range_bad(lmx, lmn)) s_bad[par][1][bq] = 1;
+      // (every interior lane of the 16 row pairs inside the block rows adds, zeros included: the bias total is a constant)
+      if (y_interior && ytr0 >= 3)
+        atomicAdd(&s_sum[par][0][y_bq],
+                  ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)(uint32_t)ls << 19) | (unsigned long long)(uint32_t)(sd + kFBiasY));
+      if (yon && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][0][0], ywd, 4);
+      if (CH && y_interior && range_bad(lmx, lmn)) s_bad[par][1][y_bq] = 1;
     }
-    // ------------------------------- staging: chroma -------------------------------
+    // ---- chroma ----
 #pragma unroll
-    for (int k = 0; k < CROUNDS; ++k) {
-      const int c = cpl[k], tr = ctr[k], wd = cwd;
-      const bool interior = wd >= 1 && wd <= SH::WC - 2;
-      const int xw = 8 * (wd - 1), bq = (xw / CW_) & 1;
-      const uint2 cm = (interior && c) ? m_colmask8(m_unpack(bq ? wins[3] : wins[2], g.lag), xw - CW_ * bq) : make_uint2(0u, 0u);
+    for (int q = 0; q < CROUNDS; ++q) {
+      const int c = cpl[q];
       uint32_t hs[4], hv[4], d16[4], mx = 0, mn = 0;
-      f_narrow<BPS>(cs_[k], g.src_bps, g.src_shift, hs);
-      f_narrow<BPS>(cd_[k], g.den_bps, g.den_shift, hv);
+      f_narrow<BPS>(cs_[q], g.src_bps, g.src_shift, hs);
+      f_narrow<BPS>(cd_[q], g.den_bps, g.den_shift, hv);
       f_residual(hs, hv, d16, mx, mn);
-      const uint32_t D0 = pk_bytes(d16[0], d16[1]), D1 = pk_bytes(d16[2], d16[3]);
-      const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)D1, 0x138, 0xf, 0xf, true);  // wave_shr:1
-      const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)D0, 0x130, 0xf, 0xf, true);  // wave_shl:1
-      if (cm.x | cm.y) m_write_copies(m_smem + (c == 2 ? OFF_CR : OFF_CB) + tr * SH::PC + xw, SH::CSC, prev1, D0, D1, next0, cm);
-      if (c && tr >= 3 && interior) {
-        int sd = 0, sd2 = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          sd = pk_dot(d16[q], 0x00010001u, sd);
-          sd2 = pk_dot(d16[q], d16[q], sd2);
-        }
-        if (sd | sd2) {
-          atomicAdd(&s_sum[par][7 * bq + 1 + 2 * c], sd);
-          atomicAdd(&s_sum[par][7 * bq + 2 + 2 * c], sd2);
-        }
+      Dc[q][0] = pk_bytes(d16[0], d16[1]);
+      Dc[q][1] = pk_bytes(d16[2], d16[3]);
+      if (c && ctr[q] >= 3 && c_interior) {
+        int sd = __builtin_amdgcn_sdot4((int)Dc[q][0], 0x01010101, 0, false);
+        sd = __builtin_amdgcn_sdot4((int)Dc[q][1], 0x01010101, sd, false);
+        int sd2 = __builtin_amdgcn_sdot4((int)Dc[q][0], (int)Dc[q][0], 0, false);
+        sd2 = __builtin_amdgcn_sdot4((int)Dc[q][1], (int)Dc[q][1], sd2, false);
+        atomicAdd(&s_sum[par][c][c_bq], ((unsigned long long)(uint32_t)sd2 << 37) | (unsigned long long)(uint32_t)(sd + kFBiasC));
       }
-      if (c && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][1][0], wd, CW_ / 8);
+      if (c && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][1][0], cwd, CW_ / 8);
     }
-    if (u + ustep < u1) request(u + ustep);
-    __syncthreads();
-    // ------------------------------- multiply -------------------------------
-    uint32_t defer = 0;
+  };
+  auto phase_b = [&](const uint32_t (&wins)[4]) {
+    if (wave < kFWaves - 1) {
+      const uint2 cm = y_interior ? m_colmask8(m_unpack(y_bq ? wins[1] : wins[0], g.lag), y_xw - 32 * y_bq) : make_uint2(0u, 0u);
+      uint2 lm = make_uint2(0u, 0u);
+      if (CH && y_interior) lm = m_colmask8(m_unpack(y_bq ? wins[3] : wins[2], g.lag), (y_xw >> sx) - CW_ * y_bq);  // the co-located chroma block's window
 #pragma unroll
-    for (int b = 0; b < kMUnitBlocks; ++b) {
-      const MWin wy = m_unpack(wins[b], g.lag);
-      if (wy.go) {
-        if (__builtin_amdgcn_readfirstlane(s_bad[par][0][b])) {
-          defer |= 1u << b;
-        } else {
-          constexpr int RPW = kBlock / kFWaves;
-          m_rows_one<RPW, SH::PY>(accY, m_smem, base_luma + 32 * b, m_rowmask(wy.ys, wy.ye) >> (wave * RPW), ZOFF);
-        }
-      }
-      if constexpr (CH) {
-        const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
-        if (wc.go) {
-          if (__builtin_amdgcn_readfirstlane(s_bad[par][1][b])) {
-            defer |= 1u << (kMUnitBlocks + b);
-          } else {
-            constexpr int RPW = CH_ / kFWaves;
-            const uint32_t rm = m_rowmask(wc.ys, wc.ye) >> (wave * RPW);
-            if constexpr (CW_ == 32) m_rows_two<RPW, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);
-            else m_steps_two<RPW / 2, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm >> h, ZOFF);
+      for (int r = 0; r < 2; ++r) {
+        const int tr = ytr0 + r;
+        const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
+        const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][0], 0x130, 0xf, 0xf, true);  // wave_shl:1
+        if (tr >= 0 && (cm.x | cm.y)) m_write_copies(m_smem + tr * SH::PY + y_xw, SH::CSY, prev1, Dy[r][0], Dy[r][1], next0, cm);
+        if constexpr (CH) {
+          const bool have = sy ? (r == 1 && tr >= 4) : tr >= 3;
+          const int cy = sy ? (tr - 4) >> 1 : tr - 3;
+          if (have && (lm.x | lm.y)) {
+            uint8_t *lp = m_smem + OFF_L + cy * SH::PC + (y_xw >> sx);
+            if (sx) *reinterpret_cast<uint32_t *>(lp) = Lw[r][0] & lm.x;
+            else *reinterpret_cast<uint2 *>(lp) = make_uint2(Lw[r][0] & lm.x, Lw[r][1] & lm.y);
           }
         }
       }
     }
-    // ---- the unit's statistics record (k3m_finish scatters it); the other parity's flags and sums -> 0 ----
+#pragma unroll
+    for (int q = 0; q < CROUNDS; ++q) {
+      const int c = cpl[q];
+      const uint2 cm = (c_interior && c) ? m_colmask8(m_unpack(c_bq ? wins[3] : wins[2], g.lag), c_xw - CW_ * c_bq) : make_uint2(0u, 0u);
+      const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dc[q][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
+      const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dc[q][0], 0x130, 0xf, 0xf, true);  // wave_shl:1
+      if (cm.x | cm.y)
+        m_write_copies(m_smem + (c == 2 ? OFF_CR : OFF_CB) + ctr[q] * SH::PC + c_xw, SH::CSC, prev1, Dc[q][0], Dc[q][1], next0, cm);
+    }
+  };
+
+#ifdef G1S_F_PHASES
+  long long t_ph[6] = {0, 0, 0, 0, 0, 0}, t_last = fpar.phase_cycles ? clock64() : 0;
+  auto stamp = [&](int ph) {
+    if (fpar.phase_cycles) {
+      const long long t = clock64();
+      t_ph[ph] += t - t_last;
+      t_last = t;
+    }
+  };
+#else
+  auto stamp = [](int) {};
+#endif
+  if (nmine > 0) {
+    request(0);
+    phase_a(0);
+    if (nmine > 1) request(1);
+  }
+  for (int k = 0; k < nmine; ++k) {
+    const int par = k & 1;
+    const uint4 e0 = s_ent[k];
+    const uint32_t ex = __builtin_amdgcn_readfirstlane(e0.x), ey = __builtin_amdgcn_readfirstlane(e0.y),
+                   ez = __builtin_amdgcn_readfirstlane(e0.z);
+    const uint32_t fbits = ex >> 24;
+    const uint32_t wins[4] = {ey & 0xffffu, ey >> 16, ez & 0xffffu, ez >> 16};  // luma block 0, 1; chroma block 0, 1
+    __syncthreads();  // the previous unit's tiles are no longer read
+    stamp(3);
+    phase_b(wins);
+    // (the sums and flags of the unit before this one: read in its multiply phase, written again two units on)
+    if (tid >= 64 && tid < 64 + 3 * kMUnitBlocks) (&s_sum[par ^ 1][0][0])[tid - 64] = 0ull;
+    else if (tid >= 128 && tid < 128 + 2 * kMUnitBlocks) (&s_bad[par ^ 1][0][0])[tid - 128] = 0;
+    stamp(0);
+    __syncthreads();
+    stamp(1);
+    // ------------------------------- multiply -------------------------------
+    uint32_t defer = 0;
+#pragma unroll
+    for (int b = 0; b < kMUnitBlocks; ++b) {
+      const bool flat_b = ((fbits >> b) & 1u) != 0;
+      const MWin wy = m_unpack(wins[b], g.lag);
+      if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][0][b])) {
+        defer |= 1u << b;  // (any flat block: the exact kernel redoes its statistics too)
+      } else if (wy.go) {
+        constexpr int RPW = kBlock / kFWaves;
+        m_rows_one<RPW, SH::PY>(accY, m_smem, base_luma + 32 * b, m_rowmask(wy.ys, wy.ye) >> (wave * RPW), ZOFF);
+      }
+      if constexpr (CH) {
+        const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
+        if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][1][b])) {
+          defer |= 1u << (kMUnitBlocks + b);
+        } else if (wc.go) {
+          constexpr int RPW = CH_ / kFWaves;
+          const uint32_t rm = m_rowmask(wc.ys, wc.ye) >> (wave * RPW);
+          if constexpr (CW_ == 32) m_rows_two<RPW, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);
+          else m_steps_two<RPW / 2, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm >> h, ZOFF);
+        }
+      }
+    }
+    // ---- the unit's statistics record (k3m_finish scatters it) ----
     if (tid < kMStatInts) {
-      ustats[(size_t)u * kMStatInts + tid] = tid == 14 ? (int)defer : s_sum[par][tid];
-    } else if (tid >= 64 && tid < 64 + kMStatInts) {
-      s_sum[par ^ 1][tid - 64] = 0;
-    } else if (tid >= 128 && tid < 128 + 2 * kMUnitBlocks) {
-      (&s_bad[par ^ 1][0][0])[tid - 128] = 0;
+      // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14: the deferral bits
+      const int b = tid >= 7 ? 1 : 0, e = tid - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
+      int val = (int)defer;
+      if (tid < 14) {
+        const unsigned long long pk = s_sum[par][c][b];
+        // contributing lanes per block: luma 16 row pairs x 4 words, chroma CBH rows x CBW / 8 words
+        const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
+        if (f == 1) val = (int)(pk >> 37);
+        else if (f == 2) val = (int)((pk >> 19) & 0x3ffffu);
+        else val = (int)(c == 0 ? (pk & 0x7ffffu) : (pk & 0x1fffffffffull)) - bias;
+      }
+      ustats[(size_t)(u0 + (uint32_t)k * ustep) * kMStatInts + tid] = val;
+    }
+    stamp(2);
+    // ---- the next unit's words have had this whole iteration to land: their arithmetic runs behind the multiplies ----
+    if (k + 1 < nmine) {
+#ifdef G1S_F_PHASES
+      if (fpar.phase_cycles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(4);
+      }
+#endif
+      phase_a(par ^ 1);
+#ifndef G1S_DBG_NOREQ
+      if (k + 2 < nmine) request(k + 2);
+#endif
+      stamp(5);
     }
   }
+#ifdef G1S_F_PHASES
+  if (fpar.phase_cycles && lane == 0) {
+    long long *o = fpar.phase_cycles + (((size_t)blockIdx.z * G + wg) * kFWaves + wave) * 6;
+    for (int k = 0; k < 6; ++k) o[k] = t_ph[k];
+  }
+#endif
 
   // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
   long long *s_S = reinterpret_cast<long long *>(m_smem);

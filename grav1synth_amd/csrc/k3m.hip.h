@@ -248,12 +248,16 @@ __device__ __forceinline__ uint32_t m_rowmask(int ys, int ye) {
 // R rows from a0 + j * P into one accumulator
 template <int R, int P>
 __device__ __forceinline__ void m_rows_one(v16i32 &acc, const uint8_t *smem, int a0, uint32_t rm, int zoff) {
-  v4i32 v[R];
+  constexpr int H = R > 4 ? 4 : R;  // rows per batch of reads
 #pragma unroll
-  for (int j = 0; j < R; ++j) v[j] = m_lds16(smem, ((rm >> j) & 1u) ? a0 + j * P : zoff);
-  __builtin_amdgcn_sched_barrier(0);
+  for (int j0 = 0; j0 < R; j0 += H) {
+    v4i32 v[H];
 #pragma unroll
-  for (int j = 0; j < R; ++j) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j], v[j], acc, 0, 0, 0);
+    for (int j = 0; j < H; ++j) v[j] = m_lds16(smem, ((rm >> (j0 + j)) & 1u) ? a0 + (j0 + j) * P : zoff);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < H; ++j) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j], v[j], acc, 0, 0, 0);
+  }
 }
 // R rows of two planes: plane A from a0 into accA, plane B from b0 into accB (chroma blocks 32 wide)
 template <int R, int P>
