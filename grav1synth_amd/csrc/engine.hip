@@ -51,7 +51,7 @@ bool use_mfma() {
 constexpr int kMTargetWgs = 768;  // accumulation workgroups per launch: 3 per CU, one round
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
 int m_wgs_per_frame(int nunits, int B) {
-  const int gmin = (nunits + kMMaxUnits - 1) / kMMaxUnits;
+  const int gmin = (nunits + (kMMaxUnits - 16) - 1) / (kMMaxUnits - 16);  // (two lists, each dealt with its own rounding)
   return (std::max(gmin, (kMTargetWgs + B - 1) / std::max(B, 1)) + 7) & ~7;  // (a multiple of 8: workgroup b of a frame on XCD b % 8)
 }
 
@@ -450,7 +450,7 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   m_only_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   // [units][unit counts][any-deferred flags][deferred-block flags]
   // ... [per-unit statistics records]
-  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 2 * (size_t)batch) + m_only_bytes +
+  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch) + m_only_bytes +
                           sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
   const size_t mpart_bytes = sizeof(long long) * 3 * kMRec *
                              ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits + 8) + kMTargetWgs + batch);
@@ -638,9 +638,9 @@ int g1s_diff::launch_front(int si) {
     z.ptr[0] = reinterpret_cast<uint32_t *>(sl.d_records);
     z.ndw[0] = (uint32_t)(L.size * B / 4);
     if (use_mfma()) {
-      z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords;  // unit counts, any-deferred flags
-      z.ndw[1] = 2 * (uint32_t)batch;
-      z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords + 2 * (size_t)batch;  // deferred-block flags
+      z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords;  // unit counts (2 lists), any-deferred flags
+      z.ndw[1] = 3 * (uint32_t)batch;
+      z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch;  // deferred-block flags
       z.ndw[3] = (uint32_t)(m_only_bytes / 4);
     } else {
       const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
@@ -798,7 +798,7 @@ MParams g1s_diff::make_mparams(const Slot &sl) const {
   mp.bad = nullptr;  // (the fused pass finds the residuals outside int8 itself)
   mp.units = reinterpret_cast<uint32_t *>(sl.d_mu);
   mp.unit_count = mp.units + (size_t)batch * m_nunits * kMUnitDwords;
-  mp.only_any = mp.unit_count + batch;
+  mp.only_any = mp.unit_count + 2 * batch;
   mp.only = reinterpret_cast<uint8_t *>(mp.only_any + batch);
   mp.partials = sl.d_mpart;
   mp.nunits = m_nunits;

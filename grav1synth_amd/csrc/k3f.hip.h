@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "k0.hip.h"
 #include "k3m.hip.h"
 #include "kernels.hip.h"
@@ -150,13 +152,24 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   const int frame = g.frame0 + (int)blockIdx.z;
   const int G = gridDim.x, wg = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t cnt = fpar.unit_count[frame];
-  // Workgroup b runs on XCD b % 8 (observed; speed only).  An XCD owns a contiguous eighth of the frame's unit list and
-  // deals it round-robin to its workgroups of this frame: horizontally adjacent units -- which share the 128-byte lines
-  // their halo columns sit in -- are then read at about the same time through the same L2.
+  // Workgroup b runs on XCD b % 8 (observed; speed only).  An XCD owns a contiguous eighth of each of the frame's two unit
+  // lists and deals it round-robin to its workgroups of this frame: horizontally adjacent units -- which share the
+  // 128-byte lines their halo columns sit in -- are then read at about the same time through the same L2.
   const int xcd = wg & 7, jx = wg >> 3, nx = (G + 7 - xcd) >> 3;  // this workgroup's rank among the nx of its XCD
-  const uint32_t c0 = (uint32_t)((unsigned long long)cnt * xcd / 8), c1 = (uint32_t)((unsigned long long)cnt * (xcd + 1) / 8);
-  const uint32_t u0 = c0 + (uint32_t)jx, u1 = c1, ustep = (uint32_t)nx;
+  const uint32_t cnt_g = fpar.unit_count[2 * frame], cnt_p = fpar.unit_count[2 * frame + 1];
+  auto share = [&](uint32_t cnt, uint32_t &first, int &n) {  // positions first, first + nx, ... (n of them) of a list of cnt
+    const uint32_t c0 = (uint32_t)((unsigned long long)cnt * xcd / 8), c1 = (uint32_t)((unsigned long long)cnt * (xcd + 1) / 8);
+    first = c0 + (uint32_t)jx;
+    n = c1 > first ? (int)((c1 - first + (uint32_t)nx - 1) / (uint32_t)nx) : 0;
+  };
+  uint32_t first_p, first_g;
+  int n_p, n_g;
+  share(cnt_p, first_p, n_p);
+  share(cnt_g, first_g, n_g);
+  // list position of this workgroup's k-th unit: its plain units first (that list grows from the back of the array)
+  auto upos = [&](int k) {
+    return k < n_p ? (uint32_t)fpar.nunits - 1u - (first_p + (uint32_t)k * (uint32_t)nx) : first_g + (uint32_t)(k - n_p) * (uint32_t)nx;
+  };
   const uint32_t *units = fpar.units + (size_t)frame * fpar.nunits * kMUnitDwords;
   int32_t *ustats = fpar.ustats + (size_t)frame * fpar.nunits * kMStatInts;
   const FramePlanes fp = fpar.ft.f[frame];
@@ -204,8 +217,8 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 
   // ---- this workgroup's units: list positions u0 + k * ustep, their entries parked in LDS ----
   __shared__ uint4 s_ent[kMMaxUnits];
-  const int nmine = u1 > u0 ? (int)((u1 - u0 + ustep - 1) / ustep) : 0;  // (<= kMMaxUnits: the host sizes G for it)
-  if (tid < nmine) s_ent[tid] = *reinterpret_cast<const uint4 *>(units + (size_t)(u0 + (uint32_t)tid * ustep) * kMUnitDwords);
+  const int nmine = n_p + n_g;  // (<= kMMaxUnits: the host sizes G for it)
+  if (tid < nmine) s_ent[tid] = *reinterpret_cast<const uint4 *>(units + (size_t)upos(tid) * kMUnitDwords);
   if (tid < 4) reinterpret_cast<uint32_t *>(m_smem + ZOFF)[tid] = 0u;
   if (tid < 2 * 3 * kMUnitBlocks) (&s_sum[0][0][0])[tid] = 0ull;
   if (tid < 2 * 2 * kMUnitBlocks) (&s_bad[0][0][0])[tid] = 0;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   u32x4 ys_[2], yd_[2];      // luma raw words: two rows, source and denoised
   u32x4 cs_[NCR], cd_[NCR];  // chroma raw words: one row a round
   uint32_t Dy[2][2], Lw[2][2], Dc[NCR][2];  // residual bytes of the luma rows / L bytes / residual bytes of the chroma rows
-  auto request = [&](int k) {
+  auto request = [&](int k) __attribute__((always_inline)) {
     const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
     const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
     const int X0y = bx0 * 32 - 8, Y0y = by * kBlock - 3, X0c = bx0 * CW_ - 8, Y0c = by * CH_ - 3;
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   const bool y_interior = ywd >= 1 && ywd <= SH::WY - 2, c_interior = cwd >= 1 && cwd <= SH::WC - 2;
   const int y_xw = 8 * (ywd - 1), y_bq = (y_xw >> 5) & 1;     // luma word: first sample of the chunk, block
   const int c_xw = 8 * (cwd - 1), c_bq = (c_xw / CW_) & 1;   // chroma word
-  auto phase_a = [&](int par) {
+  auto phase_a = [&](int par) __attribute__((always_inline)) {
     // ---- luma: residuals of the two rows, their statistics, L ----
     if (wave < kFWaves - 1) {
       uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0, keep16[4] = {0, 0, 0, 0};
@@ -373,17 +386,21 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       if (c && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][1][0], cwd, CW_ / 8);
     }
   };
-  auto phase_b = [&](const uint32_t (&wins)[4]) {
+  // PLAIN: every window of the unit is its whole block (k3m_units): no column masks, every word is written
+  auto phase_b = [&](auto plain_tag, const uint32_t (&wins)[4]) __attribute__((always_inline)) {
+    constexpr bool PLAIN = decltype(plain_tag)::value;
     if (wave < kFWaves - 1) {
-      const uint2 cm = y_interior ? m_colmask8(m_unpack(y_bq ? wins[1] : wins[0], g.lag), y_xw - 32 * y_bq) : make_uint2(0u, 0u);
-      uint2 lm = make_uint2(0u, 0u);
-      if (CH && y_interior) lm = m_colmask8(m_unpack(y_bq ? wins[3] : wins[2], g.lag), (y_xw >> sx) - CW_ * y_bq);  // the co-located chroma block's window
+      uint2 cm = make_uint2(0u, 0u), lm = make_uint2(0u, 0u);
+      if (y_interior) {
+        cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(y_bq ? wins[1] : wins[0], g.lag), y_xw - 32 * y_bq);
+        if (CH) lm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(y_bq ? wins[3] : wins[2], g.lag), (y_xw >> sx) - CW_ * y_bq);
+      }
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int tr = ytr0 + r;
         const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
         const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][0], 0x130, 0xf, 0xf, true);  // wave_shl:1
-        if (tr >= 0 && (cm.x | cm.y)) m_write_copies(m_smem + tr * SH::PY + y_xw, SH::CSY, prev1, Dy[r][0], Dy[r][1], next0, cm);
+        if (tr >= 0 && (cm.x | cm.y)) m_write_copies<!PLAIN>(m_smem + tr * SH::PY + y_xw, SH::CSY, prev1, Dy[r][0], Dy[r][1], next0, cm);
         if constexpr (CH) {
           const bool have = sy ? (r == 1 && tr >= 4) : tr >= 3;
           const int cy = sy ? (tr - 4) >> 1 : tr - 3;
@@ -398,11 +415,12 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 #pragma unroll
     for (int q = 0; q < CROUNDS; ++q) {
       const int c = cpl[q];
-      const uint2 cm = (c_interior && c) ? m_colmask8(m_unpack(c_bq ? wins[3] : wins[2], g.lag), c_xw - CW_ * c_bq) : make_uint2(0u, 0u);
+      uint2 cm = make_uint2(0u, 0u);
+      if (c_interior && c) cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(c_bq ? wins[3] : wins[2], g.lag), c_xw - CW_ * c_bq);
       const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dc[q][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
       const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dc[q][0], 0x130, 0xf, 0xf, true);  // wave_shl:1
       if (cm.x | cm.y)
-        m_write_copies(m_smem + (c == 2 ? OFF_CR : OFF_CB) + ctr[q] * SH::PC + c_xw, SH::CSC, prev1, Dc[q][0], Dc[q][1], next0, cm);
+        m_write_copies<!PLAIN>(m_smem + (c == 2 ? OFF_CR : OFF_CB) + ctr[q] * SH::PC + c_xw, SH::CSC, prev1, Dc[q][0], Dc[q][1], next0, cm);
     }
   };
 
@@ -423,77 +441,81 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
     phase_a(0);
     if (nmine > 1) request(1);
   }
-  for (int k = 0; k < nmine; ++k) {
-    const int par = k & 1;
-    const uint4 e0 = s_ent[k];
-    const uint32_t ex = __builtin_amdgcn_readfirstlane(e0.x), ey = __builtin_amdgcn_readfirstlane(e0.y),
-                   ez = __builtin_amdgcn_readfirstlane(e0.z);
-    const uint32_t fbits = ex >> 24;
-    const uint32_t wins[4] = {ey & 0xffffu, ey >> 16, ez & 0xffffu, ez >> 16};  // luma block 0, 1; chroma block 0, 1
-    __syncthreads();  // the previous unit's tiles are no longer read
-    stamp(3);
-    phase_b(wins);
-    // (the sums and flags of the unit before this one: read in its multiply phase, written again two units on)
-    if (tid >= 64 && tid < 64 + 3 * kMUnitBlocks) (&s_sum[par ^ 1][0][0])[tid - 64] = 0ull;
-    else if (tid >= 128 && tid < 128 + 2 * kMUnitBlocks) (&s_bad[par ^ 1][0][0])[tid - 128] = 0;
-    stamp(0);
-    __syncthreads();
-    stamp(1);
-    // ------------------------------- multiply -------------------------------
-    uint32_t defer = 0;
+  // units [k0, k1) of this workgroup's sequence; two calls (plain units, then the others) are ONE pipeline: the residuals and
+  // requests a unit of the first loop prepares belong to units of the second
+  auto run = [&](auto plain_tag, int k0, int k1) __attribute__((always_inline)) {
+    constexpr bool PLAIN = decltype(plain_tag)::value;
+    for (int k = k0; k < k1; ++k) {
+      const int par = k & 1;
+      const uint4 e0 = s_ent[k];
+      const uint32_t ey = __builtin_amdgcn_readfirstlane(e0.y), ez = __builtin_amdgcn_readfirstlane(e0.z);
+      const uint32_t fbits = PLAIN ? (1u << kMUnitBlocks) - 1u : __builtin_amdgcn_readfirstlane(e0.x) >> 24;
+      const uint32_t wins[4] = {ey & 0xffffu, ey >> 16, ez & 0xffffu, ez >> 16};  // luma block 0, 1; chroma block 0, 1
+      __syncthreads();  // the previous unit's tiles are no longer read
+      stamp(3);
+      phase_b(plain_tag, wins);
+      // (the sums and flags of the unit before this one: read in its multiply phase, written again two units on)
+      if (tid >= 64 && tid < 64 + 3 * kMUnitBlocks) (&s_sum[par ^ 1][0][0])[tid - 64] = 0ull;
+      else if (tid >= 128 && tid < 128 + 2 * kMUnitBlocks) (&s_bad[par ^ 1][0][0])[tid - 128] = 0;
+      stamp(0);
+      __syncthreads();
+      stamp(1);
+      // ------------------------------- multiply -------------------------------
+      uint32_t defer = 0;
 #pragma unroll
-    for (int b = 0; b < kMUnitBlocks; ++b) {
-      const bool flat_b = ((fbits >> b) & 1u) != 0;
-      const MWin wy = m_unpack(wins[b], g.lag);
-      if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][0][b])) {
-        defer |= 1u << b;  // (any flat block: the exact kernel redoes its statistics too)
-      } else if (wy.go) {
-        constexpr int RPW = kBlock / kFWaves;
-        m_rows_one<RPW, SH::PY>(accY, m_smem, base_luma + 32 * b, m_rowmask(wy.ys, wy.ye) >> (wave * RPW), ZOFF);
-      }
-      if constexpr (CH) {
-        const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
-        if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][1][b])) {
-          defer |= 1u << (kMUnitBlocks + b);
-        } else if (wc.go) {
-          constexpr int RPW = CH_ / kFWaves;
-          const uint32_t rm = m_rowmask(wc.ys, wc.ye) >> (wave * RPW);
-          if constexpr (CW_ == 32) m_rows_two<RPW, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);
-          else m_steps_two<RPW / 2, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm >> h, ZOFF);
+      for (int b = 0; b < kMUnitBlocks; ++b) {
+        const bool flat_b = ((fbits >> b) & 1u) != 0;
+        const MWin wy = m_unpack(wins[b], g.lag);
+        constexpr int RPY = kBlock / kFWaves;
+        if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][0][b])) {
+          defer |= 1u << b;  // (any flat block: the exact kernel redoes its statistics too)
+        } else if (PLAIN || wy.go) {
+          m_rows_one<RPY, SH::PY>(accY, m_smem, base_luma + 32 * b, PLAIN ? ~0u : m_rowmask(wy.ys, wy.ye) >> (wave * RPY), ZOFF);
+        }
+        if constexpr (CH) {
+          const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
+          constexpr int RPC = CH_ / kFWaves;
+          if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][1][b])) {
+            defer |= 1u << (kMUnitBlocks + b);
+          } else if (PLAIN || wc.go) {
+            const uint32_t rm = PLAIN ? ~0u : m_rowmask(wc.ys, wc.ye) >> (wave * RPC);
+            if constexpr (CW_ == 32) m_rows_two<RPC, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);
+            else m_steps_two<RPC / 2, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, PLAIN ? ~0u : rm >> h, ZOFF);
+          }
         }
       }
-    }
-    // ---- the unit's statistics record (k3m_finish scatters it) ----
-    if (tid < kMStatInts) {
-      // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14: the deferral bits
-      const int b = tid >= 7 ? 1 : 0, e = tid - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
-      int val = (int)defer;
-      if (tid < 14) {
-        const unsigned long long pk = s_sum[par][c][b];
-        // contributing lanes per block: luma 16 row pairs x 4 words, chroma CBH rows x CBW / 8 words
-        const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
-        if (f == 1) val = (int)(pk >> 37);
-        else if (f == 2) val = (int)((pk >> 19) & 0x3ffffu);
-        else val = (int)(c == 0 ? (pk & 0x7ffffu) : (pk & 0x1fffffffffull)) - bias;
+      // ---- the unit's statistics record (k3m_finish scatters it) ----
+      if (tid < kMStatInts) {
+        // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14: the deferral bits
+        const int b = tid >= 7 ? 1 : 0, e = tid - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
+        int val = (int)defer;
+        if (tid < 14) {
+          const unsigned long long pk = s_sum[par][c][b];
+          // contributing lanes per block: luma 16 row pairs x 4 words, chroma CBH rows x CBW / 8 words
+          const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
+          if (f == 1) val = (int)(pk >> 37);
+          else if (f == 2) val = (int)((pk >> 19) & 0x3ffffu);
+          else val = (int)(c == 0 ? (pk & 0x7ffffu) : (pk & 0x1fffffffffull)) - bias;
+        }
+        ustats[(size_t)upos(k) * kMStatInts + tid] = val;
       }
-      ustats[(size_t)(u0 + (uint32_t)k * ustep) * kMStatInts + tid] = val;
-    }
-    stamp(2);
-    // ---- the next unit's words have had this whole iteration to land: their arithmetic runs behind the multiplies ----
-    if (k + 1 < nmine) {
+      stamp(2);
+      // ---- the next unit's words have had this whole iteration to land: their arithmetic runs behind the multiplies ----
+      if (k + 1 < nmine) {
 #ifdef G1S_F_PHASES
-      if (fpar.phase_cycles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(4);
+        if (fpar.phase_cycles) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          stamp(4);
+        }
+#endif
+        phase_a(par ^ 1);
+        if (k + 2 < nmine) request(k + 2);
+        stamp(5);
       }
-#endif
-      phase_a(par ^ 1);
-#ifndef G1S_DBG_NOREQ
-      if (k + 2 < nmine) request(k + 2);
-#endif
-      stamp(5);
     }
-  }
+  };
+  run(std::true_type{}, 0, n_p);
+  run(std::false_type{}, n_p, nmine);
 #ifdef G1S_F_PHASES
   if (fpar.phase_cycles && lane == 0) {
     long long *o = fpar.phase_cycles + (((size_t)blockIdx.z * G + wg) * kFWaves + wave) * 6;

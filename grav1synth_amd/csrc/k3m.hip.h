@@ -44,8 +44,8 @@ struct MParams {
   const uint8_t *bad;     // [batch][2][nblocks]  residual (kind 1: or L) outside int8, when a pixel pass has flagged them; or null
   uint8_t *only;          // [batch][2][nblocks]  flat blocks left to k3_ar_generic (zeroed per batch)
   uint32_t *only_any;     // [batch]
-  uint32_t *units;        // [batch][nunits][kMUnitDwords]
-  uint32_t *unit_count;   // [batch]  (zeroed per batch)
+  uint32_t *units;        // [batch][nunits][kMUnitDwords]  (two lists, see k3m_units)
+  uint32_t *unit_count;   // [batch][2]  general units (from the front of the frame's array), plain units (from its back); zeroed per batch
   long long *partials;    // [batch][G][3][kMRec]
   int nunits;             // chunks per frame = ceil(nbw / 4) * nbh
 };
@@ -155,16 +155,12 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
       if (bx < g.nbw && mask[by * g.nbw + bx]) bits |= 1u << b;
     }
   }
-  const unsigned long long vote = __ballot(bits != 0);
-  if (vote == 0) return;
-  const int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(&mp.unit_count[frame], (uint32_t)__popcll(vote));
-  base = __shfl(base, 0, 64);
-  if (!bits) return;
-  const uint32_t pos = base + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
+  if (__ballot(bits != 0) == 0) return;
   const bool chroma = g.nplanes == 3;
   uint32_t win[2 * kMUnitBlocks];
+  // `plain`: every block of the chunk is flat and its window is the whole block, in both plane kinds -- the accumulation
+  // kernel runs those units through a loop without window masks
+  bool plain = bits == (1u << kMUnitBlocks) - 1u;
 #pragma unroll
   for (int t = 0; t < 2 * kMUnitBlocks; ++t) {
     const int kind = t / kMUnitBlocks, b = t % kMUnitBlocks, bx = kMUnitBlocks * ci + b;
@@ -173,9 +169,10 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
     const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
     const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
     const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph, g.lag);
+    if (!w.flat || w.xs != 0 || w.ys != 0 || w.xe != bw || w.ye != bh) plain = false;
     if (!w.flat) continue;
-    // the tile reaches into the left / right / upper neighbours
-    // (the fused pass, k3f.hip.h, finds the residuals outside int8 itself: no flags here)
+    // (a pixel pass may have flagged residuals outside int8: the tile reaches into the left / right / upper neighbours;
+    //  the fused pass, k3f.hip.h, finds them itself)
     bool defer = false;
     if (mp.bad) {
       const uint8_t *bad = mp.bad + ((size_t)frame * 2 + kind) * g.nblocks;
@@ -188,20 +185,35 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
     if (defer) {
       mp.only[((size_t)frame * 2 + kind) * g.nblocks + by * g.nbw + bx] = 1;
       mp.only_any[frame] = 1u;
+      plain = false;
     } else {
       win[t] = (uint32_t)w.xe | ((uint32_t)w.ye << 6) | (w.ys ? 1u << 13 : 0u) | (w.xs ? 1u << 14 : 0u) | (1u << 15);
     }
   }
+  // two lists in the frame's array: the general units from the front, the plain ones from the back
+  const int lane = threadIdx.x & 63;
+  const unsigned long long vote_g = __ballot(bits != 0 && !plain), vote_p = __ballot(bits != 0 && plain);
+  uint32_t base_g = 0, base_p = 0;
+  if (lane == 0) {
+    if (vote_g) base_g = atomicAdd(&mp.unit_count[2 * frame], (uint32_t)__popcll(vote_g));
+    if (vote_p) base_p = atomicAdd(&mp.unit_count[2 * frame + 1], (uint32_t)__popcll(vote_p));
+  }
+  base_g = __shfl(base_g, 0, 64);
+  base_p = __shfl(base_p, 0, 64);
+  if (!bits) return;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t pos = plain ? (uint32_t)mp.nunits - 1u - (base_p + (uint32_t)__popcll(vote_p & below)) : base_g + (uint32_t)__popcll(vote_g & below);
   static_assert(kMUnitBlocks == 2 && kMUnitDwords == 4, "list entry layout");
   uint32_t *e = mp.units + ((size_t)frame * mp.nunits + pos) * kMUnitDwords;
   *reinterpret_cast<uint4 *>(e) = make_uint4((uint32_t)ci | ((uint32_t)by << 12) | (bits << 24), win[0] | (win[1] << 16),
-                                             win[2] | (win[3] << 16), 0u);
+                                             win[2] | (win[3] << 16), plain ? 1u : 0u);
 }
 
 __device__ __forceinline__ uint32_t m_bytemask(int k) { return k >= 4 ? 0xffffffffu : ((1u << (8 * k)) - 1u); }
 
 // 7 shifted copies of one row word (8 samples) -> LDS.  d0, d1: the word; prev1: the dword before it,
 // next0: the dword after it.
+template <bool MASKED = true>
 __device__ __forceinline__ void m_write_copies(uint8_t *dst, int CS, uint32_t prev1, uint32_t d0, uint32_t d1, uint32_t next0,
                                                uint2 cm) {
 #pragma unroll
@@ -218,7 +230,7 @@ __device__ __forceinline__ void m_write_copies(uint8_t *dst, int CS, uint32_t pr
       w0 = __builtin_amdgcn_alignbyte(d1, d0, cx);
       w1 = __builtin_amdgcn_alignbyte(next0, d1, cx);
     }
-    *reinterpret_cast<uint2 *>(dst + cxp * CS) = make_uint2(w0 & cm.x, w1 & cm.y);
+    *reinterpret_cast<uint2 *>(dst + cxp * CS) = MASKED ? make_uint2(w0 & cm.x, w1 & cm.y) : make_uint2(w0, w1);
   }
 }
 
@@ -312,7 +324,9 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
                                                   uint8_t *__restrict__ records) {
   const int frame = g.frame0 + (int)blockIdx.y;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
-  const uint32_t cnt = mp.unit_count[frame];
+  const uint32_t cnt_g = mp.unit_count[2 * frame], cnt = cnt_g + mp.unit_count[2 * frame + 1];
+  // list position of the v-th unit of the frame: the general ones from the front, the plain ones from the back
+  auto upos = [&](uint32_t v) { return v < cnt_g ? v : (uint32_t)mp.nunits - 1u - (v - cnt_g); };
   const uint32_t *units = mp.units + (size_t)frame * mp.nunits * kMUnitDwords;
   const int32_t *us = ustats + (size_t)frame * mp.nunits * kMStatInts;
   if ((int)blockIdx.x < g.nplanes) {
@@ -327,7 +341,8 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
     // observations: the windows of the blocks that were multiplied (go and not deferred)
     __shared__ long long s_n[4];
     long long n = 0;
-    for (uint32_t u = threadIdx.x; u < cnt; u += 256) {
+    for (uint32_t v = threadIdx.x; v < cnt; v += 256) {
+      const uint32_t u = upos(v);
       const uint32_t wz = units[(size_t)u * kMUnitDwords + (c > 0 ? 2 : 1)];
       const uint32_t defer = (uint32_t)us[(size_t)u * kMStatInts + 14] >> (c > 0 ? kMUnitBlocks : 0);
 #pragma unroll
@@ -345,7 +360,8 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
   }
   const int part = (int)blockIdx.x - g.nplanes;
   const bool chroma = g.nplanes == 3;
-  for (uint32_t u = part * 256 + threadIdx.x; u < cnt; u += kMFinishWgs * 256) {
+  for (uint32_t v = part * 256 + threadIdx.x; v < cnt; v += kMFinishWgs * 256) {
+    const uint32_t u = upos(v);
     const uint32_t e0 = units[(size_t)u * kMUnitDwords];
     const int bx0 = kMUnitBlocks * (int)(e0 & 0xfffu), by = (int)((e0 >> 12) & 0xfffu);
     const int32_t *r = us + (size_t)u * kMStatInts;
