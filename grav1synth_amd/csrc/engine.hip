@@ -52,7 +52,8 @@ constexpr int kMTargetWgs = 768;  // accumulation workgroups per launch: 3 per C
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
 int m_wgs_per_frame(int nunits, int B) {
   const int gmin = (nunits + (kMMaxUnits - 16) - 1) / (kMMaxUnits - 16);  // (two lists, each dealt with its own rounding)
-  return (std::max(gmin, (kMTargetWgs + B - 1) / std::max(B, 1)) + 7) & ~7;  // (a multiple of 8: workgroup b of a frame on XCD b % 8)
+  static const int target = getenv("G1S_F_WGS") ? std::max(8, atoi(getenv("G1S_F_WGS"))) : kMTargetWgs;  // tuning aid
+  return (std::max(gmin, (target + B - 1) / std::max(B, 1)) + 7) & ~7;  // (a multiple of 8: workgroup b of a frame on XCD b % 8)
 }
 
 #define HIP_TRY(expr)                                                                      \
@@ -453,7 +454,7 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch) + m_only_bytes +
                           sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
   const size_t mpart_bytes = sizeof(long long) * 3 * kMRec *
-                             ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits + 8) + kMTargetWgs + batch);
+                             ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits + 8) + 4096 + batch);
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
                      partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes, mpart_bytes,
                      g.W, g.H, g.xdec, g.ydec, g.nplanes};
@@ -625,7 +626,10 @@ int g1s_diff::launch_front(int si) {
   static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
   hipStream_t stream = ss.compute;                                        // main stream (shadows the member)
   hipStream_t fstream = (one_stream || timing || !ss.flat) ? stream : ss.flat;  // per-kernel timing: one stream
-  hipStream_t pstream = stream;                                           // pixel pass
+  // the pixel pass of round 1's chain (K0) runs on the main stream; the fused pass has no K0: its only pixel pass before
+  // the mask is the finder's luma-source moments kernel, which joins the finder chain on the side stream and runs next to
+  // the accumulation of the batch before
+  hipStream_t pstream = use_mfma() ? fstream : stream;
   // the frame table: pinned host copy -> device, on the upload stream (idle: done long before the main
   // stream gets here); per-kernel timing / one-stream mode: in line
   FrameTable ft;
@@ -662,6 +666,7 @@ int g1s_diff::launch_front(int si) {
   if (up != stream) {
     HIP_TRY(hipEventRecord(ss.table_done[si], up));
     HIP_TRY(hipStreamWaitEvent(stream, ss.table_done[si], 0));
+    if (pstream != stream) HIP_TRY(hipStreamWaitEvent(pstream, ss.table_done[si], 0));
   }
   sl.timed = timing;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], pstream));
@@ -838,13 +843,14 @@ int g1s_diff::launch_back(int si) {
       if ((size_t)G * B <= 4096) fq.phase_cycles = d_phase;
     }
     const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = g.nplanes == 3 ? (kBlock >> g.ydec) : 0;
-    const size_t lds = (size_t)m_lds_bytes(cbw, cbh);
+    static const size_t lds_pad = getenv("G1S_F_LDS_PAD") ? (size_t)atoi(getenv("G1S_F_LDS_PAD")) : 0;  // tuning aid: fewer workgroups to a CU
+    const size_t lds = std::min((size_t)m_lds_bytes(cbw, cbh) + lds_pad, (size_t)144 * 1024);
     const dim3 gr(G, 1, B);
     const int bpsm = g.src_bps == g.den_bps ? g.src_bps : 0;  // bytes per sample at compile time unless the depths are mixed
 #define G1S_F(CW, CH, BP)                                                                                         \
   do {                                                                                                            \
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, BP>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, m_lds_bytes(CW, CH)); \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
     (void)attr_rc;                                                                                                \
     hipLaunchKernelGGL((k3f_fused<CW, CH, BP>), gr, dim3(kFThreads), lds, stream, g, fq);                          \
   } while (0)

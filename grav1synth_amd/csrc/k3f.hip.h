@@ -360,7 +360,11 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
         }
       }
       // (every interior lane of the 16 row pairs inside the block rows adds, zeros included: the bias total is a constant)
+#ifndef G1S_DBG_NOATOM
       if (y_interior && ytr0 >= 3)
+#else
+      if (y_interior && ytr0 >= 3 && sd == 12345678)
+#endif
         atomicAdd(&s_sum[par][0][y_bq],
                   ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)(uint32_t)ls << 19) | (unsigned long long)(uint32_t)(sd + kFBiasY));
       if (yon && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][0][0], ywd, 4);
@@ -381,6 +385,9 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
         sd = __builtin_amdgcn_sdot4((int)Dc[q][1], 0x01010101, sd, false);
         int sd2 = __builtin_amdgcn_sdot4((int)Dc[q][0], (int)Dc[q][0], 0, false);
         sd2 = __builtin_amdgcn_sdot4((int)Dc[q][1], (int)Dc[q][1], sd2, false);
+#ifdef G1S_DBG_NOATOM
+        if (sd == 12345678)
+#endif
         atomicAdd(&s_sum[par][c][c_bq], ((unsigned long long)(uint32_t)sd2 << 37) | (unsigned long long)(uint32_t)(sd + kFBiasC));
       }
       if (c && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][1][0], cwd, CW_ / 8);
@@ -509,7 +516,9 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
         }
 #endif
         phase_a(par ^ 1);
+#ifndef G1S_DBG_NOREQ
         if (k + 2 < nmine) request(k + 2);
+#endif
         stamp(5);
       }
     }
