@@ -48,7 +48,7 @@ bool use_mfma() {
   }();
   return v;
 }
-constexpr int kMTargetWgs = 768;  // accumulation workgroups per launch: 3 per CU, one round
+constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per CU, one round
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
 int m_wgs_per_frame(int nunits, int B) {
   const int gmin = (nunits + (kMMaxUnits - 16) - 1) / (kMMaxUnits - 16);  // (two lists, each dealt with its own rounding)
@@ -176,6 +176,7 @@ struct Slot {
   uint32_t *d_pgl = nullptr;       // partial-group lists [batch][2][pg_cap] + counts [batch][2]
   uint8_t *d_mu = nullptr;         // MFMA path: unit lists [batch][nunits], unit counts, deferred-block flags
   long long *d_mpart = nullptr;    // MFMA path: partial systems of the accumulation workgroups
+  uint8_t *d_lplane = nullptr;     // MFMA path: L at chroma resolution, int8 (luma launch -> chroma launch)
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   size_t stage_bytes_per_frame = 0;
   hipEvent_t done = nullptr;
@@ -189,12 +190,12 @@ struct Slot {
 // (one per video, or one per bench step) reuse them.
 struct SlotKey {
   int device;
-  size_t planes, records, flags, partials, defer, stage, k0, pgl, mu, mpart;
+  size_t planes, records, flags, partials, defer, stage, k0, pgl, mu, mpart, lplane;
   int W, H, xdec, ydec, nplanes;  // the zeroed padding of the K0 planes depends on the exact geometry
   bool operator==(const SlotKey &o) const {
     return device == o.device && planes == o.planes && records == o.records && flags == o.flags &&
            partials == o.partials && defer == o.defer && stage == o.stage && k0 == o.k0 && pgl == o.pgl && mu == o.mu &&
-           mpart == o.mpart &&
+           mpart == o.mpart && lplane == o.lplane &&
            W == o.W && H == o.H && xdec == o.xdec && ydec == o.ydec && nplanes == o.nplanes;
   }
 };
@@ -305,6 +306,7 @@ struct g1s_diff {
   size_t defer_bytes = 0;
   PlaneSet ps{};
   uint32_t pg_cap = 0;
+  uint32_t m_lpitch = 0, m_lframe = 0;  // MFMA path: L plane geometry
   int m_nunits = 0;          // MFMA path: chunks per frame
   size_t m_only_bytes = 0;   // ... deferred-block flags [batch][2][nblocks], 16-byte rounded
   MParams make_mparams(const Slot &sl) const;
@@ -455,8 +457,12 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
                           sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
   const size_t mpart_bytes = sizeof(long long) * 3 * kMRec *
                              ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits + 8) + 4096 + batch);
+  // L plane of a frame: block rows x chunk columns at chroma resolution (+ a slack row)
+  m_lpitch = g.nplanes == 3 ? (uint32_t)((((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * kMUnitBlocks * (kBlock >> g.xdec) + 15) & ~15) : 0u;
+  m_lframe = m_lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec) + 1);
+  const size_t lplane_bytes = use_mfma() ? (size_t)m_lframe * batch : 0;
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
-                     partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes, mpart_bytes,
+                     partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes, mpart_bytes, lplane_bytes,
                      g.W, g.H, g.xdec, g.ydec, g.nplanes};
   for (Slot &sl : slots) {
     {
@@ -487,6 +493,7 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     } else {
       HIP_TRY(hipMalloc((void **)&sl.d_mu, mu_bytes));
       HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes));
+      if (lplane_bytes) HIP_TRY(hipMalloc((void **)&sl.d_lplane, lplane_bytes));
     }
     HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
@@ -843,28 +850,38 @@ int g1s_diff::launch_back(int si) {
       if ((size_t)G * B <= 4096) fq.phase_cycles = d_phase;
     }
     const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = g.nplanes == 3 ? (kBlock >> g.ydec) : 0;
+    fq.lplane = sl.d_lplane;
+    fq.lpitch = m_lpitch;
+    fq.lframe_bytes = m_lframe;
     static const size_t lds_pad = getenv("G1S_F_LDS_PAD") ? (size_t)atoi(getenv("G1S_F_LDS_PAD")) : 0;  // tuning aid: fewer workgroups to a CU
-    const size_t lds = std::min((size_t)m_lds_bytes(cbw, cbh) + lds_pad, (size_t)144 * 1024);
     const dim3 gr(G, 1, B);
     const int bpsm = g.src_bps == g.den_bps ? g.src_bps : 0;  // bytes per sample at compile time unless the depths are mixed
-#define G1S_F(CW, CH, BP)                                                                                         \
-  do {                                                                                                            \
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, BP>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
-    (void)attr_rc;                                                                                                \
-    hipLaunchKernelGGL((k3f_fused<CW, CH, BP>), gr, dim3(kFThreads), lds, stream, g, fq);                          \
+    // two launches: the luma plane (which leaves L behind), then the two chroma planes
+#define G1S_F(CW, CH, BP, PL)                                                                                        \
+  do {                                                                                                               \
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, BP, PL>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
+    (void)attr_rc;                                                                                                   \
+    const size_t lds = std::min((size_t)f_lds_bytes(CW, CH, PL) + lds_pad, (size_t)144 * 1024);                     \
+    hipLaunchKernelGGL((k3f_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);                        \
   } while (0)
-#define G1S_FS(CW, CH)             \
-  do {                             \
-    if (bpsm == 2) G1S_F(CW, CH, 2); \
-    else if (bpsm == 1) G1S_F(CW, CH, 1); \
-    else G1S_F(CW, CH, 0);         \
+#define G1S_FS(CW, CH, PL)                 \
+  do {                                     \
+    if (bpsm == 2) G1S_F(CW, CH, 2, PL);   \
+    else if (bpsm == 1) G1S_F(CW, CH, 1, PL); \
+    else G1S_F(CW, CH, 0, PL);             \
   } while (0)
-    if (cbw == 0) G1S_FS(0, 0);
-    else if (cbw == 16 && cbh == 16) G1S_FS(16, 16);
-    else if (cbw == 16) G1S_FS(16, 32);
-    else if (cbh == 32) G1S_FS(32, 32);
-    else G1S_FS(32, 16);
+#define G1S_FP(CW, CH)  \
+  do {                  \
+    G1S_FS(CW, CH, 0);  \
+    G1S_FS(CW, CH, 1);  \
+  } while (0)
+    if (cbw == 0) G1S_FS(0, 0, 0);
+    else if (cbw == 16 && cbh == 16) G1S_FP(16, 16);
+    else if (cbw == 16) G1S_FP(16, 32);
+    else if (cbh == 32) G1S_FP(32, 32);
+    else G1S_FP(32, 16);
+#undef G1S_FP
 #undef G1S_FS
 #undef G1S_F
     hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G, (const int32_t *)fq.ustats,
@@ -1213,6 +1230,7 @@ void g1s_diff::release() {
     if (sl.d_pgl) (void)hipFree(sl.d_pgl);
     if (sl.d_mu) (void)hipFree(sl.d_mu);
     if (sl.d_mpart) (void)hipFree(sl.d_mpart);
+    if (sl.d_lplane) (void)hipFree(sl.d_lplane);
     if (sl.d_stage) (void)hipFree(sl.d_stage);
     if (sl.done) (void)hipEventDestroy(sl.done);
     for (auto &e : sl.ev)

@@ -8,16 +8,21 @@
 // A = B).  No intermediate planes go through HBM: the pass reads (flat fraction) x (1 + halo) of the
 // algorithmic bytes, the finder's luma-source pass (k1_moments) is the only other reader of the pixels.
 //
-// Workgroup = 4 waves, unit = 2 adjacent blocks of a block row (k3m_units): 36 KB of LDS, three to four
-// workgroups to a CU, each in another phase.  Per unit:
-//   staging   luma: waves 0-2 each take 6 row pairs, a lane one 8-sample word of both rows (the two rows
-//             under a 4:2:0 chroma row: L needs no cross-lane traffic), source and denoised: four 16-byte
-//             loads.  Chroma: every wave takes 10 (6) single rows of the two planes.  All loads are
-//             requested ONE UNIT AHEAD into registers.  A residual (or L) outside int8 flags the blocks
-//             whose tile holds it: they are left to the exact int32 kernel (k3_ar_generic, `only` list).
-//   multiply  wave w takes rows 8w .. 8w+7 of every luma block and its share of the chroma steps.
-// Two barriers per unit; accumulators (one 32x32 int32 per plane) stay in registers for the whole slice
-// of the frame's unit list the workgroup walks; one partial system per workgroup (k3m_reduce).
+// The pass is two launches of one kernel template, PL = 0 (luma) then PL = 1 (the two chroma planes): each
+// keeps few enough registers (one resp. two accumulators, one plane kind's words in flight) for four waves
+// to a SIMD, and a 16-20 KB tile set.  The luma launch leaves L behind as an int8 plane at chroma
+// resolution (2 MB a 4K frame) for the chroma launch.
+// Workgroup = 4 waves, unit = 2 adjacent blocks of a block row (k3m_units).  Per unit:
+//   staging   luma: a wave takes 5 row pairs, a lane one 8-sample word of both rows (the two rows under a
+//             4:2:0 chroma row: L needs no cross-lane traffic), source and denoised: four 16-byte loads.
+//             Chroma: waves 0, 1 take the rows of Cb, waves 2, 3 those of Cr, a lane one word of one row.
+//             A residual (or L) outside int8 flags the blocks whose tile holds it: they are left to the
+//             exact int32 kernel (k3_ar_generic, `only` list).
+//   multiply  wave w takes rows 8w .. 8w+7 of every luma block / its share of the chroma steps.
+// Software pipeline: iteration k writes the tile copies of unit k, multiplies them, then turns the words of
+// unit k+1 (requested a whole iteration earlier) into residual bytes behind its own MFMAs, and requests
+// the words of unit k+2.  Two barriers per unit; accumulators stay in registers for the whole slice of the
+// frame's unit lists the workgroup walks; one partial system per workgroup and plane (k3m_finish).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,7 +37,7 @@ namespace g1s {
 
 constexpr int kFWaves = 4, kFThreads = 64 * kFWaves;
 #ifndef G1S_F_OCC
-#define G1S_F_OCC 3  // waves per SIMD the fused kernel is compiled for (3 workgroups to a CU)
+#define G1S_F_OCC 4  // waves per SIMD the kernel is compiled for (4 workgroups to a CU)
 #endif
 
 struct FParams {
@@ -42,6 +47,8 @@ struct FParams {
   long long *partials;    // [batch][G][3][kMRec]
   int32_t *ustats;        // [batch][nunits][kMStatInts]  per-unit block statistics + deferral bits (k3m_finish)
   int nunits;
+  uint8_t *lplane;        // [batch][lrows][lpitch]  L (sum of the co-located luma residuals) at chroma resolution, int8
+  uint32_t lpitch, lframe_bytes;
   long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][6] cycles: tile copies, barrier, multiply, barrier, wait for the words, residuals + requests; or null
 };
 
@@ -108,8 +115,8 @@ __device__ __forceinline__ void f_flag_blocks(int *flags, int wd, int WB) {
 }
 
 // ---------------------------------------------------------------------------------
-// k3f_fused<CBW, CBH, BPS>: chroma block 32 >> xdec by 32 >> ydec (0, 0: luma only).
-// grid = (G, 1, batch), block = 256, dynamic LDS = m_lds_bytes(CBW, CBH).
+// k3f_fused<CBW, CBH, BPS, PL>: chroma block 32 >> xdec by 32 >> ydec (0, 0: luma only); PL = 0: the luma plane (and L),
+// PL = 1: the chroma planes.  grid = (G, 1, batch), block = 256, dynamic LDS = f_lds_bytes(CBW, CBH, PL).
 // ---------------------------------------------------------------------------------
 template <int CBW, int CBH>
 struct FShape {
@@ -117,14 +124,21 @@ struct FShape {
   static constexpr int CW_ = CH ? CBW : 16, CH_ = CH ? CBH : 16;
   // luma tile: rows -3 .. 31, samples -8 .. 71 of the chunk
   static constexpr int PY = m_pitch(32), WY = PY / 8, CSY = m_copy_stride(32, kBlock);
-  static constexpr int PPJ = 64 / WY, PAIRS = (kBlock + 4) / 2;  // row pairs per luma job / per tile
-  static_assert((PAIRS + PPJ - 1) / PPJ <= kFWaves - 1, "luma jobs: one per wave, the last wave has none");
+  static constexpr int PAIRS = (kBlock + 4) / 2;                                     // row pairs of the tile
+  static constexpr int PPJ = (64 / WY) < (PAIRS + kFWaves - 1) / kFWaves ? (64 / WY) : (PAIRS + kFWaves - 1) / kFWaves;  // ... per wave
+  static_assert(PPJ * kFWaves >= PAIRS, "luma row pairs: one job per wave");
   // chroma tiles: rows -3 .. CBH-1
   static constexpr int PC = m_pitch(CW_), WC = PC / 8, CSC = m_copy_stride(CW_, CH_);
   static constexpr int RC = CH_ + 3, RPW = 64 / WC;             // tile rows per plane / rows per wave and round
   // waves 0, 1 take Cb, waves 2, 3 Cr (the plane is uniform in a wave: scalar base addresses)
   static constexpr int CROUNDS = CH ? (RC + 2 * RPW - 1) / (2 * RPW) : 0;
+  static constexpr int NL = CH ? CH_ * kMUnitBlocks * CW_ / 8 : 0;  // 8-byte words of the unit's L tile (<= 256)
 };
+// LDS map: PL = 0: [luma tile][zero block]; PL = 1: [Cb tile][Cr tile][pad][L tile][zero block]
+__host__ __device__ constexpr int f_lds_tiles(int CBW, int CBH, int PL) {
+  return PL == 0 ? m_tile_bytes(32, kBlock) : 2 * m_tile_bytes(CBW, CBH) + m_l_pad(CBW, CBH) + CBH * m_pitch(CBW);
+}
+__host__ __device__ constexpr int f_lds_bytes(int CBW, int CBH, int PL) { return f_lds_tiles(CBW, CBH, PL) + 16; }
 
 __device__ __forceinline__ void f_residual(const uint32_t (&hs)[4], const uint32_t (&hv)[4], uint32_t (&d16)[4], uint32_t &mx, uint32_t &mn) {
 #pragma unroll
@@ -135,15 +149,16 @@ __device__ __forceinline__ void f_residual(const uint32_t (&hs)[4], const uint32
   }
 }
 
-template <int CBW, int CBH, int BPS>
+template <int CBW, int CBH, int BPS, int PL>
 __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParams fpar) {
   extern __shared__ __attribute__((aligned(16))) uint8_t m_smem[];
   using SH = FShape<CBW, CBH>;
   constexpr bool CH = SH::CH;
-  constexpr int CW_ = SH::CW_, CH_ = SH::CH_, CROUNDS = SH::CROUNDS, NCR = CROUNDS > 0 ? CROUNDS : 1;
-  constexpr int ZOFF = m_lds_tiles(CBW, CBH);
-  constexpr int OFF_CB = m_tile_bytes(32, kBlock), OFF_CR = OFF_CB + m_tile_bytes(CW_, CH_);
-  constexpr int OFF_L = OFF_CR + m_tile_bytes(CW_, CH_) + m_l_pad(CW_, CH_);
+  constexpr bool LUMA = PL == 0, CHROMA = PL == 1;
+  static_assert(LUMA || CH, "the chroma launch needs chroma planes");
+  constexpr int CW_ = SH::CW_, CH_ = SH::CH_, CROUNDS = CHROMA ? SH::CROUNDS : 0, NCR = CROUNDS > 0 ? CROUNDS : 1;
+  constexpr int ZOFF = f_lds_tiles(CBW, CBH, PL);
+  constexpr int OFF_CB = 0, OFF_CR = m_tile_bytes(CW_, CH_), OFF_L = 2 * m_tile_bytes(CW_, CH_) + m_l_pad(CW_, CH_);
   // block statistics, ONE 64-bit LDS atomic a lane (they all hit the same few words): [unit parity][plane][block]
   //   sum d^2 << 37 | sum src8 << 19 | sum (d + bias): every contributing lane adds its bias, their number is fixed
   __shared__ unsigned long long s_sum[2][3][kMUnitBlocks];
@@ -172,12 +187,13 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   };
   const uint32_t *units = fpar.units + (size_t)frame * fpar.nunits * kMUnitDwords;
   int32_t *ustats = fpar.ustats + (size_t)frame * fpar.nunits * kMStatInts;
+  uint8_t *lplane = fpar.lplane + (size_t)frame * fpar.lframe_bytes;
   const FramePlanes fp = fpar.ft.f[frame];
   const int sx = g.xdec, sy = g.ydec;
   const int cpw = g.W >> sx, cph = g.H >> sy;
   const int sbps = f_bps<BPS>(g.src_bps), dbps = f_bps<BPS>(g.den_bps);
 
-  // ---- this lane's operand address inside a tile, per plane kind (k3m.hip.h) ----
+  // ---- this lane's operand address inside a tile (k3m.hip.h) ----
   const int i = lane & 31, h = lane >> 5;
   int ea, ecxp, esp;
   m_entry(i, ea, ecxp, esp);
@@ -189,10 +205,10 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   const int addr_cr = esp == 1 ? OFF_L + hoff_c + woff_c : OFF_CR + base_chroma;
 
   // ---- this lane's staging work: offsets from the unit's origin (tile row 0, sample -8 of the chunk) ----
-  // luma (waves 0 .. 2): pair ypair = tile rows 2 ypair - 1, 2 ypair (= block rows 2 ypair - 4, 2 ypair - 3)
+  // luma: pair ypair = tile rows 2 ypair - 1, 2 ypair (= block rows 2 ypair - 4, 2 ypair - 3)
   const int ypl = lane / SH::WY, ywd = lane - ypl * SH::WY;
   const int ypair = wave * SH::PPJ + ypl;
-  const bool yon = wave < kFWaves - 1 && ypl < SH::PPJ && ypair < SH::PAIRS;
+  const bool yon = LUMA && ypl < SH::PPJ && ypair < SH::PAIRS;
   const int ytr0 = yon ? 2 * ypair - 1 : -9;
   // chroma: waves 0, 1 stage Cb, waves 2, 3 Cr; round k, tile row (2 k + (wave & 1)) * RPW + lane / WC
   const int cwd = lane % SH::WC;
@@ -209,16 +225,20 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   }
   // planes whose rows are 16-byte aligned take the vector loads; a chunk that reaches over the right plane edge
   // inside a word (W % 8 != 0) and unaligned planes go sample by sample
-  const bool vec_all = (g.vec_mask & (CH ? 0x3f : 0x09)) == (CH ? 0x3f : 0x09);
+  const bool vec_all = (g.vec_mask & (LUMA ? 0x09 : 0x36)) == (LUMA ? 0x09 : 0x36);
 
-  v16i32 accY, accCb, accCr;
+  v16i32 accA, accB;  // luma launch: accA; chroma launch: Cb, Cr
 #pragma unroll
-  for (int r = 0; r < 16; ++r) accY[r] = accCb[r] = accCr[r] = 0;
+  for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0;
 
-  // ---- this workgroup's units: list positions u0 + k * ustep, their entries parked in LDS ----
+  // ---- this workgroup's units: their entries parked in LDS (.w: the luma launch's deferral bits, for the chroma launch) ----
   __shared__ uint4 s_ent[kMMaxUnits];
   const int nmine = n_p + n_g;  // (<= kMMaxUnits: the host sizes G for it)
-  if (tid < nmine) s_ent[tid] = *reinterpret_cast<const uint4 *>(units + (size_t)upos(tid) * kMUnitDwords);
+  if (tid < nmine) {
+    uint4 e = *reinterpret_cast<const uint4 *>(units + (size_t)upos(tid) * kMUnitDwords);
+    if (CHROMA) e.w = (uint32_t)ustats[(size_t)upos(tid) * kMStatInts + 14];
+    s_ent[tid] = e;
+  }
   if (tid < 4) reinterpret_cast<uint32_t *>(m_smem + ZOFF)[tid] = 0u;
   if (tid < 2 * 3 * kMUnitBlocks) (&s_sum[0][0][0])[tid] = 0ull;
   if (tid < 2 * 2 * kMUnitBlocks) (&s_bad[0][0][0])[tid] = 0;
@@ -226,24 +246,33 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 
   // ---- software pipeline over the units k = 0 .. nmine - 1 ----
   //   request(k)  the plane words of unit k -> raw registers (global loads, no wait)
-  //   phase A(k)  raw words -> residual words Dy / Dc, L words, block statistics and out-of-int8 flags (LDS atomics, parity k & 1)
+  //   phase A(k)  raw words -> residual words, (luma launch) L -> its plane, block statistics and out-of-int8 flags (LDS, parity k & 1)
   //   phase B(k)  residual words -> the 7 shifted tile copies in LDS (needs the tiles free: after barrier 1)
   //   multiply(k) after barrier 2
   // Iteration k runs B(k), multiply(k), A(k + 1), request(k + 2): A's arithmetic issues behind the wave's own MFMAs,
   // and a request has a whole iteration to land.
   u32x4 ys_[2], yd_[2];      // luma raw words: two rows, source and denoised
   u32x4 cs_[NCR], cd_[NCR];  // chroma raw words: one row a round
-  uint32_t Dy[2][2], Lw[2][2], Dc[NCR][2];  // residual bytes of the luma rows / L bytes / residual bytes of the chroma rows
+  uint2 lraw = make_uint2(0u, 0u), Lk = make_uint2(0u, 0u);  // chroma launch: this thread's word of the L tile (requested / of the unit being staged)
+  uint32_t Dy[2][2], Dc[NCR][2];  // residual bytes of the luma rows / of the chroma rows
+  const bool l_on = CHROMA && tid < SH::NL;
+  constexpr int LWR = kMUnitBlocks * CW_ / 8;  // 8-byte words of an L tile row
+  const int l_row = tid / LWR, l_wd = tid - l_row * LWR;
   auto request = [&](int k) __attribute__((always_inline)) {
     const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
     const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
     const int X0y = bx0 * 32 - 8, Y0y = by * kBlock - 3, X0c = bx0 * CW_ - 8, Y0c = by * CH_ - 3;
-    const bool slow = !vec_all || ((g.W & 7) != 0 && X0y + SH::PY > g.W) || (CH && (cpw & 7) != 0 && X0c + SH::PC > cpw);
+    if constexpr (CHROMA) {
+      if (l_on) lraw = *reinterpret_cast<const uint2 *>(lplane + (size_t)(by * CH_ + l_row) * fpar.lpitch + bx0 * CW_ + 8 * l_wd);
+    }
+    const bool slow = !vec_all || (LUMA ? ((g.W & 7) != 0 && X0y + SH::PY > g.W) : ((cpw & 7) != 0 && X0c + SH::PC > cpw));
     if (__builtin_expect(slow, 0)) {
+      if constexpr (LUMA) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        ys_[r] = f_load_slow(fp.src[0], fp.src_stride[0], sbps, X0y + 8 * ywd, ytr0 + r >= 0 ? Y0y + ytr0 + r : -1, g.W, g.H);
-        yd_[r] = f_load_slow(fp.den[0], fp.den_stride[0], dbps, X0y + 8 * ywd, ytr0 + r >= 0 ? Y0y + ytr0 + r : -1, g.W, g.H);
+        for (int r = 0; r < 2; ++r) {
+          ys_[r] = f_load_slow(fp.src[0], fp.src_stride[0], sbps, X0y + 8 * ywd, ytr0 + r >= 0 ? Y0y + ytr0 + r : -1, g.W, g.H);
+          yd_[r] = f_load_slow(fp.den[0], fp.den_stride[0], dbps, X0y + 8 * ywd, ytr0 + r >= 0 ? Y0y + ytr0 + r : -1, g.W, g.H);
+        }
       }
 #pragma unroll
       for (int q = 0; q < CROUNDS; ++q) {
@@ -253,57 +282,52 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       }
       return;
     }
-    {
+    if constexpr (LUMA) {
       // (pointers to the unit's origin: not dereferenced where the origin lies outside the plane)
       const uint8_t *sb = fp.src[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.src_stride[0] + (ptrdiff_t)X0y * sbps);
       const uint8_t *db = fp.den[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.den_stride[0] + (ptrdiff_t)X0y * dbps);
-#ifdef G1S_DBG_NOHALO
-      const bool xok = X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W && ywd >= 1 && ywd <= SH::WY - 2;
-#else
       const bool xok = X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W;
-#endif
       // (the lane's offsets from the unit's origin are worked out here from values the optimiser cannot see through:
       //  hoisted out of the unit loop they would cost two registers a load -- and a spill, whose reload from scratch
       //  waits for every load in flight)
-      int l_tr = ytr0, l_wd = ywd;
-      asm volatile("" : "+v"(l_tr), "+v"(l_wd));
+      int l_tr = ytr0, l_w = ywd;
+      asm volatile("" : "+v"(l_tr), "+v"(l_w));
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int Y = Y0y + ytr0 + r;
         const bool ok = xok && ytr0 + r >= 0 && Y >= 0 && Y < g.H;
-        ys_[r] = f_load<BPS>(sb, (uint32_t)max(l_tr + r, 0) * fp.src_stride[0] + (uint32_t)(8 * l_wd * sbps), g.src_bps, ok);
-        yd_[r] = f_load<BPS>(db, (uint32_t)max(l_tr + r, 0) * fp.den_stride[0] + (uint32_t)(8 * l_wd * dbps), g.den_bps, ok);
+        ys_[r] = f_load<BPS>(sb, (uint32_t)max(l_tr + r, 0) * fp.src_stride[0] + (uint32_t)(8 * l_w * sbps), g.src_bps, ok);
+        yd_[r] = f_load<BPS>(db, (uint32_t)max(l_tr + r, 0) * fp.den_stride[0] + (uint32_t)(8 * l_w * dbps), g.den_bps, ok);
       }
     }
-    if constexpr (CH) {
+    if constexpr (CHROMA) {
       const uint8_t *sb = c_src + ((ptrdiff_t)Y0c * (ptrdiff_t)c_sst + (ptrdiff_t)X0c * sbps);
       const uint8_t *db = c_den + ((ptrdiff_t)Y0c * (ptrdiff_t)c_dst + (ptrdiff_t)X0c * dbps);
-#ifdef G1S_DBG_NOHALO
-      const bool xok = X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw && cwd >= 1 && cwd <= SH::WC - 2;
-#else
       const bool xok = X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw;
-#endif
-      int l_wd = cwd;
-      asm volatile("" : "+v"(l_wd));
+      int l_w = cwd;
+      asm volatile("" : "+v"(l_w));
 #pragma unroll
       for (int q = 0; q < CROUNDS; ++q) {
         const int Y = Y0c + ctr[q];
         const bool ok = xok && cpl[q] != 0 && Y >= 0 && Y < cph;
         int l_tr = ctr[q];
         asm volatile("" : "+v"(l_tr));
-        cs_[q] = f_load<BPS>(sb, (uint32_t)l_tr * c_sst + (uint32_t)(8 * l_wd * sbps), g.src_bps, ok);
-        cd_[q] = f_load<BPS>(db, (uint32_t)l_tr * c_dst + (uint32_t)(8 * l_wd * dbps), g.den_bps, ok);
+        cs_[q] = f_load<BPS>(sb, (uint32_t)l_tr * c_sst + (uint32_t)(8 * l_w * sbps), g.src_bps, ok);
+        cd_[q] = f_load<BPS>(db, (uint32_t)l_tr * c_dst + (uint32_t)(8 * l_w * dbps), g.den_bps, ok);
       }
     }
   };
   const bool y_interior = ywd >= 1 && ywd <= SH::WY - 2, c_interior = cwd >= 1 && cwd <= SH::WC - 2;
   const int y_xw = 8 * (ywd - 1), y_bq = (y_xw >> 5) & 1;     // luma word: first sample of the chunk, block
   const int c_xw = 8 * (cwd - 1), c_bq = (c_xw / CW_) & 1;   // chroma word
-  auto phase_a = [&](int par) __attribute__((always_inline)) {
-    // ---- luma: residuals of the two rows, their statistics, L ----
-    if (wave < kFWaves - 1) {
+  auto phase_a = [&](int k) __attribute__((always_inline)) {
+    const int par = k & 1;
+    if constexpr (LUMA) {
+      // ---- luma: residuals of the two rows, their statistics, L ----
       uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0, keep16[4] = {0, 0, 0, 0};
       int sd = 0, sd2 = 0, ls = 0;
+      const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
+      const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int tr = ytr0 + r;
@@ -323,8 +347,10 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
           ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[2], hs[3]), 0u, (uint32_t)ls);
         }
         if constexpr (CH) {
+          // ---- the chroma regressor L (chroma resolution) -> its plane, for the chroma launch ----
           uint32_t v[4] = {0, 0, 0, 0};
           bool have = false;
+          int cy = 0;
           if (sy) {
             if (r == 0) {
 #pragma unroll
@@ -333,44 +359,42 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = pk_add(keep16[q], d16[q]);
               have = tr >= 4;  // tile rows tr - 1, tr = block rows 2 cy, 2 cy + 1
+              cy = (tr - 4) >> 1;
             }
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = d16[q];
             have = tr >= 3;
+            cy = tr - 3;
           }
-          Lw[r][0] = Lw[r][1] = 0;
-          if (have) {
+          if (have && y_interior) {
+            uint8_t *lp = lplane + (size_t)(by * CH_ + cy) * fpar.lpitch + bx0 * CW_ + (y_xw >> sx);
             if (sx) {
               const uint32_t p0 = ((uint32_t)pk_dot(v[0], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[1], 0x00010001u, 0) << 16);
               const uint32_t p1 = ((uint32_t)pk_dot(v[2], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[3], 0x00010001u, 0) << 16);
               lmx = pk_max(lmx, pk_max(p0, p1));
               lmn = pk_min(lmn, pk_min(p0, p1));
-              Lw[r][0] = pk_bytes(p0, p1);
+              *reinterpret_cast<uint32_t *>(lp) = pk_bytes(p0, p1);
             } else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 lmx = pk_max(lmx, v[q]);
                 lmn = pk_min(lmn, v[q]);
               }
-              Lw[r][0] = pk_bytes(v[0], v[1]);
-              Lw[r][1] = pk_bytes(v[2], v[3]);
+              *reinterpret_cast<uint2 *>(lp) = make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
             }
           }
         }
       }
       // (every interior lane of the 16 row pairs inside the block rows adds, zeros included: the bias total is a constant)
-#ifndef G1S_DBG_NOATOM
       if (y_interior && ytr0 >= 3)
-#else
-      if (y_interior && ytr0 >= 3 && sd == 12345678)
-#endif
         atomicAdd(&s_sum[par][0][y_bq],
                   ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)(uint32_t)ls << 19) | (unsigned long long)(uint32_t)(sd + kFBiasY));
       if (yon && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][0][0], ywd, 4);
       if (CH && y_interior && range_bad(lmx, lmn)) s_bad[par][1][y_bq] = 1;
     }
     // ---- chroma ----
+    if constexpr (CHROMA) Lk = lraw;
 #pragma unroll
     for (int q = 0; q < CROUNDS; ++q) {
       const int c = cpl[q];
@@ -385,9 +409,6 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
         sd = __builtin_amdgcn_sdot4((int)Dc[q][1], 0x01010101, sd, false);
         int sd2 = __builtin_amdgcn_sdot4((int)Dc[q][0], (int)Dc[q][0], 0, false);
         sd2 = __builtin_amdgcn_sdot4((int)Dc[q][1], (int)Dc[q][1], sd2, false);
-#ifdef G1S_DBG_NOATOM
-        if (sd == 12345678)
-#endif
         atomicAdd(&s_sum[par][c][c_bq], ((unsigned long long)(uint32_t)sd2 << 37) | (unsigned long long)(uint32_t)(sd + kFBiasC));
       }
       if (c && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][1][0], cwd, CW_ / 8);
@@ -396,27 +417,22 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   // PLAIN: every window of the unit is its whole block (k3m_units): no column masks, every word is written
   auto phase_b = [&](auto plain_tag, const uint32_t (&wins)[4]) __attribute__((always_inline)) {
     constexpr bool PLAIN = decltype(plain_tag)::value;
-    if (wave < kFWaves - 1) {
-      uint2 cm = make_uint2(0u, 0u), lm = make_uint2(0u, 0u);
-      if (y_interior) {
-        cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(y_bq ? wins[1] : wins[0], g.lag), y_xw - 32 * y_bq);
-        if (CH) lm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(y_bq ? wins[3] : wins[2], g.lag), (y_xw >> sx) - CW_ * y_bq);
-      }
+    if constexpr (LUMA) {
+      uint2 cm = make_uint2(0u, 0u);
+      if (y_interior) cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(y_bq ? wins[1] : wins[0], g.lag), y_xw - 32 * y_bq);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int tr = ytr0 + r;
         const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
         const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][0], 0x130, 0xf, 0xf, true);  // wave_shl:1
         if (tr >= 0 && (cm.x | cm.y)) m_write_copies<!PLAIN>(m_smem + tr * SH::PY + y_xw, SH::CSY, prev1, Dy[r][0], Dy[r][1], next0, cm);
-        if constexpr (CH) {
-          const bool have = sy ? (r == 1 && tr >= 4) : tr >= 3;
-          const int cy = sy ? (tr - 4) >> 1 : tr - 3;
-          if (have && (lm.x | lm.y)) {
-            uint8_t *lp = m_smem + OFF_L + cy * SH::PC + (y_xw >> sx);
-            if (sx) *reinterpret_cast<uint32_t *>(lp) = Lw[r][0] & lm.x;
-            else *reinterpret_cast<uint2 *>(lp) = make_uint2(Lw[r][0] & lm.x, Lw[r][1] & lm.y);
-          }
-        }
+      }
+    }
+    if constexpr (CHROMA) {
+      if (l_on) {  // the unit's L tile: this thread's word, under the window columns of its chroma block
+        const int lb = (8 * l_wd / CW_) & 1;
+        const uint2 lm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(lb ? wins[3] : wins[2], g.lag), 8 * l_wd - CW_ * lb);
+        *reinterpret_cast<uint2 *>(m_smem + OFF_L + l_row * SH::PC + 8 * l_wd) = make_uint2(Lk.x & lm.x, Lk.y & lm.y);
       }
     }
 #pragma unroll
@@ -457,6 +473,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       const uint4 e0 = s_ent[k];
       const uint32_t ey = __builtin_amdgcn_readfirstlane(e0.y), ez = __builtin_amdgcn_readfirstlane(e0.z);
       const uint32_t fbits = PLAIN ? (1u << kMUnitBlocks) - 1u : __builtin_amdgcn_readfirstlane(e0.x) >> 24;
+      const uint32_t lbad = CHROMA ? __builtin_amdgcn_readfirstlane(e0.w) >> kMUnitBlocks : 0u;  // L outside int8 (luma launch)
       const uint32_t wins[4] = {ey & 0xffffu, ey >> 16, ez & 0xffffu, ez >> 16};  // luma block 0, 1; chroma block 0, 1
       __syncthreads();  // the previous unit's tiles are no longer read
       stamp(3);
@@ -472,39 +489,45 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 #pragma unroll
       for (int b = 0; b < kMUnitBlocks; ++b) {
         const bool flat_b = ((fbits >> b) & 1u) != 0;
-        const MWin wy = m_unpack(wins[b], g.lag);
-        constexpr int RPY = kBlock / kFWaves;
-        if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][0][b])) {
-          defer |= 1u << b;  // (any flat block: the exact kernel redoes its statistics too)
-        } else if (PLAIN || wy.go) {
-          m_rows_one<RPY, SH::PY>(accY, m_smem, base_luma + 32 * b, PLAIN ? ~0u : m_rowmask(wy.ys, wy.ye) >> (wave * RPY), ZOFF);
-        }
-        if constexpr (CH) {
+        if constexpr (LUMA) {
+          const MWin wy = m_unpack(wins[b], g.lag);
+          constexpr int RPY = kBlock / kFWaves;
+          if (CH && flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][1][b])) defer |= 1u << (kMUnitBlocks + b);  // L
+          if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][0][b])) {
+            defer |= 1u << b;  // (any flat block: the exact kernel redoes its statistics too)
+          } else if (PLAIN || wy.go) {
+            m_rows_one<RPY, SH::PY>(accA, m_smem, base_luma + 32 * b, PLAIN ? ~0u : m_rowmask(wy.ys, wy.ye) >> (wave * RPY), ZOFF);
+          }
+        } else {
           const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
           constexpr int RPC = CH_ / kFWaves;
-          if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][1][b])) {
+          if (flat_b && (__builtin_amdgcn_readfirstlane(s_bad[par][1][b]) || ((lbad >> b) & 1u))) {
             defer |= 1u << (kMUnitBlocks + b);
           } else if (PLAIN || wc.go) {
             const uint32_t rm = PLAIN ? ~0u : m_rowmask(wc.ys, wc.ye) >> (wave * RPC);
-            if constexpr (CW_ == 32) m_rows_two<RPC, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);
-            else m_steps_two<RPC / 2, SH::PC>(accCb, accCr, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, PLAIN ? ~0u : rm >> h, ZOFF);
+            if constexpr (CW_ == 32) m_rows_two<RPC, SH::PC>(accA, accB, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);
+            else m_steps_two<RPC / 2, SH::PC>(accA, accB, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, PLAIN ? ~0u : rm >> h, ZOFF);
           }
         }
       }
-      // ---- the unit's statistics record (k3m_finish scatters it) ----
+      // ---- the unit's statistics record (k3m_finish scatters it): this launch's entries ----
       if (tid < kMStatInts) {
-        // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14: the deferral bits
+        // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14 / 15: the deferral
+        // bits of the luma / chroma launch
         const int b = tid >= 7 ? 1 : 0, e = tid - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
-        int val = (int)defer;
-        if (tid < 14) {
-          const unsigned long long pk = s_sum[par][c][b];
-          // contributing lanes per block: luma 16 row pairs x 4 words, chroma CBH rows x CBW / 8 words
-          const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
-          if (f == 1) val = (int)(pk >> 37);
-          else if (f == 2) val = (int)((pk >> 19) & 0x3ffffu);
-          else val = (int)(c == 0 ? (pk & 0x7ffffu) : (pk & 0x1fffffffffull)) - bias;
+        const bool mine = tid < 14 ? (LUMA ? c == 0 : c != 0) : tid == 14 + PL;
+        if (mine) {
+          int val = (int)defer;
+          if (tid < 14) {
+            const unsigned long long pk = s_sum[par][c][b];
+            // contributing lanes per block: luma 16 row pairs x 4 words, chroma CBH rows x CBW / 8 words
+            const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
+            if (f == 1) val = (int)(pk >> 37);
+            else if (f == 2) val = (int)((pk >> 19) & 0x3ffffu);
+            else val = (int)(c == 0 ? (pk & 0x7ffffu) : (pk & 0x1fffffffffull)) - bias;
+          }
+          ustats[(size_t)upos(k) * kMStatInts + tid] = val;
         }
-        ustats[(size_t)upos(k) * kMStatInts + tid] = val;
       }
       stamp(2);
       // ---- the next unit's words have had this whole iteration to land: their arithmetic runs behind the multiplies ----
@@ -515,10 +538,8 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
           stamp(4);
         }
 #endif
-        phase_a(par ^ 1);
-#ifndef G1S_DBG_NOREQ
+        phase_a(k + 1);
         if (k + 2 < nmine) request(k + 2);
-#endif
         stamp(5);
       }
     }
@@ -533,9 +554,10 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 #endif
 
   // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
+  constexpr int NPL = LUMA ? 1 : 2, PL0 = LUMA ? 0 : 1;  // planes of this launch
   long long *s_S = reinterpret_cast<long long *>(m_smem);
   __syncthreads();
-  for (int k = tid; k < 3 * kMRec; k += kFThreads) s_S[k] = 0;
+  for (int k = tid; k < NPL * kMRec; k += kFThreads) s_S[k] = 0;
   __syncthreads();
   auto flush = [&](const v16i32 &acc, int c) {
     const bool ch = c > 0;
@@ -550,17 +572,14 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       if (ec == nc) idx = nc * nc + er;
       else if (er <= ec) idx = er * nc + ec;
       if (idx >= 0 && acc[r] != 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(&s_S[c * kMRec + idx]), (unsigned long long)(long long)acc[r]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&s_S[(c - PL0) * kMRec + idx]), (unsigned long long)(long long)acc[r]);
     }
   };
-  flush(accY, 0);
-  if (CH) {
-    flush(accCb, 1);
-    flush(accCr, 2);
-  }
+  flush(accA, PL0);
+  if (CHROMA) flush(accB, 2);
   __syncthreads();
-  long long *out = fpar.partials + ((size_t)frame * G + wg) * 3 * kMRec;
-  for (int k = tid; k < 3 * kMRec; k += kFThreads) out[k] = s_S[k];
+  long long *out = fpar.partials + (((size_t)frame * G + wg) * 3 + PL0) * kMRec;
+  for (int k = tid; k < NPL * kMRec; k += kFThreads) out[k] = s_S[k];
 }
 
 }  // namespace g1s

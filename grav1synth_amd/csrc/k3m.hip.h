@@ -315,7 +315,8 @@ __device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const ui
 // k3m_finish: what the accumulation workgroups left behind -> the frame's record.
 //   x < nplanes:  the G partial systems of plane x, summed, + nobs of the blocks that were multiplied;
 //   x >= nplanes: the per-unit statistics records (kMStatInts ints a unit: per block sum d, sum d^2, sum src8 of
-//                 luma, sum d, sum d^2 of Cb and Cr; then the deferral bits kind * 2 + block) -> block statistics
+//                 luma, sum d, sum d^2 of Cb and Cr; then the deferral bits kind * 2 + block of the luma and of the
+//                 chroma launch) -> block statistics
 //                 of the flat blocks, `only` flags of the deferred ones.
 // grid = (nplanes + kMFinishWgs, batch), block = 256.
 // ---------------------------------------------------------------------------------
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
     for (uint32_t v = threadIdx.x; v < cnt; v += 256) {
       const uint32_t u = upos(v);
       const uint32_t wz = units[(size_t)u * kMUnitDwords + (c > 0 ? 2 : 1)];
-      const uint32_t defer = (uint32_t)us[(size_t)u * kMStatInts + 14] >> (c > 0 ? kMUnitBlocks : 0);
+      const uint32_t defer = ((uint32_t)us[(size_t)u * kMStatInts + 14] | (g.nplanes == 3 ? (uint32_t)us[(size_t)u * kMStatInts + 15] : 0u)) >>
+                             (c > 0 ? kMUnitBlocks : 0);
 #pragma unroll
       for (int b = 0; b < kMUnitBlocks; ++b) {
         const MWin w = m_unpack((wz >> (16 * b)) & 0xffffu, g.lag);
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
     const uint32_t e0 = units[(size_t)u * kMUnitDwords];
     const int bx0 = kMUnitBlocks * (int)(e0 & 0xfffu), by = (int)((e0 >> 12) & 0xfffu);
     const int32_t *r = us + (size_t)u * kMStatInts;
-    const uint32_t defer = (uint32_t)r[14];
+    const uint32_t defer = (uint32_t)r[14] | (chroma ? (uint32_t)r[15] : 0u);  // (the luma and the chroma launch)
 #pragma unroll
     for (int b = 0; b < kMUnitBlocks; ++b) {
       if (!((e0 >> (24 + b)) & 1u)) continue;
