@@ -871,10 +871,17 @@ int g1s_diff::launch_back(int si) {
     else if (bpsm == 1) G1S_F(CW, CH, 1, PL); \
     else G1S_F(CW, CH, 0, PL);             \
   } while (0)
-#define G1S_FP(CW, CH)  \
-  do {                  \
-    G1S_FS(CW, CH, 0);  \
-    G1S_FS(CW, CH, 1);  \
+    // (the chroma launch, the finisher and what follows go to the copy stream -- next to the luma launch of the batch after)
+    static const bool chroma_aside = getenv("G1S_F_SERIAL") == nullptr;  // tuning aid
+#define G1S_FP(CW, CH)                                                    \
+  do {                                                                    \
+    G1S_FS(CW, CH, 0);                                                    \
+    if (side && chroma_aside) {                                           \
+      HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));               \
+      HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));       \
+      stream = ss.copy;                                                   \
+    }                                                                     \
+    G1S_FS(CW, CH, 1);                                                    \
   } while (0)
     if (cbw == 0) G1S_FS(0, 0, 0);
     else if (cbw == 16 && cbh == 16) G1S_FP(16, 16);

@@ -13,7 +13,7 @@
 // to a SIMD, and a 16-20 KB tile set.  The luma launch leaves L behind as an int8 plane at chroma
 // resolution (2 MB a 4K frame) for the chroma launch.
 // Workgroup = 4 waves, unit = 2 adjacent blocks of a block row (k3m_units).  Per unit:
-//   staging   luma: a wave takes 5 row pairs, a lane one 8-sample word of both rows (the two rows under a
+//   staging   luma: waves 0-2 take 6 row pairs each, a lane one 8-sample word of both rows (the two rows under a
 //             4:2:0 chroma row: L needs no cross-lane traffic), source and denoised: four 16-byte loads.
 //             Chroma: waves 0, 1 take the rows of Cb, waves 2, 3 those of Cr, a lane one word of one row.
 //             A residual (or L) outside int8 flags the blocks whose tile holds it: they are left to the
@@ -125,7 +125,9 @@ struct FShape {
   // luma tile: rows -3 .. 31, samples -8 .. 71 of the chunk
   static constexpr int PY = m_pitch(32), WY = PY / 8, CSY = m_copy_stride(32, kBlock);
   static constexpr int PAIRS = (kBlock + 4) / 2;                                     // row pairs of the tile
-  static constexpr int PPJ = (64 / WY) < (PAIRS + kFWaves - 1) / kFWaves ? (64 / WY) : (PAIRS + kFWaves - 1) / kFWaves;  // ... per wave
+  // ... per wave: as many as fit its 64 lanes.  The kernels are bound by the number of vector instructions the SIMDs issue, not
+  // by a wave's latency: three full waves (and an idle one) issue a quarter less than four waves of five pairs
+  static constexpr int PPJ = 64 / WY;
   static_assert(PPJ * kFWaves >= PAIRS, "luma row pairs: one job per wave");
   // chroma tiles: rows -3 .. CBH-1
   static constexpr int PC = m_pitch(CW_), WC = PC / 8, CSC = m_copy_stride(CW_, CH_);
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   // luma: pair ypair = tile rows 2 ypair - 1, 2 ypair (= block rows 2 ypair - 4, 2 ypair - 3)
   const int ypl = lane / SH::WY, ywd = lane - ypl * SH::WY;
   const int ypair = wave * SH::PPJ + ypl;
+  const bool y_wave = wave * SH::PPJ < SH::PAIRS;  // this wave has luma row pairs
   const bool yon = LUMA && ypl < SH::PPJ && ypair < SH::PAIRS;
   const int ytr0 = yon ? 2 * ypair - 1 : -9;
   // chroma: waves 0, 1 stage Cb, waves 2, 3 Cr; round k, tile row (2 k + (wave & 1)) * RPW + lane / WC
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       }
       return;
     }
-    if constexpr (LUMA) {
+    if (LUMA && y_wave) {
       // (pointers to the unit's origin: not dereferenced where the origin lies outside the plane)
       const uint8_t *sb = fp.src[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.src_stride[0] + (ptrdiff_t)X0y * sbps);
       const uint8_t *db = fp.den[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.den_stride[0] + (ptrdiff_t)X0y * dbps);
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   const int c_xw = 8 * (cwd - 1), c_bq = (c_xw / CW_) & 1;   // chroma word
   auto phase_a = [&](int k) __attribute__((always_inline)) {
     const int par = k & 1;
-    if constexpr (LUMA) {
+    if (LUMA && y_wave) {
       // ---- luma: residuals of the two rows, their statistics, L ----
       uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0, keep16[4] = {0, 0, 0, 0};
       int sd = 0, sd2 = 0, ls = 0;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   // PLAIN: every window of the unit is its whole block (k3m_units): no column masks, every word is written
   auto phase_b = [&](auto plain_tag, const uint32_t (&wins)[4]) __attribute__((always_inline)) {
     constexpr bool PLAIN = decltype(plain_tag)::value;
-    if constexpr (LUMA) {
+    if (LUMA && y_wave) {
       uint2 cm = make_uint2(0u, 0u);
       if (y_interior) cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(y_bq ? wins[1] : wins[0], g.lag), y_xw - 32 * y_bq);
 #pragma unroll
