@@ -854,7 +854,9 @@ int g1s_diff::launch_back(int si) {
     fq.lpitch = m_lpitch;
     fq.lframe_bytes = m_lframe;
     static const size_t lds_pad = getenv("G1S_F_LDS_PAD") ? (size_t)atoi(getenv("G1S_F_LDS_PAD")) : 0;  // tuning aid: fewer workgroups to a CU
-    const dim3 gr(G, 1, B);
+    fq.frames = (int)B;
+    fq.wgs = G;
+    const dim3 gr((uint32_t)G * B);
     const int bpsm = g.src_bps == g.den_bps ? g.src_bps : 0;  // bytes per sample at compile time unless the depths are mixed
     // two launches: the luma plane (which leaves L behind), then the two chroma planes
 #define G1S_F(CW, CH, BP, PL)                                                                                        \
@@ -902,7 +904,7 @@ int g1s_diff::launch_back(int si) {
         for (int v = 0; v < kFWaves; ++v)
           for (int k = 0; k < 6; ++k) tot[v][k] += (double)hc[(w * kFWaves + v) * 6 + k];
       for (int v = 0; v < kFWaves; ++v)
-        fprintf(stderr, "k3f phases, wave %d: copies %.0f  barrier %.0f  multiply %.0f  barrier %.0f  wait for words %.0f  residuals %.0f  (mean cycles per workgroup)\n",
+        fprintf(stderr, "k3f phases, wave %d: copies %.0f  barrier %.0f  multiply %.0f  requests + barrier %.0f  wait for words %.0f  residuals %.0f  (mean cycles per workgroup)\n",
                 v, tot[v][0] / (G * B), tot[v][1] / (G * B), tot[v][2] / (G * B), tot[v][3] / (G * B), tot[v][4] / (G * B), tot[v][5] / (G * B));
     }
     hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,

@@ -49,6 +49,7 @@ struct FParams {
   int nunits;
   uint8_t *lplane;        // [batch][lrows][lpitch]  L (sum of the co-located luma residuals) at chroma resolution, int8
   uint32_t lpitch, lframe_bytes;
+  int frames, wgs;        // the launch: frames x workgroups per frame, as a 1-D grid (see the kernel)
   long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][6] cycles: tile copies, barrier, multiply, barrier, wait for the words, residuals + requests; or null
 };
 
@@ -166,18 +167,18 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   __shared__ unsigned long long s_sum[2][3][kMUnitBlocks];
   __shared__ int s_bad[2][2][kMUnitBlocks];  // [unit parity][kind][block]
 
-  const int frame = g.frame0 + (int)blockIdx.z;
-  const int G = gridDim.x, wg = blockIdx.x;
+  // Workgroup b of the 1-D grid runs on XCD b % 8, and workgroups b, b + 256, ... share a CU (observed; speed only).  With
+  // frame = b % frames (frames a multiple of 8, or few), the workgroups on a CU work on ONE frame -- few distinct pages under
+  // the CU's address translation cache: issuing a load costs hundreds of cycles when it misses there -- and a frame's
+  // workgroups share an XCD, i.e. the L2 the 128-byte lines under their units' halo columns are read through.
+  const int G = fpar.wgs, frame = g.frame0 + (int)blockIdx.x % fpar.frames, wg = (int)blockIdx.x / fpar.frames;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Workgroup b runs on XCD b % 8 (observed; speed only).  An XCD owns a contiguous eighth of each of the frame's two unit
-  // lists and deals it round-robin to its workgroups of this frame: horizontally adjacent units -- which share the
-  // 128-byte lines their halo columns sit in -- are then read at about the same time through the same L2.
-  const int xcd = wg & 7, jx = wg >> 3, nx = (G + 7 - xcd) >> 3;  // this workgroup's rank among the nx of its XCD
+  // the frame's two unit lists are dealt round-robin to its workgroups: adjacent units at about the same time
+  const int nx = G, jx = wg;
   const uint32_t cnt_g = fpar.unit_count[2 * frame], cnt_p = fpar.unit_count[2 * frame + 1];
   auto share = [&](uint32_t cnt, uint32_t &first, int &n) {  // positions first, first + nx, ... (n of them) of a list of cnt
-    const uint32_t c0 = (uint32_t)((unsigned long long)cnt * xcd / 8), c1 = (uint32_t)((unsigned long long)cnt * (xcd + 1) / 8);
-    first = c0 + (uint32_t)jx;
-    n = c1 > first ? (int)((c1 - first + (uint32_t)nx - 1) / (uint32_t)nx) : 0;
+    first = (uint32_t)jx;
+    n = cnt > first ? (int)((cnt - first + (uint32_t)nx - 1) / (uint32_t)nx) : 0;
   };
   uint32_t first_p, first_g;
   int n_p, n_g;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       if (l_on) lraw = *reinterpret_cast<const uint2 *>(lplane + (size_t)(by * CH_ + l_row) * fpar.lpitch + bx0 * CW_ + 8 * l_wd);
     }
     const bool slow = !vec_all || (LUMA ? ((g.W & 7) != 0 && X0y + SH::PY > g.W) : ((cpw & 7) != 0 && X0c + SH::PC > cpw));
+#ifndef G1S_DBG_NOSLOW
     if (__builtin_expect(slow, 0)) {
       if constexpr (LUMA) {
 #pragma unroll
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       }
       return;
     }
+#endif
     if (LUMA && y_wave) {
       // (pointers to the unit's origin: not dereferenced where the origin lies outside the plane)
       const uint8_t *sb = fp.src[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.src_stride[0] + (ptrdiff_t)X0y * sbps);
@@ -480,7 +483,9 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       const uint32_t wins[4] = {ey & 0xffffu, ey >> 16, ez & 0xffffu, ez >> 16};  // luma block 0, 1; chroma block 0, 1
       __syncthreads();  // the previous unit's tiles are no longer read
       stamp(3);
+#ifndef G1S_DBG_NOCOPY
       phase_b(plain_tag, wins);
+#endif
       // (the sums and flags of the unit before this one: read in its multiply phase, written again two units on)
       if (tid >= 64 && tid < 64 + 3 * kMUnitBlocks) (&s_sum[par ^ 1][0][0])[tid - 64] = 0ull;
       else if (tid >= 128 && tid < 128 + 2 * kMUnitBlocks) (&s_bad[par ^ 1][0][0])[tid - 128] = 0;
@@ -499,7 +504,9 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
           if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][0][b])) {
             defer |= 1u << b;  // (any flat block: the exact kernel redoes its statistics too)
           } else if (PLAIN || wy.go) {
+#ifndef G1S_DBG_NOMFMA
             m_rows_one<RPY, SH::PY>(accA, m_smem, base_luma + 32 * b, PLAIN ? ~0u : m_rowmask(wy.ys, wy.ye) >> (wave * RPY), ZOFF);
+#endif
           }
         } else {
           const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
@@ -508,8 +515,11 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
             defer |= 1u << (kMUnitBlocks + b);
           } else if (PLAIN || wc.go) {
             const uint32_t rm = PLAIN ? ~0u : m_rowmask(wc.ys, wc.ye) >> (wave * RPC);
+#ifndef G1S_DBG_NOMFMA
             if constexpr (CW_ == 32) m_rows_two<RPC, SH::PC>(accA, accB, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);
             else m_steps_two<RPC / 2, SH::PC>(accA, accB, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, PLAIN ? ~0u : rm >> h, ZOFF);
+#endif
+            (void)rm;
           }
         }
       }
@@ -541,9 +551,19 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
           stamp(4);
         }
 #endif
+#ifndef G1S_DBG_NOA
         phase_a(k + 1);
+#endif
+#ifdef G1S_F_PHASES
+        if (fpar.phase_cycles) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          stamp(5);
+        }
+#endif
+#ifndef G1S_DBG_NOREQ
         if (k + 2 < nmine) request(k + 2);
-        stamp(5);
+#endif
+        stamp(3);  // (with G1S_F_PHASES: slot 3 = the requests + the wait at barrier 1)
       }
     }
   };
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   run(std::false_type{}, n_p, nmine);
 #ifdef G1S_F_PHASES
   if (fpar.phase_cycles && lane == 0) {
-    long long *o = fpar.phase_cycles + (((size_t)blockIdx.z * G + wg) * kFWaves + wave) * 6;
+    long long *o = fpar.phase_cycles + ((size_t)blockIdx.x * kFWaves + wave) * 6;
     for (int k = 0; k < 6; ++k) o[k] = t_ph[k];
   }
 #endif
