@@ -76,6 +76,9 @@ __device__ __forceinline__ void f_narrow(const u32x4 &v, int rbps, int shift, ui
 template <int BPS>
 __device__ __forceinline__ u32x4 f_load(const uint8_t *base, uint32_t off, int rbps, bool ok) {
   u32x4 r = {0u, 0u, 0u, 0u};
+  // (opaque to the optimiser: it would otherwise keep a 64-bit copy of the offset across the unit loop and lose the
+  //  scalar-base + 32-bit-offset form of the load)
+  asm volatile("" : "+v"(off));
   if (ok) {
     gptr_u8 p = as_global(base) + off;
     if (f_bps<BPS>(rbps) == 2) {
@@ -227,6 +230,14 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
     cpl[k] = on ? cplane : 0;
     ctr[k] = on ? rr : 0;
   }
+  // the lane's words: byte offsets from the unit's origin (tile row 0, sample -8 of the chunk), kept across the units
+  // (chroma launch; the luma launch has no registers to spare and works them out at each request)
+  uint32_t cso[NCR], cdo[NCR];
+#pragma unroll
+  for (int k = 0; k < CROUNDS; ++k) {
+    cso[k] = (uint32_t)ctr[k] * c_sst + (uint32_t)(8 * cwd * sbps);
+    cdo[k] = (uint32_t)ctr[k] * c_dst + (uint32_t)(8 * cwd * dbps);
+  }
   // planes whose rows are 16-byte aligned take the vector loads; a chunk that reaches over the right plane edge
   // inside a word (W % 8 != 0) and unaligned planes go sample by sample
   const bool vec_all = (g.vec_mask & (LUMA ? 0x09 : 0x36)) == (LUMA ? 0x09 : 0x36);
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   u32x4 cs_[NCR], cd_[NCR];  // chroma raw words: one row a round
   uint2 lraw = make_uint2(0u, 0u), Lk = make_uint2(0u, 0u);  // chroma launch: this thread's word of the L tile (requested / of the unit being staged)
   uint32_t Dy[2][2], Dc[NCR][2];  // residual bytes of the luma rows / of the chroma rows
+  uint32_t Lw00 = 0, Lw01 = 0, Lw10 = 0, Lw11 = 0;  // luma launch: the L bytes under the lane's rows (scalars: an array the lambdas share goes to scratch)
   const bool l_on = CHROMA && tid < SH::NL;
   constexpr int LWR = kMUnitBlocks * CW_ / 8;  // 8-byte words of an L tile row
   const int l_row = tid / LWR, l_wd = tid - l_row * LWR;
@@ -292,16 +304,18 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       // (pointers to the unit's origin: not dereferenced where the origin lies outside the plane)
       const uint8_t *sb = fp.src[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.src_stride[0] + (ptrdiff_t)X0y * sbps);
       const uint8_t *db = fp.den[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.den_stride[0] + (ptrdiff_t)X0y * dbps);
-      const bool xok = X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W;
+      // a unit whose tile lies inside the plane (all but the frame's border units) needs no per-lane bounds
+      const bool inside = X0y >= 0 && X0y + SH::PY <= g.W && Y0y >= 0 && Y0y + kBlock + 3 <= g.H;
+      const bool xok = inside || (X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W);
       // (the lane's offsets from the unit's origin are worked out here from values the optimiser cannot see through:
-      //  hoisted out of the unit loop they would cost two registers a load -- and a spill, whose reload from scratch
-      //  waits for every load in flight)
+      //  hoisted out of the unit loop they cost registers -- and a spill, whose reload from scratch waits for every
+      //  load in flight)
       int l_tr = ytr0, l_w = ywd;
       asm volatile("" : "+v"(l_tr), "+v"(l_w));
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int Y = Y0y + ytr0 + r;
-        const bool ok = xok && ytr0 + r >= 0 && Y >= 0 && Y < g.H;
+        const bool ok = xok && ytr0 + r >= 0 && (inside || (Y >= 0 && Y < g.H));
         ys_[r] = f_load<BPS>(sb, (uint32_t)max(l_tr + r, 0) * fp.src_stride[0] + (uint32_t)(8 * l_w * sbps), g.src_bps, ok);
         yd_[r] = f_load<BPS>(db, (uint32_t)max(l_tr + r, 0) * fp.den_stride[0] + (uint32_t)(8 * l_w * dbps), g.den_bps, ok);
       }
@@ -309,17 +323,14 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
     if constexpr (CHROMA) {
       const uint8_t *sb = c_src + ((ptrdiff_t)Y0c * (ptrdiff_t)c_sst + (ptrdiff_t)X0c * sbps);
       const uint8_t *db = c_den + ((ptrdiff_t)Y0c * (ptrdiff_t)c_dst + (ptrdiff_t)X0c * dbps);
-      const bool xok = X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw;
-      int l_w = cwd;
-      asm volatile("" : "+v"(l_w));
+      const bool inside = X0c >= 0 && X0c + SH::PC <= cpw && Y0c >= 0 && Y0c + CH_ + 3 <= cph;
+      const bool xok = inside || (X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw);
 #pragma unroll
       for (int q = 0; q < CROUNDS; ++q) {
         const int Y = Y0c + ctr[q];
-        const bool ok = xok && cpl[q] != 0 && Y >= 0 && Y < cph;
-        int l_tr = ctr[q];
-        asm volatile("" : "+v"(l_tr));
-        cs_[q] = f_load<BPS>(sb, (uint32_t)l_tr * c_sst + (uint32_t)(8 * l_w * sbps), g.src_bps, ok);
-        cd_[q] = f_load<BPS>(db, (uint32_t)l_tr * c_dst + (uint32_t)(8 * l_w * dbps), g.den_bps, ok);
+        const bool ok = xok && cpl[q] != 0 && (inside || (Y >= 0 && Y < cph));
+        cs_[q] = f_load<BPS>(sb, cso[q], g.src_bps, ok);
+        cd_[q] = f_load<BPS>(db, cdo[q], g.den_bps, ok);
       }
     }
   };
@@ -374,20 +385,28 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
             cy = tr - 3;
           }
           if (have && y_interior) {
-            uint8_t *lp = lplane + (size_t)(by * CH_ + cy) * fpar.lpitch + bx0 * CW_ + (y_xw >> sx);
             if (sx) {
               const uint32_t p0 = ((uint32_t)pk_dot(v[0], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[1], 0x00010001u, 0) << 16);
               const uint32_t p1 = ((uint32_t)pk_dot(v[2], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[3], 0x00010001u, 0) << 16);
               lmx = pk_max(lmx, pk_max(p0, p1));
               lmn = pk_min(lmn, pk_min(p0, p1));
-              *reinterpret_cast<uint32_t *>(lp) = pk_bytes(p0, p1);
+              const uint32_t lw = pk_bytes(p0, p1);
+              if (r == 0) Lw00 = lw;
+              else Lw10 = lw;
             } else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 lmx = pk_max(lmx, v[q]);
                 lmn = pk_min(lmn, v[q]);
               }
-              *reinterpret_cast<uint2 *>(lp) = make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
+              const uint32_t la = pk_bytes(v[0], v[1]), lb = pk_bytes(v[2], v[3]);
+              if (r == 0) {
+                Lw00 = la;
+                Lw01 = lb;
+              } else {
+                Lw10 = la;
+                Lw11 = lb;
+              }
             }
           }
         }
@@ -418,6 +437,28 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
         atomicAdd(&s_sum[par][c][c_bq], ((unsigned long long)(uint32_t)sd2 << 37) | (unsigned long long)(uint32_t)(sd + kFBiasC));
       }
       if (c && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][1][0], cwd, CW_ / 8);
+    }
+  };
+  // the L words of unit k -> the L plane (luma launch).  Global stores share the loads' counter: issued BEHIND a request they
+  // have an iteration to drain; issued before it, the request's first load waits for them (microseconds)
+  auto export_l = [&](int k) __attribute__((always_inline)) {
+    if constexpr (LUMA && CH) {
+      if (y_wave && y_interior) {
+        const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
+        const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int tr = ytr0 + r;
+          const bool have = sy ? (r == 1 && tr >= 4) : tr >= 3;
+          const int cy = sy ? (tr - 4) >> 1 : tr - 3;
+          if (have) {
+            uint8_t *lp = lplane + (size_t)(by * CH_ + cy) * fpar.lpitch + bx0 * CW_ + (y_xw >> sx);
+            const uint32_t la = r == 0 ? Lw00 : Lw10, lb = r == 0 ? Lw01 : Lw11;
+            if (sx) *reinterpret_cast<uint32_t *>(lp) = la;
+            else *reinterpret_cast<uint2 *>(lp) = make_uint2(la, lb);
+          }
+        }
+      }
     }
   };
   // PLAIN: every window of the unit is its whole block (k3m_units): no column masks, every word is written
@@ -469,6 +510,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
     request(0);
     phase_a(0);
     if (nmine > 1) request(1);
+    export_l(0);
   }
   // units [k0, k1) of this workgroup's sequence; two calls (plain units, then the others) are ONE pipeline: the residuals and
   // requests a unit of the first loop prepares belong to units of the second
@@ -523,25 +565,6 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
           }
         }
       }
-      // ---- the unit's statistics record (k3m_finish scatters it): this launch's entries ----
-      if (tid < kMStatInts) {
-        // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14 / 15: the deferral
-        // bits of the luma / chroma launch
-        const int b = tid >= 7 ? 1 : 0, e = tid - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
-        const bool mine = tid < 14 ? (LUMA ? c == 0 : c != 0) : tid == 14 + PL;
-        if (mine) {
-          int val = (int)defer;
-          if (tid < 14) {
-            const unsigned long long pk = s_sum[par][c][b];
-            // contributing lanes per block: luma 16 row pairs x 4 words, chroma CBH rows x CBW / 8 words
-            const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
-            if (f == 1) val = (int)(pk >> 37);
-            else if (f == 2) val = (int)((pk >> 19) & 0x3ffffu);
-            else val = (int)(c == 0 ? (pk & 0x7ffffu) : (pk & 0x1fffffffffull)) - bias;
-          }
-          ustats[(size_t)upos(k) * kMStatInts + tid] = val;
-        }
-      }
       stamp(2);
       // ---- the next unit's words have had this whole iteration to land: their arithmetic runs behind the multiplies ----
       if (k + 1 < nmine) {
@@ -563,8 +586,28 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 #ifndef G1S_DBG_NOREQ
         if (k + 2 < nmine) request(k + 2);
 #endif
-        stamp(3);  // (with G1S_F_PHASES: slot 3 = the requests + the wait at barrier 1)
+        export_l(k + 1);
       }
+      // ---- the unit's statistics record (k3m_finish scatters it): this launch's entries; behind the request, like the L words ----
+      if (tid < kMStatInts) {
+        // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14 / 15: the deferral
+        // bits of the luma / chroma launch
+        const int b = tid >= 7 ? 1 : 0, e = tid - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
+        const bool mine = tid < 14 ? (LUMA ? c == 0 : c != 0) : tid == 14 + PL;
+        if (mine) {
+          int val = (int)defer;
+          if (tid < 14) {
+            const unsigned long long pk = s_sum[par][c][b];
+            // contributing lanes per block: luma 16 row pairs x 4 words, chroma CBH rows x CBW / 8 words
+            const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
+            if (f == 1) val = (int)(pk >> 37);
+            else if (f == 2) val = (int)((pk >> 19) & 0x3ffffu);
+            else val = (int)(c == 0 ? (pk & 0x7ffffu) : (pk & 0x1fffffffffull)) - bias;
+          }
+          ustats[(size_t)upos(k) * kMStatInts + tid] = val;
+        }
+      }
+      stamp(3);  // (with G1S_F_PHASES: slot 3 = the requests, the stores, the wait at barrier 1)
     }
   };
   run(std::true_type{}, 0, n_p);
