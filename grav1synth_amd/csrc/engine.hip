@@ -38,16 +38,27 @@ thread_local std::string g_global_error;
 constexpr uint32_t kDefaultBatch = 32;
 constexpr int kK3Chunks = 48;
 
-// The AR accumulation runs fused with the residual pass on the matrix cores (k3f.hip.h) unless G1S_K3=dot4 asks
-// for round 1's chain -- K0 pixel pass, int8 planes, lag-structured v_dot4 kernels (k0.hip.h, k3q.hip.h) -- which is
-// kept so that the two can be compared bit for bit.
-bool use_mfma() {
-  static const bool v = [] {
+// The AR accumulation is an exact int8 SYRK on the matrix cores (k3f.hip.h). G1S_K3 selects where its bytes come from:
+//   fused (default)   the accumulation kernel reads the source / denoised planes of the flat blocks' tiles itself and takes
+//                     the block statistics on the way: no pixel pass but the finder's moments of the luma source, no
+//                     intermediate planes (HBM traffic below the algorithmic bytes when not every block is flat);
+//   planes            the pixel pass K0 (k0.hip.h: one streaming pass -> int8 residual and L planes, block statistics,
+//                     the finder's moments) runs first, the accumulation kernel stages K0's planes (a copy);
+//   dot4              round 1's chain -- K0, then the lag-structured v_dot4 kernels (k3q.hip.h).
+// All three are bit-exact against each other and the oracle (tests/test_gpu_k3_modes.py); fused and planes measure the
+// same on the 4K workload ("What bounds the pass").
+int k3_mode() {
+  static const int v = [] {
     const char *e = getenv("G1S_K3");
-    return !(e && std::strcmp(e, "dot4") == 0);
+    if (e && std::strcmp(e, "dot4") == 0) return 0;
+    if (e && std::strcmp(e, "planes") == 0) return 2;
+    return 1;
   }();
   return v;
 }
+bool use_mfma() { return k3_mode() != 0; }
+bool use_k0() { return k3_mode() != 1; }
+bool use_planes() { return k3_mode() == 2; }
 constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per CU, one round
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
 int m_wgs_per_frame(int nunits, int B) {
@@ -220,6 +231,7 @@ struct StreamSet {
   hipEvent_t kernels_done[kSlots] = {};
   hipEvent_t mask_done[kSlots] = {};
   hipEvent_t pix_done[kSlots] = {};
+  hipEvent_t k0_done[kSlots] = {};
   hipEvent_t table_done[kSlots] = {};
 };
 std::vector<StreamSet> g_stream_cache;
@@ -248,6 +260,7 @@ bool acquire_streams(int device, StreamSet &out) {
     ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&out.pix_done[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&out.k0_done[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&out.table_done[i], hipEventDisableTiming) == hipSuccess;
   return ok;
 }
@@ -439,13 +452,17 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     frame_bytes += ((pw * d->bytes_per_sample + 15) & ~size_t(15)) * ph;
   }
   size_t partial_bytes = 0, k0_bytes = 0, pgl_bytes = 0;
-  if (!use_mfma()) {  // the lag-structured path serves every lag (1 and 2 through lag-3 tiles and a scratch lag-3 system)
-    partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart + kAr3);
+  defer_bytes = 0;
+  if (use_k0()) {
     const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
-    // [cls][bad][lists u32 x6 per frame][counts]
-    defer_bytes = 2 * cls_bytes + sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 8);
+    // [cls][bad][lists u32 x6 per frame][counts]   (the matrix-core path: [cls][bad] only)
+    defer_bytes = 2 * cls_bytes;
     ps = make_planeset(g);
     k0_bytes = (size_t)ps.frame_bytes * batch;
+  }
+  if (!use_mfma()) {  // the lag-structured path serves every lag (1 and 2 through lag-3 tiles and a scratch lag-3 system)
+    partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart + kAr3);
+    defer_bytes += sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 8);
     pg_cap = (uint32_t)g.nblocks * 256u;
     pgl_bytes = sizeof(uint32_t) * ((size_t)batch * 2 * pg_cap + (size_t)batch * 2);
   }
@@ -453,14 +470,16 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
   m_only_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   // [units][unit counts][any-deferred flags][deferred-block flags]
   // ... [per-unit statistics records]
-  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch) + m_only_bytes +
-                          sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
-  const size_t mpart_bytes = sizeof(long long) * 3 * kMRec *
-                             ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits + 8) + 4096 + batch);
+  const size_t mu_bytes = !use_mfma() ? 0
+                                      : sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch) + m_only_bytes +
+                                            sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
+  const size_t mpart_bytes = !use_mfma() ? 0
+                                         : sizeof(long long) * 3 * kMRec *
+                                               ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits + 8) + 4096 + batch);
   // L plane of a frame: block rows x chunk columns at chroma resolution (+ a slack row)
   m_lpitch = g.nplanes == 3 ? (uint32_t)((((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * kMUnitBlocks * (kBlock >> g.xdec) + 15) & ~15) : 0u;
   m_lframe = m_lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec) + 1);
-  const size_t lplane_bytes = use_mfma() ? (size_t)m_lframe * batch : 0;
+  const size_t lplane_bytes = k3_mode() == 1 ? (size_t)m_lframe * batch : 0;
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
                      partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes, mpart_bytes, lplane_bytes,
                      g.W, g.H, g.xdec, g.ydec, g.nplanes};
@@ -484,17 +503,16 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
     HIP_TRY(hipHostMalloc((void **)&sl.h_records, slot_key.records, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&sl.d_flags, slot_key.flags));
     HIP_TRY(hipMalloc((void **)&sl.d_k1, sizeof(int32_t) * ((size_t)g.nblocks * batch * (kMomInts + 1) + batch)));
-    if (partial_bytes) {
-      HIP_TRY(hipMalloc((void **)&sl.d_partials, partial_bytes));
-      HIP_TRY(hipMalloc((void **)&sl.d_defer, defer_bytes));
+    if (partial_bytes) HIP_TRY(hipMalloc((void **)&sl.d_partials, partial_bytes));
+    if (defer_bytes) HIP_TRY(hipMalloc((void **)&sl.d_defer, defer_bytes));
+    if (k0_bytes) {
       HIP_TRY(hipMalloc((void **)&sl.d_k0, k0_bytes));
-      HIP_TRY(hipMemset(sl.d_k0, 0, k0_bytes));  // the padding of the w8 planes stays zero for good
-      HIP_TRY(hipMalloc((void **)&sl.d_pgl, pgl_bytes));
-    } else {
-      HIP_TRY(hipMalloc((void **)&sl.d_mu, mu_bytes));
-      HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes));
-      if (lplane_bytes) HIP_TRY(hipMalloc((void **)&sl.d_lplane, lplane_bytes));
+      HIP_TRY(hipMemset(sl.d_k0, 0, k0_bytes));  // the padding of the planes stays zero for good
     }
+    if (pgl_bytes) HIP_TRY(hipMalloc((void **)&sl.d_pgl, pgl_bytes));
+    if (mu_bytes) HIP_TRY(hipMalloc((void **)&sl.d_mu, mu_bytes));
+    if (mpart_bytes) HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes));
+    if (lplane_bytes) HIP_TRY(hipMalloc((void **)&sl.d_lplane, lplane_bytes));
     HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
   }
@@ -636,7 +654,7 @@ int g1s_diff::launch_front(int si) {
   // the pixel pass of round 1's chain (K0) runs on the main stream; the fused pass has no K0: its only pixel pass before
   // the mask is the finder's luma-source moments kernel, which joins the finder chain on the side stream and runs next to
   // the accumulation of the batch before
-  hipStream_t pstream = use_mfma() ? fstream : stream;
+  hipStream_t pstream = use_k0() ? stream : fstream;
   // the frame table: pinned host copy -> device, on the upload stream (idle: done long before the main
   // stream gets here); per-kernel timing / one-stream mode: in line
   FrameTable ft;
@@ -653,6 +671,11 @@ int g1s_diff::launch_front(int si) {
       z.ndw[1] = 3 * (uint32_t)batch;
       z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch;  // deferred-block flags
       z.ndw[3] = (uint32_t)(m_only_bytes / 4);
+      if (use_k0()) {
+        const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
+        z.ptr[2] = reinterpret_cast<uint32_t *>(sl.d_defer + cls_bytes);  // K0's bad flags
+        z.ndw[2] = (uint32_t)(cls_bytes / 4);
+      }
     } else {
       const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
       z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_partials);
@@ -691,7 +714,7 @@ int g1s_diff::launch_front(int si) {
     CertifyLists cl;
     cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
     cl.count = cl.list + (size_t)g.nblocks * batch;
-    if (use_mfma()) {
+    if (!use_k0()) {
       // the finder's moments of the luma source: the only pass over pixels that are not in a flat block's tile
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
       if (!force_literal) {
@@ -731,6 +754,7 @@ int g1s_diff::launch_front(int si) {
 #undef G1S_K0
 #undef G1S_K0P
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
+      if (use_planes() && pstream != fstream) HIP_TRY(hipEventRecord(ss.k0_done[si], pstream));
     } else if (!force_literal) {
       const dim3 mg((g.nblocks + 7) / 8, B);
       if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
@@ -807,7 +831,8 @@ QParams g1s_diff::make_qparams(const Slot &sl) const {
 
 MParams g1s_diff::make_mparams(const Slot &sl) const {
   MParams mp;
-  mp.bad = nullptr;  // (the fused pass finds the residuals outside int8 itself)
+  // (the fused pass finds the residuals outside int8 itself; K0 flags them per block)
+  mp.bad = use_planes() ? sl.d_defer + (((size_t)geom.nblocks * 2 * batch + 15) & ~size_t(15)) : nullptr;
   mp.units = reinterpret_cast<uint32_t *>(sl.d_mu);
   mp.unit_count = mp.units + (size_t)batch * m_nunits * kMUnitDwords;
   mp.only_any = mp.unit_count + 2 * batch;
@@ -824,7 +849,17 @@ int g1s_diff::launch_back(int si) {
   static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
   hipStream_t stream = ss.compute;
   const bool side = !(one_stream || sl.timed || !ss.flat);
-  if (side) HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));  // the mask, the window planes, the area lists
+  // (K0 + planes: the whole accumulation goes to the copy stream, next to the pixel pass of the batch after -- one streams
+  //  through HBM, the other lives in LDS and the matrix cores)
+  static const bool acc_aside_env = getenv("G1S_F_MAIN") == nullptr;  // tuning aid
+  const bool acc_aside = side && use_planes() && acc_aside_env;
+  if (acc_aside) {
+    HIP_TRY(hipStreamWaitEvent(ss.copy, ss.mask_done[si], 0));
+    HIP_TRY(hipStreamWaitEvent(ss.copy, ss.k0_done[si], 0));
+    stream = ss.copy;
+  } else if (side) {
+    HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));  // the mask, the window planes, the area lists
+  }
   FrameTable ft;
   ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);  // (uploaded by the front half)
   const bool fast_ok = use_mfma() || !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
@@ -856,6 +891,9 @@ int g1s_diff::launch_back(int si) {
     static const size_t lds_pad = getenv("G1S_F_LDS_PAD") ? (size_t)atoi(getenv("G1S_F_LDS_PAD")) : 0;  // tuning aid: fewer workgroups to a CU
     fq.frames = (int)B;
     fq.wgs = G;
+    fq.planes = sl.d_k0;
+    fq.ps = ps;
+    const bool planes = use_planes();
     const dim3 gr((uint32_t)G * B);
     const int bpsm = g.src_bps == g.den_bps ? g.src_bps : 0;  // bytes per sample at compile time unless the depths are mixed
     // two launches: the luma plane (which leaves L behind), then the two chroma planes
@@ -864,8 +902,12 @@ int g1s_diff::launch_back(int si) {
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, BP, PL>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
     (void)attr_rc;                                                                                                   \
+    static const hipError_t attr_rp = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, 1, PL, 1>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
+    (void)attr_rp;                                                                                                   \
     const size_t lds = std::min((size_t)f_lds_bytes(CW, CH, PL) + lds_pad, (size_t)144 * 1024);                     \
-    hipLaunchKernelGGL((k3f_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);                        \
+    if (planes) hipLaunchKernelGGL((k3f_fused<CW, CH, 1, PL, 1>), gr, dim3(kFThreads), lds, stream, g, fq);          \
+    else hipLaunchKernelGGL((k3f_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);                   \
   } while (0)
 #define G1S_FS(CW, CH, PL)                 \
   do {                                     \
@@ -878,7 +920,7 @@ int g1s_diff::launch_back(int si) {
 #define G1S_FP(CW, CH)                                                    \
   do {                                                                    \
     G1S_FS(CW, CH, 0);                                                    \
-    if (side && chroma_aside) {                                           \
+    if (side && chroma_aside && !acc_aside) {                             \
       HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));               \
       HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));       \
       stream = ss.copy;                                                   \
@@ -893,8 +935,8 @@ int g1s_diff::launch_back(int si) {
 #undef G1S_FP
 #undef G1S_FS
 #undef G1S_F
-    hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G, (const int32_t *)fq.ustats,
-                       sl.d_records);
+    hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + (planes ? 0 : kMFinishWgs), B), dim3(256), 0, stream, g, mp, G,
+                       planes ? (const int32_t *)nullptr : (const int32_t *)fq.ustats, sl.d_records);
     if (fq.phase_cycles) {
       std::vector<long long> hc((size_t)G * B * kFWaves * 6);
       (void)hipStreamSynchronize(stream);
@@ -1062,7 +1104,7 @@ int g1s_diff::drain_front(int si) {
     float ms_k0 = 0;  // round 1's chain: K0 (counted with the accumulation); fused pass: the finder's moments pass
     if (k0_timed) HIP_TRY(hipEventElapsedTime(&ms_k0, sl.ev[5], sl.ev[4]));
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
-    if (use_mfma()) {
+    if (!use_k0()) {
       stats.ms_flat_features += ms;
       stats.ms_residual += ms_k0;
       ms_k0 = 0;
@@ -1073,7 +1115,7 @@ int g1s_diff::drain_front(int si) {
     stats.ms_flat_select += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
     stats.ms_ar_accumulate += ms + ms_k0;
-    if (!use_mfma()) stats.ms_residual += ms_k0;
+    if (use_k0()) stats.ms_residual += ms_k0;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
     stats.ms_total_gpu += ms;
     {

@@ -50,6 +50,8 @@ struct FParams {
   uint8_t *lplane;        // [batch][lrows][lpitch]  L (sum of the co-located luma residuals) at chroma resolution, int8
   uint32_t lpitch, lframe_bytes;
   int frames, wgs;        // the launch: frames x workgroups per frame, as a 1-D grid (see the kernel)
+  const uint8_t *planes;  // SRC = 1: the int8 planes of the pixel pass K0 (k0.hip.h), [batch] x ps.frame_bytes
+  PlaneSet ps;
   long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][6] cycles: tile copies, barrier, multiply, barrier, wait for the words, residuals + requests; or null
 };
 
@@ -155,12 +157,15 @@ __device__ __forceinline__ void f_residual(const uint32_t (&hs)[4], const uint32
   }
 }
 
-template <int CBW, int CBH, int BPS, int PL>
+// SRC = 0: the words come from the source / denoised planes (the fused pass); SRC = 1: from the int8 residual and L planes
+// the pixel pass K0 left behind (k0.hip.h), which also took the statistics and flagged the residuals outside int8 (k3m_units
+// then lists no window for those blocks): staging is a copy
+template <int CBW, int CBH, int BPS, int PL, int SRC = 0>
 __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParams fpar) {
   extern __shared__ __attribute__((aligned(16))) uint8_t m_smem[];
   using SH = FShape<CBW, CBH>;
   constexpr bool CH = SH::CH;
-  constexpr bool LUMA = PL == 0, CHROMA = PL == 1;
+  constexpr bool LUMA = PL == 0, CHROMA = PL == 1, RAW = SRC == 0;
   static_assert(LUMA || CH, "the chroma launch needs chroma planes");
   constexpr int CW_ = SH::CW_, CH_ = SH::CH_, CROUNDS = CHROMA ? SH::CROUNDS : 0, NCR = CROUNDS > 0 ? CROUNDS : 1;
   constexpr int ZOFF = f_lds_tiles(CBW, CBH, PL);
@@ -251,7 +256,8 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   const int nmine = n_p + n_g;  // (<= kMMaxUnits: the host sizes G for it)
   if (tid < nmine) {
     uint4 e = *reinterpret_cast<const uint4 *>(units + (size_t)upos(tid) * kMUnitDwords);
-    if (CHROMA) e.w = (uint32_t)ustats[(size_t)upos(tid) * kMStatInts + 14];
+    if (CHROMA && RAW) e.w = (uint32_t)ustats[(size_t)upos(tid) * kMStatInts + 14];
+    if (!RAW) e.w = 0u;
     s_ent[tid] = e;
   }
   if (tid < 4) reinterpret_cast<uint32_t *>(m_smem + ZOFF)[tid] = 0u;
@@ -278,6 +284,39 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
     const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
     const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
     const int X0y = bx0 * 32 - 8, Y0y = by * kBlock - 3, X0c = bx0 * CW_ - 8, Y0c = by * CH_ - 3;
+    if constexpr (!RAW) {
+      // K0's planes: sample (x, y) of a residual plane at byte (y + 3) * pitch + 8 + x (zero padding around the plane); L without padding
+      const uint8_t *fpl = fpar.planes + (size_t)frame * fpar.ps.frame_bytes;
+      if constexpr (LUMA) {
+        if (y_wave) {
+          const uint32_t pitch = fpar.ps.pitch[0];
+          const uint8_t *b = fpl + fpar.ps.off_d[0] + (size_t)(by * kBlock) * pitch + bx0 * 32;
+          const bool cok = (uint32_t)(bx0 * 32 + 8 * ywd + 8) <= pitch;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            uint2 w = make_uint2(0u, 0u);
+            if (cok && ytr0 + r >= 0) w = *reinterpret_cast<const uint2 *>(b + (uint32_t)(ytr0 + r) * pitch + 8u * (uint32_t)ywd);
+            ys_[r].x = w.x;
+            ys_[r].y = w.y;
+          }
+        }
+      } else {
+        const uint32_t pitch = fpar.ps.pitch[1];
+        const uint8_t *b = fpl + fpar.ps.off_d[cplane] + (size_t)(by * CH_) * pitch + bx0 * CW_;
+        const bool cok = (uint32_t)(bx0 * CW_ + 8 * cwd + 8) <= pitch;
+#pragma unroll
+        for (int q = 0; q < CROUNDS; ++q) {
+          uint2 w = make_uint2(0u, 0u);
+          if (cok && cpl[q]) w = *reinterpret_cast<const uint2 *>(b + (uint32_t)ctr[q] * pitch + 8u * (uint32_t)cwd);
+          cs_[q].x = w.x;
+          cs_[q].y = w.y;
+        }
+        lraw = make_uint2(0u, 0u);
+        if (l_on && (uint32_t)(bx0 * CW_ + 8 * l_wd + 8) <= fpar.ps.lpitch)
+          lraw = *reinterpret_cast<const uint2 *>(fpl + fpar.ps.off_l + (size_t)(by * CH_ + l_row) * fpar.ps.lpitch + bx0 * CW_ + 8 * l_wd);
+      }
+      return;
+    }
     if constexpr (CHROMA) {
       if (l_on) lraw = *reinterpret_cast<const uint2 *>(lplane + (size_t)(by * CH_ + l_row) * fpar.lpitch + bx0 * CW_ + 8 * l_wd);
     }
@@ -339,6 +378,23 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   const int c_xw = 8 * (cwd - 1), c_bq = (c_xw / CW_) & 1;   // chroma word
   auto phase_a = [&](int k) __attribute__((always_inline)) {
     const int par = k & 1;
+    if constexpr (!RAW) {  // the words ARE the residual bytes
+      if (LUMA && y_wave) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          Dy[r][0] = ys_[r].x;
+          Dy[r][1] = ys_[r].y;
+        }
+      }
+      if constexpr (CHROMA) Lk = lraw;
+#pragma unroll
+      for (int q = 0; q < CROUNDS; ++q) {
+        Dc[q][0] = cs_[q].x;
+        Dc[q][1] = cs_[q].y;
+      }
+      (void)par;
+      return;
+    }
     if (LUMA && y_wave) {
       // ---- luma: residuals of the two rows, their statistics, L ----
       uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0, keep16[4] = {0, 0, 0, 0};
@@ -442,7 +498,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   // the L words of unit k -> the L plane (luma launch).  Global stores share the loads' counter: issued BEHIND a request they
   // have an iteration to drain; issued before it, the request's first load waits for them (microseconds)
   auto export_l = [&](int k) __attribute__((always_inline)) {
-    if constexpr (LUMA && CH) {
+    if constexpr (LUMA && CH && RAW) {
       if (y_wave && y_interior) {
         const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
         const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
@@ -589,7 +645,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
         export_l(k + 1);
       }
       // ---- the unit's statistics record (k3m_finish scatters it): this launch's entries; behind the request, like the L words ----
-      if (tid < kMStatInts) {
+      if (RAW && tid < kMStatInts) {
         // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14 / 15: the deferral
         // bits of the luma / chroma launch
         const int b = tid >= 7 ? 1 : 0, e = tid - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;

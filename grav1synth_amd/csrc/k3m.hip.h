@@ -321,6 +321,7 @@ __device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const ui
 // grid = (nplanes + kMFinishWgs, batch), block = 256.
 // ---------------------------------------------------------------------------------
 constexpr int kMStatInts = 16, kMFinishWgs = 4;
+// ustats == nullptr: a pixel pass took the statistics and the deferrals (K0 + k3m_units): only the systems and nobs.
 __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, const int32_t *__restrict__ ustats,
                                                   uint8_t *__restrict__ records) {
   const int frame = g.frame0 + (int)blockIdx.y;
@@ -345,8 +346,9 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
     for (uint32_t v = threadIdx.x; v < cnt; v += 256) {
       const uint32_t u = upos(v);
       const uint32_t wz = units[(size_t)u * kMUnitDwords + (c > 0 ? 2 : 1)];
-      const uint32_t defer = ((uint32_t)us[(size_t)u * kMStatInts + 14] | (g.nplanes == 3 ? (uint32_t)us[(size_t)u * kMStatInts + 15] : 0u)) >>
-                             (c > 0 ? kMUnitBlocks : 0);
+      const uint32_t defer = !ustats ? 0u
+                                     : ((uint32_t)us[(size_t)u * kMStatInts + 14] | (g.nplanes == 3 ? (uint32_t)us[(size_t)u * kMStatInts + 15] : 0u)) >>
+                                           (c > 0 ? kMUnitBlocks : 0);
 #pragma unroll
       for (int b = 0; b < kMUnitBlocks; ++b) {
         const MWin w = m_unpack((wz >> (16 * b)) & 0xffffu, g.lag);
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
     if (threadIdx.x == 0) ar[nc * nc + nc] += s_n[0] + s_n[1] + s_n[2] + s_n[3];
     return;
   }
+  if (!ustats) return;
   const int part = (int)blockIdx.x - g.nplanes;
   const bool chroma = g.nplanes == 3;
   for (uint32_t v = part * 256 + threadIdx.x; v < cnt; v += kMFinishWgs * 256) {

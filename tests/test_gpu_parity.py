@@ -94,6 +94,26 @@ def test_records_and_table_match_oracle(case):
     assert mine == tbl
 
 
+def test_accumulation_modes_agree():
+    """G1S_K3 = fused (default: matrix-core accumulation straight from the source planes), planes (pixel pass K0 + the
+    matrix-core kernel on its int8 planes) and dot4 (round 1: K0 + lag-structured v_dot4 kernels) must give the same
+    records and tables, bit for bit -- small odd formats, 12-bit residuals outside int8, the 4K workload."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    lines = {}
+    for mode in ("fused", "planes", "dot4"):
+        env = dict(os.environ, G1S_K3=mode)
+        p = subprocess.run([sys.executable, "-m", "tests.k3_mode_digest"], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert p.returncode == 0, f"{mode}: {p.stderr[-2000:]}"
+        lines[mode] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert lines["fused"] == lines["planes"], "fused vs planes"
+    assert lines["fused"] == lines["dot4"], "fused vs dot4"
+
+
 def test_batched_equals_unbatched_and_oracle():
     """Batching/pipelining must not change anything: 7 frames with batch 3."""
     spec = SynthSpec(320, 192, 8)
