@@ -2,12 +2,18 @@
 """bench.py -- `diff` throughput on MI355X (BASELINE.json metric).
 
 A "step" is one pass of the whole hot path (flat-block finder, AR accumulation,
-block statistics, ordered fold) over one batch of synthetic frame pairs that
-are already resident in HBM.  Workload at any N: 3840x2160 10-bit 4:2:0,
+block statistics, ordered fold) over one job of synthetic frame pairs that are
+already resident in HBM.  Workload at any N: 3840x2160 10-bit 4:2:0,
 ar_coeff_lag 3, chroma (BASELINE.json configs[2], the one the metric is quoted
-on); each rank owns its own `--frames` frame pairs per step (weak scaling,
-frame sharding), exchanges the per-frame integer records with ONE RCCL
-all-gather per step, and rank 0 runs the ordered fold over all N*frames records.
+on).  N > 1: the video is dealt to the ranks batch by batch (frame sharding,
+weak scaling: every rank owns `--frames` x `--cycles` frame pairs per step);
+per batch round the ranks all-gather their frames' small latest-state blobs
+(RCCL) and rank 0 merges them in order -- no collective on the pixel path.
+
+The timed region is `--steps` such jobs between barrier + synchronize pairs.
+After it, one more (untimed) job runs with HIP events around every kernel
+launch: the `roofline` object comes from those, the `cpu_baseline` object from
+the oracle (tests' checker) timed on the host cores over a bounded sample.
 
 Prints ONE JSON line on rank 0.
 """
@@ -50,7 +56,7 @@ def main() -> None:
     ap.add_argument("--workload", default="4k10", choices=sorted(WORKLOADS))
     ap.add_argument("--flat", action="store_true", help="all-flat stress variant (no textured region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,11 +114,12 @@ def main() -> None:
     nplanes = 3 if chroma else 1
 
     stats_total = None
+    kernel_times = {}
     last_tbl = None
     window_samples = None  # per plane, of the last frame of the timed-kernels step
 
     def one_step(timing: bool):
-        nonlocal stats_total, last_tbl, window_samples
+        nonlocal stats_total, last_tbl, window_samples, kernel_times
         if world > 1:
             # streaming frame shards: per batch one small all-gather of latest states, rank 0 merges in order
             sd = StreamingShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
@@ -129,6 +136,8 @@ def main() -> None:
                 sd.diff_prepared(prepared, W, H, nplanes, sync_torch=False)
         segs = sd.finish()  # (exchange +) ordered fold; rank 0 holds the table
         st = sd.generator.stats()
+        if timing:
+            kernel_times = sd.generator.kernel_times()
         if segs is not None:
             last_tbl = format_tbl(segs)
         if timing:
@@ -165,35 +174,51 @@ def main() -> None:
     # ---- per-kernel HIP-event timing, in separate (untimed) steps: events between
     # kernels serialise nothing here but we keep them out of the headline number ----
     st = one_step(True)
-    kernels = {
+    families = {
         "k1_flat_features": (st.ms_flat_features, st.launches_flat_features),
         "k2_flat_select": (st.ms_flat_select, st.launches_flat_select),
         "k3_ar_accumulate": (st.ms_ar_accumulate, st.launches_ar_accumulate),
     }
-    dom = max(kernels, key=lambda k: kernels[k][0])
-    dom_ms, dom_launches = kernels[dom]
-    frames_per_launch = FJ / max(dom_launches, 1)
+    # HIP events around every launch of the timed job (one stream): kernel name -> (ms, launches)
+    kt = {k: v for k, v in kernel_times.items() if v[1] > 0}
+    dom = max(kt, key=lambda k: kt[k][0]) if kt else max(families, key=lambda k: families[k][0])
+    dom_ms, dom_launches = kt[dom] if kt else families[dom]
+    n_batches = max(st.launches_ar_accumulate, 1)
+    frames_per_launch = FJ / n_batches
+    # bpp bytes per luma pixel of a frame pair = every source and denoised sample once
     alg_bytes_per_launch = bpp * W * H * frames_per_launch
-    avg_launch_ms = dom_ms / max(dom_launches, 1)
-    achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    # the whole pass over one batch: every kernel from the finder's first to the accumulation's last, alone on the chip
+    batch_ms = (sum(v[0] for v in kt.values()) if kt else st.ms_total_gpu) / n_batches
+    achieved = alg_bytes_per_launch / (batch_ms * 1e-3) / 1e9 if batch_ms > 0 else 0.0
+    bps = 1 if bd == 8 else 2
+    cpx = (W >> xdec) * (H >> ydec) if chroma else 0
+
+    def own_bytes(name):
+        """algorithmic bytes one launch of this kernel exists to read, per frame pair (None: not a pixel kernel)"""
+        if name.startswith("k3f_fused"):
+            t = [x.strip(" >") for x in name.split("<")[1].split(",")]
+            if t[4] == "1":  # staging the int8 planes of the pixel pass
+                return (W * H if t[3] == "0" else 2 * cpx + cpx)
+            return 2 * bps * W * H if t[3] == "0" else 2 * bps * 2 * cpx
+        if name.startswith("k1_moments"):
+            return bps * W * H
+        if name.startswith("k0_residual"):
+            return bpp * W * H
+        return None
+
+    ob = own_bytes(dom)
+    dom_avg_ms = dom_ms / max(dom_launches, 1)
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as f:
-                traffic = json.load(f).get(args.workload, {}).get(dom)
+                traffic = json.load(f).get(args.workload, {}).get(os.environ.get("G1S_K3", "fused"))
         except Exception:
             traffic = None
 
     total_px = float(W) * H * F * args.cycles * args.steps * world
     value = total_px / elapsed / 1e6
-    valu = None
-    if window_samples and lag == 3:
-        macs = window_samples[0] * 324 + sum(window_samples[1:]) * 350
-        fps_all = value * 1e6 / (W * H)
-        valu = {"window_samples_per_frame": window_samples, "gmac_per_frame": macs / 1e9,
-                "achieved_tmac_s": macs * fps_all / world / 1e12, "dot4_peak_tmac_s": 133.0,
-                "frac": macs * fps_all / world / 1e12 / 133.0}
     out = {
         "metric": "diff Mpixels/s (luma pixels of frame pairs fully processed: flat-block finder + AR accumulation + block stats + ordered fold)",
         "value": value,
@@ -206,13 +231,16 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8/i32/i64 exact-integer accumulation + f64 flat-block features",
+        "dtype": "i8 x i8 -> i32 matrix-core products, i64 sums (exact integers) + f64 flat-block features",
         "data": "synthetic (deterministic integer generator, grav1synth_amd/synth.py), device-resident",
         "config": {
             "workload": f"diff {W}x{H} {bd}-bit {'4:2:0' if (xdec, ydec) == (1, 1) else '4:4:4' if (xdec, ydec) == (0, 0) else '4:2:2'}, ar_coeff_lag={lag}, {'chroma' if chroma else 'luma-only'} ({args.workload}{', all-flat' if args.flat else ''})",
             "frames_per_rank_per_step": FJ,
             "resident_frames_per_rank": F,
             "batch_frames": args.batch,
+            "accumulation": {"fused": "exact int8 SYRK on the matrix cores (v_mfma_i32_32x32x32_i8), residual fused into the consumer -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01",
+                             "planes": "pixel pass K0 -> int8 planes -> exact int8 SYRK on the matrix cores",
+                             "dot4": "round 1: pixel pass K0 -> int8 planes -> lag-structured v_dot4 kernels"}[os.environ.get("G1S_K3", "fused")],
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
             "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if world > 1 else "single GPU",
@@ -220,51 +248,80 @@ def main() -> None:
         "hbm_roofline_frac_whole_job": (value * bpp * 1e6 / 1e9) / (HBM_PEAK_GBS * world),
         "roofline": {
             "bound": "hbm",
+            # the kernel with the most time in a batch, by the name rocprofv3 prints; its family; and what `achieved` covers
             "kernel": dom,
+            "family": "k3_ar_accumulate" if dom.startswith(("k3", "k0")) else "k1_flat_features" if dom.startswith("k1") else "k2_flat_select",
+            "scope": "all kernels of one batch (the pass needs every one of them to have read a frame pair once): "
+                     "algorithmic bytes of the batch / sum of their HIP-event durations, one stream",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "avg_launch_ms": avg_launch_ms,
+            "avg_launch_ms": batch_ms,
             "alg_bytes_per_launch": alg_bytes_per_launch,
-            "all_kernels_ms_per_frame": {k: v[0] / FJ for k, v in kernels.items()},
-            "host_fold_ms_per_frame": st.ms_host_fold / FJ,
-            # SURVEY 8(d), caveat H1: the accumulation is VALU work.  Algorithmic MACs of a frame = window samples x
-            # (324 luma / 350 chroma: unique products + right-hand sides of add_block_observations); the kernels execute
-            # about a sixth of them (46 lag sums instead of 324 products on full groups).  Peak = measured v_dot4 rate.
-            "valu_algorithmic": valu,
-            # inside k3_ar_accumulate: K0, the one pass over the source / denoised planes (the HBM-streaming kernel)
-            "k0_residual": {
-                "ms_per_frame": st.ms_residual / FJ,
-                "achieved": (bpp * W * H * FJ / (st.ms_residual * 1e-3) / 1e9) if st.ms_residual > 0 else None,
-                "unit": "GB/s",
-                "frac": (bpp * W * H * FJ / (st.ms_residual * 1e-3) / 1e9 / HBM_PEAK_GBS) if st.ms_residual > 0 else None,
+            "frames_per_launch": frames_per_launch,
+            "dominant_kernel": {
+                "name": dom,
+                "avg_launch_ms": dom_avg_ms,
+                "share_of_batch": dom_avg_ms / batch_ms if batch_ms > 0 else None,
+                # the bytes this one kernel exists to read (its planes), against its own duration
+                "alg_bytes_per_launch": ob * frames_per_launch if ob else None,
+                "achieved": (ob * frames_per_launch / (dom_avg_ms * 1e-3) / 1e9) if ob and dom_avg_ms > 0 else None,
             },
+            "kernels_us_per_launch": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
+            "families_ms_per_frame": {k: v[0] / FJ for k, v in families.items()},
+            "host_fold_ms_per_frame": st.ms_host_fold / FJ,
+            "accumulation": os.environ.get("G1S_K3", "fused"),
         },
     }
 
-    # ---- CPU baseline: the oracle (a port, scalar f64, 1 thread) on a bounded sample ----
+    # ---- CPU baseline: the oracle (a port: scalar f64, the reference's operation order) on a bounded sample,
+    #      one thread, then T = all host cores (T independent generators, one per thread -- the reference's `diff`
+    #      is sequential per video, so all cores means T videos / frame shards at once) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+
         from tests.oracle_binding import OracleDiff
 
         n_cpu = max(1, args.cpu_frames)
-        o = OracleDiff(fps.numerator, fps.denominator, bd, bd, lag, chroma)
         host = []
         for k in range(n_cpu):
             s, d = frames[k]
             host.append(([p.cpu().numpy() for p in s], [p.cpu().numpy() for p in d]))
+
+        def oracle_job(rows):
+            o = OracleDiff(fps.numerator, fps.denominator, bd, bd, lag, chroma)
+            for s, d in host:
+                if rows:  # a strip of full-width block rows (same row length, format and flat fraction; fewer rows)
+                    s = [np.ascontiguousarray(p[: rows >> (ydec if i else 0)]) for i, p in enumerate(s)]
+                    d = [np.ascontiguousarray(p[: rows >> (ydec if i else 0)]) for i, p in enumerate(d)]
+                o.diff_frame(s, d, xdec, ydec)  # (ctypes releases the GIL for the call)
+            o.finish()
+
         t0 = time.perf_counter()
-        for s, d in host:
-            o.diff_frame(s, d, xdec, ydec)
-        o.finish()
-        cpu_s = time.perf_counter() - t0
+        oracle_job(0)
+        one_s = time.perf_counter() - t0
+        nproc = os.cpu_count() or 1
+        try:
+            nproc = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        # all cores: every thread a strip, sized so that the leg stays near 20 s even if the threads scale no better than 8x
+        strip = H if nproc <= 8 else max(32, min(H, (int(H * 8 * 20.0 / (one_s * nproc)) // 32) * 32))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(nproc) as ex:
+            list(ex.map(oracle_job, [strip if strip < H else 0] * nproc))
+        all_s = time.perf_counter() - t0
         out["cpu_baseline"] = {
-            "value": W * H * n_cpu / cpu_s / 1e6,
+            "value": W * strip * n_cpu * nproc / all_s / 1e6,
             "unit": "Mpixels/s",
-            "cores": 1,
+            "cores": nproc,
+            "nproc": nproc,
             "kind": "port",
-            "sample": f"{n_cpu} frame pair(s) of the same workload through oracle/liborc_diff.so (scalar f64, reference operation order), {cpu_s:.1f} s",
+            "sample": f"{nproc} threads x {n_cpu} frame pair(s) of the same workload cut to a {W}x{strip} strip, one oracle generator (oracle/liborc_diff.so: scalar f64, "
+                      f"reference operation order) per thread, {all_s:.1f} s",
+            "one_thread": {"value": W * H * n_cpu / one_s / 1e6, "cores": 1, "sample": f"{n_cpu} frame pair(s), {one_s:.1f} s"},
         }
     if rank == 0:
         print(json.dumps(out))

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libg1s_diff.so")
+LIB_PATH = os.environ.get("G1S_LIB") or os.path.join(_HERE, "libg1s_diff.so")  # (G1S_LIB: an instrumented build, tools/ only)
 
 G1S_OK = 0
 ERRORS = {
@@ -144,6 +144,7 @@ SYMBOLS = [
     ("g1s_tbl_segment_for", C.c_long, [C.POINTER(G1SSegment), C.c_size_t, C.c_uint64]),
     ("g1s_diff_get_stats", C.c_int, [C.c_void_p, C.POINTER(G1SStats)]),
     ("g1s_diff_set_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("g1s_diff_kernel_times", C.c_long, [C.c_void_p, C.c_char_p, C.c_size_t]),
     ("g1s_diff_set_flat_finder", C.c_int, [C.c_void_p, C.c_int]),
     ("g1s_diff_last_record", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("g1s_record_geometry", C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4),

@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -194,6 +195,10 @@ struct Slot {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: finder start, k2 start, k3 start, k3 end, k0 end, k0 start
   uint32_t count = 0;
   bool timed = false;
+  // per-kernel timing (g1s_diff_set_timing): an event before each launch, the name of the kernel it precedes
+  std::vector<hipEvent_t> kev;
+  std::vector<std::string> kname;
+  size_t nk = 0;
 };
 
 // Process-wide cache of slot buffers: pinned-host and device allocations cost
@@ -361,6 +366,21 @@ struct g1s_diff {
   bool timing = false;
   int flat_literal = 0;  // flat-block finder: literal f64 evaluation of every block (1: lane per block, 2: wave per block)
   g1s_stats_t stats{};
+  std::map<std::string, std::pair<double, uint64_t>> ktimes;  // timed batches: kernel name -> (ms, launches)
+  std::mutex ktimes_mutex;
+  // timed batches run on one stream: an event before each launch (and one after the last), named after the kernel
+  int kmark(Slot &sl, hipStream_t st, const char *name) {
+    if (!sl.timed) return G1S_OK;
+    if (sl.nk == sl.kev.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return fail(G1S_ERR_HIP, "hipEventCreate failed");
+      sl.kev.push_back(e);
+      sl.kname.emplace_back();
+    }
+    if (hipEventRecord(sl.kev[sl.nk], st) != hipSuccess) return fail(G1S_ERR_HIP, "hipEventRecord failed");
+    sl.kname[sl.nk++] = name ? name : "";
+    return G1S_OK;
+  }
 
   int fail(int code, const std::string &msg) {
     err = msg;
@@ -699,6 +719,7 @@ int g1s_diff::launch_front(int si) {
     if (pstream != stream) HIP_TRY(hipStreamWaitEvent(pstream, ss.table_done[si], 0));
   }
   sl.timed = timing;
+  sl.nk = 0;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], pstream));
   // (the fused pass serves every format; round 1's chain has no structured path for 4:4:0)
   const bool fast_ok = use_mfma() || !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
@@ -719,6 +740,7 @@ int g1s_diff::launch_front(int si) {
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
       if (!force_literal) {
         const dim3 mg((g.nblocks + 7) / 8, B);
+        kmark(sl, pstream, g.src_bps == 1 ? "k1_moments<1>" : "k1_moments<2>");
         if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
         else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, pstream, ft, g, mom);
       }
@@ -743,6 +765,7 @@ int g1s_diff::launch_front(int si) {
       // needs only that one and starts next to the chroma half (bandwidth bound) instead of spending its
       // whole length next to the VALU-bound lag kernels.
       static const bool k0_split_env = getenv("G1S_K0_ONE") == nullptr;  // tuning aid
+      kmark(sl, pstream, "k0_residual");
       if (pstream != fstream && g.nplanes == 3 && k0_split_env) {
         G1S_K0(1);
         HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
@@ -764,8 +787,10 @@ int g1s_diff::launch_front(int si) {
       if (!pix_recorded) HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
       HIP_TRY(hipStreamWaitEvent(fstream, ss.pix_done[si], 0));
     }
+    kmark(sl, fstream, "k1_certify");
     hipLaunchKernelGGL(k1_certify, dim3((g.nblocks + 255) / 256, B), dim3(256), 0, fstream, g, fc, (const int32_t *)mom,
                        sl.d_records, sl.d_flags, cl, force_literal);
+    kmark(sl, fstream, literal_mode == 1 ? "k1_flat_features" : "k1_flat_block");
     if (literal_mode == 1) {  // every block: one lane per block
       dim3 grid((g.nblocks + 63) / 64, B);
       if (g.src_bps == 1)
@@ -785,17 +810,20 @@ int g1s_diff::launch_front(int si) {
     }
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
+  kmark(sl, fstream, "k2_flat_select");
   hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
   if (fast_ok && use_mfma()) {
     // the unit lists (chunks with a flat block) need the flat mask
     const MParams mp = make_mparams(sl);
+    kmark(sl, fstream, "k3m_units");
     hipLaunchKernelGGL(k3m_units, dim3((m_nunits + 255) / 256, B), dim3(256), 0, fstream, g, (const uint8_t *)sl.d_records, mp);
   } else if (fast_ok) {
     // the window bit planes and the area lists need the flat mask: small kernels after K2
     const QParams qp = make_qparams(sl);
     const int kinds = g.nplanes == 3 ? 2 : 1;
     const uint32_t wdw = std::max(ps.wpitch[0], kinds == 2 ? ps.wpitch[1] : 0u) / 4;
+    kmark(sl, fstream, "k3_windows + k3_classify");
     // one workgroup per block row and dword column: the kernel runs off the critical path, next to the lag kernels,
     // so the fewest instructions win (measured: split 1 / 2 / 4 = +1.0 / +0.7 / 0 %)
     constexpr int kWinSplit = 1;
@@ -804,6 +832,7 @@ int g1s_diff::launch_front(int si) {
     hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, B), dim3(kClsThreads), 0, fstream, g,
                        (const uint8_t *)sl.d_records, qp);
   }
+  kmark(sl, fstream, nullptr);
   if (fstream != stream) HIP_TRY(hipEventRecord(ss.mask_done[si], fstream));
   HIP_TRY(hipGetLastError());
   return G1S_OK;
@@ -891,6 +920,10 @@ int g1s_diff::launch_back(int si) {
     static const size_t lds_pad = getenv("G1S_F_LDS_PAD") ? (size_t)atoi(getenv("G1S_F_LDS_PAD")) : 0;  // tuning aid: fewer workgroups to a CU
     fq.frames = (int)B;
     fq.wgs = G;
+    // units to workgroups: contiguous runs of the lists (measured +2..4 % over round-robin in the pipelined job, although a
+    // kernel alone on the chip is 5 % slower: the runs' loads disturb the kernels next to it less)
+    static const int deal_env = getenv("G1S_F_DEAL") ? atoi(getenv("G1S_F_DEAL")) : 1;  // tuning aid
+    fq.deal = deal_env;
     fq.planes = sl.d_k0;
     fq.ps = ps;
     const bool planes = use_planes();
@@ -906,6 +939,9 @@ int g1s_diff::launch_back(int si) {
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
     (void)attr_rp;                                                                                                   \
     const size_t lds = std::min((size_t)f_lds_bytes(CW, CH, PL) + lds_pad, (size_t)144 * 1024);                     \
+    char kn_[64];                                                                                                    \
+    snprintf(kn_, sizeof(kn_), "k3f_fused<%d, %d, %d, %d, %d>", CW, CH, planes ? 1 : BP, PL, planes ? 1 : 0);        \
+    kmark(sl, stream, kn_);                                                                                          \
     if (planes) hipLaunchKernelGGL((k3f_fused<CW, CH, 1, PL, 1>), gr, dim3(kFThreads), lds, stream, g, fq);          \
     else hipLaunchKernelGGL((k3f_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);                   \
   } while (0)
@@ -935,6 +971,7 @@ int g1s_diff::launch_back(int si) {
 #undef G1S_FP
 #undef G1S_FS
 #undef G1S_F
+    kmark(sl, stream, "k3m_finish");
     hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + (planes ? 0 : kMFinishWgs), B), dim3(256), 0, stream, g, mp, G,
                        planes ? (const int32_t *)nullptr : (const int32_t *)fq.ustats, sl.d_records);
     if (fq.phase_cycles) {
@@ -949,6 +986,7 @@ int g1s_diff::launch_back(int si) {
         fprintf(stderr, "k3f phases, wave %d: copies %.0f  barrier %.0f  multiply %.0f  requests + barrier %.0f  wait for words %.0f  residuals %.0f  (mean cycles per workgroup)\n",
                 v, tot[v][0] / (G * B), tot[v][1] / (G * B), tot[v][2] / (G * B), tot[v][3] / (G * B), tot[v][4] / (G * B), tot[v][5] / (G * B));
     }
+    kmark(sl, stream, "k3_ar_generic");
     hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                        sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
   } else if (fast_ok) {
@@ -956,6 +994,7 @@ int g1s_diff::launch_back(int si) {
     // then the generic int32 kernel on mixed / deferred areas
     const QParams qp = make_qparams(sl);
     const uint32_t Bs = B;
+    kmark(sl, stream, "k3_lag + k3_partial_dense + k3q_reduce + k3q_generic");
     const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
     // One round of workgroups: as many per frame as stay resident together (occupancy x CUs / batch,
     // a multiple of 8 for the XCD-aware list slices), but never more than 128 areas each (int32 sums).
@@ -1022,9 +1061,11 @@ int g1s_diff::launch_back(int si) {
     if (qp.ar3) hipLaunchKernelGGL(k3q_compact, dim3(g.nplanes, Bs), dim3(256), 0, stream, g, qp, sl.d_records);
   } else {
     const int chunks = std::min(kK3Chunks, g.nblocks);
+    kmark(sl, stream, "k3_ar_generic");
     hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g, sl.d_records,
                        (const uint8_t *)nullptr, (const uint32_t *)nullptr);
   }
+  kmark(sl, stream, nullptr);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[3], stream));
   HIP_TRY(hipGetLastError());
   // records D2H on the copy stream (behind the tail kernels): the main stream goes straight on to the next batch
@@ -1118,6 +1159,16 @@ int g1s_diff::drain_front(int si) {
     if (use_k0()) stats.ms_residual += ms_k0;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
     stats.ms_total_gpu += ms;
+    {
+      std::lock_guard<std::mutex> lk(ktimes_mutex);
+      for (size_t i = 0; i + 1 < sl.nk; ++i) {
+        if (sl.kname[i].empty()) continue;  // (the gap between the two halves of a batch)
+        HIP_TRY(hipEventElapsedTime(&ms, sl.kev[i], sl.kev[i + 1]));
+        auto &kt = ktimes[sl.kname[i]];
+        kt.first += ms;
+        kt.second += 1;
+      }
+    }
     {
       std::vector<uint32_t> cnt(batch);
       HIP_TRY(hipMemcpy(cnt.data(), reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)geom.nblocks * batch * (kMomInts + 1),
@@ -1286,6 +1337,7 @@ void g1s_diff::release() {
     if (sl.done) (void)hipEventDestroy(sl.done);
     for (auto &e : sl.ev)
       if (e) (void)hipEventDestroy(e);
+    for (auto &e : sl.kev) (void)hipEventDestroy(e);
     sl = Slot{};
   }
   d_lut = nullptr;  // shared per device
@@ -1706,6 +1758,21 @@ int g1s_diff_get_stats(const g1s_diff_t *g, g1s_stats_t *out) {
   *out = g->stats;
   out->ms_host_fold = g->ms_fold_front + g->ms_fold_back;  // (the two stages overlap across batches)
   return G1S_OK;
+}
+long g1s_diff_kernel_times(g1s_diff_t *g, char *buf, size_t cap) {
+  if (!g || (!buf && cap)) return G1S_ERR_INVALID;
+  std::string out;
+  {
+    std::lock_guard<std::mutex> lk(g->ktimes_mutex);
+    for (const auto &kv : g->ktimes) {
+      char line[256];
+      snprintf(line, sizeof(line), "%s\t%.6f\t%llu\n", kv.first.c_str(), kv.second.first, (unsigned long long)kv.second.second);
+      out += line;
+    }
+  }
+  if (out.size() > cap) return G1S_ERR_CAPACITY;
+  std::memcpy(buf, out.data(), out.size());
+  return (long)out.size();
 }
 int g1s_diff_set_flat_finder(g1s_diff_t *g, int mode) {
   if (!g) return G1S_ERR_INVALID;

@@ -50,6 +50,7 @@ struct FParams {
   uint8_t *lplane;        // [batch][lrows][lpitch]  L (sum of the co-located luma residuals) at chroma resolution, int8
   uint32_t lpitch, lframe_bytes;
   int frames, wgs;        // the launch: frames x workgroups per frame, as a 1-D grid (see the kernel)
+  int deal;               // units to workgroups: 0 round-robin, 1 contiguous runs
   const uint8_t *planes;  // SRC = 1: the int8 planes of the pixel pass K0 (k0.hip.h), [batch] x ps.frame_bytes
   PlaneSet ps;
   long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][6] cycles: tile copies, barrier, multiply, barrier, wait for the words, residuals + requests; or null
@@ -184,9 +185,15 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   // the frame's two unit lists are dealt round-robin to its workgroups: adjacent units at about the same time
   const int nx = G, jx = wg;
   const uint32_t cnt_g = fpar.unit_count[2 * frame], cnt_p = fpar.unit_count[2 * frame + 1];
-  auto share = [&](uint32_t cnt, uint32_t &first, int &n) {  // positions first, first + nx, ... (n of them) of a list of cnt
-    first = (uint32_t)jx;
-    n = cnt > first ? (int)((cnt - first + (uint32_t)nx - 1) / (uint32_t)nx) : 0;
+  const uint32_t ustride = fpar.deal ? 1u : (uint32_t)nx;
+  auto share = [&](uint32_t cnt, uint32_t &first, int &n) {  // positions first, first + ustride, ... (n of them) of a list of cnt
+    if (fpar.deal) {  // a contiguous run: the line under a unit's right halo is the next unit's own
+      first = (uint32_t)((unsigned long long)cnt * (uint32_t)jx / (uint32_t)nx);
+      n = (int)((uint32_t)((unsigned long long)cnt * (uint32_t)(jx + 1) / (uint32_t)nx) - first);
+    } else {
+      first = (uint32_t)jx;
+      n = cnt > first ? (int)((cnt - first + (uint32_t)nx - 1) / (uint32_t)nx) : 0;
+    }
   };
   uint32_t first_p, first_g;
   int n_p, n_g;
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   share(cnt_g, first_g, n_g);
   // list position of this workgroup's k-th unit: its plain units first (that list grows from the back of the array)
   auto upos = [&](int k) {
-    return k < n_p ? (uint32_t)fpar.nunits - 1u - (first_p + (uint32_t)k * (uint32_t)nx) : first_g + (uint32_t)(k - n_p) * (uint32_t)nx;
+    return k < n_p ? (uint32_t)fpar.nunits - 1u - (first_p + (uint32_t)k * ustride) : first_g + (uint32_t)(k - n_p) * ustride;
   };
   const uint32_t *units = fpar.units + (size_t)frame * fpar.nunits * kMUnitDwords;
   int32_t *ustats = fpar.ustats + (size_t)frame * fpar.nunits * kMStatInts;
@@ -345,7 +352,10 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       const uint8_t *db = fp.den[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.den_stride[0] + (ptrdiff_t)X0y * dbps);
       // a unit whose tile lies inside the plane (all but the frame's border units) needs no per-lane bounds
       const bool inside = X0y >= 0 && X0y + SH::PY <= g.W && Y0y >= 0 && Y0y + kBlock + 3 <= g.H;
-      const bool xok = inside || (X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W);
+      bool xok = inside || (X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W);
+#ifdef G1S_DBG_NOHALO
+      xok = xok && ywd >= 1 && ywd <= SH::WY - 2;
+#endif
       // (the lane's offsets from the unit's origin are worked out here from values the optimiser cannot see through:
       //  hoisted out of the unit loop they cost registers -- and a spill, whose reload from scratch waits for every
       //  load in flight)
@@ -363,7 +373,10 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       const uint8_t *sb = c_src + ((ptrdiff_t)Y0c * (ptrdiff_t)c_sst + (ptrdiff_t)X0c * sbps);
       const uint8_t *db = c_den + ((ptrdiff_t)Y0c * (ptrdiff_t)c_dst + (ptrdiff_t)X0c * dbps);
       const bool inside = X0c >= 0 && X0c + SH::PC <= cpw && Y0c >= 0 && Y0c + CH_ + 3 <= cph;
-      const bool xok = inside || (X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw);
+      bool xok = inside || (X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw);
+#ifdef G1S_DBG_NOHALO
+      xok = xok && cwd >= 1 && cwd <= SH::WC - 2;
+#endif
 #pragma unroll
       for (int q = 0; q < CROUNDS; ++q) {
         const int Y = Y0c + ctr[q];

@@ -255,6 +255,18 @@ class DiffGenerator:
     def set_timing(self, enable: bool) -> None:
         self._L.g1s_diff_set_timing(self._h, int(enable))
 
+    def kernel_times(self) -> dict:
+        """Timed batches (set_timing): kernel name -> (milliseconds, launches), HIP events around each launch."""
+        buf = C.create_string_buffer(1 << 14)
+        n = self._L.g1s_diff_kernel_times(self._h, buf, len(buf))
+        if n < 0:
+            self._check(int(n))
+        out = {}
+        for line in buf.raw[:n].decode().splitlines():
+            name, ms, launches = line.split("\t")
+            out[name] = (float(ms), int(launches))
+        return out
+
     def set_flat_finder(self, mode) -> None:
         """0 / False (default): certified fast path; 1 / True: the literal f64 evaluation of every block,
         one lane per block; 2: of every block, one wave per block."""

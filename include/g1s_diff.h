@@ -191,6 +191,10 @@ typedef struct {
 int g1s_diff_get_stats(const g1s_diff_t *, g1s_stats_t *out);
 /* Enable per-kernel HIP-event timing (off by default: events serialise batches). */
 int g1s_diff_set_timing(g1s_diff_t *, int enable);
+/* Timed batches: one line per kernel, "name\tmilliseconds\tlaunches\n" (HIP events around each launch, on the
+ * stream the kernel runs on; the names are the ones rocprofv3 --kernel-trace prints).  Returns the number of bytes
+ * written (no NUL) or G1S_ERR_CAPACITY. */
+long g1s_diff_kernel_times(g1s_diff_t *, char *buf, size_t cap);
 /* Flat-block finder: 0 (default) = integer moments + certified evaluation, literal f64 evaluation (one
  * wave per block) only for the blocks the certificate leaves open; 1 = literal evaluation of every
  * block, one lane per block; 2 = of every block, one wave per block (all three must agree bit for

@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/profile_round.sh TAG -- the measurement set of a round, on the GPU box:
+#   gpurun_out/TAG_bench.json           the default bench.py line
+#   gpurun_out/TAG_kt/                  rocprofv3 --kernel-trace --stats of the same command (shorter)
+#   gpurun_out/TAG_kt1/                 same on one stream (G1S_ONE_STREAM=1: every kernel alone on the chip)
+#   gpurun_out/TAG_fetch/, TAG_write/   PMC passes (FETCH_SIZE, WRITE_SIZE), each in its own run
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd "$ROOT"
+mkdir -p gpurun_out
+timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+tail -c 600 gpurun_out/${TAG}_bench.json; echo
+B="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+bash tools/prof.sh ${TAG}_kt --kernel-trace --stats -- $B > /dev/null
+G1S_ONE_STREAM=1 bash tools/prof.sh ${TAG}_kt1 --kernel-trace --stats -- $B > /dev/null
+G1S_ONE_STREAM=1 bash tools/prof.sh ${TAG}_fetch --pmc FETCH_SIZE -- python $ROOT/bench.py --steps 1 --warmup 1 --frames 32 --cycles 2 --no-cpu-baseline > /dev/null
+G1S_ONE_STREAM=1 bash tools/prof.sh ${TAG}_write --pmc WRITE_SIZE -- python $ROOT/bench.py --steps 1 --warmup 1 --frames 32 --cycles 2 --no-cpu-baseline > /dev/null
+for d in kt kt1; do echo "== $d"; python tools/kstats.py gpurun_out/${TAG}_$d; done
+for d in fetch write; do echo "== $d"; python tools/pmc_summary.py gpurun_out/${TAG}_$d | grep -v "^==" ; done
+find gpurun_out -name "*kernel_trace.csv" -size +8M -delete
+find gpurun_out -name "*counter_collection.csv" -size +8M -delete
