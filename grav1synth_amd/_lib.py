@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("G1S_LIB") or os.path.join(_HERE, "libg1s_diff.so")  # (G1S_LIB: an instrumented build, tools/ only)
 
 G1S_OK = 0
+G1S_ERR_CAPACITY = -8
 ERRORS = {
     -1: "G1S_ERR_INVALID",
     -2: "G1S_ERR_DIM_MISMATCH",
@@ -145,6 +146,7 @@ SYMBOLS = [
     ("g1s_diff_get_stats", C.c_int, [C.c_void_p, C.POINTER(G1SStats)]),
     ("g1s_diff_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("g1s_diff_kernel_times", C.c_long, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    ("g1s_diff_frames_released", C.c_uint64, [C.c_void_p]),
     ("g1s_diff_set_flat_finder", C.c_int, [C.c_void_p, C.c_int]),
     ("g1s_diff_last_record", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("g1s_record_geometry", C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4),

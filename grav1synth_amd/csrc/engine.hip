@@ -16,6 +16,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -93,34 +94,41 @@ class Pool {
     cv_.notify_all();
     for (auto &t : workers_) t.join();
   }
-  // runs fn(i) for i in [0, n); the caller participates
+  // runs fn(i) for i in [0, n); the caller participates.  Every call has its own job object (function, count, claim and
+  // completion counters): a worker that comes late to an earlier job holds THAT job, finds it exhausted and goes back to
+  // sleep -- it can never claim an index of a newer job or run the newer function with an older count.
   void parallel_for(int n, const std::function<void(int)> &fn) {
     if (n <= 0) return;
+    auto job = std::make_shared<Job>();
+    job->fn = &fn;
+    job->n = n;
     {
       std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn;
-      n_ = n;
-      next_.store(0);
-      done_.store(0);
+      job_ = job;
       ++epoch_;
     }
     cv_.notify_all();
-    work();
+    work(*job);
     std::unique_lock<std::mutex> lk(m_);
-    cv_done_.wait(lk, [this] { return done_.load() == n_; });
-    fn_ = nullptr;
+    cv_done_.wait(lk, [&] { return job->done.load() == job->n; });
+    if (job_ == job) job_.reset();
   }
 
  private:
-  void work() {
+  struct Job {
+    const std::function<void(int)> *fn = nullptr;
+    int n = 0;
+    std::atomic<int> next{0}, done{0};
+  };
+  void work(Job &job) {
     int mine = 0;
     for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= n_) break;
-      (*fn_)(i);
+      const int i = job.next.fetch_add(1);
+      if (i >= job.n) break;
+      (*job.fn)(i);  // (fn outlives the job: parallel_for returns only when done == n)
       ++mine;
     }
-    if (mine && done_.fetch_add(mine) + mine == n_) {
+    if (mine && job.done.fetch_add(mine) + mine == job.n) {
       std::lock_guard<std::mutex> lk(m_);  // (the waiter checks under this lock: no lost wake-up)
       cv_done_.notify_all();
     }
@@ -128,22 +136,21 @@ class Pool {
   void loop() {
     uint64_t seen = 0;
     for (;;) {
+      std::shared_ptr<Job> job;
       {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
         if (stop_) return;
         seen = epoch_;
+        job = job_;
       }
-      work();
+      if (job) work(*job);
     }
   }
   std::vector<std::thread> workers_;
   std::mutex m_;
   std::condition_variable cv_, cv_done_;
-  const std::function<void(int)> *fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0;
-  std::atomic<int> done_{0};
+  std::shared_ptr<Job> job_;
   uint64_t epoch_ = 0;
   bool stop_ = false;
 };
@@ -200,6 +207,28 @@ struct Slot {
   std::vector<std::string> kname;
   size_t nk = 0;
 };
+
+static void free_slot(Slot &sl) {
+  if (sl.h_planes) (void)hipHostFree(sl.h_planes);
+  if (sl.d_planes) (void)hipFree(sl.d_planes);
+  if (sl.d_records) (void)hipFree(sl.d_records);
+  if (sl.h_records) (void)hipHostFree(sl.h_records);
+  if (sl.d_flags) (void)hipFree(sl.d_flags);
+  if (sl.d_k1) (void)hipFree(sl.d_k1);
+  if (sl.d_partials) (void)hipFree(sl.d_partials);
+  if (sl.d_defer) (void)hipFree(sl.d_defer);
+  if (sl.d_k0) (void)hipFree(sl.d_k0);
+  if (sl.d_pgl) (void)hipFree(sl.d_pgl);
+  if (sl.d_mu) (void)hipFree(sl.d_mu);
+  if (sl.d_mpart) (void)hipFree(sl.d_mpart);
+  if (sl.d_lplane) (void)hipFree(sl.d_lplane);
+  if (sl.d_stage) (void)hipFree(sl.d_stage);
+  if (sl.done) (void)hipEventDestroy(sl.done);
+  for (auto &e : sl.ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto &e : sl.kev) (void)hipEventDestroy(e);
+  sl = Slot{};
+}
 
 // Process-wide cache of slot buffers: pinned-host and device allocations cost
 // hundreds of microseconds each; consecutive generators of the same geometry
@@ -349,6 +378,7 @@ struct g1s_diff {
   std::deque<int> in_flight;       // submitted, not yet picked up by the drainer
   bool slot_busy[kSlots] = {};     // submitted and not yet drained
   uint64_t submitted = 0, drained = 0;  // batches
+  uint64_t frames_released = 0;         // frame pairs of the drained batches (their inputs are no longer read)
   bool drainer_stop = false;
   NoiseFold *fold = nullptr;
   Pool *pool = nullptr;
@@ -361,8 +391,11 @@ struct g1s_diff {
   std::vector<uint8_t> last_record;
   std::string err;
   int deferred = G1S_OK;
-  int sticky = G1S_OK;  // a fold error kills the generator (the reference `?`-propagates out of main)
+  // a fold error, a HIP error or a batch that failed to launch or drain kills the generator: every later call, finish
+  // included, returns it (the reference `?`-propagates out of main; a table with frames silently missing is worse)
+  std::atomic<int> sticky{G1S_OK};
   bool finished = false;
+  std::vector<g1s_segment_t> final_segs;  // what finish() returned (kept: a too-small buffer can be retried)
   bool timing = false;
   int flat_literal = 0;  // flat-block finder: literal f64 evaluation of every block (1: lane per block, 2: wave per block)
   g1s_stats_t stats{};
@@ -388,10 +421,13 @@ struct g1s_diff {
   }
   int fail_hip(const char *msg) {
     err = msg;
+    int ok = G1S_OK;
+    sticky.compare_exchange_strong(ok, G1S_ERR_HIP);
     return G1S_ERR_HIP;
   }
 
   int set_geometry(const g1s_frame_t *s, const g1s_frame_t *d);
+  int set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d);
   int append(const g1s_frame_t *s, const g1s_frame_t *d);
   int submit(int si);        // front half now; back half now or with the next batch's front half
   int launch_front(int si);  // zero, pixel pass, flat-block finder, window planes, area lists
@@ -430,7 +466,14 @@ static void make_flat_consts(FlatConsts &fc) {
   }
 }
 
+// (an allocation that fails half way leaves no half-built slot behind: a retry starts from nothing)
 int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
+  const int rc = set_geometry_alloc(s, d);
+  if (rc)
+    for (Slot &sl : slots) free_slot(sl);
+  return rc;
+}
+int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
   shape = *s;
   if (batch_auto) {
     // about 265 Mpixels a launch group (32 4K frames): the per-launch costs of the small kernels are the same
@@ -562,6 +605,7 @@ int g1s_diff::append(const g1s_frame_t *s, const g1s_frame_t *d) {
     return fail(G1S_ERR_DIM_MISMATCH, "frame geometry changed mid-stream");
   }
   Slot &sl = slots[cur];
+  if (sl.count >= batch) return fail(G1S_ERR_STATE, "the previous batch failed to launch");
   FramePlanes &fp = sl.h_planes[sl.count];
   std::memset(&fp, 0, sizeof(fp));
   const uint32_t np = (uint32_t)geom.nplanes;
@@ -1100,6 +1144,8 @@ void g1s_diff::drainer_main() {
     {
       std::lock_guard<std::mutex> lk(dm);
       if (rc && deferred == G1S_OK) deferred = rc;
+      int ok = G1S_OK;
+      if (rc) sticky.compare_exchange_strong(ok, rc);  // (the batch is missing from the fold: no table from here on)
       front_failed[si] = rc != G1S_OK;
       fold_q.push_back(si);
     }
@@ -1117,12 +1163,16 @@ void g1s_diff::folder_main() {
       si = fold_q.front();
       fold_q.pop_front();
     }
+    const uint32_t nframes = slots[si].count;  // (drain_back hands the slot back empty)
     const int rc = drain_back(si);
     {
       std::lock_guard<std::mutex> lk(dm);
       if (rc && deferred == G1S_OK) deferred = rc;
+      int ok = G1S_OK;
+      if (rc) sticky.compare_exchange_strong(ok, rc);
       slot_busy[si] = false;
       ++drained;
+      frames_released += nframes;
     }
     cv_free.notify_all();
   }
@@ -1320,25 +1370,7 @@ void g1s_diff::release() {
         continue;
       }
     }
-    if (sl.h_planes) (void)hipHostFree(sl.h_planes);
-    if (sl.d_planes) (void)hipFree(sl.d_planes);
-    if (sl.d_records) (void)hipFree(sl.d_records);
-    if (sl.h_records) (void)hipHostFree(sl.h_records);
-    if (sl.d_flags) (void)hipFree(sl.d_flags);
-    if (sl.d_k1) (void)hipFree(sl.d_k1);
-    if (sl.d_partials) (void)hipFree(sl.d_partials);
-    if (sl.d_defer) (void)hipFree(sl.d_defer);
-    if (sl.d_k0) (void)hipFree(sl.d_k0);
-    if (sl.d_pgl) (void)hipFree(sl.d_pgl);
-    if (sl.d_mu) (void)hipFree(sl.d_mu);
-    if (sl.d_mpart) (void)hipFree(sl.d_mpart);
-    if (sl.d_lplane) (void)hipFree(sl.d_lplane);
-    if (sl.d_stage) (void)hipFree(sl.d_stage);
-    if (sl.done) (void)hipEventDestroy(sl.done);
-    for (auto &e : sl.ev)
-      if (e) (void)hipEventDestroy(e);
-    for (auto &e : sl.kev) (void)hipEventDestroy(e);
-    sl = Slot{};
+    free_slot(sl);
   }
   d_lut = nullptr;  // shared per device
   stream = nullptr;
@@ -1492,17 +1524,20 @@ int g1s_diff_sync(g1s_diff_t *g) {
 
 int g1s_diff_finish(g1s_diff_t *g, g1s_segment_t *out, size_t cap, size_t *n_out) {
   if (!g) return G1S_ERR_INVALID;
-  if (g->finished) return g->fail(G1S_ERR_STATE, "generator already finished");
   if (g->records_only || g->latest_only)
     return g->fail(G1S_ERR_STATE, "records_only / latest_only generator: use g1s_diff_take_* + g1s_fold_*");
-  const int rc = g1s_diff_sync(g);
-  if (rc) return rc;
-  g->finished = true;
-  std::vector<g1s_segment_t> segs;
-  g->fold->finish(segs);
+  // The segments stay in the object: a call whose buffer is too small reports the count and loses nothing -- the caller
+  // sizes the buffer from *n_out and calls again (the reference's Vec has no cap: src/main.rs:524).
+  if (!g->finished) {
+    const int rc = g1s_diff_sync(g);
+    if (rc) return rc;
+    g->fold->finish(g->final_segs);
+    g->finished = true;  // no more frames
+  }
+  const std::vector<g1s_segment_t> &segs = g->final_segs;
   if (n_out) *n_out = segs.size();
-  if (segs.size() > cap) return g->fail(G1S_ERR_CAPACITY, "segment buffer too small");
-  std::memcpy(out, segs.data(), sizeof(g1s_segment_t) * segs.size());
+  if (segs.size() > cap || (!out && !segs.empty())) return g->fail(G1S_ERR_CAPACITY, "segment buffer too small");
+  if (!segs.empty()) std::memcpy(out, segs.data(), sizeof(g1s_segment_t) * segs.size());
   return G1S_OK;
 }
 
@@ -1609,6 +1644,7 @@ struct g1s_fold {
   uint32_t lag;
   std::string err;
   bool finished = false;
+  std::vector<g1s_segment_t> final_segs;  // what finish() returned (kept: a too-small buffer can be retried)
   Pool *pool = nullptr;
   std::vector<FrameLatest> latest;
   g1s_fold(int64_t a, int64_t b, uint32_t lag_) : fold(a, b, lag_), lag(lag_) {}
@@ -1700,16 +1736,17 @@ int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, 
 }
 int g1s_fold_finish(g1s_fold_t *f, g1s_segment_t *out, size_t cap, size_t *n_out) {
   if (!f) return G1S_ERR_INVALID;
-  if (f->finished) return G1S_ERR_STATE;
-  f->finished = true;
-  std::vector<g1s_segment_t> segs;
-  f->fold.finish(segs);
+  if (!f->finished) {
+    f->fold.finish(f->final_segs);
+    f->finished = true;  // no more records; the segments stay here, so a too-small buffer can be retried
+  }
+  const std::vector<g1s_segment_t> &segs = f->final_segs;
   if (n_out) *n_out = segs.size();
-  if (segs.size() > cap) {
+  if (segs.size() > cap || (!out && !segs.empty())) {
     f->err = "segment buffer too small";
     return G1S_ERR_CAPACITY;
   }
-  std::memcpy(out, segs.data(), sizeof(g1s_segment_t) * segs.size());
+  if (!segs.empty()) std::memcpy(out, segs.data(), sizeof(g1s_segment_t) * segs.size());
   return G1S_OK;
 }
 void g1s_fold_free(g1s_fold_t *f) { delete f; }
@@ -1758,6 +1795,11 @@ int g1s_diff_get_stats(const g1s_diff_t *g, g1s_stats_t *out) {
   *out = g->stats;
   out->ms_host_fold = g->ms_fold_front + g->ms_fold_back;  // (the two stages overlap across batches)
   return G1S_OK;
+}
+uint64_t g1s_diff_frames_released(g1s_diff_t *g) {
+  if (!g) return 0;
+  std::lock_guard<std::mutex> lk(g->dm);
+  return g->frames_released;
 }
 long g1s_diff_kernel_times(g1s_diff_t *g, char *buf, size_t cap) {
   if (!g || (!buf && cap)) return G1S_ERR_INVALID;

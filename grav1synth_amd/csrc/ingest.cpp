@@ -350,9 +350,9 @@ int g1s_diff_y4m_files(const char *source_path, const char *denoised_path, const
     goto done;
   }
   rc = g1s_diff_finish(g, segs.data(), segs.size(), &n);
-  if (rc == G1S_ERR_CAPACITY) {
-    set_err(err, errcap, "more than 64 grain table segments");
-    goto done;
+  if (rc == G1S_ERR_CAPACITY) {  // more scene cuts than the first guess: the segments are still there, ask again
+    segs.resize(n);
+    rc = g1s_diff_finish(g, segs.data(), segs.size(), &n);
   }
   if (rc) {
     set_err(err, errcap, g1s_diff_last_error(g));

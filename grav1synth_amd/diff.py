@@ -9,6 +9,7 @@ libg1s_diff.so; this module only marshals pointers.
 from __future__ import annotations
 
 import ctypes as C
+from collections import deque
 from dataclasses import dataclass, field
 from fractions import Fraction
 from typing import List, Optional, Sequence, Tuple, Union
@@ -180,7 +181,10 @@ class DiffGenerator:
                                        C.byref(opts))
         if not self._h:
             raise G1SError(-5, self._L.g1s_last_global_error().decode())
-        self._keep: list = []
+        # device-resident inputs must outlive the kernels that read them: (frames handed over so far, objects), pruned
+        # by g1s_diff_frames_released -- a long stream pins a few batches, not every frame until finish
+        self._keep: deque = deque()
+        self._fed = 0
         self._finished = False
         self.records_only = records_only
         self.fps = fr
@@ -195,8 +199,20 @@ class DiffGenerator:
         if (fs.on_device or fd.on_device):
             if sync_torch:
                 torch.cuda.current_stream().synchronize()  # producer (torch) -> consumer (engine stream)
-            self._keep.extend(keep)  # device planes must outlive the queued kernels
+            self._keep.append((self._fed + 1, keep))  # device planes must outlive the queued kernels
+        self._fed += 1
         self._check(self._L.g1s_diff_frame(self._h, C.byref(fs), C.byref(fd)))
+        self._prune()
+
+    def _prune(self) -> None:
+        if self._keep:
+            done = int(self._L.g1s_diff_frames_released(self._h))
+            while self._keep and self._keep[0][0] <= done:
+                self._keep.popleft()
+
+    def frames_released(self) -> int:
+        """g1s_diff_frames_released: frame pairs whose planes the generator no longer reads."""
+        return int(self._L.g1s_diff_frames_released(self._h))
 
     # -- many frame pairs in one FFI call (g1s_diff_frames) -------------------------------
     @staticmethod
@@ -215,8 +231,10 @@ class DiffGenerator:
     def diff_prepared(self, prepared: "PreparedFrames", sync_torch: bool = True) -> None:
         if sync_torch and torch is not None and torch.cuda.is_available():
             torch.cuda.current_stream().synchronize()
-        self._keep.append(prepared)
+        self._keep.append((self._fed + prepared.n, prepared))
+        self._fed += prepared.n
         self._check(self._L.g1s_diff_frames(self._h, prepared.src, prepared.den, prepared.n))
+        self._prune()
 
     def sync(self) -> None:
         self._check(self._L.g1s_diff_sync(self._h))
@@ -224,9 +242,15 @@ class DiffGenerator:
 
     # -- DiffGenerator::finish (src/main.rs:524) ----------------------------------------
     def finish(self) -> List[GrainTableSegment]:
-        arr = (G1SSegment * 1024)()
+        cap = 64
+        arr = (G1SSegment * cap)()
         n = C.c_size_t()
-        self._check(self._L.g1s_diff_finish(self._h, arr, 1024, C.byref(n)))
+        rc = self._L.g1s_diff_finish(self._h, arr, cap, C.byref(n))
+        if rc == _lib.G1S_ERR_CAPACITY:  # the segments stay in the generator: ask again with room for all of them
+            cap = n.value
+            arr = (G1SSegment * cap)()
+            rc = self._L.g1s_diff_finish(self._h, arr, cap, C.byref(n))
+        self._check(rc)
         self._finished = True
         self._keep.clear()
         return [GrainTableSegment.from_c(arr[i]) for i in range(n.value)]
@@ -409,9 +433,14 @@ class RecordFold:
             raise G1SError(rc, self._L.g1s_fold_last_error(self._h).decode())
 
     def finish(self) -> List[GrainTableSegment]:
-        arr = (G1SSegment * 1024)()
+        cap = 64
+        arr = (G1SSegment * cap)()
         n = C.c_size_t()
-        rc = self._L.g1s_fold_finish(self._h, arr, 1024, C.byref(n))
+        rc = self._L.g1s_fold_finish(self._h, arr, cap, C.byref(n))
+        if rc == _lib.G1S_ERR_CAPACITY:
+            cap = n.value
+            arr = (G1SSegment * cap)()
+            rc = self._L.g1s_fold_finish(self._h, arr, cap, C.byref(n))
         if rc != 0:
             raise G1SError(rc, self._L.g1s_fold_last_error(self._h).decode())
         return [GrainTableSegment.from_c(arr[i]) for i in range(n.value)]

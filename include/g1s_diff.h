@@ -121,8 +121,14 @@ int g1s_diff_frame(g1s_diff_t *, const g1s_frame_t *source, const g1s_frame_t *d
 int g1s_diff_frames(g1s_diff_t *, const g1s_frame_t *source, const g1s_frame_t *denoised, size_t n);
 /* Drain all queued work (kernels + ordered fold). */
 int g1s_diff_sync(g1s_diff_t *);
-/* DiffGenerator::finish (src/main.rs:524).  Consumes the generator: afterwards
- * only g1s_diff_free / g1s_diff_last_error / g1s_diff_get_stats are legal. */
+/* How many frame pairs, counted in the order they were handed over, the generator is done reading: the planes of
+ * on_device frames (and of host frames, which are copied at the call anyway) before that count may be freed or
+ * overwritten.  Monotonic; reaches the number of frames handed over after g1s_diff_sync / g1s_diff_finish.  A caller
+ * that streams device-resident frames polls this instead of keeping every frame alive until the end. */
+uint64_t g1s_diff_frames_released(g1s_diff_t *);
+/* DiffGenerator::finish (src/main.rs:524).  Ends the stream: afterwards no more frames are accepted.  *n_out = the
+ * number of segments; if cap is too small the call returns G1S_ERR_CAPACITY with *n_out set and NOTHING is lost --
+ * call again with a buffer of *n_out segments (the reference's Vec has no cap). */
 int g1s_diff_finish(g1s_diff_t *, g1s_segment_t *out, size_t cap, size_t *n_out);
 void g1s_diff_free(g1s_diff_t *);
 /* anyhow::Error text of the last failure ("" if none). */
@@ -161,6 +167,7 @@ int g1s_fold_push(g1s_fold_t *, const void *record, size_t size_bytes);
 int g1s_fold_push_many(g1s_fold_t *, const void *records, size_t stride_bytes, size_t n);
 /* n latest states, stride_bytes apart, in frame order: the ordered half only. */
 int g1s_fold_push_latest(g1s_fold_t *, const void *blobs, size_t stride_bytes, size_t n);
+/* Same contract as g1s_diff_finish: G1S_ERR_CAPACITY leaves the segments in place for a second call. */
 int g1s_fold_finish(g1s_fold_t *, g1s_segment_t *out, size_t cap, size_t *n_out);
 void g1s_fold_free(g1s_fold_t *);
 const char *g1s_fold_last_error(const g1s_fold_t *);

@@ -114,6 +114,28 @@ def test_accumulation_modes_agree():
     assert lines["fused"] == lines["dot4"], "fused vs dot4"
 
 
+def test_streamed_device_frames_are_released_batch_by_batch():
+    """A long GPU-resident stream must not pin every frame until finish: g1s_diff_frames_released tells the caller
+    which frame pairs the generator is done reading, and the Python mirror prunes its keep-alives by it."""
+    import time
+
+    spec = SynthSpec(320, 192, 8)
+    g = DiffGenerator(Fraction(24, 1), 8, 8, batch_frames=4)
+    n, worst = 64, 0
+    for k in range(n):
+        s, d = make_pair(spec, k % 5, device="cuda")
+        g.diff_frame(s, d, spec.xdec, spec.ydec)
+        del s, d
+        if k % 8 == 7:
+            time.sleep(0.02)  # (let the pipeline drain a little: a real producer is slower than these tiny frames)
+        worst = max(worst, len(g._keep))
+        assert g.frames_released() <= k + 1
+    assert worst <= 4 * 4 + 8, f"{worst} frame pairs pinned at once"  # four slots of four frames + what the sleep covers
+    g.sync()
+    assert g.frames_released() == n
+    assert len(g.finish()) >= 1
+
+
 def test_batched_equals_unbatched_and_oracle():
     """Batching/pipelining must not change anything: 7 frames with batch 3."""
     spec = SynthSpec(320, 192, 8)

@@ -87,6 +87,29 @@ def test_fold_segmentation_matches_oracle():
     assert format_tbl(out) == tbl
 
 
+def test_finish_with_a_small_buffer_loses_nothing():
+    """g1s_fold_finish (same contract as g1s_diff_finish): a buffer that is too small reports the segment count with
+    G1S_ERR_CAPACITY and keeps the segments; the second call, sized from the count, gets all of them."""
+    from grav1synth_amd._lib import G1SSegment
+
+    a = SynthSpec(320, 192, 8)
+    b = SynthSpec(320, 192, 8, gain_scale=3)
+    specs = [a, a, a, b, b, b]
+    fps = Fraction(30000, 1001)
+    fold = RecordFold(fps, 3)
+    tbl, segs = oracle_run(a, range(6), fps=fps, specs_per_frame=specs,
+                           collect=lambda o, k: fold.push(record_from_oracle(o, a, 3, 3).buf))
+    L = _lib.lib()
+    n = C.c_size_t()
+    one = (G1SSegment * 1)()
+    assert L.g1s_fold_finish(fold._h, one, 1, C.byref(n)) == _lib.G1S_ERR_CAPACITY
+    assert n.value == len(segs) >= 2
+    assert L.g1s_fold_finish(fold._h, None, 0, C.byref(n)) == _lib.G1S_ERR_CAPACITY and n.value == len(segs)
+    out = fold.finish()  # the mirror's own retry path works on the same object
+    assert format_tbl(out) == tbl
+    assert format_tbl(fold.finish()) == tbl  # and finish stays repeatable
+
+
 def test_fold_rejects_bad_records():
     fold = RecordFold(Fraction(24, 1), 3)
     with pytest.raises(_lib.G1SError):
