@@ -23,6 +23,7 @@ ERRORS = {
     -6: "G1S_ERR_HIP",
     -7: "G1S_ERR_STATE",
     -8: "G1S_ERR_CAPACITY",
+    -9: "G1S_ERR_UNSUPPORTED",
 }
 
 
@@ -113,6 +114,19 @@ class G1SY4MInfo(C.Structure):
     ]
 
 
+class G1SFilterDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("top", C.c_uint64),
+        ("bottom", C.c_uint64),
+        ("left", C.c_uint64),
+        ("right", C.c_uint64),
+        ("width", C.c_uint64),
+        ("height", C.c_uint64),
+        ("alg", C.c_char * 16),
+    ]
+
+
 NEXT_FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(G1SFrame))
 
 # every symbol include/g1s_diff.h declares: (name, restype, argtypes)
@@ -158,6 +172,13 @@ SYMBOLS = [
                                           C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_uint32))]),
     ("g1s_diff_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    ("g1s_filters_new", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("g1s_filters_len", C.c_size_t, [C.c_void_p]),
+    ("g1s_filters_get", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(G1SFilterDesc)]),
+    ("g1s_filters_apply", C.c_int, [C.c_void_p, C.POINTER(G1SFrame), C.POINTER(G1SFrame), C.c_char_p, C.c_size_t]),
+    ("g1s_filters_free", None, [C.c_void_p]),
+    ("g1s_diff_run_filtered", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     ("g1s_y4m_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("g1s_y4m_get_info", C.c_int, [C.c_void_p, C.POINTER(G1SY4MInfo)]),
     ("g1s_y4m_next", C.c_int, [C.c_void_p, C.POINTER(G1SFrame)]),
@@ -165,6 +186,8 @@ SYMBOLS = [
     ("g1s_y4m_close", None, [C.c_void_p]),
     ("g1s_diff_y4m_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(G1SOpts),
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    ("g1s_diff_y4m_files_filtered", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(G1SOpts), C.c_char_p,
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
 ]
 
 _lib = None

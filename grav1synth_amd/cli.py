@@ -1,0 +1,95 @@
+"""`python -m grav1synth_amd diff SOURCE DENOISED -o OUT [-y] [-f FILTERS]` -- the front door of the path.
+
+The `diff` command of the reference (Commands::Diff, /root/reference/src/main.rs:347-533, arguments :846-870) for .y4m
+inputs, around g1s_diff_y4m_files_filtered: the same refusals in the same order, with the same texts, and like the
+reference every refusal is a logged line and a normal exit --
+
+  * an input path equal to the output path              (src/main.rs:354-360)
+  * source path equal to denoised path                  (src/main.rs:362-368)
+  * a filter chain that does not parse                  (src/main.rs:370-380: "Invalid filter chain: {e}")
+  * an existing output without -y and without a "yes"   (src/main.rs:382-394)
+
+-- then the frame-pair loop, finish, the table (src/main.rs:414-529) and the two closing lines (:531-532)."""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+from typing import List, Optional
+
+log = logging.getLogger("grav1synth")
+
+SAME_AS_OUTPUT = ("Input and output paths are the same. This is probably a typo, because this would overwrite your "
+                  "input. Exiting.")
+SAME_INPUTS = ("Source and denoised paths are the same. This is probably a typo, because this would always compute an "
+               "empty diff. Exiting.")
+NOT_OVERWRITING = "Not overwriting existing file. Exiting."
+
+
+def _confirm(prompt: str) -> bool:
+    """dialoguer::Confirm: y / n on the terminal; without a terminal nobody can say yes."""
+    if not sys.stdin.isatty():
+        return False
+    try:
+        return input(f"{prompt} [y/n] ").strip().lower() in ("y", "yes")
+    except EOFError:
+        return False
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="grav1synth_amd", description="MI355X-native `grav1synth diff`")
+    sub = ap.add_subparsers(dest="command", required=True)
+    d = sub.add_parser("diff", help="Compares a source video to a denoised video and generates a film grain table (y4m inputs).")
+    d.add_argument("source", help="The untouched source file to inspect.")
+    d.add_argument("denoised", help="The denoised file to inspect.")
+    d.add_argument("-o", "--output", required=True, help="The path to the output film grain table.")
+    d.add_argument("-y", "--overwrite", action="store_true", help="Overwrite the output file without prompting.")
+    d.add_argument("-f", "--filters", default=None,
+                   help='A semicolon-separated list of filters to apply to the source before running the diff, e.g. '
+                        '"crop:top=42,left=64".  crop: top, bottom, left, right.  resize (width, height, alg) parses like the '
+                        "reference's but is not supported here.")
+    d.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: the current device)")
+    return ap
+
+
+def diff_command(source: str, denoised: str, output: str, overwrite: bool = False, filters: Optional[str] = None,
+                 device: int = -1, confirm=_confirm) -> int:
+    """Returns the number of frame pairs diffed, or -1 when the command refused to run (a logged line, exit 0)."""
+    from .filters import FilterChain, FilterError
+    from .ingest import diff_y4m_files
+
+    if source == output or denoised == output:
+        log.error(SAME_AS_OUTPUT)
+        return -1
+    if source == denoised:
+        log.error(SAME_INPUTS)
+        return -1
+    if filters is not None:
+        try:
+            FilterChain(filters).close()
+        except FilterError as e:
+            log.error("Invalid filter chain: %s", e)
+            return -1
+    if os.path.exists(output) and not overwrite and not confirm(f"File {output} exists. Overwrite?"):
+        log.warning(NOT_OVERWRITING)
+        return -1
+    frames, _unequal = diff_y4m_files(source, denoised, output, device=device, filters=filters)  # (logs "Computed diff for N frames")
+    log.info("Done, wrote output file to %s", output)
+    return frames
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    args = build_parser().parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(levelname)s %(message)s", stream=sys.stderr)
+    if args.command == "diff":
+        try:
+            diff_command(args.source, args.denoised, args.output, args.overwrite, args.filters, args.device)
+        except Exception as e:  # `?` out of main: the error, a non-zero exit
+            log.error("%s", e)
+            return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1549,6 +1549,10 @@ void g1s_diff_free(g1s_diff_t *g) {
 }
 
 const char *g1s_diff_last_error(const g1s_diff_t *g) { return g ? g->err.c_str() : ""; }
+// (internal, ingest.cpp: the frame-pair loop prefixes errors with the index of the pair)
+void g1s_diff_set_error_text_(g1s_diff_t *g, const char *msg) {
+  if (g && msg) g->err = msg;
+}
 
 size_t g1s_record_size(uint32_t width, uint32_t height, uint32_t xdec, uint32_t ydec, uint32_t nplanes,
                        uint32_t lag) {

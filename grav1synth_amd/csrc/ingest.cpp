@@ -297,39 +297,88 @@ void g1s_y4m_close(g1s_y4m_t *y) {
   delete y;
 }
 
-int g1s_diff_run(g1s_diff_t *g, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
-                 void *denoised_user, uint64_t *frames_out, int *unequal_out) {
+// (engine.hip) replaces the generator's error text: the loop below prefixes errors with the index of the frame pair
+extern "C" void g1s_diff_set_error_text_(g1s_diff_t *, const char *);
+
+int g1s_diff_run_filtered(g1s_diff_t *g, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
+                          void *denoised_user, const g1s_filters_t *filters, uint64_t *frames_out, int *unequal_out) {
   if (!g || !source || !denoised) return G1S_ERR_INVALID;
   uint64_t frames = 0;
   int unequal = 0;
+  int rc = G1S_OK;
+  auto note = [&](const std::string &what) {
+    g1s_diff_set_error_text_(g, ("frame " + std::to_string(frames) + ": " + what).c_str());
+  };
   for (;;) {
-    // get_filtered_frame_pair (src/main.rs:615-629): one frame from each reader, source first
+    // get_filtered_frame_pair (src/main.rs:615-629): one frame from each reader, source first; the filter chain on
+    // the source frame only
     g1s_frame_t s, d;
     const int rs = source(source_user, &s);
     const int rd = denoised(denoised_user, &d);
-    if (rs < 0) return rs;
-    if (rd < 0) return rd;
+    if (rs < 0 || rd < 0) {
+      rc = rs < 0 ? rs : rd;
+      note(std::string(rs < 0 ? "source" : "denoised") + " reader failed");
+      break;
+    }
     if (rs == 0 && rd == 0) break;  // (None, None)
     if (rs == 0 || rd == 0) {       // "Videos did not have equal frame counts. Resulting grain table may
       unequal = 1;                  //  not be as expected." -- a warning, then the loop ends (src/main.rs:449-455)
       break;
     }
-    const int rc = g1s_diff_frame(g, &s, &d);  // `?`: the first error ends the command
-    if (rc) return rc;
+    if (filters) {
+      char ferr[320] = "";
+      g1s_frame_t cropped;
+      rc = g1s_filters_apply(filters, &s, &cropped, ferr, sizeof(ferr));
+      if (rc) {
+        note(ferr);
+        break;
+      }
+      s = cropped;
+    }
+    rc = g1s_diff_frame(g, &s, &d);  // `?`: the first error ends the command
+    if (rc) {
+      // (an error of an EARLIER, queued batch surfaces here too: the text says which call, the engine's says what)
+      note(std::string("diff_frame: ") + g1s_diff_last_error(g));
+      break;
+    }
     ++frames;
   }
   if (frames_out) *frames_out = frames;
   if (unequal_out) *unequal_out = unequal;
-  return G1S_OK;
+  return rc;
+}
+
+int g1s_diff_run(g1s_diff_t *g, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
+                 void *denoised_user, uint64_t *frames_out, int *unequal_out) {
+  return g1s_diff_run_filtered(g, source, source_user, denoised, denoised_user, nullptr, frames_out, unequal_out);
 }
 
 int g1s_diff_y4m_files(const char *source_path, const char *denoised_path, const char *out_tbl_path,
                        const g1s_opts_t *opts, uint64_t *frames_out, int *unequal_out, char *err, size_t errcap) {
+  return g1s_diff_y4m_files_filtered(source_path, denoised_path, out_tbl_path, opts, nullptr, frames_out, unequal_out, err, errcap);
+}
+
+int g1s_diff_y4m_files_filtered(const char *source_path, const char *denoised_path, const char *out_tbl_path,
+                                const g1s_opts_t *opts, const char *filter_text, uint64_t *frames_out, int *unequal_out,
+                                char *err, size_t errcap) {
+  g1s_filters_t *filters = nullptr;
+  if (filter_text && *filter_text) {  // src/main.rs:370-380: "Invalid filter chain: {e}", nothing is opened
+    char ferr[256] = "";
+    filters = g1s_filters_new(filter_text, ferr, sizeof(ferr));
+    if (!filters) {
+      set_err(err, errcap, std::string("Invalid filter chain: ") + ferr);
+      return G1S_ERR_INVALID;
+    }
+  }
   g1s_y4m_t *ys = g1s_y4m_open(source_path, err, errcap);
-  if (!ys) return G1S_ERR_INVALID;
+  if (!ys) {
+    g1s_filters_free(filters);
+    return G1S_ERR_INVALID;
+  }
   g1s_y4m_t *yd = g1s_y4m_open(denoised_path, err, errcap);
   if (!yd) {
     g1s_y4m_close(ys);
+    g1s_filters_free(filters);
     return G1S_ERR_INVALID;
   }
   int rc = G1S_OK;
@@ -343,10 +392,12 @@ int g1s_diff_y4m_files(const char *source_path, const char *denoised_path, const
     rc = G1S_ERR_NO_DEVICE;
     goto done;
   }
-  rc = g1s_diff_run(g, g1s_y4m_next, ys, g1s_y4m_next, yd, frames_out, unequal_out);
+  rc = g1s_diff_run_filtered(g, g1s_y4m_next, ys, g1s_y4m_next, yd, filters, frames_out, unequal_out);
   if (rc) {
-    const char *e = g1s_diff_last_error(g);
-    set_err(err, errcap, (e && *e) ? e : (ys->failed ? ys->error : yd->error));
+    std::string e = g1s_diff_last_error(g);  // "frame N: ..."
+    if (ys->failed) e += " (" + ys->error + ")";
+    else if (yd->failed) e += " (" + yd->error + ")";
+    set_err(err, errcap, e);
     goto done;
   }
   rc = g1s_diff_finish(g, segs.data(), segs.size(), &n);
@@ -361,6 +412,7 @@ int g1s_diff_y4m_files(const char *source_path, const char *denoised_path, const
   rc = g1s_write_tbl(out_tbl_path, segs.data(), n);
   if (rc) set_err(err, errcap, std::string("cannot write ") + out_tbl_path);
 done:
+  g1s_filters_free(filters);
   if (g) g1s_diff_free(g);
   g1s_y4m_close(ys);
   g1s_y4m_close(yd);

@@ -84,15 +84,15 @@ class Y4MReader:
 
 
 def diff_y4m_files(source: str, denoised: str, output: str, *, ar_coeff_lag: int = 3, luma_only: bool = False,
-                   batch_frames: int = 0, device: int = -1) -> Tuple[int, bool]:
-    """`grav1synth diff SOURCE DENOISED -o OUTPUT` for .y4m inputs.  Returns (frames, unequal)."""
+                   batch_frames: int = 0, device: int = -1, filters: Optional[str] = None) -> Tuple[int, bool]:
+    """`grav1synth diff SOURCE DENOISED -o OUTPUT [-f FILTERS]` for .y4m inputs.  Returns (frames, unequal)."""
     L = _lib.lib()
     opts = G1SOpts(C.sizeof(G1SOpts), device, ar_coeff_lag, int(luma_only), batch_frames, 0)
     frames = C.c_uint64(0)
     unequal = C.c_int(0)
     err = C.create_string_buffer(512)
-    rc = L.g1s_diff_y4m_files(str(source).encode(), str(denoised).encode(), str(output).encode(), C.byref(opts),
-                              C.byref(frames), C.byref(unequal), err, len(err))
+    rc = L.g1s_diff_y4m_files_filtered(str(source).encode(), str(denoised).encode(), str(output).encode(), C.byref(opts),
+                                       filters.encode() if filters else None, C.byref(frames), C.byref(unequal), err, len(err))
     if rc:
         raise RuntimeError(err.value.decode() or f"g1s_diff_y4m_files failed ({rc})")
     if unequal.value:

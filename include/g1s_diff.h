@@ -41,7 +41,8 @@ enum {
   G1S_ERR_NO_DEVICE = -5,     /* no usable HIP device or kernel image */
   G1S_ERR_HIP = -6,           /* a HIP runtime call failed (see last_error) */
   G1S_ERR_STATE = -7,         /* call not legal in this state (e.g. after finish) */
-  G1S_ERR_CAPACITY = -8       /* output buffer too small */
+  G1S_ERR_CAPACITY = -8,      /* output buffer too small */
+  G1S_ERR_UNSUPPORTED = -9    /* valid request this path does not serve (the resize filter) */
 };
 
 /* One decoded frame == v_frame::Frame<T> as produced by
@@ -235,6 +236,35 @@ typedef int (*g1s_next_frame_fn)(void *user, g1s_frame_t *out);
 int g1s_diff_run(g1s_diff_t *, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
                  void *denoised_user, uint64_t *frames, int *unequal);
 
+/* ---- `--filters` (N3): FilterChain of /root/reference/src/filters.rs ---- */
+/* FilterChain::new (src/filters.rs:16-110): "name:arg=value,...;name:..." with the filters crop (top, bottom, left,
+ * right) and resize (width, height, alg = hermite | catmullrom | mitchell | lanczos | spline36; default catmullrom).
+ * Same grammar, same error texts ("Invalid filter syntax in \"..\"", "Unrecognized filter \"..\"", "Unrecognized crop
+ * arg \"..\"", "invalid digit found in string", "Both width and height must be provided to resize filter", ...).
+ * NULL + reason in err on a parse error; "" is the empty chain. */
+typedef struct g1s_filters g1s_filters_t;
+typedef struct {
+  uint32_t kind;                     /* 0 = crop, 1 = resize */
+  uint64_t top, bottom, left, right; /* crop */
+  uint64_t width, height;            /* resize */
+  char alg[16];                      /* resize */
+} g1s_filter_desc_t;
+g1s_filters_t *g1s_filters_new(const char *text, char *err, size_t errcap);
+size_t g1s_filters_len(const g1s_filters_t *);
+int g1s_filters_get(const g1s_filters_t *, size_t i, g1s_filter_desc_t *out);
+/* FilterChain::apply (src/filters.rs:112-116) on a frame descriptor.  crop is extent arithmetic: *out points into
+ * *in's planes (host or device), same strides, smaller width / height -- no sample is touched, so it costs nothing on
+ * the device.  Crop amounts must be multiples of the chroma subsampling and leave at least one sample
+ * (G1S_ERR_INVALID otherwise).  A chain with a resize filter parses but is refused here: G1S_ERR_UNSUPPORTED, with
+ * the filter named in err.  filters == NULL: *out = *in. */
+int g1s_filters_apply(const g1s_filters_t *, const g1s_frame_t *in, g1s_frame_t *out, char *err, size_t errcap);
+void g1s_filters_free(g1s_filters_t *);
+/* g1s_diff_run with get_filtered_frame_pair's filter step (src/main.rs:615-629): the chain is applied to every SOURCE
+ * frame before the pair is handed to diff_frame; the denoised frame is taken as it comes.  A frame index goes with
+ * every error text.  filters == NULL: exactly g1s_diff_run. */
+int g1s_diff_run_filtered(g1s_diff_t *, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
+                          void *denoised_user, const g1s_filters_t *filters, uint64_t *frames, int *unequal);
+
 /* YUV4MPEG2 frame source: stands where the libav reader stands in the reference (what reaches the
  * estimator is the same planar Y,U,V u8 / little-endian u16 frame, src/reader.rs:172-212).  Frames
  * are read ahead by a thread (big frames: four positional reads at a time) into pinned host memory (a ring
@@ -256,6 +286,10 @@ void g1s_y4m_close(g1s_y4m_t *);
  * the source, bit depths from each file, the loop above, finish, "filmgrn1" table to out_tbl. */
 int g1s_diff_y4m_files(const char *source, const char *denoised, const char *out_tbl, const g1s_opts_t *opts,
                        uint64_t *frames, int *unequal, char *err, size_t errcap);
+/* The same with `-f FILTERS` (src/main.rs:370-380): filters = NULL or "" for none.  A chain that does not parse:
+ * G1S_ERR_INVALID and err = "Invalid filter chain: <reason>" (the reference logs that line and exits). */
+int g1s_diff_y4m_files_filtered(const char *source, const char *denoised, const char *out_tbl, const g1s_opts_t *opts,
+                                const char *filters, uint64_t *frames, int *unequal, char *err, size_t errcap);
 
 #ifdef __cplusplus
 }

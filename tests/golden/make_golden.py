@@ -24,8 +24,18 @@ GOLDEN = {
 }
 
 
+# BASELINE.json's configurations at their full sizes (configs[1], configs[0]'s 1080p 4:2:0 sibling, configs[4]'s format):
+# minutes of oracle time, so the CPU suite does not regenerate them -- `python -m tests.golden.make_golden full` does --
+# and the `-m gpu` suite compares the HIP path's table with the committed bytes (tests/test_gpu_parity.py).
+FULL_SIZE = {
+    "oracle_full_1920x1080_8b_lag2_luma.tbl": dict(spec=SynthSpec(1920, 1080, 8), frames=3, lag=2, chroma=False),
+    "oracle_full_1920x1080_8b_420_lag3.tbl": dict(spec=SynthSpec(1920, 1080, 8), frames=3, lag=3, chroma=True),
+    "oracle_full_7680x4320_10b_444_lag3.tbl": dict(spec=SynthSpec(7680, 4320, 10, xdec=0, ydec=0), frames=2, lag=3, chroma=True),
+}
+
+
 def generate(name):
-    g = GOLDEN[name]
+    g = GOLDEN[name] if name in GOLDEN else FULL_SIZE[name]
     spec = g["spec"]
     specs = None
     fps = Fraction(24, 1)
@@ -38,7 +48,7 @@ def generate(name):
 
 
 if __name__ == "__main__":
-    for name in GOLDEN:
+    for name in (FULL_SIZE if sys.argv[1:] == ["full"] else GOLDEN):
         with open(os.path.join(HERE, name), "wb") as f:
             f.write(generate(name))
         print("wrote", name)

@@ -1,0 +1,109 @@
+"""N3: the `--filters` parser and the front door's refusal rules, host side (no GPU).
+
+The parser cases are the reference's own (FilterChain tests, /root/reference/src/filters.rs:199-363), one for one: same
+inputs, same parsed values, same error fragments."""
+import logging
+
+import numpy as np
+import pytest
+
+from grav1synth_amd.diff import Frame
+from grav1synth_amd.filters import Crop, FilterChain, FilterError, Resize
+
+
+def _err(text):
+    with pytest.raises(FilterError) as e:
+        FilterChain(text)
+    return str(e.value)
+
+
+def test_new_accepts_empty_filter_chain():
+    assert FilterChain("").filters == []
+
+
+def test_new_parses_crop_filter_args():
+    assert FilterChain("crop:top=1,bottom=2,left=3,right=4").filters == [Crop(1, 2, 3, 4)]
+
+
+def test_new_parses_resize_filter_with_default_algorithm():
+    assert FilterChain("resize:width=1920,height=1080").filters == [Resize(1920, 1080, "catmullrom")]
+
+
+@pytest.mark.parametrize("alg", ["hermite", "catmullrom", "mitchell", "lanczos", "spline36"])
+def test_new_parses_resize_filter_with_all_supported_algorithms(alg):
+    assert FilterChain(f"resize:width=640,height=360,alg={alg}").filters == [Resize(640, 360, alg)]
+
+
+def test_new_parses_multiple_filters_in_order():
+    assert FilterChain("crop:top=4;resize:width=320,height=240,alg=lanczos").filters == [Crop(4, 0, 0, 0), Resize(320, 240, "lanczos")]
+
+
+@pytest.mark.parametrize("text,fragment", [
+    ("crop", 'Invalid filter syntax in "crop"'),
+    ("rotate:degrees=90", 'Unrecognized filter "rotate"'),
+    ("crop:top", 'Invalid filter syntax in "top"'),
+    ("crop:width=12", 'Unrecognized crop arg "width"'),
+    ("crop:top=abc", "invalid digit found in string"),
+    ("resize:width=640,height", 'Invalid filter syntax in "height"'),
+    ("resize:width=640,height=360,scale=2", 'Unrecognized resize arg "scale"'),
+    ("resize:width=640,height=360,alg=nearest", 'Unrecognized resize algorithm "nearest"'),
+    ("resize:width=640", "Both width and height must be provided to resize filter"),
+    ("resize:height=360", "Both width and height must be provided to resize filter"),
+    ("resize:width=wide,height=360", "invalid digit found in string"),
+    ("resize:width=640,height=tall", "invalid digit found in string"),
+    # beyond the reference's tests, same grammar: empty pieces, empty numbers, numbers past usize
+    ("crop:top=1;", 'Invalid filter syntax in ""'),
+    ("crop:", 'Invalid filter syntax in ""'),
+    ("crop:top=", "cannot parse integer from empty string"),
+    ("crop:top=99999999999999999999999", "number too large to fit in target type"),
+    ("crop:top=-1", "invalid digit found in string"),
+])
+def test_new_rejects(text, fragment):
+    assert fragment in _err(text)
+
+
+def test_crop_is_extent_arithmetic_on_the_planes():
+    y = np.arange(64 * 96, dtype=np.uint16).reshape(64, 96)
+    u = np.arange(32 * 48, dtype=np.uint16).reshape(32, 48)
+    f = FilterChain("crop:top=4,left=8;crop:bottom=2,right=6").apply(Frame([y, u, u + 1], 1, 1))
+    assert f.planes[0].shape == (58, 82) and f.planes[1].shape == (29, 41)
+    assert f.planes[0][0, 0] == y[4, 8] and f.planes[1][0, 0] == u[2, 4] and f.planes[2][-1, -1] == u[30, 44] + 1
+    assert np.shares_memory(f.planes[0], y)  # views: no sample was copied
+
+
+def test_crop_must_fall_on_chroma_samples_and_leave_something():
+    y = np.zeros((64, 96), np.uint8)
+    u = np.zeros((32, 48), np.uint8)
+    with pytest.raises(FilterError, match="multiples of the chroma subsampling"):
+        FilterChain("crop:left=3").apply(Frame([y, u, u], 1, 1))
+    FilterChain("crop:left=3").apply(Frame([y], 1, 1))  # luma only: any amount
+    with pytest.raises(FilterError, match="leaves nothing"):
+        FilterChain("crop:top=32,bottom=32").apply(Frame([y, u, u], 1, 1))
+
+
+def test_resize_parses_but_is_refused_at_apply():
+    y = np.zeros((64, 96), np.uint8)
+    with pytest.raises(FilterError, match="resize filter is not supported"):
+        FilterChain("resize:width=48,height=32").apply(Frame([y], 1, 1))
+
+
+def test_front_door_refusals(tmp_path, caplog):
+    """src/main.rs:354-394: each refusal is one logged line and a normal return; nothing is opened or written."""
+    from grav1synth_amd import cli
+
+    a, b, out = str(tmp_path / "a.y4m"), str(tmp_path / "b.y4m"), str(tmp_path / "o.tbl")
+    with caplog.at_level(logging.INFO, logger="grav1synth"):
+        assert cli.diff_command(a, b, a) == -1
+        assert cli.diff_command(a, b, b) == -1
+        assert caplog.records[-1].getMessage() == cli.SAME_AS_OUTPUT and caplog.records[-1].levelname == "ERROR"
+        assert cli.diff_command(a, a, out) == -1
+        assert caplog.records[-1].getMessage() == cli.SAME_INPUTS
+        assert cli.diff_command(a, b, out, filters="crop:up=2") == -1
+        assert caplog.records[-1].getMessage() == 'Invalid filter chain: Unrecognized crop arg "up"'
+        open(out, "w").write("keep me")
+        asked = []
+        assert cli.diff_command(a, b, out, confirm=lambda p: asked.append(p) or False) == -1
+        assert asked == [f"File {out} exists. Overwrite?"]
+        assert caplog.records[-1].getMessage() == cli.NOT_OVERWRITING and caplog.records[-1].levelname == "WARNING"
+        assert open(out).read() == "keep me"
+    assert cli.main(["diff", a, a, "-o", out]) == 0  # a refusal is not a failure (`return Ok(())`)

@@ -114,6 +114,156 @@ def test_accumulation_modes_agree():
     assert lines["fused"] == lines["dot4"], "fused vs dot4"
 
 
+@pytest.mark.parametrize("name", ["oracle_full_1920x1080_8b_lag2_luma.tbl", "oracle_full_1920x1080_8b_420_lag3.tbl",
+                                  "oracle_full_7680x4320_10b_444_lag3.tbl"])
+def test_full_size_tables_match_the_committed_oracle_goldens(name):
+    """BASELINE.json's configurations at their FULL sizes -- 1080p 8-bit lag 2 luma-only (configs[1]), 1080p 8-bit 4:2:0
+    lag 3, 8K 10-bit 4:4:4 lag 3 (configs[4]'s format) -- against tables the oracle wrote for the same seeded frames
+    (tests/golden/make_golden.py full: minutes of CPU time, committed as data): byte-identical."""
+    import os
+
+    from tests.golden import make_golden
+
+    gd = make_golden.FULL_SIZE[name]
+    spec, lag, chroma = gd["spec"], gd["lag"], gd["chroma"]
+    with open(os.path.join(os.path.dirname(__file__), "golden", name), "rb") as f:
+        want = f.read()
+    g = DiffGenerator(Fraction(24, 1), spec.bit_depth, spec.bit_depth, ar_coeff_lag=lag, luma_only=not chroma, batch_frames=2)
+    for k in range(gd["frames"]):
+        s, d = make_pair(spec, k, device="cuda")
+        if not chroma:
+            s, d = s[:1], d[:1]
+        g.diff_frame(Frame(s, spec.xdec, spec.ydec), Frame(d, spec.xdec, spec.ydec))
+        del s, d
+    assert format_tbl(g.finish()) == want
+
+
+def _padded(planes, spec, top, bottom, left, right, fill):
+    """the planes with a border around them (what the crop filter takes off again)"""
+    out = []
+    for c, p in enumerate(planes):
+        sx, sy = (spec.xdec, spec.ydec) if c else (0, 0)
+        t, b, l, r = top >> sy, bottom >> sy, left >> sx, right >> sx
+        q = np.full((p.shape[0] + t + b, p.shape[1] + l + r), fill + c, dtype=p.dtype)
+        q[t:t + p.shape[0], l:l + p.shape[1]] = p
+        out.append(q)
+    return out
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_front_door_with_a_cropped_source_equals_the_oracle_on_the_cropped_planes(tmp_path, bd, caplog):
+    """N3 + the front door: `diff SOURCE DENOISED -o OUT -y -f crop:...` on .y4m files whose source carries a border
+    (letterbox) the denoised file does not: the table must be, byte for byte, the oracle's table for the bare planes --
+    the crop is extent arithmetic in the frame descriptors, the kernels see a smaller frame with the same strides."""
+    import logging
+
+    from grav1synth_amd import cli
+    from grav1synth_amd.ingest import write_y4m
+
+    spec = SynthSpec(320, 200, bd)
+    top, bottom, left, right = 6, 2, 16, 4
+    nframes = 3
+    src, den = [], []
+    for k in range(nframes):
+        s, d = np_pair(spec, k)
+        src.append(_padded(s, spec, top, bottom, left, right, 37))
+        den.append(d)
+    fps = Fraction(30000, 1001)
+    a, b, out = str(tmp_path / "source.y4m"), str(tmp_path / "denoised.y4m"), str(tmp_path / "out.tbl")
+    write_y4m(a, src, bd, spec.xdec, spec.ydec, fps)
+    write_y4m(b, den, bd, spec.xdec, spec.ydec, fps)
+    want, _ = oracle_run(spec, range(nframes), fps=fps)
+    open(out, "w").write("stale")
+    with caplog.at_level(logging.INFO):
+        n = cli.diff_command(a, b, out, overwrite=True, filters=f"crop:top={top},bottom={bottom},left={left},right={right}")
+    assert n == nframes
+    assert open(out, "rb").read() == want
+    msgs = [r.getMessage() for r in caplog.records]
+    assert f"Computed diff for {nframes} frames" in msgs and f"Done, wrote output file to {out}" in msgs  # src/main.rs:531-532
+    # without the filter the geometry differs: the reference's error, with the frame pair it happened on
+    from grav1synth_amd.ingest import diff_y4m_files
+    with pytest.raises(RuntimeError, match=r"frame 0: .*dimensions do not match"):
+        diff_y4m_files(a, b, out)
+    # a resize in the chain parses and is refused when the first frame arrives
+    with pytest.raises(RuntimeError, match=r"frame 0: resize:width=320,height=200,alg=catmullrom -- the resize filter is not supported"):
+        diff_y4m_files(a, b, out, filters="resize:width=320,height=200")
+
+
+def test_cropped_device_frames_equal_the_oracle():
+    """FilterChain.apply on device-resident planes (torch views: pointer + extent arithmetic, unaligned rows)."""
+    from grav1synth_amd.filters import FilterChain
+
+    spec = SynthSpec(326, 198, 10)
+    chain = FilterChain("crop:top=2,left=6;crop:bottom=4,right=2")
+    want, _ = oracle_run(spec, range(2))
+    g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=2)
+    keep = []
+    for k in range(2):
+        s, d = np_pair(spec, k)
+        big = [torch.from_numpy(p).cuda() for p in _padded(s, spec, 2, 4, 6, 2, 900)]
+        dd = [torch.from_numpy(p).cuda() for p in d]
+        keep.append((big, dd))
+        g.diff_frame(chain.apply(Frame(big, spec.xdec, spec.ydec)), Frame(dd, spec.xdec, spec.ydec))
+    assert format_tbl(g.finish()) == want
+
+
+def test_truncated_y4m_reports_the_frame_index(tmp_path):
+    """N2: an error of the frame-pair loop names the frame pair (g1s_diff_run_filtered)."""
+    from grav1synth_amd.ingest import diff_y4m_files, write_y4m
+
+    spec = SynthSpec(320, 192, 8)
+    src, den = [], []
+    for k in range(4):
+        s, d = np_pair(spec, k)
+        src.append(s)
+        den.append(d)
+    a, b = str(tmp_path / "a.y4m"), str(tmp_path / "b.y4m")
+    write_y4m(a, src, 8, 1, 1)
+    write_y4m(b, den, 8, 1, 1)
+    size = __import__("os").path.getsize(b)
+    with open(b, "r+b") as f:
+        f.truncate(size - 1000)  # the 4th denoised frame is short
+    with pytest.raises(RuntimeError, match=r"frame 3: denoised reader failed"):
+        diff_y4m_files(a, b, str(tmp_path / "o.tbl"))
+
+
+def test_hip_table_drives_the_apply_lookup():
+    """N1 closure: the table the HIP path emits for a two-segment job, read back with g1s_parse_tbl and walked with
+    g1s_tbl_segment_for over the frames' presentation times, stamps every frame with the right segment and advances that
+    segment's seed by DEFAULT_GRAIN_SEED per hit (wrapping u16) -- `apply`'s per-frame lookup,
+    /root/reference/src/parser/frame.rs:617-633 (its test :4590-4608: seed 100 -> 100 + DEFAULT_GRAIN_SEED)."""
+    from grav1synth_amd.tbl import GrainTable, parse_tbl_native
+
+    DEFAULT_GRAIN_SEED = 10956
+    a = SynthSpec(320, 192, 8)
+    b = SynthSpec(320, 192, 8, gain_scale=3)
+    specs = [a, a, a, b, b, b]
+    fps = Fraction(30000, 1001)
+    g = DiffGenerator(fps, 8, 8, batch_frames=4)
+    for k, sp in enumerate(specs):
+        s, d = make_pair(sp, k, device="cuda")
+        g.diff_frame(s, d, sp.xdec, sp.ydec)
+    out = g.finish()
+    assert len(out) >= 2
+    text = format_tbl(out)
+    segs = parse_tbl_native(text)
+    assert [(x.start_time, x.end_time, x.random_seed) for x in segs] == [(x.start_time, x.end_time, x.random_seed) for x in out]
+    table = GrainTable(segs)
+    hits = [0] * len(segs)
+    assert segs[0].end_time == (3 * 10_000_000 * fps.denominator) // fps.numerator, "the first cut sits at frame 3"
+    for k in range(len(specs)):
+        ts = (k * 10_000_000 * fps.denominator) // fps.numerator  # the frame's presentation time in the table's 10 MHz ticks
+        want = next(i for i, x in enumerate(segs) if x.start_time <= ts < x.end_time)
+        assert (want == 0) == (k < 3)
+        seg = table.segment_for(ts)
+        assert seg is not None and seg.start_time == segs[want].start_time
+        hits[want] += 1
+        assert seg.random_seed == (segs[want].random_seed + hits[want] * DEFAULT_GRAIN_SEED) & 0xFFFF
+        assert seg.scaling_points_y == segs[want].scaling_points_y and seg.ar_coeffs_y == segs[want].ar_coeffs_y
+    assert sum(hits) == len(specs) and hits[0] == 3
+    assert table.segment_for(segs[-1].end_time) is None  # past the end: `apply` leaves the frame alone
+
+
 def test_streamed_device_frames_are_released_batch_by_batch():
     """A long GPU-resident stream must not pin every frame until finish: g1s_diff_frames_released tells the caller
     which frame pairs the generator is done reading, and the Python mirror prunes its keep-alives by it."""
