@@ -161,6 +161,7 @@ SYMBOLS = [
     ("g1s_diff_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("g1s_diff_kernel_times", C.c_long, [C.c_void_p, C.c_char_p, C.c_size_t]),
     ("g1s_diff_frames_released", C.c_uint64, [C.c_void_p]),
+    ("g1s_diff_frames_copied", C.c_uint64, [C.c_void_p, C.c_uint64]),
     ("g1s_diff_set_flat_finder", C.c_int, [C.c_void_p, C.c_int]),
     ("g1s_diff_last_record", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("g1s_record_geometry", C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4),
@@ -182,6 +183,7 @@ SYMBOLS = [
     ("g1s_y4m_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("g1s_y4m_get_info", C.c_int, [C.c_void_p, C.POINTER(G1SY4MInfo)]),
     ("g1s_y4m_next", C.c_int, [C.c_void_p, C.POINTER(G1SFrame)]),
+    ("g1s_y4m_bind", C.c_int, [C.c_void_p, C.c_void_p]),
     ("g1s_y4m_last_error", C.c_char_p, [C.c_void_p]),
     ("g1s_y4m_close", None, [C.c_void_p]),
     ("g1s_diff_y4m_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(G1SOpts),

@@ -202,6 +202,7 @@ struct Slot {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: finder start, k2 start, k3 start, k3 end, k0 end, k0 start
   uint32_t count = 0;
   bool timed = false;
+  bool async_in = false;  // the batch holds frames whose H2D copies were queued on the upload stream
   // per-kernel timing (g1s_diff_set_timing): an event before each launch, the name of the kernel it precedes
   std::vector<hipEvent_t> kev;
   std::vector<std::string> kname;
@@ -379,6 +380,12 @@ struct g1s_diff {
   bool slot_busy[kSlots] = {};     // submitted and not yet drained
   uint64_t submitted = 0, drained = 0;  // batches
   uint64_t frames_released = 0;         // frame pairs of the drained batches (their inputs are no longer read)
+  // asynchronous host -> device copies of pinned frames (on_device == 2): one event per frame pair, in order
+  std::mutex h2d_mutex;
+  std::deque<std::pair<uint64_t, hipEvent_t>> h2d_pending;  // (frame pairs handed over up to and including this one, copies done)
+  std::vector<hipEvent_t> h2d_free;
+  uint64_t frames_appended = 0;
+  hipEvent_t h2d_order = nullptr;  // copies -> table upload when the two run on different streams
   bool drainer_stop = false;
   NoiseFold *fold = nullptr;
   Pool *pool = nullptr;
@@ -429,6 +436,7 @@ struct g1s_diff {
   int set_geometry(const g1s_frame_t *s, const g1s_frame_t *d);
   int set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d);
   int append(const g1s_frame_t *s, const g1s_frame_t *d);
+  uint64_t frames_copied(uint64_t wait_for);
   int submit(int si);        // front half now; back half now or with the next batch's front half
   int launch_front(int si);  // zero, pixel pass, flat-block finder, window planes, area lists
   int launch_back(int si);   // accumulation kernels, records D2H, hand-over to the drainer
@@ -609,7 +617,8 @@ int g1s_diff::append(const g1s_frame_t *s, const g1s_frame_t *d) {
   FramePlanes &fp = sl.h_planes[sl.count];
   std::memset(&fp, 0, sizeof(fp));
   const uint32_t np = (uint32_t)geom.nplanes;
-  const bool any_host = !s->on_device || !d->on_device;
+  const bool any_host = s->on_device != 1 || d->on_device != 1;
+  bool any_async = false;
   if (any_host && !sl.d_stage)
     HIP_TRY(hipMalloc((void **)&sl.d_stage, sl.stage_bytes_per_frame * batch));
   uint8_t *stage = any_host ? sl.d_stage + sl.stage_bytes_per_frame * sl.count : nullptr;
@@ -619,14 +628,26 @@ int g1s_diff::append(const g1s_frame_t *s, const g1s_frame_t *d) {
       const size_t pw = c ? (f->width >> f->xdec) : f->width, ph = c ? (f->height >> f->ydec) : f->height;
       const uint8_t *ptr;
       uint32_t stride;
-      if (f->on_device) {
+      if (f->on_device == 1) {
         ptr = (const uint8_t *)f->data[c];
         stride = (uint32_t)f->stride_bytes[c];
       } else {
         const size_t row = (pw * f->bytes_per_sample + 15) & ~size_t(15);
-        // the `&Frame` borrow ends when this call returns: copy now
-        HIP_TRY(hipMemcpy2D(stage, row, f->data[c], f->stride_bytes[c], pw * f->bytes_per_sample, ph,
-                            hipMemcpyHostToDevice));
+        if (f->on_device == 2) {
+          // pinned host memory the caller keeps valid until g1s_diff_frames_copied() covers this frame: queued on the
+          // upload stream (the table upload of the batch follows on that stream, the kernels wait for that), the call
+          // returns at once -- file reads, copies and the kernels of earlier batches overlap
+          hipStream_t cs = ss.upload ? ss.upload : stream;
+          if (f->stride_bytes[c] == row && pw * f->bytes_per_sample == row)
+            HIP_TRY(hipMemcpyAsync(stage, f->data[c], row * ph, hipMemcpyHostToDevice, cs));
+          else
+            HIP_TRY(hipMemcpy2DAsync(stage, row, f->data[c], f->stride_bytes[c], pw * f->bytes_per_sample, ph, hipMemcpyHostToDevice, cs));
+          any_async = true;
+        } else {
+          // the `&Frame` borrow ends when this call returns: copy now
+          HIP_TRY(hipMemcpy2D(stage, row, f->data[c], f->stride_bytes[c], pw * f->bytes_per_sample, ph,
+                              hipMemcpyHostToDevice));
+        }
         ptr = stage;
         stride = (uint32_t)row;
         stage += row * ph;
@@ -640,9 +661,40 @@ int g1s_diff::append(const g1s_frame_t *s, const g1s_frame_t *d) {
       }
     }
   }
+  {
+    std::lock_guard<std::mutex> lk(h2d_mutex);
+    ++frames_appended;
+    if (any_async) {
+      hipEvent_t e;
+      if (!h2d_free.empty()) {
+        e = h2d_free.back();
+        h2d_free.pop_back();
+      } else {
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(e, ss.upload ? ss.upload : stream));
+      h2d_pending.emplace_back(frames_appended, e);
+      sl.async_in = true;
+    }
+  }
   sl.count++;
   if (sl.count == batch) return submit(cur);
   return G1S_OK;
+}
+
+// how many frame pairs' host planes are no longer needed (every on_device == 0 frame at once; on_device == 2 frames when
+// their queued copies have run); wait_for > 0: block until that many are
+uint64_t g1s_diff::frames_copied(uint64_t wait_for) {
+  std::lock_guard<std::mutex> lk(h2d_mutex);
+  wait_for = std::min(wait_for, frames_appended);
+  while (!h2d_pending.empty()) {
+    const auto front = h2d_pending.front();
+    if (front.first <= wait_for) (void)hipEventSynchronize(front.second);
+    else if (hipEventQuery(front.second) != hipSuccess) break;
+    h2d_free.push_back(front.second);
+    h2d_pending.pop_front();
+  }
+  return h2d_pending.empty() ? frames_appended : h2d_pending.front().first - 1;
 }
 
 Geom g1s_diff::batch_geom(const Slot &sl) const {
@@ -724,6 +776,15 @@ int g1s_diff::launch_front(int si) {
   FrameTable ft;
   ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);
   hipStream_t up = (fstream == stream || !ss.upload) ? stream : ss.upload;
+  if (sl.async_in) {  // queued frame copies: on the upload stream; everything below waits for `up`
+    hipStream_t cs = ss.upload ? ss.upload : stream;
+    if (cs != up) {
+      if (!h2d_order) HIP_TRY(hipEventCreateWithFlags(&h2d_order, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(h2d_order, cs));
+      HIP_TRY(hipStreamWaitEvent(up, h2d_order, 0));
+    }
+    sl.async_in = false;
+  }
   HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, up));
   {
     // all per-batch zero fills in one launch: records, lag / masked accumulators, bad flags + list counters
@@ -1372,6 +1433,12 @@ void g1s_diff::release() {
     }
     free_slot(sl);
   }
+  for (auto &pe : h2d_pending) (void)hipEventDestroy(pe.second);
+  h2d_pending.clear();
+  for (auto &e : h2d_free) (void)hipEventDestroy(e);
+  h2d_free.clear();
+  if (h2d_order) (void)hipEventDestroy(h2d_order);
+  h2d_order = nullptr;
   d_lut = nullptr;  // shared per device
   stream = nullptr;
   delete fold;
@@ -1799,6 +1866,11 @@ int g1s_diff_get_stats(const g1s_diff_t *g, g1s_stats_t *out) {
   *out = g->stats;
   out->ms_host_fold = g->ms_fold_front + g->ms_fold_back;  // (the two stages overlap across batches)
   return G1S_OK;
+}
+uint64_t g1s_diff_frames_copied(g1s_diff_t *g, uint64_t wait_for) {
+  if (!g) return 0;
+  (void)hipSetDevice(g->device);
+  return g->frames_copied(wait_for);
 }
 uint64_t g1s_diff_frames_released(g1s_diff_t *g) {
   if (!g) return 0;

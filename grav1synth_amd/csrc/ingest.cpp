@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -52,8 +53,14 @@ struct PinnedBuf {
   }
 };
 
-constexpr int kRing = 4;  // frames read ahead per file
-constexpr int kReadThreads = 4;  // positional reads in flight per frame
+constexpr int kRing = 6;  // pinned frame buffers per file: read ahead + lent to the generator until their copies have run
+constexpr int kMaxReadThreads = 16;
+// positional reads in flight per frame (G1S_Y4M_READ_THREADS: tuning aid)
+static const int kReadThreads = [] {
+  const char *e = getenv("G1S_Y4M_READ_THREADS");
+  const int n = e ? atoi(e) : 3;  // (measured: 1 -> 22, 2 -> 25..32, 3 -> 31, 4 -> 28, 8 -> 26 GB/s through two readers)
+  return n < 1 ? 1 : (n > kMaxReadThreads ? kMaxReadThreads : n);
+}();
 
 }  // namespace
 
@@ -70,6 +77,10 @@ struct g1s_y4m {
   std::deque<int> ready;  // ring indices holding a frame
   int free_slots = kRing;
   int held = -1;          // ring index lent to the consumer by the last g1s_y4m_next
+  // bound to a generator (g1s_y4m_bind): frames go out as on_device = 2 and stay lent until their copies have run
+  g1s_diff_t *bound = nullptr;
+  std::deque<std::pair<int, uint64_t>> lent;  // (ring index, frame pairs the generator must have copied before it is free)
+  uint64_t frames_out = 0;
   bool eof = false, stop = false, failed = false;
   std::string error;
   uint64_t frames_read = 0;
@@ -92,7 +103,7 @@ struct g1s_y4m {
     if (frame_bytes >= (size_t)kReadThreads << 20 && at >= 0) {
       const int fd = fileno(f);
       const size_t chunk = ((frame_bytes + kReadThreads - 1) / kReadThreads + 4095) & ~size_t(4095);
-      bool good[kReadThreads];
+      bool good[kMaxReadThreads];
       auto part = [&](int t) {
         size_t o = std::min(frame_bytes, chunk * (size_t)t), end = std::min(frame_bytes, o + chunk);
         good[t] = true;
@@ -105,10 +116,10 @@ struct g1s_y4m {
           o += (size_t)n;
         }
       };
-      std::thread helpers[kReadThreads - 1];
+      std::thread helpers[kMaxReadThreads - 1];
       for (int t = 1; t < kReadThreads; ++t) helpers[t - 1] = std::thread(part, t);
       part(0);
-      for (auto &h : helpers) h.join();
+      for (int t = 1; t < kReadThreads; ++t) helpers[t - 1].join();
       for (int t = 0; t < kReadThreads; ++t) ok = ok && good[t];
       if (ok && fseeko(f, at + (off_t)frame_bytes, SEEK_SET) != 0) ok = false;
     } else {
@@ -256,16 +267,40 @@ int g1s_y4m_next(void *user, g1s_frame_t *out) {
   int idx;
   {
     std::unique_lock<std::mutex> lk(y->m);
-    if (y->held >= 0) {  // the frame lent by the previous call goes back to the reader
+    if (y->held >= 0) {  // the frame lent by the previous call goes back to the reader ...
+      if (y->bound) {
+        y->lent.emplace_back(y->held, y->frames_out);  // ... once the generator has copied it (frame pair frames_out - 1)
+      } else {
+        ++y->free_slots;
+        y->cv.notify_all();
+      }
       y->held = -1;
-      ++y->free_slots;
-      y->cv.notify_all();
+    }
+    if (y->bound) {
+      // (a) what has been copied meanwhile; (b) never sit on more than half of the ring: wait for the oldest copy
+      lk.unlock();
+      uint64_t copied = g1s_diff_frames_copied(y->bound, 0);
+      lk.lock();
+      for (;;) {
+        while (!y->lent.empty() && y->lent.front().second <= copied) {
+          y->lent.pop_front();
+          ++y->free_slots;
+          y->cv.notify_all();
+        }
+        if ((int)y->lent.size() <= kRing / 2) break;
+        const uint64_t need = y->lent.front().second;
+        lk.unlock();
+        copied = g1s_diff_frames_copied(y->bound, need);
+        lk.lock();
+        if (copied < need) break;  // (the frame never reached the generator: nothing to wait for)
+      }
     }
     y->cv.wait(lk, [&] { return !y->ready.empty() || y->eof; });
     if (y->ready.empty()) return y->failed ? G1S_ERR_INVALID : 0;  // 0: end of stream
     idx = y->ready.front();
     y->ready.pop_front();
     y->held = idx;
+    ++y->frames_out;
   }
   std::memset(out, 0, sizeof *out);
   out->width = y->info.width;
@@ -278,8 +313,16 @@ int g1s_y4m_next(void *user, g1s_frame_t *out) {
     out->data[c] = y->ring[idx].p + y->plane_off[c];
     out->stride_bytes[c] = y->row_bytes[c];
   }
-  out->on_device = 0;
+  out->on_device = y->bound ? 2 : 0;
   return 1;
+}
+
+int g1s_y4m_bind(g1s_y4m_t *y, g1s_diff_t *g) {
+  if (!y) return G1S_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(y->m);
+  if (y->frames_out && g != y->bound) return G1S_ERR_STATE;  // (frame i of the reader = frame pair i of the generator)
+  y->bound = g;
+  return G1S_OK;
 }
 
 const char *g1s_y4m_last_error(const g1s_y4m_t *y) { return y ? y->error.c_str() : ""; }
@@ -391,6 +434,12 @@ int g1s_diff_y4m_files_filtered(const char *source_path, const char *denoised_pa
     set_err(err, errcap, g1s_last_global_error());
     rc = G1S_ERR_NO_DEVICE;
     goto done;
+  }
+  // the readers' pinned rings feed the generator directly: copies are queued, the loop goes on reading
+  static const bool sync_ingest = getenv("G1S_INGEST_SYNC") != nullptr;  // comparison aid (tools/bench_ingest.py)
+  if (!sync_ingest) {
+    g1s_y4m_bind(ys, g);
+    g1s_y4m_bind(yd, g);
   }
   rc = g1s_diff_run_filtered(g, g1s_y4m_next, ys, g1s_y4m_next, yd, filters, frames_out, unequal_out);
   if (rc) {

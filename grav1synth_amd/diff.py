@@ -133,7 +133,7 @@ class Frame:
                 isz = p.element_size()
                 f.data[i] = p.data_ptr()
                 f.stride_bytes[i] = p.stride(0) * isz
-                dev = p.is_cuda
+                dev = 1 if p.is_cuda else (2 if p.is_pinned() else 0)  # pinned host tensors: copied asynchronously
             else:
                 p = np.asarray(p)
                 if p.strides[1] != p.dtype.itemsize:
@@ -141,14 +141,14 @@ class Frame:
                 isz = p.dtype.itemsize
                 f.data[i] = p.ctypes.data
                 f.stride_bytes[i] = p.strides[0]
-                dev = False
+                dev = 0
             if on_dev is None:
                 on_dev = dev
             elif on_dev != dev:
                 raise ValueError("all planes of a frame must live on the same side (host or device)")
             f.bytes_per_sample = isz
             keep.append(p)
-        f.on_device = int(bool(on_dev))
+        f.on_device = int(on_dev or 0)
         return f
 
 
@@ -197,7 +197,7 @@ class DiffGenerator:
         keep: list = []
         fs, fd = s.to_c(keep), d.to_c(keep)
         if (fs.on_device or fd.on_device):
-            if sync_torch:
+            if sync_torch and (fs.on_device == 1 or fd.on_device == 1):
                 torch.cuda.current_stream().synchronize()  # producer (torch) -> consumer (engine stream)
             self._keep.append((self._fed + 1, keep))  # device planes must outlive the queued kernels
         self._fed += 1

@@ -58,8 +58,12 @@ typedef struct {
   size_t stride_bytes[3];
   int32_t on_device;        /* 0: host memory, copied before the call returns (the
                                `&Frame` borrow of src/main.rs:442).
-                               1: device (HIP) memory of this process; must stay
-                               valid and unmodified until g1s_diff_sync()/finish */
+                               1: device (HIP) memory of this process; must stay valid and
+                               unmodified until g1s_diff_frames_released() covers the frame
+                               (g1s_diff_sync()/finish at the latest).
+                               2: PINNED host memory (hipHostMalloc / hipHostRegister): the copy
+                               is queued and the call returns at once; must stay valid and
+                               unmodified until g1s_diff_frames_copied() covers the frame */
 } g1s_frame_t;
 
 /* POD mirror of av1_grain::GrainTableSegment, field for field as consumed by
@@ -127,6 +131,10 @@ int g1s_diff_sync(g1s_diff_t *);
  * overwritten.  Monotonic; reaches the number of frames handed over after g1s_diff_sync / g1s_diff_finish.  A caller
  * that streams device-resident frames polls this instead of keeping every frame alive until the end. */
 uint64_t g1s_diff_frames_released(g1s_diff_t *);
+/* Same count for the HOST planes of frames handed over with on_device == 2 (pinned, copied asynchronously): frame
+ * pairs before the returned count have been copied to the device.  wait_for > 0: block until at least that many have
+ * (clamped to the frames handed over).  Frames with on_device 0 or 1 count as copied when their call returns. */
+uint64_t g1s_diff_frames_copied(g1s_diff_t *, uint64_t wait_for);
 /* DiffGenerator::finish (src/main.rs:524).  Ends the stream: afterwards no more frames are accepted.  *n_out = the
  * number of segments; if cap is too small the call returns G1S_ERR_CAPACITY with *n_out set and NOTHING is lost --
  * call again with a buffer of *n_out segments (the reference's Vec has no cap). */
@@ -280,6 +288,11 @@ typedef struct {
 g1s_y4m_t *g1s_y4m_open(const char *path, char *err, size_t errcap); /* NULL on failure, reason in err */
 int g1s_y4m_get_info(const g1s_y4m_t *, g1s_y4m_info_t *out);
 int g1s_y4m_next(void *y4m, g1s_frame_t *out); /* a g1s_next_frame_fn; user = the g1s_y4m_t* */
+/* Bind the reader to the generator its frames go to (frame i of the reader = frame pair i of the generator): frames
+ * then come out with on_device = 2 -- g1s_diff_frame queues their copies straight from the reader's pinned ring and
+ * returns -- and the reader recycles a ring buffer only when g1s_diff_frames_copied() covers its frame.  Close the
+ * reader after the generator has synced / finished.  NULL unbinds. */
+int g1s_y4m_bind(g1s_y4m_t *, g1s_diff_t *);
 const char *g1s_y4m_last_error(const g1s_y4m_t *);
 void g1s_y4m_close(g1s_y4m_t *);
 /* `grav1synth diff SOURCE DENOISED -o OUT` for two .y4m files (src/main.rs:414-531): frame rate from

@@ -207,6 +207,27 @@ def test_cropped_device_frames_equal_the_oracle():
     assert format_tbl(g.finish()) == want
 
 
+def test_pinned_host_frames_are_copied_asynchronously_and_give_the_same_table():
+    """N2: on_device = 2 (pinned host planes): g1s_diff_frame queues the copies and returns; g1s_diff_frames_copied
+    says when the planes may be reused; the table is the oracle's."""
+    spec = SynthSpec(322, 190, 10)
+    want, _ = oracle_run(spec, range(5))
+    g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=2)
+    L = g._L
+    for k in range(5):
+        s, d = np_pair(spec, k)
+        ps = [torch.from_numpy(p).pin_memory() for p in s]
+        pd = [torch.from_numpy(p).pin_memory() for p in d]
+        f = Frame(ps, spec.xdec, spec.ydec)
+        assert f.to_c([]).on_device == 2
+        g.diff_frame(f, Frame(pd, spec.xdec, spec.ydec))
+        assert L.g1s_diff_frames_copied(g._h, 0) <= k + 1
+        assert L.g1s_diff_frames_copied(g._h, k + 1) == k + 1  # wait for this frame: now its planes may be overwritten
+        for p in ps + pd:
+            p.fill_(0)
+    assert format_tbl(g.finish()) == want
+
+
 def test_truncated_y4m_reports_the_frame_index(tmp_path):
     """N2: an error of the frame-pair loop names the frame pair (g1s_diff_run_filtered)."""
     from grav1synth_amd.ingest import diff_y4m_files, write_y4m
