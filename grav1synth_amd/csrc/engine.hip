@@ -1699,6 +1699,63 @@ int g1s_diff_take_latest(g1s_diff_t *g, int sync, void *buf, size_t cap_bytes, s
   return G1S_OK;
 }
 
+// ---- frame-shard rounds: the exchange protocol (what goes into a round's message, which batch, in which order the root
+//      merges) lives here; the transport (RCCL / MPI / torch.distributed gather of fixed-size buffers) stays with the host
+namespace {
+constexpr uint32_t kShardMagic = 0x4d315347u;  // "GS1M"
+struct ShardHeader {
+  uint32_t magic, count, lag, batch_frames;
+};
+}  // namespace
+size_t g1s_shard_msg_size(uint32_t ar_coeff_lag, uint32_t batch_frames) {
+  return ar_coeff_lag >= 1 && ar_coeff_lag <= 3 ? sizeof(ShardHeader) + (size_t)batch_frames * latest_blob_size(ar_coeff_lag) : 0;
+}
+int g1s_shard_msg_from_latest(const void *blobs, size_t n, uint32_t ar_coeff_lag, uint32_t batch_frames, void *msg, size_t cap_bytes) {
+  if (!msg || (!blobs && n) || ar_coeff_lag < 1 || ar_coeff_lag > 3 || n > batch_frames) return G1S_ERR_INVALID;
+  const size_t total = g1s_shard_msg_size(ar_coeff_lag, batch_frames), bs = latest_blob_size(ar_coeff_lag);
+  if (cap_bytes < total) return G1S_ERR_CAPACITY;
+  std::memset(msg, 0, total);
+  const ShardHeader h{kShardMagic, (uint32_t)n, ar_coeff_lag, batch_frames};
+  std::memcpy(msg, &h, sizeof(h));
+  if (n) std::memcpy((uint8_t *)msg + sizeof(h), blobs, n * bs);
+  return G1S_OK;
+}
+int g1s_shard_pack(g1s_diff_t *g, int flush, void *msg, size_t cap_bytes) {
+  if (!g || !msg) return G1S_ERR_INVALID;
+  if (!g->latest_only) return g->fail(G1S_ERR_STATE, "not a latest_only generator (records_only = 2)");
+  const size_t total = g1s_shard_msg_size(g->lag, g->batch), bs = latest_blob_size(g->lag);
+  if (cap_bytes < total) return g->fail(G1S_ERR_CAPACITY, "shard message buffer too small");
+  uint64_t limit;  // batches that may go out by now: a function of the call sequence only (lock step across ranks)
+  if (flush) {
+    const int rc = g1s_diff_sync(g);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g->dm);
+    limit = g->submitted;
+  } else {
+    {
+      std::lock_guard<std::mutex> lk(g->dm);
+      limit = g->submitted >= 2 ? g->submitted - 2 : 0;
+    }
+    g->wait_drained(limit);
+    {
+      const int pending = take_deferred(g);
+      if (pending) return pending;
+    }
+  }
+  std::lock_guard<std::mutex> lk(g->dm);
+  size_t n = 0;
+  if (g->delivered < limit && !g->latest_batches.empty()) {  // ONE batch a round, the oldest not sent yet
+    n = g->latest_batches.front();
+    g->latest_batches.pop_front();
+    g->delivered += 1;
+  }
+  const int rc = g1s_shard_msg_from_latest(n ? g->latest_out.data() : nullptr, n, g->lag, g->batch, msg, cap_bytes);
+  if (rc) return rc;
+  g->latest_out.erase(g->latest_out.begin(), g->latest_out.begin() + n * bs);
+  g->latest_out_frames -= n;
+  return G1S_OK;
+}
+
 size_t g1s_latest_size(uint32_t ar_coeff_lag) { return ar_coeff_lag >= 1 && ar_coeff_lag <= 3 ? latest_blob_size(ar_coeff_lag) : 0; }
 
 int g1s_latest_from_record(const void *record, size_t size_bytes, uint32_t ar_coeff_lag, void *blob, size_t cap_bytes) {
@@ -1818,6 +1875,25 @@ int g1s_fold_finish(g1s_fold_t *f, g1s_segment_t *out, size_t cap, size_t *n_out
     return G1S_ERR_CAPACITY;
   }
   if (!segs.empty()) std::memcpy(out, segs.data(), sizeof(g1s_segment_t) * segs.size());
+  return G1S_OK;
+}
+int g1s_shard_merge(g1s_fold_t *f, const void *msgs, size_t stride_bytes, uint32_t world) {
+  if (!f || !msgs || !world) return G1S_ERR_INVALID;
+  // global frame order: rounds in order (the caller's job), within a round the ranks in order -- batch j of the video
+  // went to rank j % world
+  for (uint32_t r = 0; r < world; ++r) {
+    const uint8_t *m = (const uint8_t *)msgs + (size_t)r * stride_bytes;
+    ShardHeader h;
+    std::memcpy(&h, m, sizeof(h));
+    if (h.magic != kShardMagic || h.lag != f->lag || h.count > h.batch_frames ||
+        stride_bytes < g1s_shard_msg_size(h.lag, h.batch_frames)) {
+      f->err = "bad shard message from rank " + std::to_string(r);
+      return G1S_ERR_INVALID;
+    }
+    if (!h.count) continue;
+    const int rc = g1s_fold_push_latest(f, m + sizeof(h), latest_blob_size(h.lag), h.count);
+    if (rc) return rc;
+  }
   return G1S_OK;
 }
 void g1s_fold_free(g1s_fold_t *f) { delete f; }

@@ -375,14 +375,22 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
       const double luma_gain = out.st[0].ar_gain;
       const double noise_gain = lat.ar_gain;
       const double corr = is_chroma ? lat.ar.x[n] : 0;
+      // Two passes over the flat blocks, raster order both times.  First the measurements themselves -- independent
+      // from block to block (six divisions and a square root each: the core overlaps them across iterations) --
+      // then their accumulation into the equation system, whose f64 sums must run in the reference's order.
+      // Every operation and its operands are those of the single loop this replaces: same bits.
+      std::vector<double> &mx = out.scratch_mean, &my = out.scratch_std;
+      mx.clear();
+      my.clear();
       for (int by = 0; by < nbh; ++by) {
+        const int sh = std::min((hh >> sy) - by * bh, bh);
+        const int lh = std::min(hh - by * kBlock, kBlock);
         for (int bx = 0; bx < nbw; ++bx) {
           const int bi = by * nbw + bx;
           if (!mask[bi]) continue;
-          const int sh = std::min((hh >> sy) - by * bh, bh);
           const int sw = std::min((w >> sx) - bx * bw, bw);
           if (sw * sh > kBlock) {
-            const int lw = std::min(w - bx * kBlock, kBlock), lh = std::min(hh - by * kBlock, kBlock);
+            const int lw = std::min(w - bx * kBlock, kBlock);
             const double block_mean = (double)luma_sum[bi] / (lw * lh);
             double noise_mean = (double)sum_d[bi];
             const double noise_sq = (double)sum_d2[bi];
@@ -392,10 +400,12 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
             const double cl = corr * luma_strength;
             const double t0 = noise_var / 16, t1 = noise_var - cl * cl;
             const double uncorr_std = std::sqrt(t0 > t1 ? t0 : t1);
-            lat.strength.add_measurement(block_mean, uncorr_std / noise_gain);
+            mx.push_back(block_mean);
+            my.push_back(uncorr_std / noise_gain);
           }
         }
       }
+      for (size_t k = 0; k < mx.size(); ++k) lat.strength.add_measurement(mx[k], my[k]);
     }
     if (!lat.strength.solve()) return fail(G1S_ERR_SOLVE, "Solving latest noise strength failed!");
   }

@@ -73,6 +73,7 @@ struct FrameLatest {
   uint32_t nplanes = 0;
   int status = 0;  // G1S_OK or error code
   std::string err;
+  std::vector<double> scratch_mean, scratch_std;  // compute_latest: a plane's block measurements before they are accumulated
 };
 // Thread-safe: record -> latest state (AR solve, measurements, strength solve).
 int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &out);

@@ -65,48 +65,32 @@ def fold_records(per_rank: List[np.ndarray], fps, ar_coeff_lag: int = 3) -> List
 _GATHER_TO_ROOT_OK = True  # falls back to an all-gather if the backend refuses a rooted gather
 
 
-def gather_latest_round(blobs: np.ndarray, blob_size: int, max_frames: int, dist,
-                        device: Optional[torch.device] = None) -> Optional[List[np.ndarray]]:
-    """One round of the streaming exchange: every rank contributes the latest states of ONE batch
-    ([n_r, blob_size], n_r <= max_frames; fixed-size message: [count | blobs]).  Only rank 0 merges, so
-    the round is a gather to rank 0 (RCCL: send/recv over xGMI; 1/N of an all-gather's traffic).
-    Returns the per-rank arrays in rank order on rank 0, None on the other ranks."""
+def gather_msgs(msg: np.ndarray, dist, device: Optional[torch.device] = None) -> Optional[np.ndarray]:
+    """The transport of a round: every rank's fixed-size message (g1s_shard_pack) to rank 0 -- [world, bytes] there, None
+    elsewhere.  RCCL: a rooted gather (send/recv over xGMI, 1/N of an all-gather's traffic); gloo in the tests."""
     global _GATHER_TO_ROOT_OK
-    world = dist.get_world_size()
-    rank = dist.get_rank()
-    backend = dist.get_backend()
+    world, rank, backend = dist.get_world_size(), dist.get_rank(), dist.get_backend()
     dev = device if (backend == "nccl" and device is not None) else torch.device("cpu")
-    n_local = int(blobs.shape[0])
-    msg = torch.zeros(16 + max_frames * blob_size, dtype=torch.uint8)
-    msg[:8] = torch.from_numpy(np.array([n_local], dtype=np.int64).view(np.uint8))
-    if n_local:
-        msg[16 : 16 + n_local * blob_size] = torch.from_numpy(np.ascontiguousarray(blobs).reshape(-1))
-    msg = msg.to(dev)
+    t = torch.from_numpy(msg).to(dev)
     host = None
     if _GATHER_TO_ROOT_OK:
         try:
-            parts = [torch.empty_like(msg) for _ in range(world)] if rank == 0 else None
-            dist.gather(msg, gather_list=parts, dst=0)
+            parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+            dist.gather(t, gather_list=parts, dst=0)
             if rank == 0:
                 host = torch.stack(parts).cpu().numpy()
         except (RuntimeError, NotImplementedError):  # raised on every rank alike, before any traffic
             _GATHER_TO_ROOT_OK = False
     if not _GATHER_TO_ROOT_OK:
         if backend == "nccl":
-            out = torch.empty((world, msg.numel()), dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(out, msg)
+            out = torch.empty((world, t.numel()), dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(out, t)
             host = out.cpu().numpy() if rank == 0 else None
         else:
-            parts = [torch.empty_like(msg) for _ in range(world)]
-            dist.all_gather(parts, msg)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
             host = torch.stack(parts).numpy() if rank == 0 else None
-    if host is None:
-        return None
-    res = []
-    for r in range(world):
-        n_r = int(host[r, :8].view(np.int64)[0])
-        res.append(host[r, 16 : 16 + n_r * blob_size].reshape(n_r, blob_size))
-    return res
+    return host
 
 
 class StreamingShardedDiff:
@@ -116,7 +100,8 @@ class StreamingShardedDiff:
     brings the round's states to rank 0, which merges them in global frame order while the GPUs are
     already on the next batch.  The ordered merge (3-5 us a frame, on its own thread) is all that stays serial.
 
-    Every rank must feed the same number of batches of `batch_frames` frames (the last may be short)."""
+    Every rank makes the same number of calls: diff_prepared for a batch of `batch_frames` frames (the video's last
+    batch may be short), idle_round when a round has no batch for it."""
 
     def __init__(self, fps, source_bit_depth: int, denoised_bit_depth: int, *, ar_coeff_lag: int = 3,
                  luma_only: bool = False, device: int = -1, batch_frames: int = 16, group=None):
@@ -128,12 +113,10 @@ class StreamingShardedDiff:
         self.generator = DiffGenerator(fps, source_bit_depth, denoised_bit_depth, ar_coeff_lag=ar_coeff_lag,
                                        luma_only=luma_only, device=device, batch_frames=batch_frames,
                                        records_only=2 if group is not None else False)
-        self._blob = 0
         self._fold = None
-        self._queue: List[np.ndarray] = []  # this rank's delivered, not yet exchanged batches
+        self._msg_bytes = 0
         if group is not None:
-            from .diff import latest_size
-            self._blob = latest_size(ar_coeff_lag)
+            self._msg_bytes = int(self.generator._L.g1s_shard_msg_size(ar_coeff_lag, batch_frames))
             if group.get_rank() == 0:
                 self._fold = RecordFold(fps, ar_coeff_lag)
                 self._merge_q = queue.Queue()
@@ -148,32 +131,28 @@ class StreamingShardedDiff:
     # pixel pass queued, accumulation queued, draining (csrc/engine.hip, kSlots)
     PIPELINE_BATCHES = 4
 
-    def _exchange_one(self) -> None:
-        """One fixed-size round: the next undelivered batch of every rank (possibly none)."""
-        mine = self._queue.pop(0) if self._queue else np.zeros((0, self._blob), dtype=np.uint8)
-        per_rank = gather_latest_round(mine, self._blob, self.batch, self.dist, self._dev)
+    def _exchange_one(self, flush: bool = False) -> None:
+        """One fixed-size round.  The protocol is the library's (g1s_shard_pack: which batch goes out, the message;
+        g1s_shard_merge: the root's order); this class only moves the bytes -- one gather to rank 0."""
+        L = self.generator._L
+        msg = np.zeros(self._msg_bytes, dtype=np.uint8)
+        self.generator._check(L.g1s_shard_pack(self.generator._h, int(flush), msg.ctypes.data, msg.nbytes))
+        gathered = gather_msgs(msg, self.dist, self._dev)
         if self._fold is not None:
-            # global order: batch by batch, ranks in order within a batch; the merge itself runs on a
-            # thread of its own (the C call drops the GIL): this thread goes back to feeding its GPU
-            blobs = [b for b in per_rank if len(b)]
-            if blobs:
-                self._merge_q.put(np.concatenate(blobs) if len(blobs) > 1 else blobs[0])
+            # the merge itself runs on a thread of its own (the C call drops the GIL): this thread goes back to feeding its GPU
+            self._merge_q.put(gathered)
 
     def _merge_main(self) -> None:
+        L = self.generator._L
         while True:
             item = self._merge_q.get()
             if item is None:
                 return
             if self._merge_err is None:
-                try:
-                    self._fold.push_latest_many(item)
-                except Exception as e:  # surfaces in finish()
-                    self._merge_err = e
-
-    def _collect(self, sync: bool) -> None:
-        blobs = self.generator.take_latest(self.PIPELINE_BATCHES * self.batch, sync=sync)
-        for k in range(0, len(blobs), self.batch):
-            self._queue.append(blobs[k:k + self.batch])
+                rc = L.g1s_shard_merge(self._fold._h, item.ctypes.data, item.strides[0], item.shape[0])
+                if rc:  # surfaces in finish()
+                    from ._lib import G1SError
+                    self._merge_err = G1SError(rc, L.g1s_fold_last_error(self._fold._h).decode())
 
     def diff_prepared(self, prepared, sync_torch: bool = True) -> None:
         """Feeds ONE batch (this rank's next batch in the global order)."""
@@ -181,16 +160,20 @@ class StreamingShardedDiff:
         if self.dist is not None:
             # the states of an earlier batch (which one is a function of the call sequence only, so every
             # rank contributes the same batch index; nothing on the first calls)
-            self._collect(sync=False)
+            self._exchange_one()
+
+    def idle_round(self) -> None:
+        """A round in which this rank has no batch to feed (the video's batch count is not a multiple of the rank
+        count: the last round is short): it still takes part in the round's exchange, contributing whatever of its
+        earlier batches is ready -- every rank makes the same number of diff_prepared + idle_round calls."""
+        if self.dist is not None:
             self._exchange_one()
 
     def finish(self) -> Optional[List[GrainTableSegment]]:
         if self.dist is None:
             return self.generator.finish()
-        self._collect(sync=True)
         for _ in range(self.PIPELINE_BATCHES):
-            self._exchange_one()
-        assert not self._queue
+            self._exchange_one(flush=True)
         if self._fold is None:
             return None
         self._stop_merger()

@@ -159,6 +159,23 @@ int g1s_diff_take_records(g1s_diff_t *, void *buf, size_t cap_bytes, size_t *n_f
  * (waits for them if need be; deterministic, so that ranks deliver the same batches in the same
  * round); sync = 1: everything queued so far. */
 int g1s_diff_take_latest(g1s_diff_t *, int sync, void *buf, size_t cap_bytes, size_t *n_frames);
+
+/* ---- frame-shard rounds (one process per GPU): the exchange protocol behind the ABI, the transport with the host ----
+ * The video is dealt to the N ranks batch by batch (batch j of batch_frames frame pairs -> rank j % N).  The job runs in
+ * ROUNDS; in a round every rank (1) feeds its next batch, if the video still has one for it, (2) calls g1s_shard_pack,
+ * (3) takes part in ONE gather of the fixed-size messages to rank 0 -- ncclAllGather / ncclSend+Recv on RCCL, MPI_Gather,
+ * torch.distributed.gather: whatever the host application owns; this library links no communication library --
+ * and rank 0 hands the N gathered messages, rank order, to g1s_shard_merge.  After the last feeding round every rank runs
+ * 4 more rounds with flush = 1 (the batches still in the generator's pipeline).  Rank 0's fold then finishes the table:
+ * identical, byte for byte, to one generator fed the whole video (the states are exact; only their merge is ordered).
+ * Message = 16-byte header + batch_frames latest states (g1s_latest_size() each, ~27 KB): N x 0.9 MB a round at 4K. */
+size_t g1s_shard_msg_size(uint32_t ar_coeff_lag, uint32_t batch_frames);
+/* This rank's message of the round: the latest states of ONE batch -- the oldest one not sent yet among those fed before
+ * the two most recent feeds (flush = 0: the same batch index on every rank, however far each runs ahead; waits for it)
+ * or among all (flush = 1: drains the generator first) -- or an empty message.  records_only = 2 generators. */
+int g1s_shard_pack(g1s_diff_t *, int flush, void *msg, size_t cap_bytes);
+/* A message from latest states made elsewhere (g1s_latest_from_record): n <= batch_frames. */
+int g1s_shard_msg_from_latest(const void *blobs, size_t n, uint32_t ar_coeff_lag, uint32_t batch_frames, void *msg, size_t cap_bytes);
 size_t g1s_latest_size(uint32_t ar_coeff_lag);
 /* The per-frame half of the fold on the host: record -> latest state.  Thread-safe.  A frame
  * that fails (not enough flat blocks, singular system) yields a blob that carries the error;
@@ -176,6 +193,9 @@ int g1s_fold_push(g1s_fold_t *, const void *record, size_t size_bytes);
 int g1s_fold_push_many(g1s_fold_t *, const void *records, size_t stride_bytes, size_t n);
 /* n latest states, stride_bytes apart, in frame order: the ordered half only. */
 int g1s_fold_push_latest(g1s_fold_t *, const void *blobs, size_t stride_bytes, size_t n);
+/* Rank 0: the `world` gathered messages of one round, stride_bytes apart, rank order -> the ordered merge.  Rounds must
+ * be merged in order. */
+int g1s_shard_merge(g1s_fold_t *, const void *msgs, size_t stride_bytes, uint32_t world);
 /* Same contract as g1s_diff_finish: G1S_ERR_CAPACITY leaves the segments in place for a second call. */
 int g1s_fold_finish(g1s_fold_t *, g1s_segment_t *out, size_t cap, size_t *n_out);
 void g1s_fold_free(g1s_fold_t *);

@@ -58,14 +58,19 @@ def test_two_rank_shard_equals_single_process(tmp_path, nframes):
     assert open(out, "rb").read() == want
 
 
-def _stream_worker(rank, world, port, nbatches, batch, out_path):
-    """Streaming frame-shard fold: global batch j goes to rank j % world; per round ONE all-gather of
-    latest states (the per-frame half of the fold done where the frame lives); rank 0 merges in order."""
+def _stream_worker(rank, world, port, total_batches, batch, out_path):
+    """Streaming frame-shard fold over the library's round protocol: global batch j goes to rank j % world; per round every
+    rank packs ONE message (g1s_shard_msg_from_latest here: the latest states come from oracle-made records; a GPU rank
+    uses g1s_shard_pack), one gather to rank 0 (grav1synth_amd.dist.gather_msgs, gloo), g1s_shard_merge there.  The batch
+    count is odd: in the last round rank 1 has nothing and sends an empty message."""
     sys.path.insert(0, ROOT)
+    import ctypes as C
+
     import torch.distributed as dist
 
+    from grav1synth_amd import _lib
     from grav1synth_amd.diff import RecordFold, format_tbl, latest_from_records, latest_size
-    from grav1synth_amd.dist import gather_latest_round
+    from grav1synth_amd.dist import gather_msgs
     from grav1synth_amd.synth import SynthSpec
     from tests.helpers import np_pair, record_from_oracle
     from tests.oracle_binding import OracleDiff
@@ -73,23 +78,36 @@ def _stream_worker(rank, world, port, nbatches, batch, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = _lib.lib()
     spec = SynthSpec(256, 160, 8)
     fold = RecordFold(Fraction(24, 1), 3) if rank == 0 else None
     bs = latest_size(3)
-    for k in range(nbatches):  # this rank's k-th batch is global batch k * world + rank
-        recs = []
-        for i in range(batch):
-            o = OracleDiff(24, 1, 8, 8, 3, True)
-            s, d = np_pair(spec, (k * world + rank) * batch + i)
-            o.diff_frame(s, d, 1, 1)
-            recs.append(record_from_oracle(o, spec, 3, 3).buf)
-        blobs = latest_from_records(np.stack(recs), 3)
-        assert blobs.shape == (batch, bs)
-        per_rank = gather_latest_round(blobs, bs, 2 * batch, dist)
+    msg_bytes = L.g1s_shard_msg_size(3, batch)
+    assert msg_bytes == 16 + batch * bs
+    rounds = (total_batches + world - 1) // world
+    for r in range(rounds):
+        j = r * world + rank  # this rank's global batch in round r
+        blobs = np.zeros((0, bs), dtype=np.uint8)
+        if j < total_batches:
+            recs = []
+            for i in range(batch):
+                o = OracleDiff(24, 1, 8, 8, 3, True)
+                s, d = np_pair(spec, j * batch + i)
+                o.diff_frame(s, d, 1, 1)
+                recs.append(record_from_oracle(o, spec, 3, 3).buf)
+            blobs = latest_from_records(np.stack(recs), 3)
+            assert blobs.shape == (batch, bs)
+        msg = np.zeros(msg_bytes, dtype=np.uint8)
+        assert L.g1s_shard_msg_from_latest(blobs.ctypes.data if len(blobs) else None, len(blobs), 3, batch, msg.ctypes.data, msg.nbytes) == 0
+        gathered = gather_msgs(msg, dist)
         if fold is not None:
-            for b in per_rank:
-                fold.push_latest_many(b)
+            assert gathered.shape == (world, msg_bytes)
+            assert L.g1s_shard_merge(fold._h, gathered.ctypes.data, gathered.strides[0], world) == 0
+        else:
+            assert gathered is None
     if rank == 0:
+        bad = np.zeros((world, msg_bytes), dtype=np.uint8)  # no magic: refused, nothing merged
+        assert L.g1s_shard_merge(fold._h, bad.ctypes.data, bad.strides[0], world) == -1
         with open(out_path, "wb") as f:
             f.write(format_tbl(fold.finish()))
     dist.barrier()
@@ -100,34 +118,9 @@ def test_two_rank_streaming_fold_equals_single_process(tmp_path):
     from grav1synth_amd.synth import SynthSpec
     from tests.helpers import oracle_run
 
-    nbatches, batch = 2, 2
+    total_batches, batch = 3, 2
     out = str(tmp_path / "streamed.tbl")
     port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_stream_worker, args=(2, port, nbatches, batch, out), nprocs=2, join=True)
-    want, _ = oracle_run(SynthSpec(256, 160, 8), range(2 * nbatches * batch))
+    mp.spawn(_stream_worker, args=(2, port, total_batches, batch, out), nprocs=2, join=True)
+    want, _ = oracle_run(SynthSpec(256, 160, 8), range(total_batches * batch))
     assert open(out, "rb").read() == want
-
-
-def test_latest_blobs_equal_record_fold():
-    """push_latest(latest_from_record(r)) == push(r), and a failing frame travels inside its blob."""
-    from grav1synth_amd.diff import G1SError, Record, RecordFold, format_tbl, latest_from_records
-    from grav1synth_amd.synth import SynthSpec
-    from tests.helpers import np_pair, record_from_oracle
-    from tests.oracle_binding import OracleDiff
-
-    spec = SynthSpec(256, 160, 8)
-    recs = []
-    for k in range(3):
-        o = OracleDiff(24, 1, 8, 8, 3, True)
-        s, d = np_pair(spec, k)
-        o.diff_frame(s, d, 1, 1)
-        recs.append(record_from_oracle(o, spec, 3, 3).buf)
-    recs = np.stack(recs)
-    a, b = RecordFold(Fraction(24, 1), 3), RecordFold(Fraction(24, 1), 3)
-    a.push_many(recs)
-    b.push_latest_many(latest_from_records(recs, 3))
-    assert format_tbl(a.finish()) == format_tbl(b.finish())
-    blank = Record.blank(256, 160, 1, 1, 3, 3).buf[None, :]  # no flat blocks
-    c = RecordFold(Fraction(24, 1), 3)
-    with pytest.raises(G1SError):
-        c.push_latest_many(latest_from_records(blank, 3))

@@ -94,6 +94,50 @@ def test_records_and_table_match_oracle(case):
     assert mine == tbl
 
 
+def test_two_ranks_stream_a_sharded_job_on_one_device(tmp_path):
+    """StreamingShardedDiff -- the class `bench.py --gpus N` runs -- with TWO ranks (gloo, both on this one GPU): five
+    batches dealt round-robin (an odd count: rank 1 sits out the last round), a scene cut inside a batch, the
+    lock-step exchange of latest states, the ordered merge on rank 0.  The table must be the single generator's and
+    the oracle's, byte for byte."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from tests import dist_gpu_worker as w
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "sharded.tbl")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   G1S_FOLD_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, "-m", "tests.dist_gpu_worker", out], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(x[-1500:] for x in logs)
+    want, segs = oracle_run(w.A, range(len(w.SPECS)), fps=w.FPS, specs_per_frame=w.SPECS)
+    assert len(segs) >= 2
+    g = DiffGenerator(w.FPS, 8, 8, batch_frames=w.BATCH)
+    for k, sp in enumerate(w.SPECS):
+        s, d = make_pair(sp, k, device="cuda")
+        g.diff_frame(s, d, 1, 1)
+    single = format_tbl(g.finish())
+    assert single == want
+    assert open(out, "rb").read() == want
+
+
 def test_accumulation_modes_agree():
     """G1S_K3 = fused (default: matrix-core accumulation straight from the source planes), planes (pixel pass K0 + the
     matrix-core kernel on its int8 planes) and dot4 (round 1: K0 + lag-structured v_dot4 kernels) must give the same
