@@ -49,6 +49,11 @@ constexpr int kK3Chunks = 48;
 //   dot4              round 1's chain -- K0, then the lag-structured v_dot4 kernels (k3q.hip.h).
 // All three are bit-exact against each other and the oracle (tests/test_gpu_k3_modes.py); fused and planes measure the
 // same on the 4K workload ("What bounds the pass").
+// timing experiments: G1S_DBG_SKIP=name[,name...] leaves kernels out (wrong results; never set in tests or bench lines)
+bool dbg_skip(const char *name) {
+  static const std::string v = getenv("G1S_DBG_SKIP") ? std::string(",") + getenv("G1S_DBG_SKIP") + "," : std::string();
+  return !v.empty() && v.find(std::string(",") + name + ",") != std::string::npos;
+}
 int k3_mode() {
   static const int v = [] {
     const char *e = getenv("G1S_K3");
@@ -846,7 +851,8 @@ int g1s_diff::launch_front(int si) {
       if (!force_literal) {
         const dim3 mg((g.nblocks + 7) / 8, B);
         kmark(sl, pstream, g.src_bps == 1 ? "k1_moments<1>" : "k1_moments<2>");
-        if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
+        if (dbg_skip("moments")) {
+        } else if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
         else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, pstream, ft, g, mom);
       }
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
@@ -893,7 +899,7 @@ int g1s_diff::launch_front(int si) {
       HIP_TRY(hipStreamWaitEvent(fstream, ss.pix_done[si], 0));
     }
     kmark(sl, fstream, "k1_certify");
-    hipLaunchKernelGGL(k1_certify, dim3((g.nblocks + 255) / 256, B), dim3(256), 0, fstream, g, fc, (const int32_t *)mom,
+    if (!dbg_skip("certify")) hipLaunchKernelGGL(k1_certify, dim3((g.nblocks + 255) / 256, B), dim3(256), 0, fstream, g, fc, (const int32_t *)mom,
                        sl.d_records, sl.d_flags, cl, force_literal);
     kmark(sl, fstream, literal_mode == 1 ? "k1_flat_features" : "k1_flat_block");
     if (literal_mode == 1) {  // every block: one lane per block
@@ -904,7 +910,7 @@ int g1s_diff::launch_front(int si) {
       else
         hipLaunchKernelGGL((k1_flat_features<2, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
                            (const uint32_t *)cl.list, (const uint32_t *)cl.count);
-    } else {  // the few blocks the certificate leaves open (mode 2, a test aid: every block): one wave per block
+    } else if (!dbg_skip("flatblock")) {  // the few blocks the certificate leaves open (mode 2, a test aid: every block): one wave per block
       dim3 grid(kFbGrid, B);
       if (g.src_bps == 1)
         hipLaunchKernelGGL(k1_flat_block<1>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
@@ -916,7 +922,7 @@ int g1s_diff::launch_front(int si) {
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
   kmark(sl, fstream, "k2_flat_select");
-  hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
+  if (!dbg_skip("k2")) hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
   if (fast_ok && use_mfma()) {
     // the unit lists (chunks with a flat block) need the flat mask
@@ -1077,7 +1083,7 @@ int g1s_diff::launch_back(int si) {
 #undef G1S_FS
 #undef G1S_F
     kmark(sl, stream, "k3m_finish");
-    hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + (planes ? 0 : kMFinishWgs), B), dim3(256), 0, stream, g, mp, G,
+    if (!dbg_skip("finish")) hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + (planes ? 0 : kMFinishWgs), B), dim3(256), 0, stream, g, mp, G,
                        planes ? (const int32_t *)nullptr : (const int32_t *)fq.ustats, sl.d_records);
     if (fq.phase_cycles) {
       std::vector<long long> hc((size_t)G * B * kFWaves * 6);
