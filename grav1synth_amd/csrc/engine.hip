@@ -70,7 +70,8 @@ constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per 
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
 int m_wgs_per_frame(int nunits, int B) {
   const int gmin = (nunits + (kMMaxUnits - 16) - 1) / (kMMaxUnits - 16);  // (two lists, each dealt with its own rounding)
-  static const int target = getenv("G1S_F_WGS") ? std::max(8, atoi(getenv("G1S_F_WGS"))) : kMTargetWgs;  // tuning aid
+  const char *e = getenv("G1S_F_WGS");  // tuning / test aid (read at every call: a test sets it for its own generator)
+  const int target = e ? std::max(8, atoi(e)) : kMTargetWgs;
   return (std::max(gmin, (target + B - 1) / std::max(B, 1)) + 7) & ~7;  // (a multiple of 8: workgroup b of a frame on XCD b % 8)
 }
 
@@ -1098,8 +1099,9 @@ int g1s_diff::launch_back(int si) {
                 v, tot[v][0] / (G * B), tot[v][1] / (G * B), tot[v][2] / (G * B), tot[v][3] / (G * B), tot[v][4] / (G * B), tot[v][5] / (G * B));
     }
     kmark(sl, stream, "k3_ar_generic");
-    hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
-                       sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
+    if (!dbg_skip("generic"))
+      hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
+                         sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
   } else if (fast_ok) {
     // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
     // then the generic int32 kernel on mixed / deferred areas

@@ -534,14 +534,18 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   auto phase_b = [&](auto plain_tag, const uint32_t (&wins)[4]) __attribute__((always_inline)) {
     constexpr bool PLAIN = decltype(plain_tag)::value;
     if (LUMA && y_wave) {
+      // every word of a block that is multiplied is written, the fully masked ones (columns past a window that ends at the
+      // plane's right edge) as zeros: the multiplies read all 32 positions of the block's rows
       uint2 cm = make_uint2(0u, 0u);
-      if (y_interior) cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(y_bq ? wins[1] : wins[0], g.lag), y_xw - 32 * y_bq);
+      const uint32_t wsel = y_bq ? wins[1] : wins[0];
+      const bool wr = y_interior && (PLAIN || ((wsel >> 15) & 1u) != 0);
+      if (y_interior) cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(wsel, g.lag), y_xw - 32 * y_bq);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int tr = ytr0 + r;
         const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
         const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][0], 0x130, 0xf, 0xf, true);  // wave_shl:1
-        if (tr >= 0 && (cm.x | cm.y)) m_write_copies<!PLAIN>(m_smem + tr * SH::PY + y_xw, SH::CSY, prev1, Dy[r][0], Dy[r][1], next0, cm);
+        if (tr >= 0 && wr) m_write_copies<!PLAIN>(m_smem + tr * SH::PY + y_xw, SH::CSY, prev1, Dy[r][0], Dy[r][1], next0, cm);
       }
     }
     if constexpr (CHROMA) {
@@ -555,10 +559,12 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
     for (int q = 0; q < CROUNDS; ++q) {
       const int c = cpl[q];
       uint2 cm = make_uint2(0u, 0u);
-      if (c_interior && c) cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(c_bq ? wins[3] : wins[2], g.lag), c_xw - CW_ * c_bq);
+      const uint32_t wsel = c_bq ? wins[3] : wins[2];
+      const bool wr = c_interior && c && (PLAIN || ((wsel >> 15) & 1u) != 0);
+      if (c_interior && c) cm = PLAIN ? make_uint2(~0u, ~0u) : m_colmask8(m_unpack(wsel, g.lag), c_xw - CW_ * c_bq);
       const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dc[q][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
       const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dc[q][0], 0x130, 0xf, 0xf, true);  // wave_shl:1
-      if (cm.x | cm.y)
+      if (wr)
         m_write_copies<!PLAIN>(m_smem + (c == 2 ? OFF_CR : OFF_CB) + ctr[q] * SH::PC + c_xw, SH::CSC, prev1, Dc[q][0], Dc[q][1], next0, cm);
     }
   };

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
       for (int dy = -1; dy <= 0; ++dy)
         for (int dx = -1; dx <= 1; ++dx) {
           const int x = bx + dx, y = by + dy;
-          if (x >= 0 && x < g.nbw && y >= 0 && bad[y * g.nbw + x]) defer = true;
+          if (x >= 0 && x < g.nbw && y >= 0 && y < g.nbh && bad[y * g.nbw + x]) defer = true;
         }
     }
     if (defer) {

@@ -541,6 +541,72 @@ def test_large_residuals_take_the_deferred_path(bd, xdec, ydec, lag):
     assert format_tbl(g.finish()) == ofmt(o.finish())
 
 
+@pytest.mark.parametrize("seed", [3, 77])
+def test_ragged_sizes_with_isolated_large_residuals(seed):
+    """Random frame sizes whose last block column is partial (a window that ends at the plane's right edge leaves
+    whole 8-sample words of a multiplied block outside it: they must reach the matrix cores as zeros, not as what
+    the LDS held before), all lags and chroma formats, a few |src - den| > 127 samples on the denoised side:
+    every integer sum of every frame's record equals the oracle's."""
+    import random
+
+    from tests.oracle_binding import OracleDiff
+
+    rng = random.Random(seed)
+    for k in range(30):
+        w, h = rng.randint(66, 300), rng.randint(66, 300)
+        bd = rng.choice([8, 10])
+        xd, yd = rng.choice([(1, 1), (1, 0), (0, 0)])
+        lag = rng.choice([3, 2, 1])
+        spec = SynthSpec(w, h, bd, xdec=xd, ydec=yd, textured=rng.random() < 0.6)
+        s, d = np_pair(spec, k)
+        d = [p.copy() for p in d]
+        nr = np.random.default_rng(rng.randint(0, 1 << 30))
+        for c in range(3):
+            hh, ww = d[c].shape
+            for _ in range(int(nr.integers(0, 4))):
+                y, x = int(nr.integers(0, hh)), int(nr.integers(0, ww))
+                d[c][y, x] = 0 if (int(s[c][y, x]) >> (bd - 8)) > 140 else (255 << (bd - 8))
+        o = OracleDiff(24, 1, bd, bd, lag, True)
+        try:
+            o.diff_frame(s, d, xd, yd)
+        except RuntimeError:
+            continue  # (no flat block at all: the oracle refuses like the reference)
+        g = DiffGenerator(Fraction(24, 1), bd, bd, ar_coeff_lag=lag, batch_frames=1)
+        try:
+            g.diff_frame(Frame(s, xd, yd), Frame(d, xd, yd))
+            g.sync()
+            r = g.last_record()
+            for c in range(3):
+                S, Sb, n = o.ar_sums(c)
+                S2, Sb2, n2 = r.ar_sums(c)
+                assert n == n2 and np.array_equal(S, S2) and np.array_equal(Sb, Sb2), f"case {k}: {w}x{h} {bd}b xd{xd} yd{yd} lag{lag}, plane {c}"
+        finally:
+            g.close()
+
+
+@pytest.mark.parametrize("lag", [3, 2])
+def test_partial_last_column_with_many_units_per_workgroup(lag, monkeypatch):
+    """The same property where a workgroup of the accumulation pass walks many units (few workgroups per frame):
+    a plain unit before a unit at the plane's right edge leaves its residuals in the LDS words the edge unit masks."""
+    from tests.oracle_binding import OracleDiff, format_tbl as ofmt
+
+    monkeypatch.setenv("G1S_F_WGS", "8")
+    spec = SynthSpec(1000, 360, 10, xdec=1, ydec=1, textured=False)  # 31.25 blocks wide: windows 8 - lag wide in the last column
+    o = OracleDiff(24, 1, 10, 10, lag, True)
+    g = DiffGenerator(Fraction(24, 1), 10, 10, ar_coeff_lag=lag, batch_frames=2)
+    for k in range(2):
+        s, d = np_pair(spec, k)
+        o.diff_frame(s, d, 1, 1)
+        g.diff_frame(Frame(s, 1, 1), Frame(d, 1, 1))
+    g.sync()
+    r = g.last_record()
+    for c in range(3):
+        S, Sb, n = o.ar_sums(c)
+        S2, Sb2, n2 = r.ar_sums(c)
+        assert n == n2 and np.array_equal(S, S2) and np.array_equal(Sb, Sb2), f"plane {c}"
+    assert format_tbl(g.finish()) == ofmt(o.finish())
+
+
 @pytest.mark.parametrize("spec,nframes", [(SynthSpec(320, 200, 10), 5), (SynthSpec(288, 160, 8, xdec=0, ydec=0), 4)],
                          ids=["10b420", "8b444"])
 def test_y4m_files_give_the_table_of_the_in_memory_path_and_of_the_oracle(tmp_path, spec, nframes):
