@@ -184,6 +184,13 @@ SYMBOLS = [
     ("g1s_filters_free", None, [C.c_void_p]),
     ("g1s_diff_run_filtered", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    ("g1s_estimate_new", C.c_void_p, [C.c_uint32, C.c_int32, C.c_uint32]),
+    ("g1s_estimate_frame", C.c_int, [C.c_void_p, C.POINTER(G1SFrame)]),
+    ("g1s_estimate_finish", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("g1s_estimate_set_timing", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    ("g1s_estimate_last_error", C.c_char_p, [C.c_void_p]),
+    ("g1s_estimate_free", None, [C.c_void_p]),
+    ("g1s_format_estimates", C.c_long, [C.POINTER(C.c_double), C.c_size_t, C.c_char_p, C.c_size_t]),
     ("g1s_y4m_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("g1s_y4m_get_info", C.c_int, [C.c_void_p, C.POINTER(G1SY4MInfo)]),
     ("g1s_y4m_next", C.c_int, [C.c_void_p, C.POINTER(G1SFrame)]),

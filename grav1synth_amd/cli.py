@@ -50,6 +50,12 @@ def build_parser() -> argparse.ArgumentParser:
                         '"crop:top=42,left=64".  crop: top, bottom, left, right.  resize (width, height, alg) parses like the '
                         "reference's but is not supported here.")
     d.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: the current device)")
+    e = sub.add_parser("estimate", help="Estimates the amount of noise in a source video, frame by frame (y4m input; the reference's "
+                                        "`estimate`, feature \"unstable\").")
+    e.add_argument("source", help="The source file to inspect.")
+    e.add_argument("-o", "--output", required=True, help="The path to the output file.")
+    e.add_argument("-y", "--overwrite", action="store_true", help="Overwrite the output file without prompting.")
+    e.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: the current device)")
     return ap
 
 
@@ -79,6 +85,22 @@ def diff_command(source: str, denoised: str, output: str, overwrite: bool = Fals
     return frames
 
 
+def estimate_command(source: str, output: str, overwrite: bool = False, device: int = -1, confirm=_confirm) -> int:
+    """Commands::Estimate (src/main.rs:534-608): the refusals of :541-560, one estimate_plane_noise per frame, "filmgrn1" and a
+    "{:.3}" line per frame (-1 for None), "Done, wrote output file to ...".  Returns the frame count, -1 after a refusal."""
+    from .estimate import estimate_y4m_file
+
+    if source == output:
+        log.error(SAME_AS_OUTPUT)
+        return -1
+    if os.path.exists(output) and not overwrite and not confirm(f"File {output} exists. Overwrite?"):
+        log.warning(NOT_OVERWRITING)
+        return -1
+    frames = estimate_y4m_file(source, output, device=device)
+    log.info("Done, wrote output file to %s", output)
+    return frames
+
+
 def main(argv: Optional[List[str]] = None) -> int:
     args = build_parser().parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(levelname)s %(message)s", stream=sys.stderr)
@@ -86,6 +108,12 @@ def main(argv: Optional[List[str]] = None) -> int:
         try:
             diff_command(args.source, args.denoised, args.output, args.overwrite, args.filters, args.device)
         except Exception as e:  # `?` out of main: the error, a non-zero exit
+            log.error("%s", e)
+            return 1
+    elif args.command == "estimate":
+        try:
+            estimate_command(args.source, args.output, args.overwrite, args.device)
+        except Exception as e:
             log.error("%s", e)
             return 1
     return 0

@@ -324,6 +324,26 @@ int g1s_diff_y4m_files(const char *source, const char *denoised, const char *out
 int g1s_diff_y4m_files_filtered(const char *source, const char *denoised, const char *out_tbl, const g1s_opts_t *opts,
                                 const char *filters, uint64_t *frames, int *unequal, char *err, size_t errcap);
 
+/* ---- N4: `grav1synth estimate` (feature "unstable", src/main.rs:534-608): the single-source noise estimator ---- */
+/* av1_grain::estimate_plane_noise(&frame.y_plane, bit_depth) per frame (the port of libaom's
+ * av1_estimate_noise_from_single_plane: Sobel-gated mean |Laplacian| of the luma plane), on the device: one pass over
+ * the luma plane, exact integer sums, the f64 formed on the host with the reference's three operations.
+ * g1s_estimate_new: NULL without a HIP device (no CPU fallback) or for a bit depth outside 8..16. */
+typedef struct g1s_estimate g1s_estimate_t;
+g1s_estimate_t *g1s_estimate_new(uint32_t bit_depth, int32_t device, uint32_t batch_frames);
+/* One frame (only data[0], the luma plane, is read; on_device 0 = host, copied before the call returns; 1 = device,
+ * valid until the next g1s_estimate_finish or until batch_frames more frames have been handed over). */
+int g1s_estimate_frame(g1s_estimate_t *, const g1s_frame_t *frame);
+/* frame_estimates (src/main.rs:563-590): one f64 per frame, -1.0 where the reference has None (fewer than 16 smooth
+ * pixels).  G1S_ERR_CAPACITY leaves them in place (*n_out = count); more frames may follow. */
+int g1s_estimate_finish(g1s_estimate_t *, double *out, size_t cap, size_t *n_out);
+/* HIP-event time of the kernel launches so far (enable = 1 from the next batch on). */
+int g1s_estimate_set_timing(g1s_estimate_t *, int enable, double *ms_kernel, uint64_t *frames);
+const char *g1s_estimate_last_error(const g1s_estimate_t *);
+void g1s_estimate_free(g1s_estimate_t *);
+/* The command's output (src/main.rs:596-603): "filmgrn1\n" then "{:.3}\n" per frame.  Bytes written or G1S_ERR_CAPACITY. */
+long g1s_format_estimates(const double *estimates, size_t n, char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,12 @@ def lib():
     if not os.path.exists(_LIB_PATH):
         build()
     L = C.CDLL(_LIB_PATH)
+    if not hasattr(L, "orc_estimate_plane_noise"):  # a library from before the estimator was added
+        del L
+        build()
+        L = C.CDLL(_LIB_PATH)
+    L.orc_estimate_plane_noise.restype = C.c_double
+    L.orc_estimate_plane_noise.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]
     L.orc_diff_new.restype = C.c_void_p
     L.orc_diff_new.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_diff_frame.restype = C.c_int
@@ -97,6 +103,14 @@ def lib():
     L.orc_format_tbl.argtypes = [C.POINTER(OrcSegment), C.c_int, C.c_char_p, C.c_size_t]
     _lib = L
     return L
+
+
+def estimate_plane_noise(plane: np.ndarray, bit_depth: int) -> Optional[float]:
+    """av1_grain::estimate_plane_noise as restated in oracle/estimate_oracle.c (None = fewer than 16 smooth pixels)."""
+    p = np.ascontiguousarray(plane)
+    assert p.dtype == (np.uint8 if bit_depth == 8 else np.uint16)
+    v = lib().orc_estimate_plane_noise(p.ctypes.data, p.strides[0], p.shape[1], p.shape[0], bit_depth)
+    return None if v == -1.0 else float(v)
 
 
 def _np_frame(planes: Sequence[np.ndarray], xdec: int, ydec: int) -> OrcFrame:
