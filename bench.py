@@ -52,7 +52,7 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=256, help="frame pairs per rank per step (one video chunk per step)")
     ap.add_argument("--cycles", type=int, default=8,
                     help="a step feeds the resident frames this many times over: one job of frames x cycles frame pairs")
-    ap.add_argument("--batch", type=int, default=32, help="frames per kernel launch group (<= 256)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per kernel launch group (<= 256)")
     ap.add_argument("--workload", default="4k10", choices=sorted(WORKLOADS))
     ap.add_argument("--flat", action="store_true", help="all-flat stress variant (no textured region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -71,7 +71,8 @@ constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per 
 int m_wgs_per_frame(int nunits, int B) {
   const int gmin = (nunits + (kMMaxUnits - 16) - 1) / (kMMaxUnits - 16);  // (two lists, each dealt with its own rounding)
   const char *e = getenv("G1S_F_WGS");  // tuning / test aid (read at every call: a test sets it for its own generator)
-  const int target = e ? std::max(8, atoi(e)) : kMTargetWgs;
+  // (at least 32 workgroups to a frame: 64-frame launches are two resident rounds)
+  const int target = e ? std::max(8, atoi(e)) : std::max(kMTargetWgs, 32 * B);
   return (std::max(gmin, (target + B - 1) / std::max(B, 1)) + 7) & ~7;  // (a multiple of 8: workgroup b of a frame on XCD b % 8)
 }
 
@@ -362,6 +363,7 @@ struct g1s_diff {
   uint32_t pg_cap = 0;
   uint32_t m_lpitch = 0, m_lframe = 0;  // MFMA path: L plane geometry
   int m_nunits = 0;          // MFMA path: chunks per frame
+  size_t m_wg_cap = 0;       // ... workgroups (partial systems) the slots hold
   size_t m_only_bytes = 0;   // ... deferred-block flags [batch][2][nblocks], 16-byte rounded
   MParams make_mparams(const Slot &sl) const;
   SlotKey slot_key{};
@@ -490,10 +492,11 @@ int g1s_diff::set_geometry(const g1s_frame_t *s, const g1s_frame_t *d) {
 int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
   shape = *s;
   if (batch_auto) {
-    // about 265 Mpixels a launch group (32 4K frames): the per-launch costs of the small kernels are the same
-    // for small frames, so they get more frames per launch (1080p: 128)
+    // about 530 Mpixels a launch group (64 4K frames; measured: 32 -> 64 frames a launch +12 % on the 4K job, no gain
+    // beyond): the per-launch costs of the small kernels are the same for small frames, so they get more frames per
+    // launch (1080p: 128)
     const uint64_t px = (uint64_t)s->width * s->height;
-    batch = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(kDefaultBatch, (265000000ull + px / 2) / std::max<uint64_t>(px, 1)));
+    batch = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(kDefaultBatch, (530000000ull + px / 2) / std::max<uint64_t>(px, 1)));
   }
   const uint32_t np = luma_only ? 1u : (uint32_t)s->nplanes;
   L = make_layout(s->width, s->height, np, lag);
@@ -550,9 +553,10 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
   const size_t mu_bytes = !use_mfma() ? 0
                                       : sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch) + m_only_bytes +
                                             sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
-  const size_t mpart_bytes = !use_mfma() ? 0
-                                         : sizeof(long long) * 3 * kMRec *
-                                               ((size_t)batch * ((m_nunits + kMMaxUnits - 1) / kMMaxUnits + 8) + 4096 + batch);
+  // one partial system per accumulation workgroup and plane: the most workgroups a launch of 1 .. batch frames asks for
+  m_wg_cap = 0;
+  for (uint32_t b = 1; b <= batch; ++b) m_wg_cap = std::max(m_wg_cap, (size_t)b * m_wgs_per_frame(m_nunits, (int)b));
+  const size_t mpart_bytes = !use_mfma() ? 0 : sizeof(long long) * 3 * kMRec * m_wg_cap;
   // L plane of a frame: block rows x chunk columns at chroma resolution (+ a slack row)
   m_lpitch = g.nplanes == 3 ? (uint32_t)((((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * kMUnitBlocks * (kBlock >> g.xdec) + 15) & ~15) : 0u;
   m_lframe = m_lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec) + 1);
@@ -1016,7 +1020,8 @@ int g1s_diff::launch_back(int si) {
     fq.partials = mp.partials;
     fq.ustats = reinterpret_cast<int32_t *>(mp.only + m_only_bytes);
     fq.nunits = m_nunits;
-    const int G = m_wgs_per_frame(m_nunits, (int)B);
+    int G = m_wgs_per_frame(m_nunits, (int)B);
+    if ((size_t)G * B > m_wg_cap) G = m_wgs_per_frame(m_nunits, 1 << 20);  // (G1S_F_WGS raised after the slots were sized: the fewest that hold the units)
     // profiling aid: G1S_F_PHASES=1 prints, per batch, the cycles the accumulation waves spent in each phase
     static const bool phases = getenv("G1S_F_PHASES") != nullptr;
     static long long *d_phase = nullptr;
@@ -1084,7 +1089,7 @@ int g1s_diff::launch_back(int si) {
 #undef G1S_FS
 #undef G1S_F
     kmark(sl, stream, "k3m_finish");
-    if (!dbg_skip("finish")) hipLaunchKernelGGL(k3m_finish, dim3(g.nplanes + (planes ? 0 : kMFinishWgs), B), dim3(256), 0, stream, g, mp, G,
+    if (!dbg_skip("finish")) hipLaunchKernelGGL(k3m_finish, dim3(kMFinishParts * g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G,
                        planes ? (const int32_t *)nullptr : (const int32_t *)fq.ustats, sl.d_records);
     if (fq.phase_cycles) {
       std::vector<long long> hc((size_t)G * B * kFWaves * 6);

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,7 +40,7 @@ struct EstParams {
   const EstFrame *frames;
   unsigned long long *sums;  // [frames][2]: accum, count
   int W, H, bps, shift;
-  int col_strips, row_strips;
+  int col_strips, row_strips, strip_rows;
 };
 
 // the 8 samples of a word, widened; outside the plane: zeros (never used by an output pixel that counts)
@@ -146,6 +147,214 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_estimate(EstParams ep) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// k_estimate_pk: the same sums in packed 16-bit arithmetic, for depths 8 .. 12 (every intermediate fits 16 bits:
+// |Gx|, |Gy| <= 4 * 4095, their sum + rounding <= 32768 as u16, |Laplacian| <= 8 * 4095).  Only the simplest
+// 32-bit VALU operations issue at two cycles a wave on gfx950 (v_sub, v_and, shifts); everything else -- v_max,
+// three-operand forms, every v_pk_* -- takes four (tools/valu_rate.hip), so a packed operation is two pixels
+// for the price of one.  Both stencils are separable and the horizontal parts are carried down the strip:
+//   per input row    H = l - r,  S = l + 2 c + r,  T = l - 2 c + r        (l, r: the row shifted by one sample)
+//   per output row   Gx = H0 + 2 H1 + H2,  Gy = S0 - S2,  Laplacian = T0 - 2 T1 + T2
+// 27 packed operations per pixel pair and row instead of ~34 scalar ones per pixel.  The smooth-pixel mask is
+// a 0/1 per half (sign bit of ga - 50), the masked sum is one v_dot2_u32_u16.  Exact integers: same sums as
+// k_estimate (compared on every test case).  A lane holds one 8-sample word (4 dwords) of the row; the sample
+// left / right of the word comes from the neighbouring lane (DPP wave shifts).
+// ---------------------------------------------------------------------------------
+// (global address space: a pointer read from memory is `flat` to the compiler otherwise, and flat loads wait on the LDS counter too)
+#define EST_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t est_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t est_u32x4 __attribute__((ext_vector_type(4)));
+typedef const EST_GLOBAL uint8_t *est_gptr;
+__device__ __forceinline__ est_gptr est_global(const uint8_t *p) { return (est_gptr)(uintptr_t)p; }
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ i16x2 as_i(uint32_t v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ uint32_t bits(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t bits(i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_abs(uint32_t v) {
+  const i16x2 a = as_i(v), z = {0, 0};
+  return bits(__builtin_elementwise_max(a, (i16x2)(z - a)));
+}
+
+// a * k + c per 16-bit half, k an inline constant (one instruction where the compiler writes a shift and an add)
+__device__ __forceinline__ uint32_t pk_mad2(uint32_t a, uint32_t c) {
+  uint32_t r;
+  asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_madm2(uint32_t a, uint32_t c) {
+  uint32_t r;
+  asm("v_pk_mad_i16 %0, %1, -2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c));
+  return r;
+}
+
+struct EstRow {
+  uint32_t H[4], S[4], T[4];
+};
+
+// the lane's word of row y as 4 dwords of packed 16-bit samples (zeros outside the plane)
+template <int BPS>
+__device__ __forceinline__ void est_load_pk(const EstFrame &fr, int y, int x0, int W, int H, bool fast, uint32_t (&w)[4]) {
+  w[0] = w[1] = w[2] = w[3] = 0u;
+  if (y < 0 || y >= H || x0 >= W || x0 + 8 <= 0) return;
+  est_gptr row = est_global(fr.y) + (size_t)y * fr.stride;
+  if (fast && x0 >= 0 && x0 + 8 <= W) {
+    if (BPS == 2) {
+      const est_u32x4 v = *(const EST_GLOBAL est_u32x4 *)(row + (size_t)x0 * 2);
+      w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    } else {
+      const est_u32x2 v = *(const EST_GLOBAL est_u32x2 *)(row + x0);
+      w[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u);
+      w[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
+      w[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u);
+      w[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {  // unaligned planes, words over an edge of the plane
+    const int x = x0 + k;
+    if (x >= 0 && x < W) {
+      const uint32_t v = BPS == 2 ? (uint32_t)((const EST_GLOBAL uint16_t *)row)[x] : (uint32_t)row[x];
+      w[k >> 1] |= v << (16 * (k & 1));
+    }
+  }
+}
+
+__device__ __forceinline__ void est_derive(const uint32_t (&c)[4], EstRow &r) {
+  const uint32_t prev = (uint32_t)__builtin_amdgcn_mov_dpp((int)c[3], 0x138, 0xf, 0xf, true);  // wave_shr:1: lane - 1's last dword
+  const uint32_t next = (uint32_t)__builtin_amdgcn_mov_dpp((int)c[0], 0x130, 0xf, 0xf, true);  // wave_shl:1: lane + 1's first
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t P = q ? c[q - 1] : prev, N = q < 3 ? c[q + 1] : next;
+    const uint32_t l = __builtin_amdgcn_alignbyte(c[q], P, 2), rr = __builtin_amdgcn_alignbyte(N, c[q], 2);
+    const uint32_t lr = bits((u16x2)(as_u(l) + as_u(rr)));
+    r.H[q] = bits((u16x2)(as_u(l) - as_u(rr)));
+    r.S[q] = pk_mad2(c[q], lr);
+    r.T[q] = pk_madm2(c[q], lr);
+  }
+}
+
+// Output rows per wave strip: chosen by the host so that the launch is a whole number of resident rounds (8 waves a SIMD:
+// 8192 waves on the chip): with 64-row strips a 32-frame 4K launch was 8704 waves -- 1.06 rounds, the last 6 % of the waves
+// alone on the chip for as long as the first 94 % took.
+constexpr int kPkMaxStripRows = 256;  // (the two 16-bit pixel counters of a lane hold 4 * rows each)
+
+// the fast form: the lane's word lies inside the plane's rows or wholly outside (then any in-plane word will do: every
+// pixel it could reach is masked), the rows are 16-byte (8-byte) aligned: one unconditional vector load, nothing to wait for
+// at the load -- the request for row y + 2 is in flight while row y is worked on
+template <int BPS>
+__device__ __forceinline__ void est_load_fast(est_gptr base, uint32_t stride, int y, uint32_t xoff, uint32_t (&w)[4]) {
+  est_gptr p = base + (size_t)y * stride + xoff;
+  if (BPS == 2) {
+    const est_u32x4 v = *(const EST_GLOBAL est_u32x4 *)p;
+    w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+  } else {
+    const est_u32x2 v = *(const EST_GLOBAL est_u32x2 *)p;
+    w[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u);
+    w[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
+    w[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u);
+    w[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
+  }
+}
+
+template <int BPS, bool FAST>
+__device__ __forceinline__ void est_strip(const EstFrame &fr, int W, int H, int shift, int x0, int y_first, int y_last, int lane,
+                                          uint32_t &accum, uint32_t &count) {
+  const uint32_t halfpk = shift ? 0x00010001u << (shift - 1) : 0u;
+  // smooth: (|Gx| + |Gy| + half) >> shift < 50  <=>  |Gx| + |Gy| < (50 << shift) - half
+  const uint32_t thrpk = 0x00010001u * (uint32_t)((kEdgeThreshold << shift) - (shift ? 1 << (shift - 1) : 0));
+  const u16x2 sh = {(unsigned short)shift, (unsigned short)shift};
+  // output columns of this lane: 1 <= x < W - 1, lanes 1 .. 62 (lanes 0 and 63 carry the halo columns)
+  uint32_t cm[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int x = x0 + 2 * q;
+    const bool ok = lane >= 1 && lane <= 62;
+    cm[q] = (ok && x >= 1 && x < W - 1 ? 1u : 0u) | (ok && x + 1 >= 1 && x + 1 < W - 1 ? 0x10000u : 0u);
+  }
+  // (rows are wave-uniform: the row address is scalar arithmetic, the lane adds its column offset)
+  const est_gptr base = est_global(fr.y);
+  const uint32_t xoff = (uint32_t)(min(max(x0, 0), max(W - 8, 0)) * BPS);  // (FAST: W is a multiple of 8, >= 8)
+  auto load = [&](int y, uint32_t (&w)[4]) __attribute__((always_inline)) {
+    if (FAST) est_load_fast<BPS>(base, fr.stride, min(y, H - 1), xoff, w);
+    else est_load_pk<BPS>(fr, y, x0, W, H, false, w);
+  };
+  uint32_t cnt = 0;
+  const u16x2 fifteen = {15, 15};
+  auto output = [&](const EstRow &a, const EstRow &b, const EstRow &c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t gx = pk_mad2(b.H[q], bits((i16x2)(as_i(a.H[q]) + as_i(c.H[q]))));
+      const uint32_t gy = bits((i16x2)(as_i(a.S[q]) - as_i(c.S[q])));
+      const u16x2 g = as_u(pk_abs(gx)) + as_u(pk_abs(gy));  // <= 32760
+      const uint32_t on = bits((u16x2)((u16x2)(g - as_u(thrpk)) >> fifteen)) & cm[q];
+      const uint32_t v = pk_madm2(b.T[q], bits((i16x2)(as_i(a.T[q]) + as_i(c.T[q]))));
+      const u16x2 lv = (u16x2)(as_u(pk_abs(v)) + as_u(halfpk)) >> sh;
+      accum = __builtin_amdgcn_udot2(lv, as_u(on), accum, false);
+      cnt += on;  // (two 16-bit counters: at most 4 * kPkMaxStripRows each)
+    }
+  };
+  uint32_t w0[4], w1[4], w2[4];
+  EstRow r0, r1, r2;
+  load(y_first - 1, w0);
+  est_derive(w0, r0);
+  load(y_first, w0);
+  est_derive(w0, r1);
+  load(y_first + 1, w0);
+  load(y_first + 2, w1);
+  // three output rows a turn: the rows rotate through the names, not through registers; loads two rows ahead of their use
+  // (the rows past the strip's last are requested and dropped)
+  int y = y_first;
+  for (; y + 3 <= y_last; y += 3) {
+    load(y + 3, w2);
+    est_derive(w0, r2);
+    output(r0, r1, r2);
+    load(y + 4, w0);
+    est_derive(w1, r0);
+    output(r1, r2, r0);
+    load(y + 5, w1);
+    est_derive(w2, r1);
+    output(r2, r0, r1);
+  }
+  if (y < y_last) {
+    est_derive(w0, r2);
+    output(r0, r1, r2);
+    if (y + 1 < y_last) {
+      est_derive(w1, r0);
+      output(r1, r2, r0);
+    }
+  }
+  count = (cnt & 0xffffu) + (cnt >> 16);
+}
+
+template <int BPS>
+__global__ __launch_bounds__(64 * kWavesPerWg) void k_estimate_pk(EstParams ep) {
+  const int frame = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int strip = blockIdx.x * kWavesPerWg + wave;
+  if (strip >= ep.col_strips * ep.row_strips) return;
+  // (column strips are the fast index: the waves of a workgroup read adjacent kilobytes of the same rows)
+  const int cs = strip % ep.col_strips, rs = strip / ep.col_strips;
+  const EstFrame fr = ep.frames[frame];
+  const int W = ep.W, H = ep.H;
+  const bool fast = (((uintptr_t)fr.y | fr.stride) & (BPS == 2 ? 15 : 7)) == 0 && (W & 7) == 0;  // (uniform)
+  const int x0 = cs * kColsPerWave - 8 + 8 * lane;
+  const int y_first = 1 + rs * ep.strip_rows, y_last = min(y_first + ep.strip_rows, H - 1);  // output rows [y_first, y_last)
+  uint32_t accum = 0, count = 0;
+  if (fast) est_strip<BPS, true>(fr, W, H, ep.shift, x0, y_first, y_last, lane, accum, count);
+  else est_strip<BPS, false>(fr, W, H, ep.shift, x0, y_first, y_last, lane, accum, count);
+  for (int o = 32; o; o >>= 1) {
+    accum += __shfl_down(accum, o);
+    count += __shfl_down(count, o);
+  }
+  if (lane == 0 && (accum | count)) {
+    atomicAdd(&ep.sums[2 * frame], (unsigned long long)accum);
+    atomicAdd(&ep.sums[2 * frame + 1], (unsigned long long)count);
+  }
+}
+
 constexpr double kSqrtPiBy2 = 1.2533141373155003;  // SQRT_PI_BY_2
 
 }  // namespace
@@ -193,12 +402,34 @@ int g1s_estimate::flush() {
   ep.H = (int)H;
   ep.bps = (int)bps;
   ep.shift = (int)bit_depth - 8;
+  // depths up to 12 bits: the packed 16-bit kernel; deeper samples (or G1S_ESTIMATE=wide, a test aid): 32-bit arithmetic
+  const char *mode = getenv("G1S_ESTIMATE");
+  const bool packed = bit_depth <= 12 && !(mode && std::strcmp(mode, "wide") == 0);
   ep.col_strips = ((int)W - 1 + kColsPerWave - 1) / kColsPerWave;
-  ep.row_strips = ((int)H - 2 + kStripRows - 1) / kStripRows;
+  int strip_rows = kStripRows;
+  if (packed && H >= 3) {
+    // whole resident rounds: k rounds of `resident` waves, the smallest k whose strips are at most kPkMaxStripRows rows
+    int cus = 256, wgs_per_cu = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (bps == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, k_estimate_pk<2>, 64 * kWavesPerWg, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, k_estimate_pk<1>, 64 * kWavesPerWg, 0);
+    if (wgs_per_cu < 1) wgs_per_cu = 5;
+    const long resident = (long)cus * wgs_per_cu * kWavesPerWg, cols = (long)ep.col_strips * B, rows = (long)H - 2;
+    for (long k = 1;; ++k) {
+      const long rs = std::max(1L, k * resident / cols);  // row strips a frame
+      strip_rows = (int)((rows + rs - 1) / rs);
+      if (strip_rows <= kPkMaxStripRows) break;
+    }
+    strip_rows = std::max(strip_rows, 8);
+  }
+  ep.strip_rows = strip_rows;
+  ep.row_strips = ((int)H - 2 + strip_rows - 1) / strip_rows;
   if (W >= 3 && H >= 3) {
     const dim3 grid((ep.col_strips * ep.row_strips + kWavesPerWg - 1) / kWavesPerWg, B);
     if (timing) EST_TRY(hipEventRecord(ev0, stream));
-    if (bps == 2) hipLaunchKernelGGL(k_estimate<2>, grid, dim3(64 * kWavesPerWg), 0, stream, ep);
+    if (packed && bps == 2) hipLaunchKernelGGL(k_estimate_pk<2>, grid, dim3(64 * kWavesPerWg), 0, stream, ep);
+    else if (packed) hipLaunchKernelGGL(k_estimate_pk<1>, grid, dim3(64 * kWavesPerWg), 0, stream, ep);
+    else if (bps == 2) hipLaunchKernelGGL(k_estimate<2>, grid, dim3(64 * kWavesPerWg), 0, stream, ep);
     else hipLaunchKernelGGL(k_estimate<1>, grid, dim3(64 * kWavesPerWg), 0, stream, ep);
     if (timing) EST_TRY(hipEventRecord(ev1, stream));
   }

@@ -313,76 +313,80 @@ __device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const ui
 
 // ---------------------------------------------------------------------------------
 // k3m_finish: what the accumulation workgroups left behind -> the frame's record.
-//   x < nplanes:  the G partial systems of plane x, summed, + nobs of the blocks that were multiplied;
-//   x >= nplanes: the per-unit statistics records (kMStatInts ints a unit: per block sum d, sum d^2, sum src8 of
+//   x < 3 * nplanes:  a third (256 entries) of the G partial systems of plane x / 3, summed;
+//   x >= 3 * nplanes: the per-unit statistics records (kMStatInts ints a unit: per block sum d, sum d^2, sum src8 of
 //                 luma, sum d, sum d^2 of Cb and Cr; then the deferral bits kind * 2 + block of the luma and of the
-//                 chroma launch) -> block statistics
-//                 of the flat blocks, `only` flags of the deferred ones.
-// grid = (nplanes + kMFinishWgs, batch), block = 256.
+//                 chroma launch) -> block statistics of the flat blocks, `only` flags of the deferred ones; and nobs of
+//                 the blocks that were multiplied (one atomic per workgroup and plane).
+// grid = (3 * nplanes + kMFinishWgs, batch), block = 256.  Every thread has at most one entry / one unit: the kernel is a
+// few dependent loads deep (it was 55 us as 7 workgroups a frame that looped).
 // ---------------------------------------------------------------------------------
-constexpr int kMStatInts = 16, kMFinishWgs = 4;
+constexpr int kMStatInts = 16, kMFinishWgs = 12, kMFinishParts = 3;
+static_assert(kMFinishParts * 256 >= 26 * 26 + 26, "k3m_finish: one entry per thread");
 // ustats == nullptr: a pixel pass took the statistics and the deferrals (K0 + k3m_units): only the systems and nobs.
 __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, const int32_t *__restrict__ ustats,
                                                   uint8_t *__restrict__ records) {
   const int frame = g.frame0 + (int)blockIdx.y;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
+  if ((int)blockIdx.x < kMFinishParts * g.nplanes) {
+    const int c = (int)blockIdx.x / kMFinishParts, nc = g.n + (c > 0);
+    const int k = ((int)blockIdx.x - c * kMFinishParts) * 256 + (int)threadIdx.x;
+    if (k >= nc * nc + nc) return;
+    long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
+    const long long *p = mp.partials + (size_t)frame * G * 3 * kMRec + (size_t)c * kMRec + k;
+    long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int w = 0;
+    for (; w + 4 <= G; w += 4) {  // (independent loads in flight)
+      s0 += p[(size_t)(w + 0) * 3 * kMRec];
+      s1 += p[(size_t)(w + 1) * 3 * kMRec];
+      s2 += p[(size_t)(w + 2) * 3 * kMRec];
+      s3 += p[(size_t)(w + 3) * 3 * kMRec];
+    }
+    for (; w < G; ++w) s0 += p[(size_t)w * 3 * kMRec];
+    ar[k] += (s0 + s1) + (s2 + s3);
+    return;
+  }
   const uint32_t cnt_g = mp.unit_count[2 * frame], cnt = cnt_g + mp.unit_count[2 * frame + 1];
   // list position of the v-th unit of the frame: the general ones from the front, the plain ones from the back
   auto upos = [&](uint32_t v) { return v < cnt_g ? v : (uint32_t)mp.nunits - 1u - (v - cnt_g); };
   const uint32_t *units = mp.units + (size_t)frame * mp.nunits * kMUnitDwords;
   const int32_t *us = ustats + (size_t)frame * mp.nunits * kMStatInts;
-  if ((int)blockIdx.x < g.nplanes) {
-    const int c = blockIdx.x, nc = g.n + (c > 0);
-    long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
-    const long long *p = mp.partials + (size_t)frame * G * 3 * kMRec + (size_t)c * kMRec;
-    for (int k = threadIdx.x; k < nc * nc + nc; k += 256) {
-      long long s = 0;
-      for (int w = 0; w < G; ++w) s += p[(size_t)w * 3 * kMRec + k];
-      ar[k] += s;
-    }
-    // observations: the windows of the blocks that were multiplied (go and not deferred)
-    __shared__ long long s_n[4];
-    long long n = 0;
-    for (uint32_t v = threadIdx.x; v < cnt; v += 256) {
-      const uint32_t u = upos(v);
-      const uint32_t wz = units[(size_t)u * kMUnitDwords + (c > 0 ? 2 : 1)];
-      const uint32_t defer = !ustats ? 0u
-                                     : ((uint32_t)us[(size_t)u * kMStatInts + 14] | (g.nplanes == 3 ? (uint32_t)us[(size_t)u * kMStatInts + 15] : 0u)) >>
-                                           (c > 0 ? kMUnitBlocks : 0);
-#pragma unroll
-      for (int b = 0; b < kMUnitBlocks; ++b) {
-        const MWin w = m_unpack((wz >> (16 * b)) & 0xffffu, g.lag);
-        if (w.go && !((defer >> b) & 1u)) n += (long long)(w.xe - w.xs) * (w.ye - w.ys);
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-    if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) ar[nc * nc + nc] += s_n[0] + s_n[1] + s_n[2] + s_n[3];
-    return;
-  }
-  if (!ustats) return;
-  const int part = (int)blockIdx.x - g.nplanes;
+  const int part = (int)blockIdx.x - kMFinishParts * g.nplanes;
   const bool chroma = g.nplanes == 3;
+  long long n_y = 0, n_c = 0;  // observations: the windows of the blocks that were multiplied (go and not deferred)
   for (uint32_t v = part * 256 + threadIdx.x; v < cnt; v += kMFinishWgs * 256) {
     const uint32_t u = upos(v);
-    const uint32_t e0 = units[(size_t)u * kMUnitDwords];
+    const uint4 e = *reinterpret_cast<const uint4 *>(units + (size_t)u * kMUnitDwords);
+    const uint32_t e0 = e.x;
     const int bx0 = kMUnitBlocks * (int)(e0 & 0xfffu), by = (int)((e0 >> 12) & 0xfffu);
     const int32_t *r = us + (size_t)u * kMStatInts;
-    const uint32_t defer = (uint32_t)r[14] | (chroma ? (uint32_t)r[15] : 0u);  // (the luma and the chroma launch)
+    int32_t rv[kMStatInts];
+    if (ustats) {
+#pragma unroll
+      for (int q = 0; q < kMStatInts / 4; ++q) {
+        const int4 t = *reinterpret_cast<const int4 *>(r + 4 * q);
+        rv[4 * q] = t.x, rv[4 * q + 1] = t.y, rv[4 * q + 2] = t.z, rv[4 * q + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kMStatInts; ++q) rv[q] = 0;
+    }
+    const uint32_t defer = (uint32_t)rv[14] | (chroma ? (uint32_t)rv[15] : 0u);  // (the luma and the chroma launch)
 #pragma unroll
     for (int b = 0; b < kMUnitBlocks; ++b) {
-      if (!((e0 >> (24 + b)) & 1u)) continue;
+      const MWin wy = m_unpack((e.y >> (16 * b)) & 0xffffu, g.lag), wc = m_unpack((e.z >> (16 * b)) & 0xffffu, g.lag);
+      if (wy.go && !((defer >> b) & 1u)) n_y += (long long)(wy.xe - wy.xs) * (wy.ye - wy.ys);
+      if (wc.go && !((defer >> (kMUnitBlocks + b)) & 1u)) n_c += (long long)(wc.xe - wc.xs) * (wc.ye - wc.ys);
+      if (!ustats || !((e0 >> (24 + b)) & 1u)) continue;
       const int blk = by * g.nbw + bx0 + b;
-      reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = r[7 * b + 0];
-      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)r[7 * b + 1];
-      reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)r[7 * b + 2];
+      reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = rv[7 * b + 0];
+      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)rv[7 * b + 1];
+      reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)rv[7 * b + 2];
       if (chroma) {
-        reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = r[7 * b + 3];
-        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)r[7 * b + 4];
-        reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = r[7 * b + 5];
-        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)r[7 * b + 6];
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = rv[7 * b + 3];
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)rv[7 * b + 4];
+        reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = rv[7 * b + 5];
+        reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)rv[7 * b + 6];
       }
 #pragma unroll
       for (int kind = 0; kind < 2; ++kind)
@@ -391,6 +395,22 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
           mp.only_any[frame] = 1u;
         }
     }
+  }
+  __shared__ long long s_n[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n_y += __shfl_xor(n_y, o, 64);
+    n_c += __shfl_xor(n_c, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_n[0][threadIdx.x >> 6] = n_y;
+    s_n[1][threadIdx.x >> 6] = n_c;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < g.nplanes) {
+    const int c = threadIdx.x, nc = g.n + (c > 0);
+    const long long n = c ? s_n[1][0] + s_n[1][1] + s_n[1][2] + s_n[1][3] : s_n[0][0] + s_n[0][1] + s_n[0][2] + s_n[0][3];
+    if (n) atomicAdd(reinterpret_cast<unsigned long long *>(rec + g.off_ar[c]) + (nc * nc + nc), (unsigned long long)n);
   }
 }
 

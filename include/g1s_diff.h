@@ -98,8 +98,8 @@ typedef struct {
   int32_t device;         /* HIP device ordinal; -1 = current device */
   uint32_t ar_coeff_lag;  /* 1..3; 0 = default (3, the reference's NOISE_MODEL_LAG) */
   uint32_t luma_only;     /* 1 = skip chroma planes (extension; reference: 0) */
-  uint32_t batch_frames;  /* frames per kernel batch (<= 256); 0 = default: about 265 Mpixels' worth
-                             (32 at 4K, 128 at 1080p) */
+  uint32_t batch_frames;  /* frames per kernel batch (<= 256); 0 = default: about 530 Mpixels' worth
+                             (64 at 4K, 128 at 1080p) */
   uint32_t records_only;  /* frame-shard mode: do not fold here (the ordered fold runs
                              after the exchange, see g1s_fold_*).
                              0 = fold locally (single GPU);

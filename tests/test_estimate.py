@@ -91,6 +91,38 @@ GPU_CASES = [
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bd", [8, 10, 12, 14, 16])
+def test_hip_estimator_at_the_extremes_of_the_sample_range(bd, monkeypatch):
+    """Full-range content: the packed 16-bit kernel (depths <= 12) holds |Gx| + |Gy| + rounding <= 32768 and |Laplacian| <= 8 * 4095
+    in 16 bits; deeper samples take the 32-bit kernel.  Uniform noise over the whole range, a 0 / max checkerboard, isolated
+    max samples on zero, a field one step under the edge threshold -- against the oracle, and packed against 32-bit."""
+    import torch
+
+    from grav1synth_amd.estimate import NoiseEstimator
+
+    rng = np.random.default_rng(bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    mx = (1 << bd) - 1
+    H, W = 70, 504
+    planes = [rng.integers(0, mx + 1, (H, W)).astype(dt),
+              ((np.indices((H, W)).sum(0) & 1) * mx).astype(dt),
+              (rng.random((H, W)) < 0.02).astype(dt) * dt(mx),
+              (rng.integers(0, 2, (H, W)) * (5 << (bd - 8))).astype(dt),
+              np.full((H, W), mx, dt)]
+    want = [estimate_plane_noise(p, bd) for p in planes]
+    for mode in ("", "wide"):
+        if mode:
+            monkeypatch.setenv("G1S_ESTIMATE", mode)
+        est = NoiseEstimator(bd, batch_frames=8)
+        keep = [torch.from_numpy(p).cuda() for p in planes]
+        for t in keep:
+            est.estimate_frame(t)
+        got = est.finish()
+        est.close()
+        assert got == want, mode
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("spec,where", GPU_CASES, ids=lambda x: x if isinstance(x, str) else f"{x.width}x{x.height}_{x.bit_depth}b")
 def test_hip_estimates_equal_the_oracle(spec, where):
     import torch

@@ -35,6 +35,25 @@ __global__ __launch_bounds__(256) void rate(int *out, int a0, int b0) {
       if (OP == 11) acc[i] = __builtin_amdgcn_alignbit(a, acc[i], 8);
       if (OP == 12) acc[i] = (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)(b + i), (unsigned)acc[i]);
       if (OP == 13) acc[i] = (acc[i] >> 8) | (a << 24);
+      if (OP == 14) asm volatile("v_pk_add_u16 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+      if (OP == 15) asm volatile("v_pk_sub_i16 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+      if (OP == 16) asm volatile("v_pk_max_i16 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+      if (OP == 17) asm volatile("v_pk_mad_u16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+      if (OP == 18) asm volatile("v_pk_lshrrev_b16 %0, 3, %0" : "+v"(acc[i]));
+      if (OP == 19) asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+      if (OP == 20) asm volatile("v_sad_u16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+      if (OP == 21) asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+      if (OP == 22) asm volatile("v_lshl_add_u32 %0, %1, 1, %0" : "+v"(acc[i]) : "v"(a));
+      if (OP == 23) asm volatile("v_max_i32 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+      if (OP == 24) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+      if (OP == 25) asm volatile("v_pk_mul_lo_u16 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+      if (OP == 26) asm volatile("v_and_b32 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+      if (OP == 27) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(acc[i]));
+      if (OP == 28) asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(acc[i]));
+      if (OP == 29) asm volatile("v_sad_u32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+      if (OP == 30) asm volatile("v_cmp_lt_i32 vcc, %1, %0\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc[i]) : "v"(a) : "vcc");
+      if (OP == 31) asm volatile("v_pk_add_i16 %0, %1, %0 neg_lo:[1,0] neg_hi:[1,0]" : "+v"(acc[i]) : "v"(a));
+      if (OP == 32) asm volatile("v_pk_ashrrev_i16 %0, 15, %0" : "+v"(acc[i]));
     }
     a += it;
   }
@@ -78,5 +97,24 @@ int main() {
   run<11>("v_alignbit_b32", 0);
   run<12>("v_sad_u8", 0);
   run<13>("v_lshr+v_lshl_or (2)", 0);
+  run<14>("v_pk_add_u16", 0);
+  run<15>("v_pk_sub_i16", 0);
+  run<16>("v_pk_max_i16", 0);
+  run<17>("v_pk_mad_u16", 0);
+  run<18>("v_pk_lshrrev_b16", 0);
+  run<19>("v_dot2_u32_u16", 2);
+  run<20>("v_sad_u16", 0);
+  run<21>("v_add3_u32", 0);
+  run<22>("v_lshl_add_u32", 0);
+  run<23>("v_max_i32", 0);
+  run<24>("v_sub_u32", 0);
+  run<25>("v_pk_mul_lo_u16", 0);
+  run<26>("v_and_b32", 0);
+  run<27>("v_lshrrev_b32", 0);
+  run<28>("v_bfe_u32", 0);
+  run<29>("v_sad_u32", 0);
+  run<30>("v_cmp+v_addc (2)", 0);
+  run<31>("v_pk_add_i16 neg", 0);
+  run<32>("v_pk_ashrrev_i16", 0);
   return 0;
 }
