@@ -1023,12 +1023,14 @@ int g1s_diff::launch_back(int si) {
     int G = m_wgs_per_frame(m_nunits, (int)B);
     if ((size_t)G * B > m_wg_cap) G = m_wgs_per_frame(m_nunits, 1 << 20);  // (G1S_F_WGS raised after the slots were sized: the fewest that hold the units)
     // profiling aid: G1S_F_PHASES=1 prints, per batch, the cycles the accumulation waves spent in each phase
-    static const bool phases = getenv("G1S_F_PHASES") != nullptr;
+    // (G1S_F_PHASES=1: the luma launch, 2: the chroma launch)
+    static const int phases = getenv("G1S_F_PHASES") ? atoi(getenv("G1S_F_PHASES")) : 0;
     static long long *d_phase = nullptr;
     fq.phase_cycles = nullptr;
+    long long *phase_buf = nullptr;
     if (phases) {
-      if (!d_phase) (void)hipMalloc((void **)&d_phase, sizeof(long long) * 6 * kFWaves * 4096);
-      if ((size_t)G * B <= 4096) fq.phase_cycles = d_phase;
+      if (!d_phase) (void)hipMalloc((void **)&d_phase, sizeof(long long) * 8 * kFWaves * 4096);
+      if ((size_t)G * B <= 4096) phase_buf = d_phase;
     }
     const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = g.nplanes == 3 ? (kBlock >> g.ydec) : 0;
     fq.lplane = sl.d_lplane;
@@ -1059,6 +1061,7 @@ int g1s_diff::launch_back(int si) {
     char kn_[64];                                                                                                    \
     snprintf(kn_, sizeof(kn_), "k3f_fused<%d, %d, %d, %d, %d>", CW, CH, planes ? 1 : BP, PL, planes ? 1 : 0);        \
     kmark(sl, stream, kn_);                                                                                          \
+    fq.phase_cycles = phases == PL + 1 ? phase_buf : nullptr;                                                        \
     if (planes) hipLaunchKernelGGL((k3f_fused<CW, CH, 1, PL, 1>), gr, dim3(kFThreads), lds, stream, g, fq);          \
     else hipLaunchKernelGGL((k3f_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);                   \
   } while (0)
@@ -1091,17 +1094,18 @@ int g1s_diff::launch_back(int si) {
     kmark(sl, stream, "k3m_finish");
     if (!dbg_skip("finish")) hipLaunchKernelGGL(k3m_finish, dim3(kMFinishParts * g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G,
                        planes ? (const int32_t *)nullptr : (const int32_t *)fq.ustats, sl.d_records);
-    if (fq.phase_cycles) {
-      std::vector<long long> hc((size_t)G * B * kFWaves * 6);
+    if (phase_buf) {
+      std::vector<long long> hc((size_t)G * B * kFWaves * 8);
       (void)hipStreamSynchronize(stream);
       (void)hipMemcpy(hc.data(), d_phase, hc.size() * sizeof(long long), hipMemcpyDeviceToHost);
-      double tot[kFWaves][6] = {};
+      double tot[kFWaves][8] = {};
       for (size_t w = 0; w < (size_t)G * B; ++w)
         for (int v = 0; v < kFWaves; ++v)
-          for (int k = 0; k < 6; ++k) tot[v][k] += (double)hc[(w * kFWaves + v) * 6 + k];
+          for (int k = 0; k < 8; ++k) tot[v][k] += (double)hc[(w * kFWaves + v) * 8 + k];
       for (int v = 0; v < kFWaves; ++v)
-        fprintf(stderr, "k3f phases, wave %d: copies %.0f  barrier %.0f  multiply %.0f  requests + barrier %.0f  wait for words %.0f  residuals %.0f  (mean cycles per workgroup)\n",
-                v, tot[v][0] / (G * B), tot[v][1] / (G * B), tot[v][2] / (G * B), tot[v][3] / (G * B), tot[v][4] / (G * B), tot[v][5] / (G * B));
+        fprintf(stderr, "k3f phases (%s launch), wave %d: copies %.0f  barrier 2 %.0f  multiply %.0f  wait for words %.0f  residuals %.0f  requests %.0f  stores %.0f  barrier 1 %.0f  (mean cycles per workgroup)\n",
+                phases == 1 ? "luma" : "chroma", v, tot[v][0] / (G * B), tot[v][1] / (G * B), tot[v][2] / (G * B), tot[v][4] / (G * B), tot[v][5] / (G * B), tot[v][6] / (G * B),
+                tot[v][7] / (G * B), tot[v][3] / (G * B));
     }
     kmark(sl, stream, "k3_ar_generic");
     if (!dbg_skip("generic"))

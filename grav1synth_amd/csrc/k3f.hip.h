@@ -53,7 +53,7 @@ struct FParams {
   int deal;               // units to workgroups: 0 round-robin, 1 contiguous runs
   const uint8_t *planes;  // SRC = 1: the int8 planes of the pixel pass K0 (k0.hip.h), [batch] x ps.frame_bytes
   PlaneSet ps;
-  long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][6] cycles: tile copies, barrier, multiply, barrier, wait for the words, residuals + requests; or null
+  long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][8] cycles: tile copies, barrier 2, multiply, barrier 1, wait for the words, residuals, requests, stores; or null
 };
 
 // BPS: bytes per sample known at compile time (1, 2), or 0: given at run time (mixed depths)
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   //   sum d^2 << 37 | sum src8 << 19 | sum (d + bias): every contributing lane adds its bias, their number is fixed
   __shared__ unsigned long long s_sum[2][3][kMUnitBlocks];
   __shared__ int s_bad[2][2][kMUnitBlocks];  // [unit parity][kind][block]
+  __shared__ int s_ring[4][kMStatInts];      // statistics records on their way out (wave 3)
 
   // Workgroup b of the 1-D grid runs on XCD b % 8, and workgroups b, b + 256, ... share a CU (observed; speed only).  With
   // frame = b % frames (frames a multiple of 8, or few), the workgroups on a CU work on ONE frame -- few distinct pages under
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   };
 
 #ifdef G1S_F_PHASES
-  long long t_ph[6] = {0, 0, 0, 0, 0, 0}, t_last = fpar.phase_cycles ? clock64() : 0;
+  long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = fpar.phase_cycles ? clock64() : 0;
   auto stamp = [&](int ph) {
     if (fpar.phase_cycles) {
       const long long t = clock64();
@@ -661,17 +662,23 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 #ifndef G1S_DBG_NOREQ
         if (k + 2 < nmine) request(k + 2);
 #endif
+        stamp(6);
         export_l(k + 1);
       }
-      // ---- the unit's statistics record (k3m_finish scatters it): this launch's entries; behind the request, like the L words ----
-      if (RAW && tid < kMStatInts) {
+      // ---- the unit's statistics record (k3m_finish scatters it): this launch's entries.  A global store costs the wave
+      // that issues it a few hundred cycles at the memory pipe's door, and the slowest wave sets the workgroup's pace: the
+      // records go through a four-unit ring in LDS and leave four at a time, from wave 3 (which stages no luma rows) ----
+      if (RAW && wave == kFWaves - 1) {
         // entry 7 b + {0: luma sum d, 1: sum d^2, 2: sum src8, 3 / 4: Cb sum d / sum d^2, 5 / 6: Cr}; 14 / 15: the deferral
         // bits of the luma / chroma launch
-        const int b = tid >= 7 ? 1 : 0, e = tid - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
-        const bool mine = tid < 14 ? (LUMA ? c == 0 : c != 0) : tid == 14 + PL;
-        if (mine) {
+        auto mine_entry = [](int t) {
+          const int b = t >= 7 ? 1 : 0, e = t - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2);
+          return t < 14 ? (LUMA ? c == 0 : c != 0) : t == 14 + PL;
+        };
+        if (lane < kMStatInts && mine_entry(lane)) {
+          const int b = lane >= 7 ? 1 : 0, e = lane - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
           int val = (int)defer;
-          if (tid < 14) {
+          if (lane < 14) {
             const unsigned long long pk = s_sum[par][c][b];
             // contributing lanes per block: luma 16 row pairs x 4 words, chroma CBH rows x CBW / 8 words
             const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
@@ -679,18 +686,22 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
             else if (f == 2) val = (int)((pk >> 19) & 0x3ffffu);
             else val = (int)(c == 0 ? (pk & 0x7ffffu) : (pk & 0x1fffffffffull)) - bias;
           }
-          ustats[(size_t)upos(k) * kMStatInts + tid] = val;
+          s_ring[k & 3][lane] = val;
+        }
+        if ((k & 3) == 3 || k == nmine - 1) {  // (the wave's own LDS writes above are ordered before these reads)
+          const int first = k & ~3, u = lane >> 4, e = lane & 15;
+          if (first + u <= k && mine_entry(e)) ustats[(size_t)upos(first + u) * kMStatInts + e] = s_ring[u][e];
         }
       }
-      stamp(3);  // (with G1S_F_PHASES: slot 3 = the requests, the stores, the wait at barrier 1)
+      stamp(7);  // (with G1S_F_PHASES: slot 6 = the requests, 7 = the stores, 3 = the wait at barrier 1)
     }
   };
   run(std::true_type{}, 0, n_p);
   run(std::false_type{}, n_p, nmine);
 #ifdef G1S_F_PHASES
   if (fpar.phase_cycles && lane == 0) {
-    long long *o = fpar.phase_cycles + ((size_t)blockIdx.x * kFWaves + wave) * 6;
-    for (int k = 0; k < 6; ++k) o[k] = t_ph[k];
+    long long *o = fpar.phase_cycles + ((size_t)blockIdx.x * kFWaves + wave) * 8;
+    for (int k = 0; k < 8; ++k) o[k] = t_ph[k];
   }
 #endif
 
