@@ -1043,6 +1043,7 @@ int g1s_diff::launch_back(int si) {
     // kernel alone on the chip is 5 % slower: the runs' loads disturb the kernels next to it less)
     static const int deal_env = getenv("G1S_F_DEAL") ? atoi(getenv("G1S_F_DEAL")) : 1;  // tuning aid
     fq.deal = deal_env;
+    { const char *e = getenv("G1S_F_REUSE"); fq.reuse = e ? atoi(e) : 1; }  // test / tuning aid (0: every halo word is read)
     fq.planes = sl.d_k0;
     fq.ps = ps;
     const bool planes = use_planes();

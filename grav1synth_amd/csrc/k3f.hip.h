@@ -51,6 +51,7 @@ struct FParams {
   uint32_t lpitch, lframe_bytes;
   int frames, wgs;        // the launch: frames x workgroups per frame, as a 1-D grid (see the kernel)
   int deal;               // units to workgroups: 0 round-robin, 1 contiguous runs
+  int reuse;              // 1: (luma launch) the left halo word of a unit whose left neighbour was the unit before it in the run is not read
   const uint8_t *planes;  // SRC = 1: the int8 planes of the pixel pass K0 (k0.hip.h), [batch] x ps.frame_bytes
   PlaneSet ps;
   long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][8] cycles: tile copies, barrier 2, multiply, barrier 1, wait for the words, residuals, requests, stores; or null
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   int32_t *ustats = fpar.ustats + (size_t)frame * fpar.nunits * kMStatInts;
   uint8_t *lplane = fpar.lplane + (size_t)frame * fpar.lframe_bytes;
   const FramePlanes fp = fpar.ft.f[frame];
-  const int sx = g.xdec, sy = g.ydec;
+  // (the chroma block shape IS the subsampling: known at compile time -- the registers and branches of the other formats go)
+  constexpr int sx = CH && CBW == 16 ? 1 : 0, sy = CH && CBH == 16 ? 1 : 0;
   const int cpw = g.W >> sx, cph = g.H >> sy;
   const int sbps = f_bps<BPS>(g.src_bps), dbps = f_bps<BPS>(g.den_bps);
 
@@ -264,6 +266,15 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   const int nmine = n_p + n_g;  // (<= kMMaxUnits: the host sizes G for it)
   if (tid < nmine) {
     uint4 e = *reinterpret_cast<const uint4 *>(units + (size_t)upos(tid) * kMUnitDwords);
+    // bit 31 of .x: the unit before this one in the workgroup's sequence is its left neighbour in the block row (the usual
+    // case in a contiguous run of the lists).  The three samples left of the unit's columns are then the last samples of
+    // that unit's words -- still in this wave's registers, WY - 3 lanes away -- and the left halo word of every row is not
+    // read from memory: a row of a luma unit is two 128-byte lines instead of three (the memory pipe of a CU takes a few
+    // cycles per LINE a load touches, however little of it is used: profiles/r02_k3f_counters.txt).
+    if (RAW && LUMA && fpar.reuse && tid > 0) {
+      const uint32_t a = units[(size_t)upos(tid - 1) * kMUnitDwords] & 0xffffffu, here = e.x & 0xffffffu;
+      if ((a & 0xfff000u) == (here & 0xfff000u) && (a & 0xfffu) + 1u == (here & 0xfffu)) e.x |= 1u << 31;
+    }
     if (CHROMA && RAW) e.w = (uint32_t)ustats[(size_t)upos(tid) * kMStatInts + 14];
     if (!RAW) e.w = 0u;
     s_ent[tid] = e;
@@ -284,6 +295,8 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   u32x4 cs_[NCR], cd_[NCR];  // chroma raw words: one row a round
   uint2 lraw = make_uint2(0u, 0u), Lk = make_uint2(0u, 0u);  // chroma launch: this thread's word of the L tile (requested / of the unit being staged)
   uint32_t Dy[2][2], Dc[NCR][2];  // residual bytes of the luma rows / of the chroma rows
+  uint32_t DlastY[2] = {0u, 0u};  // luma launch: the last dword of the words of the unit before
+  bool carry_y = false;           // ... its last word held a residual outside int8
   uint32_t Lw00 = 0, Lw01 = 0, Lw10 = 0, Lw11 = 0;  // luma launch: the L bytes under the lane's rows (scalars: an array the lambdas share goes to scratch)
   const bool l_on = CHROMA && tid < SH::NL;
   constexpr int LWR = kMUnitBlocks * CW_ / 8;  // 8-byte words of an L tile row
@@ -292,6 +305,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
     const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
     const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
     const int X0y = bx0 * 32 - 8, Y0y = by * kBlock - 3, X0c = bx0 * CW_ - 8, Y0c = by * CH_ - 3;
+    const bool aL = (ex >> 31) != 0;  // the left halo word is the left neighbour's own last word: not read
     if constexpr (!RAW) {
       // K0's planes: sample (x, y) of a residual plane at byte (y + 3) * pitch + 8 + x (zero padding around the plane); L without padding
       const uint8_t *fpl = fpar.planes + (size_t)frame * fpar.ps.frame_bytes;
@@ -329,7 +343,6 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       if (l_on) lraw = *reinterpret_cast<const uint2 *>(lplane + (size_t)(by * CH_ + l_row) * fpar.lpitch + bx0 * CW_ + 8 * l_wd);
     }
     const bool slow = !vec_all || (LUMA ? ((g.W & 7) != 0 && X0y + SH::PY > g.W) : ((cpw & 7) != 0 && X0c + SH::PC > cpw));
-#ifndef G1S_DBG_NOSLOW
     if (__builtin_expect(slow, 0)) {
       if constexpr (LUMA) {
 #pragma unroll
@@ -346,7 +359,6 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       }
       return;
     }
-#endif
     if (LUMA && y_wave) {
       // (pointers to the unit's origin: not dereferenced where the origin lies outside the plane)
       const uint8_t *sb = fp.src[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.src_stride[0] + (ptrdiff_t)X0y * sbps);
@@ -354,9 +366,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       // a unit whose tile lies inside the plane (all but the frame's border units) needs no per-lane bounds
       const bool inside = X0y >= 0 && X0y + SH::PY <= g.W && Y0y >= 0 && Y0y + kBlock + 3 <= g.H;
       bool xok = inside || (X0y + 8 * ywd >= 0 && X0y + 8 * ywd + 8 <= g.W);
-#ifdef G1S_DBG_NOHALO
-      xok = xok && ywd >= 1 && ywd <= SH::WY - 2;
-#endif
+      xok = xok && !(aL && ywd == 0);
       // (the lane's offsets from the unit's origin are worked out here from values the optimiser cannot see through:
       //  hoisted out of the unit loop they cost registers -- and a spill, whose reload from scratch waits for every
       //  load in flight)
@@ -375,9 +385,6 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       const uint8_t *db = c_den + ((ptrdiff_t)Y0c * (ptrdiff_t)c_dst + (ptrdiff_t)X0c * dbps);
       const bool inside = X0c >= 0 && X0c + SH::PC <= cpw && Y0c >= 0 && Y0c + CH_ + 3 <= cph;
       bool xok = inside || (X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw);
-#ifdef G1S_DBG_NOHALO
-      xok = xok && cwd >= 1 && cwd <= SH::WC - 2;
-#endif
 #pragma unroll
       for (int q = 0; q < CROUNDS; ++q) {
         const int Y = Y0c + ctr[q];
@@ -485,7 +492,12 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       if (y_interior && ytr0 >= 3)
         atomicAdd(&s_sum[par][0][y_bq],
                   ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)(uint32_t)ls << 19) | (unsigned long long)(uint32_t)(sd + kFBiasY));
-      if (yon && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][0][0], ywd, 4);
+      // (a residual outside int8 flags the blocks whose tile holds it; with the left halo word unread, the last word of the
+      //  unit before -- carried -- flags this unit's first block)
+      const bool badw = yon && range_bad(mx, mn);
+      if (badw) f_flag_blocks(&s_bad[par][0][0], ywd, 4);
+      if ((ex >> 31) && carry_y) s_bad[par][0][0] = 1;
+      carry_y = badw && ywd == SH::WY - 2;
       if (CH && y_interior && range_bad(lmx, lmn)) s_bad[par][1][y_bq] = 1;
     }
     // ---- chroma ----
@@ -532,7 +544,9 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
     }
   };
   // PLAIN: every window of the unit is its whole block (k3m_units): no column masks, every word is written
-  auto phase_b = [&](auto plain_tag, const uint32_t (&wins)[4]) __attribute__((always_inline)) {
+  // aL: the unit before is the left neighbour -- its last dword is the dword left of this unit's words (WY - 3 lanes away:
+  // the same row pair, word 8)
+  auto phase_b = [&](auto plain_tag, const uint32_t (&wins)[4], bool aL) __attribute__((always_inline)) {
     constexpr bool PLAIN = decltype(plain_tag)::value;
     if (LUMA && y_wave) {
       // every word of a block that is multiplied is written, the fully masked ones (columns past a window that ends at the
@@ -544,8 +558,13 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int tr = ytr0 + r;
-        const uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
+        uint32_t prev1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][1], 0x138, 0xf, 0xf, true);  // wave_shr:1
         const uint32_t next0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)Dy[r][0], 0x130, 0xf, 0xf, true);  // wave_shl:1
+        if (aL) {
+          const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + SH::WY - 3), (int)DlastY[r]);
+          if (ywd == 1) prev1 = v;
+        }
+        DlastY[r] = Dy[r][1];
         if (tr >= 0 && wr) m_write_copies<!PLAIN>(m_smem + tr * SH::PY + y_xw, SH::CSY, prev1, Dy[r][0], Dy[r][1], next0, cm);
       }
     }
@@ -596,14 +615,13 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       const int par = k & 1;
       const uint4 e0 = s_ent[k];
       const uint32_t ey = __builtin_amdgcn_readfirstlane(e0.y), ez = __builtin_amdgcn_readfirstlane(e0.z);
-      const uint32_t fbits = PLAIN ? (1u << kMUnitBlocks) - 1u : __builtin_amdgcn_readfirstlane(e0.x) >> 24;
+      const uint32_t ex0 = __builtin_amdgcn_readfirstlane(e0.x);
+      const uint32_t fbits = PLAIN ? (1u << kMUnitBlocks) - 1u : ex0 >> 24;
       const uint32_t lbad = CHROMA ? __builtin_amdgcn_readfirstlane(e0.w) >> kMUnitBlocks : 0u;  // L outside int8 (luma launch)
       const uint32_t wins[4] = {ey & 0xffffu, ey >> 16, ez & 0xffffu, ez >> 16};  // luma block 0, 1; chroma block 0, 1
       __syncthreads();  // the previous unit's tiles are no longer read
       stamp(3);
-#ifndef G1S_DBG_NOCOPY
-      phase_b(plain_tag, wins);
-#endif
+      phase_b(plain_tag, wins, (ex0 >> 31) != 0);
       // (the sums and flags of the unit before this one: read in its multiply phase, written again two units on)
       if (tid >= 64 && tid < 64 + 3 * kMUnitBlocks) (&s_sum[par ^ 1][0][0])[tid - 64] = 0ull;
       else if (tid >= 128 && tid < 128 + 2 * kMUnitBlocks) (&s_bad[par ^ 1][0][0])[tid - 128] = 0;
@@ -622,9 +640,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
           if (flat_b && __builtin_amdgcn_readfirstlane(s_bad[par][0][b])) {
             defer |= 1u << b;  // (any flat block: the exact kernel redoes its statistics too)
           } else if (PLAIN || wy.go) {
-#ifndef G1S_DBG_NOMFMA
             m_rows_one<RPY, SH::PY>(accA, m_smem, base_luma + 32 * b, PLAIN ? ~0u : m_rowmask(wy.ys, wy.ye) >> (wave * RPY), ZOFF);
-#endif
           }
         } else {
           const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
@@ -633,10 +649,8 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
             defer |= 1u << (kMUnitBlocks + b);
           } else if (PLAIN || wc.go) {
             const uint32_t rm = PLAIN ? ~0u : m_rowmask(wc.ys, wc.ye) >> (wave * RPC);
-#ifndef G1S_DBG_NOMFMA
             if constexpr (CW_ == 32) m_rows_two<RPC, SH::PC>(accA, accB, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);
             else m_steps_two<RPC / 2, SH::PC>(accA, accB, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, PLAIN ? ~0u : rm >> h, ZOFF);
-#endif
             (void)rm;
           }
         }
@@ -650,18 +664,14 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
           stamp(4);
         }
 #endif
-#ifndef G1S_DBG_NOA
         phase_a(k + 1);
-#endif
 #ifdef G1S_F_PHASES
         if (fpar.phase_cycles) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           stamp(5);
         }
 #endif
-#ifndef G1S_DBG_NOREQ
         if (k + 2 < nmine) request(k + 2);
-#endif
         stamp(6);
         export_l(k + 1);
       }
