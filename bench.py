@@ -213,7 +213,13 @@ def main() -> None:
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as f:
-                traffic = json.load(f).get(args.workload, {}).get(os.environ.get("G1S_K3", "fused"))
+                tj = json.load(f).get(args.workload, {})
+                mode = os.environ.get("G1S_K3", "fused")
+                # measured HBM bytes per frame pair (PMC passes, tools/profile_round.sh) x the frames of a launch
+                if mode + "_per_frame" in tj:
+                    traffic = tj[mode + "_per_frame"] * frames_per_launch
+                else:
+                    traffic = tj.get(mode)
         except Exception:
             traffic = None
 

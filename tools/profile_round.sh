@@ -14,8 +14,11 @@ tail -c 600 gpurun_out/${TAG}_bench.json; echo
 B="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
 bash tools/prof.sh ${TAG}_kt --kernel-trace --stats -- $B > /dev/null
 G1S_ONE_STREAM=1 bash tools/prof.sh ${TAG}_kt1 --kernel-trace --stats -- $B > /dev/null
-G1S_ONE_STREAM=1 bash tools/prof.sh ${TAG}_fetch --pmc FETCH_SIZE -- python $ROOT/bench.py --steps 1 --warmup 1 --frames 32 --cycles 2 --no-cpu-baseline > /dev/null
-G1S_ONE_STREAM=1 bash tools/prof.sh ${TAG}_write --pmc WRITE_SIZE -- python $ROOT/bench.py --steps 1 --warmup 1 --frames 32 --cycles 2 --no-cpu-baseline > /dev/null
+# PMC passes: the lean driver (frames made on the CPU: no torch kernels under the profiler), two 64-frame launches, one stream
+for c in FETCH_SIZE WRITE_SIZE; do
+  n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+  bash tools/prof.sh ${TAG}_$n --pmc $c -- python $ROOT/tools/diff_pmc.py 2 > /dev/null
+done
 for d in kt kt1; do echo "== $d"; python tools/kstats.py gpurun_out/${TAG}_$d; done
 for d in fetch write; do echo "== $d"; python tools/pmc_summary.py gpurun_out/${TAG}_$d | grep -v "^==" ; done
 find gpurun_out -name "*kernel_trace.csv" -size +8M -delete
