@@ -916,13 +916,13 @@ int g1s_diff::launch_front(int si) {
         hipLaunchKernelGGL((k1_flat_features<2, true>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
                            (const uint32_t *)cl.list, (const uint32_t *)cl.count);
     } else if (!dbg_skip("flatblock")) {  // the few blocks the certificate leaves open (mode 2, a test aid: every block): one wave per block
-      dim3 grid(kFbGrid, B);
+      dim3 grid(kFbGrid);
       if (g.src_bps == 1)
         hipLaunchKernelGGL(k1_flat_block<1>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
-                           (const uint32_t *)cl.list, (const uint32_t *)cl.count);
+                           (const uint32_t *)cl.list, (const uint32_t *)cl.count, (int)B);
       else
         hipLaunchKernelGGL(k1_flat_block<2>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
-                           (const uint32_t *)cl.list, (const uint32_t *)cl.count);
+                           (const uint32_t *)cl.list, (const uint32_t *)cl.count, (int)B);
     }
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));

@@ -344,24 +344,36 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom
 // pixels are worked out in parallel and laid down in LDS in raster order; every sum the reference
 // takes sequentially is then one lane adding its array front to back from 0.0 (3 chains for the
 // plane fit, 5 for the gradient sums), so each sum sees the same operands in the same order.
-// grid = (kFbGrid, batch), block = 64; a workgroup strides over the frame's list.
+// grid = (kFbGrid), block = 64: the listed blocks of ALL frames of the launch, taken as one sequence, are dealt
+// round-robin to one resident round of workgroups (3 to a CU by their 46 KB of LDS).  (A grid of 128 workgroups per
+// frame was 8192 workgroups a 64-frame launch for ~420 listed blocks: dispatching the idle ones, 46 KB of LDS each,
+// took as long as the work.)
 // ----------------------------------------------------------------------------
-constexpr int kFbGrid = 128;
+constexpr int kFbGrid = 768;
 constexpr int kFbInner = (kBlock - 2) * (kBlock - 2);
 template <int BPS>
 __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g, FlatConsts fc,
                                                     const double *__restrict__ lut_g, uint8_t *__restrict__ records,
                                                     uint8_t *__restrict__ flags, const uint32_t *__restrict__ list,
-                                                    const uint32_t *__restrict__ count) {
+                                                    const uint32_t *__restrict__ count, int nframes) {
   __shared__ double lut[256];
   __shared__ double s_v[kBlock * kBlock];  // pixel / 255, later the residual
   __shared__ double s_t[5 * kFbInner];     // [3][1024] fit products, then [5][900] gradient terms
-  const int lane = threadIdx.x, frame = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int W = (int)gridDim.x, w = (int)blockIdx.x;
+  bool have_lut = false;
+  int pos0 = 0;  // position of the frame's first listed block in the launch's sequence
+  for (int frame = 0; frame < nframes; ++frame) {
   const int n = (int)count[frame];
-  if ((int)blockIdx.x >= n) return;
-  for (int i = lane; i < 256; i += 64) lut[i] = lut_g[i];
+  const int it0 = ((w - pos0) % W + W) % W;
+  pos0 += n;
+  if (it0 >= n) continue;
+  if (!have_lut) {
+    for (int i = lane; i < 256; i += 64) lut[i] = lut_g[i];
+    have_lut = true;
+  }
   const FramePlanes fp = ft.f[frame];
-  for (int it = blockIdx.x; it < n; it += gridDim.x) {
+  for (int it = it0; it < n; it += W) {
     const int blk = (int)list[(size_t)frame * g.nblocks + it];
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int ox = bx * kBlock, oy = by * kBlock;
@@ -424,6 +436,7 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
     const double Gxx = __shfl(sum, 0, 64), Gxy = __shfl(sum, 1, 64), Gyy = __shfl(sum, 2, 64);
     const double mean = __shfl(sum, 3, 64), var = __shfl(sum, 4, 64);
     if (lane == 0) flat_decide(Gxx, Gxy, Gyy, var, mean, g, records, flags, frame, blk);
+  }
   }
 }
 
