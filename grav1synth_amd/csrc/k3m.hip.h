@@ -144,17 +144,26 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
   const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
   const int gx = (g.nbw + kMUnitBlocks - 1) / kMUnitBlocks;
   const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
+  // The six mask bytes a unit's windows depend on -- its two blocks, their left and right neighbours, the two blocks above --
+  // are read up front, unconditionally and independently (outside the frame: 0): the kernel is as long as its longest chain
+  // of dependent loads, and block_window per block and kind was five of them in a row, four times over (35 us a launch).
   uint32_t bits = 0;
   int by = 0, ci = 0;
+  int m_l = 0, m_0 = 0, m_1 = 0, m_r = 0, u_0 = 0, u_1 = 0;
   if (idx < mp.nunits) {
     by = idx / gx;
     ci = idx - by * gx;
-#pragma unroll
-    for (int b = 0; b < kMUnitBlocks; ++b) {
-      const int bx = kMUnitBlocks * ci + b;
-      if (bx < g.nbw && mask[by * g.nbw + bx]) bits |= 1u << b;
-    }
+    const int bxa = kMUnitBlocks * ci;
+    auto at = [&](int x, int y) { return (x >= 0 && x < g.nbw && y >= 0 && y < g.nbh) ? (int)mask[y * g.nbw + x] : 0; };
+    m_l = at(bxa - 1, by);
+    m_0 = at(bxa, by);
+    m_1 = at(bxa + 1, by);
+    m_r = at(bxa + 2, by);
+    u_0 = at(bxa, by - 1);
+    u_1 = at(bxa + 1, by - 1);
+    bits = (m_0 ? 1u : 0u) | (m_1 ? 2u : 0u);
   }
+  static_assert(kMUnitBlocks == 2, "k3m_units: two blocks a unit");
   if (__ballot(bits != 0) == 0) return;
   const bool chroma = g.nplanes == 3;
   uint32_t win[2 * kMUnitBlocks];
@@ -168,7 +177,14 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
     if (!((bits >> b) & 1u) || (kind && !chroma)) continue;
     const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
     const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
-    const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph, g.lag);
+    // block_window (k0.hip.h) on the bytes read above
+    const int left = b ? m_0 : m_l, right = b ? m_r : m_1, up = b ? u_1 : u_0;
+    Win w{1, 0, 0, 0, 0};
+    w.ys = up ? 0 : g.lag;
+    w.xs = left ? 0 : g.lag;
+    w.ye = min(ph - by * bh, bh);
+    w.xe = min(pw - bx * bw - g.lag, right ? bw : (bw - g.lag));
+    if (w.xe <= w.xs || w.ye <= w.ys) w.flat = 0;  // empty window
     if (!w.flat || w.xs != 0 || w.ys != 0 || w.xe != bw || w.ye != bh) plain = false;
     if (!w.flat) continue;
     // (a pixel pass may have flagged residuals outside int8: the tile reaches into the left / right / upper neighbours;
