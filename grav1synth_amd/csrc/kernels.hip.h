@@ -452,39 +452,65 @@ constexpr int kK2Threads = 1024;
 constexpr int kK2PerThread = 8;  // scores kept in registers: up to 8192 blocks (a 4K frame has 8160)
 __global__ __launch_bounds__(kK2Threads) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
                                                              const uint8_t *__restrict__ flags) {
-  __shared__ uint32_t s_cnt[2][kK2Threads / 64];
+  __shared__ uint32_t s_hist[256], s_wsum[4], s_sel[2];
   const int frame = blockIdx.x;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint32_t *sc = reinterpret_cast<const uint32_t *>(rec + g.off_scores);
   const int nb = g.nblocks;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const bool in_regs = nb <= kK2Threads * kK2PerThread;
   uint32_t v[kK2PerThread];
 #pragma unroll
   for (int k = 0; k < kK2PerThread; ++k) {
     const int i = tid + k * kK2Threads;
-    v[k] = i < nb ? sc[i] : 0xffffffffu;  // the filler is never below a candidate
+    v[k] = i < nb ? sc[i] : 0xffffffffu;  // the filler sorts last
   }
-  const uint32_t rank = (uint32_t)(nb * 90 / 100);  // 0-based rank in ascending order
+  // The k-th smallest pattern, a byte at a time from the top (radix select: 4 passes of histogram + scan; bit by bit it was
+  // 32 rounds of count + barrier, 33 us a launch whatever the frame).  `rank` = 0-based rank among the patterns that share
+  // the bytes decided so far.
+  uint32_t rank = (uint32_t)(nb * 90 / 100);
   uint32_t thr = 0;
-  for (int bit = 31; bit >= 0; --bit) {
-    const uint32_t cand = thr | (1u << bit);
-    int c = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    const uint32_t himask = pass ? ~0u << (shift + 8) : 0u;  // the bytes decided so far
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
     if (in_regs) {
 #pragma unroll
-      for (int k = 0; k < kK2PerThread; ++k) c += v[k] < cand ? 1 : 0;
+      for (int k = 0; k < kK2PerThread; ++k)
+        if ((v[k] & himask) == thr) atomicAdd(&s_hist[(v[k] >> shift) & 0xffu], 1u);
     } else {
-      for (int i = tid; i < nb; i += kK2Threads) c += sc[i] < cand ? 1 : 0;
+      for (int i = tid; i < nb; i += kK2Threads) {
+        const uint32_t x = sc[i];
+        if ((x & himask) == thr) atomicAdd(&s_hist[(x >> shift) & 0xffu], 1u);
+      }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    uint32_t *slot = s_cnt[bit & 1];  // double buffered: one barrier per round
-    if (lane == 0) slot[wave] = (uint32_t)c;
     __syncthreads();
-    uint32_t total = 0;
+    // exclusive prefix of the 256 bins (threads 0 .. 255: four waves), the bin that holds the rank
+    uint32_t c = 0, incl = 0;
+    if (tid < 256) {
+      c = s_hist[tid];
+      incl = c;
 #pragma unroll
-    for (int w = 0; w < kK2Threads / 64; ++w) total += slot[w];
-    if (total <= rank) thr = cand;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) s_wsum[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t base = 0;
+      for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
+      const uint32_t excl = base + incl - c;
+      if (c != 0 && excl <= rank && rank < excl + c) {
+        s_sel[0] = (uint32_t)tid;
+        s_sel[1] = excl;
+      }
+    }
+    __syncthreads();
+    thr |= s_sel[0] << shift;
+    rank -= s_sel[1];
   }
   // thr = bit pattern of the threshold score
   uint8_t *mask = rec + g.off_mask;
