@@ -177,6 +177,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   __shared__ unsigned long long s_sum[2][3][kMUnitBlocks];
   __shared__ int s_bad[2][2][kMUnitBlocks];  // [unit parity][kind][block]
   __shared__ int s_ring[4][kMStatInts];      // statistics records on their way out (wave 3)
+  __shared__ uint2 s_L[2][PL == 0 && SH::NL > 0 ? SH::NL : 1];  // luma launch: the L tile of a unit on its way to the L plane (wave 3)
 
   // Workgroup b of the 1-D grid runs on XCD b % 8, and workgroups b, b + 256, ... share a CU (observed; speed only).  With
   // frame = b % frames (frames a multiple of 8, or few), the workgroups on a CU work on ONE frame -- few distinct pages under
@@ -521,24 +522,39 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       if (c && range_bad(mx, mn)) f_flag_blocks(&s_bad[par][1][0], cwd, CW_ / 8);
     }
   };
-  // the L words of unit k -> the L plane (luma launch).  Global stores share the loads' counter: issued BEHIND a request they
-  // have an iteration to drain; issued before it, the request's first load waits for them (microseconds)
+  // the L words of unit k -> the L plane (luma launch).  A global store costs the staging waves ~500 cycles a unit at the
+  // memory pipe's door (profiles/r02_k3f_counters.txt): they leave the words in an LDS tile (parity k & 1) and wave 3,
+  // which stages no rows, stores the tile -- one 8-byte word a lane -- behind barrier 1 of the unit's own iteration.
   auto export_l = [&](int k) __attribute__((always_inline)) {
     if constexpr (LUMA && CH && RAW) {
       if (y_wave && y_interior) {
-        const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
-        const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
+        uint8_t *tile = reinterpret_cast<uint8_t *>(&s_L[k & 1][0]);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int tr = ytr0 + r;
           const bool have = sy ? (r == 1 && tr >= 4) : tr >= 3;
           const int cy = sy ? (tr - 4) >> 1 : tr - 3;
           if (have) {
-            uint8_t *lp = lplane + (size_t)(by * CH_ + cy) * fpar.lpitch + bx0 * CW_ + (y_xw >> sx);
+            uint8_t *lp = tile + cy * (kMUnitBlocks * CW_) + (y_xw >> sx);
             const uint32_t la = r == 0 ? Lw00 : Lw10, lb = r == 0 ? Lw01 : Lw11;
             if (sx) *reinterpret_cast<uint32_t *>(lp) = la;
             else *reinterpret_cast<uint2 *>(lp) = make_uint2(la, lb);
           }
+        }
+      }
+    }
+  };
+  auto flush_l = [&](int k) __attribute__((always_inline)) {
+    if constexpr (LUMA && CH && RAW) {
+      if (wave == kFWaves - 1) {
+        const uint32_t ex = __builtin_amdgcn_readfirstlane(s_ent[k].x);
+        const int bx0 = kMUnitBlocks * (int)(ex & 0xfffu), by = (int)((ex >> 12) & 0xfffu);
+        constexpr int LW = kMUnitBlocks * CW_ / 8;  // 8-byte words of an L tile row
+#pragma unroll
+        for (int w0 = 0; w0 < SH::NL; w0 += 64) {
+          const int w = w0 + lane, row = w / LW, wd = w - row * LW;
+          if (w < SH::NL)
+            *reinterpret_cast<uint2 *>(lplane + (size_t)(by * CH_ + row) * fpar.lpitch + bx0 * CW_ + 8 * wd) = s_L[k & 1][w];
         }
       }
     }
@@ -622,6 +638,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       __syncthreads();  // the previous unit's tiles are no longer read
       stamp(3);
       phase_b(plain_tag, wins, (ex0 >> 31) != 0);
+      flush_l(k);
       // (the sums and flags of the unit before this one: read in its multiply phase, written again two units on)
       if (tid >= 64 && tid < 64 + 3 * kMUnitBlocks) (&s_sum[par ^ 1][0][0])[tid - 64] = 0ull;
       else if (tid >= 128 && tid < 128 + 2 * kMUnitBlocks) (&s_bad[par ^ 1][0][0])[tid - 128] = 0;
