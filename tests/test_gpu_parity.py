@@ -541,6 +541,21 @@ def test_large_residuals_take_the_deferred_path(bd, xdec, ydec, lag):
     assert format_tbl(g.finish()) == ofmt(o.finish())
 
 
+def test_native_shard_driver_over_rccl():
+    """tools/shard_native.cpp: the round protocol of include/g1s_diff.h driven from C++ -- one process, one generator per
+    visible device, the per-round gather over RCCL (ncclSend / ncclRecv in a group, ncclCommInitAll) -- gives the table of a
+    single generator byte for byte (a scene change inside the video, a last batch that is short)."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "shard_native")
+    if not os.path.exists(exe):
+        pytest.skip("tools/shard_native not built (make -C grav1synth_amd/csrc)")
+    r = subprocess.run([exe, "0", "38", "4"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "IDENTICAL" in r.stdout
+
+
 @pytest.mark.parametrize("seed", [3, 77])
 def test_ragged_sizes_with_isolated_large_residuals(seed):
     """Random frame sizes whose last block column is partial (a window that ends at the plane's right edge leaves
