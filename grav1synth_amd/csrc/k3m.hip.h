@@ -290,7 +290,9 @@ __device__ __forceinline__ void m_rows_one(v16i32 &acc, const uint8_t *smem, int
 // R rows of two planes: plane A from a0 into accA, plane B from b0 into accB (chroma blocks 32 wide)
 template <int R, int P>
 __device__ __forceinline__ void m_rows_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, uint32_t rm, int zoff) {
-  constexpr int H = R > 4 ? 4 : R;  // rows per batch of reads
+  // (two rows a batch: 16 operand registers next to the two accumulators' 32; four rows a batch were 32, and the 32-wide
+  //  chroma launches spilled in their hot loops)
+  constexpr int H = R > 2 ? 2 : R;  // rows per batch of reads
 #pragma unroll
   for (int j0 = 0; j0 < R; j0 += H) {
     v4i32 va[H], vb[H];
@@ -312,18 +314,23 @@ __device__ __forceinline__ void m_rows_two(v16i32 &accA, v16i32 &accB, const uin
 // that bit 2 j is this lane's row of step j
 template <int S, int P>
 __device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, uint32_t rml, int zoff) {
-  v4i32 va[S], vb[S];
+  constexpr int H = S > 2 ? 2 : S;  // steps per batch of reads (16 operand registers)
+  static_assert(S % H == 0, "steps per wave");
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    const bool ok = ((rml >> (2 * j)) & 1u) != 0;
-    va[j] = m_lds16(smem, ok ? a0 + 2 * j * P : zoff);
-    vb[j] = m_lds16(smem, ok ? b0 + 2 * j * P : zoff);
-  }
-  __builtin_amdgcn_sched_barrier(0);
+  for (int j0 = 0; j0 < S; j0 += H) {
+    v4i32 va[H], vb[H];
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[j], va[j], accA, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb[j], vb[j], accB, 0, 0, 0);
+    for (int j = 0; j < H; ++j) {
+      const bool ok = ((rml >> (2 * (j0 + j))) & 1u) != 0;
+      va[j] = m_lds16(smem, ok ? a0 + 2 * (j0 + j) * P : zoff);
+      vb[j] = m_lds16(smem, ok ? b0 + 2 * (j0 + j) * P : zoff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[j], va[j], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb[j], vb[j], accB, 0, 0, 0);
+    }
   }
 }
 
