@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void k1_moments(const FrameTable ft, Geom g, i
   uint32_t pu[8], pd[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    pu[k] = (uint32_t)__shfl_up((int)pk[k], 1, 32);
-    pd[k] = (uint32_t)__shfl_down((int)pk[k], 1, 32);
+    // (DPP wave shifts: a move each, no LDS crossbar; the rows they get wrong -- the first and the last of a block, whose
+    //  neighbour lane belongs to the other block of the wave -- are not interior rows and use neither)
+    pu[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk[k], 0x138, 0xf, 0xf, true);  // wave_shr:1: the row above
+    pd[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk[k], 0x130, 0xf, 0xf, true);  // wave_shl:1: the row below
   }
   int32_t s[14];
   row_moments(pk, pu, pd, yi, s);
