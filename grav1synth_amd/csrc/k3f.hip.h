@@ -373,12 +373,25 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       //  load in flight)
       int l_tr = ytr0, l_w = ywd;
       asm volatile("" : "+v"(l_tr), "+v"(l_w));
+      if (inside) {
+        // Every lane loads, no predicate (a wave is as fast as its instruction count: a predicated load is a compare, an
+        // exec save, a branch, the load, an exec restore and the zeroes of the other arm).  Tile row -1 and the lanes past
+        // the last row pair read row 0 -- nothing uses what they get; the left halo lane of a unit whose neighbour holds
+        // its samples re-reads word 1 (the same 128-byte line: no halo line is touched).
+        if (aL && ywd == 0) l_w = 1;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int Y = Y0y + ytr0 + r;
-        const bool ok = xok && ytr0 + r >= 0 && (inside || (Y >= 0 && Y < g.H));
-        ys_[r] = f_load<BPS>(sb, (uint32_t)max(l_tr + r, 0) * fp.src_stride[0] + (uint32_t)(8 * l_w * sbps), g.src_bps, ok);
-        yd_[r] = f_load<BPS>(db, (uint32_t)max(l_tr + r, 0) * fp.den_stride[0] + (uint32_t)(8 * l_w * dbps), g.den_bps, ok);
+        for (int r = 0; r < 2; ++r) {
+          ys_[r] = f_load<BPS>(sb, (uint32_t)max(l_tr + r, 0) * fp.src_stride[0] + (uint32_t)(8 * l_w * sbps), g.src_bps, true);
+          yd_[r] = f_load<BPS>(db, (uint32_t)max(l_tr + r, 0) * fp.den_stride[0] + (uint32_t)(8 * l_w * dbps), g.den_bps, true);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int Y = Y0y + ytr0 + r;
+          const bool ok = xok && ytr0 + r >= 0 && Y >= 0 && Y < g.H;
+          ys_[r] = f_load<BPS>(sb, (uint32_t)max(l_tr + r, 0) * fp.src_stride[0] + (uint32_t)(8 * l_w * sbps), g.src_bps, ok);
+          yd_[r] = f_load<BPS>(db, (uint32_t)max(l_tr + r, 0) * fp.den_stride[0] + (uint32_t)(8 * l_w * dbps), g.den_bps, ok);
+        }
       }
     }
     if constexpr (CHROMA) {
@@ -386,12 +399,20 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       const uint8_t *db = c_den + ((ptrdiff_t)Y0c * (ptrdiff_t)c_dst + (ptrdiff_t)X0c * dbps);
       const bool inside = X0c >= 0 && X0c + SH::PC <= cpw && Y0c >= 0 && Y0c + CH_ + 3 <= cph;
       bool xok = inside || (X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw);
+      if (inside) {  // (every lane loads: the idle lanes of a round read row 0, unused)
 #pragma unroll
-      for (int q = 0; q < CROUNDS; ++q) {
-        const int Y = Y0c + ctr[q];
-        const bool ok = xok && cpl[q] != 0 && (inside || (Y >= 0 && Y < cph));
-        cs_[q] = f_load<BPS>(sb, cso[q], g.src_bps, ok);
-        cd_[q] = f_load<BPS>(db, cdo[q], g.den_bps, ok);
+        for (int q = 0; q < CROUNDS; ++q) {
+          cs_[q] = f_load<BPS>(sb, cso[q], g.src_bps, true);
+          cd_[q] = f_load<BPS>(db, cdo[q], g.den_bps, true);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < CROUNDS; ++q) {
+          const int Y = Y0c + ctr[q];
+          const bool ok = xok && cpl[q] != 0 && Y >= 0 && Y < cph;
+          cs_[q] = f_load<BPS>(sb, cso[q], g.src_bps, ok);
+          cd_[q] = f_load<BPS>(db, cdo[q], g.den_bps, ok);
+        }
       }
     }
   };
@@ -645,6 +666,14 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
       stamp(0);
       __syncthreads();
       stamp(1);
+#ifdef G1S_DBG_SALU
+      {  // issue-rate probe: G1S_DBG_SALU harmless scalar instructions per unit
+        int x_ = __builtin_amdgcn_readfirstlane(lane & 0);
+#pragma unroll
+        for (int q_ = 0; q_ < G1S_DBG_SALU; ++q_) asm volatile("s_add_i32 %0, %0, 1" : "+s"(x_));
+        asm volatile("" ::"s"(x_));
+      }
+#endif
       // ------------------------------- multiply -------------------------------
       uint32_t defer = 0;
 #pragma unroll
