@@ -541,6 +541,46 @@ def test_large_residuals_take_the_deferred_path(bd, xdec, ydec, lag):
     assert format_tbl(g.finish()) == ofmt(o.finish())
 
 
+def test_left_halo_reuse_changes_no_sum(monkeypatch):
+    """G1S_F_REUSE=0 (every halo word of a luma unit is read from memory) and the default (the left halo word comes from
+    the registers of the unit before, where that unit is the left neighbour) give the same integer sums and the same table:
+    wide frames (long runs of adjacent units), few workgroups per frame (every workgroup walks many units), a few
+    out-of-int8 residuals in last / first words of units (the carried flag)."""
+    spec = SynthSpec(1280, 352, 10, xdec=1, ydec=1, textured=False)
+    frames = []
+    rng = np.random.default_rng(5)
+    for k in range(3):
+        s, d = np_pair(spec, k)
+        d = [p.copy() for p in d]
+        for _ in range(6):  # the last word of a unit / the first word of the next one
+            y = int(rng.integers(0, spec.height)); u = int(rng.integers(1, spec.width // 64 - 1))
+            x = 64 * u - 1 - int(rng.integers(0, 3)) if rng.random() < 0.5 else 64 * u + int(rng.integers(0, 3))
+            d[0][y, x] = 0 if (int(s[0][y, x]) >> 2) > 140 else (255 << 2)
+        frames.append((s, d))
+    out = {}
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("G1S_F_REUSE", reuse)
+        monkeypatch.setenv("G1S_F_WGS", "64")
+        g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=3)
+        for s, d in frames:
+            g.diff_frame(Frame(s, 1, 1), Frame(d, 1, 1))
+        g.sync()
+        r = g.last_record()
+        sums = [r.ar_sums(c) for c in range(3)]
+        out[reuse] = (sums, format_tbl(g.finish()))
+    for c in range(3):
+        a, b = out["1"][0][c], out["0"][0][c]
+        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), f"plane {c}"
+    assert out["1"][1] == out["0"][1]
+    # and against the oracle
+    from tests.oracle_binding import OracleDiff, format_tbl as ofmt
+
+    o = OracleDiff(24, 1, 10, 10, 3, True)
+    for s, d in frames:
+        o.diff_frame(s, d, 1, 1)
+    assert out["1"][1] == ofmt(o.finish())
+
+
 def test_native_shard_driver_over_rccl():
     """tools/shard_native.cpp: the round protocol of include/g1s_diff.h driven from C++ -- one process, one generator per
     visible device, the per-round gather over RCCL (ncclSend / ncclRecv in a group, ncclCommInitAll) -- gives the table of a
