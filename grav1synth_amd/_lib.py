@@ -149,6 +149,7 @@ SYMBOLS = [
     ("g1s_shard_msg_size", C.c_size_t, [C.c_uint32, C.c_uint32]),
     ("g1s_shard_pack", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     ("g1s_shard_msg_from_latest", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]),
+    ("g1s_shard_msg_from_latest_at", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t]),
     ("g1s_shard_merge", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
     ("g1s_latest_from_record", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]),
     ("g1s_fold_push_latest", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),

@@ -28,13 +28,29 @@ NOT_OVERWRITING = "Not overwriting existing file. Exiting."
 
 
 def _confirm(prompt: str) -> bool:
-    """dialoguer::Confirm: y / n on the terminal; without a terminal nobody can say yes."""
+    """dialoguer::Confirm::interact()?: y / n on the terminal.  Without a terminal dialoguer returns an error, which the
+    reference's `?` turns into a non-zero exit (src/main.rs:382-394): the same here (main() reports it and returns 1)."""
     if not sys.stdin.isatty():
-        return False
+        raise OSError("IO error: not a terminal")
     try:
         return input(f"{prompt} [y/n] ").strip().lower() in ("y", "yes")
     except EOFError:
-        return False
+        raise OSError("IO error: unexpected end of input")
+
+
+def _same_path(a: str, b: str) -> bool:
+    """`PathBuf == PathBuf` as the reference compares its arguments (src/main.rs:354, :362): component by component, so
+    repeated separators, a trailing separator and `.` components inside the path do not matter (a leading `./` and `..` do:
+    std::path::Path::components)."""
+    def components(p: str):
+        parts = p.split("/")
+        out = ["/"] if p.startswith("/") else []
+        for i, c in enumerate(parts):
+            if c == "" or (c == "." and (i > 0 or p.startswith("/"))):
+                continue
+            out.append(c)
+        return out
+    return components(a) == components(b)
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -65,10 +81,10 @@ def diff_command(source: str, denoised: str, output: str, overwrite: bool = Fals
     from .filters import FilterChain, FilterError
     from .ingest import diff_y4m_files
 
-    if source == output or denoised == output:
+    if _same_path(source, output) or _same_path(denoised, output):
         log.error(SAME_AS_OUTPUT)
         return -1
-    if source == denoised:
+    if _same_path(source, denoised):
         log.error(SAME_INPUTS)
         return -1
     if filters is not None:
@@ -90,7 +106,7 @@ def estimate_command(source: str, output: str, overwrite: bool = False, device: 
     "{:.3}" line per frame (-1 for None), "Done, wrote output file to ...".  Returns the frame count, -1 after a refusal."""
     from .estimate import estimate_y4m_file
 
-    if source == output:
+    if _same_path(source, output):
         log.error(SAME_AS_OUTPUT)
         return -1
     if os.path.exists(output) and not overwrite and not confirm(f"File {output} exists. Overwrite?"):

@@ -1721,22 +1721,33 @@ int g1s_diff_take_latest(g1s_diff_t *g, int sync, void *buf, size_t cap_bytes, s
 //      merges) lives here; the transport (RCCL / MPI / torch.distributed gather of fixed-size buffers) stays with the host
 namespace {
 constexpr uint32_t kShardMagic = 0x4d315347u;  // "GS1M"
+constexpr uint32_t kShardNoIndex = 0xffffffffu;  // a message without a batch index: merged in arrival order
 struct ShardHeader {
   uint32_t magic, count, lag, batch_frames;
+  // which of the SENDING rank's batches this is (0, 1, ...): global batch = local_batch * world + rank.  The root merges
+  // by this index, not by arrival: ranks that have fed different numbers of batches (an idle rank in a short last round)
+  // send different local batches in the same round
+  uint32_t local_batch, reserved;
 };
 }  // namespace
 size_t g1s_shard_msg_size(uint32_t ar_coeff_lag, uint32_t batch_frames) {
   return ar_coeff_lag >= 1 && ar_coeff_lag <= 3 ? sizeof(ShardHeader) + (size_t)batch_frames * latest_blob_size(ar_coeff_lag) : 0;
 }
-int g1s_shard_msg_from_latest(const void *blobs, size_t n, uint32_t ar_coeff_lag, uint32_t batch_frames, void *msg, size_t cap_bytes) {
+int g1s_shard_msg_from_latest_at(const void *blobs, size_t n, uint32_t ar_coeff_lag, uint32_t batch_frames, uint64_t local_batch,
+                                 void *msg, size_t cap_bytes) {
   if (!msg || (!blobs && n) || ar_coeff_lag < 1 || ar_coeff_lag > 3 || n > batch_frames) return G1S_ERR_INVALID;
+  if (local_batch != G1S_SHARD_NO_INDEX && local_batch >= kShardNoIndex) return G1S_ERR_INVALID;
   const size_t total = g1s_shard_msg_size(ar_coeff_lag, batch_frames), bs = latest_blob_size(ar_coeff_lag);
   if (cap_bytes < total) return G1S_ERR_CAPACITY;
   std::memset(msg, 0, total);
-  const ShardHeader h{kShardMagic, (uint32_t)n, ar_coeff_lag, batch_frames};
+  const ShardHeader h{kShardMagic, (uint32_t)n, ar_coeff_lag, batch_frames,
+                      local_batch == G1S_SHARD_NO_INDEX ? kShardNoIndex : (uint32_t)local_batch, 0u};
   std::memcpy(msg, &h, sizeof(h));
   if (n) std::memcpy((uint8_t *)msg + sizeof(h), blobs, n * bs);
   return G1S_OK;
+}
+int g1s_shard_msg_from_latest(const void *blobs, size_t n, uint32_t ar_coeff_lag, uint32_t batch_frames, void *msg, size_t cap_bytes) {
+  return g1s_shard_msg_from_latest_at(blobs, n, ar_coeff_lag, batch_frames, G1S_SHARD_NO_INDEX, msg, cap_bytes);
 }
 int g1s_shard_pack(g1s_diff_t *g, int flush, void *msg, size_t cap_bytes) {
   if (!g || !msg) return G1S_ERR_INVALID;
@@ -1762,12 +1773,14 @@ int g1s_shard_pack(g1s_diff_t *g, int flush, void *msg, size_t cap_bytes) {
   }
   std::lock_guard<std::mutex> lk(g->dm);
   size_t n = 0;
+  uint64_t local_batch = G1S_SHARD_NO_INDEX;
   if (g->delivered < limit && !g->latest_batches.empty()) {  // ONE batch a round, the oldest not sent yet
     n = g->latest_batches.front();
     g->latest_batches.pop_front();
+    local_batch = g->delivered;  // (the message says which one: the root orders by it)
     g->delivered += 1;
   }
-  const int rc = g1s_shard_msg_from_latest(n ? g->latest_out.data() : nullptr, n, g->lag, g->batch, msg, cap_bytes);
+  const int rc = g1s_shard_msg_from_latest_at(n ? g->latest_out.data() : nullptr, n, g->lag, g->batch, local_batch, msg, cap_bytes);
   if (rc) return rc;
   g->latest_out.erase(g->latest_out.begin(), g->latest_out.begin() + n * bs);
   g->latest_out_frames -= n;
@@ -1793,6 +1806,9 @@ struct g1s_fold {
   std::vector<g1s_segment_t> final_segs;  // what finish() returned (kept: a too-small buffer can be retried)
   Pool *pool = nullptr;
   std::vector<FrameLatest> latest;
+  // g1s_shard_merge: indexed batches that arrived ahead of the next one in the global order (global batch -> its states)
+  std::map<uint64_t, std::vector<uint8_t>> early;
+  uint64_t next_batch = 0;
   g1s_fold(int64_t a, int64_t b, uint32_t lag_) : fold(a, b, lag_), lag(lag_) {}
 };
 
@@ -1882,6 +1898,11 @@ int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, 
 }
 int g1s_fold_finish(g1s_fold_t *f, g1s_segment_t *out, size_t cap, size_t *n_out) {
   if (!f) return G1S_ERR_INVALID;
+  if (!f->early.empty()) {  // (a caller that stopped before the flush rounds, or a rank that skipped a batch)
+    f->err = "frame-shard merge: batch " + std::to_string(f->next_batch) + " never arrived (" + std::to_string(f->early.size()) +
+             " later batch(es) are waiting for it)";
+    return G1S_ERR_STATE;
+  }
   if (!f->finished) {
     f->fold.finish(f->final_segs);
     f->finished = true;  // no more records; the segments stay here, so a too-small buffer can be retried
@@ -1897,9 +1918,11 @@ int g1s_fold_finish(g1s_fold_t *f, g1s_segment_t *out, size_t cap, size_t *n_out
 }
 int g1s_shard_merge(g1s_fold_t *f, const void *msgs, size_t stride_bytes, uint32_t world) {
   if (!f || !msgs || !world) return G1S_ERR_INVALID;
-  // global frame order: rounds in order (the caller's job), within a round the ranks in order -- batch j of the video
-  // went to rank j % world
-  for (uint32_t r = 0; r < world; ++r) {
+  // Global frame order: batch j of the video went to rank j % world, and a message says which of its rank's batches it
+  // carries, so global batch = local_batch * world + rank.  Batches are merged strictly in that order; one that arrives
+  // before its predecessors (a rank that has fed fewer batches sends an older local batch in the same round) waits here.
+  // Messages without an index (g1s_shard_msg_from_latest) are merged as they come: rounds in order, ranks in order.
+  for (uint32_t r = 0; r < world; ++r) {  // (validate the whole round before merging any of it)
     const uint8_t *m = (const uint8_t *)msgs + (size_t)r * stride_bytes;
     ShardHeader h;
     std::memcpy(&h, m, sizeof(h));
@@ -1908,9 +1931,41 @@ int g1s_shard_merge(g1s_fold_t *f, const void *msgs, size_t stride_bytes, uint32
       f->err = "bad shard message from rank " + std::to_string(r);
       return G1S_ERR_INVALID;
     }
+  }
+  const size_t bs = latest_blob_size(f->lag);
+  for (uint32_t r = 0; r < world; ++r) {
+    const uint8_t *m = (const uint8_t *)msgs + (size_t)r * stride_bytes;
+    ShardHeader h;
+    std::memcpy(&h, m, sizeof(h));
     if (!h.count) continue;
-    const int rc = g1s_fold_push_latest(f, m + sizeof(h), latest_blob_size(h.lag), h.count);
-    if (rc) return rc;
+    if (h.local_batch == kShardNoIndex) {
+      if (!f->early.empty()) {
+        f->err = "frame-shard merge: a message without a batch index while indexed batches are waiting";
+        return G1S_ERR_STATE;
+      }
+      const int rc = g1s_fold_push_latest(f, m + sizeof(h), bs, h.count);
+      if (rc) return rc;
+      continue;
+    }
+    const uint64_t j = (uint64_t)h.local_batch * world + r;
+    if (j < f->next_batch || f->early.count(j)) {
+      f->err = "frame-shard merge: batch " + std::to_string(j) + " arrived twice (rank " + std::to_string(r) + ")";
+      return G1S_ERR_STATE;
+    }
+    if (j == f->next_batch) {
+      const int rc = g1s_fold_push_latest(f, m + sizeof(h), bs, h.count);
+      if (rc) return rc;
+      ++f->next_batch;
+    } else {
+      f->early.emplace(j, std::vector<uint8_t>(m + sizeof(h), m + sizeof(h) + (size_t)h.count * bs));
+    }
+    while (!f->early.empty() && f->early.begin()->first == f->next_batch) {
+      const std::vector<uint8_t> &v = f->early.begin()->second;
+      const int rc = g1s_fold_push_latest(f, v.data(), bs, v.size() / bs);
+      if (rc) return rc;
+      f->early.erase(f->early.begin());
+      ++f->next_batch;
+    }
   }
   return G1S_OK;
 }

@@ -193,7 +193,8 @@ int g1s_filters_apply(const g1s_filters_t *f, const g1s_frame_t *in, g1s_frame_t
         return G1S_ERR_UNSUPPORTED;
       }
       // crop: the frame must keep at least one sample, and with decimated chroma the cut must fall on a chroma sample
-      if (x.left + x.right >= fr.width || x.top + x.bottom >= fr.height) {
+      // (each amount on its own: the parser accepts anything up to UINT64_MAX and a sum would wrap)
+      if (x.left >= fr.width || x.right >= fr.width - x.left || x.top >= fr.height || x.bottom >= fr.height - x.top) {
         set_err(err, errcap, "crop:top=" + std::to_string(x.top) + ",bottom=" + std::to_string(x.bottom) + ",left=" + std::to_string(x.left) +
                                  ",right=" + std::to_string(x.right) + " leaves nothing of a " + std::to_string(fr.width) + "x" +
                                  std::to_string(fr.height) + " frame");

@@ -113,11 +113,16 @@ Plane = Union[np.ndarray, "torch.Tensor"]
 class Frame:
     """A decoded frame: 1 or 3 planes (Y, U, V), u8 or u16 samples, like the
     `v_frame::Frame<T>` built at src/reader.rs:183-209.  Planes may be numpy
-    arrays (host) or torch tensors (host or HIP device)."""
+    arrays (host) or torch tensors (host or HIP device).
+
+    Host planes are copied before diff_frame returns (the `&Frame` borrow of the reference).  `async_host=True`
+    (pinned torch tensors only) queues the copies on the upload stream instead and returns at once: the caller
+    must not touch the planes until `DiffGenerator.frames_copied()` covers the frame."""
 
     planes: Sequence[Plane]
     xdec: int = 1
     ydec: int = 1
+    async_host: bool = False
 
     def to_c(self, keep: list) -> G1SFrame:
         f = G1SFrame()
@@ -133,7 +138,10 @@ class Frame:
                 isz = p.element_size()
                 f.data[i] = p.data_ptr()
                 f.stride_bytes[i] = p.stride(0) * isz
-                dev = 1 if p.is_cuda else (2 if p.is_pinned() else 0)  # pinned host tensors: copied asynchronously
+                if self.async_host and not p.is_cuda and not p.is_pinned():
+                    raise ValueError("async_host needs pinned host tensors")
+                # (a pinned tensor is usually a staging buffer its owner refills: synchronous unless asked otherwise)
+                dev = 1 if p.is_cuda else (2 if self.async_host else 0)
             else:
                 p = np.asarray(p)
                 if p.strides[1] != p.dtype.itemsize:
@@ -141,6 +149,8 @@ class Frame:
                 isz = p.dtype.itemsize
                 f.data[i] = p.ctypes.data
                 f.stride_bytes[i] = p.strides[0]
+                if self.async_host:
+                    raise ValueError("async_host needs pinned host tensors")
                 dev = 0
             if on_dev is None:
                 on_dev = dev
@@ -209,6 +219,11 @@ class DiffGenerator:
             done = int(self._L.g1s_diff_frames_released(self._h))
             while self._keep and self._keep[0][0] <= done:
                 self._keep.popleft()
+
+    def frames_copied(self, wait_for: int = 0) -> int:
+        """g1s_diff_frames_copied: frame pairs whose host planes (Frame(..., async_host=True)) have been copied -- their
+        buffers may be refilled.  wait_for = k blocks until frame pair k (1-based count) has been copied."""
+        return int(self._L.g1s_diff_frames_copied(self._h, int(wait_for)))
 
     def frames_released(self) -> int:
         """g1s_diff_frames_released: frame pairs whose planes the generator no longer reads."""

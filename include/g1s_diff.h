@@ -168,14 +168,23 @@ int g1s_diff_take_latest(g1s_diff_t *, int sync, void *buf, size_t cap_bytes, si
  * and rank 0 hands the N gathered messages, rank order, to g1s_shard_merge.  After the last feeding round every rank runs
  * 4 more rounds with flush = 1 (the batches still in the generator's pipeline).  Rank 0's fold then finishes the table:
  * identical, byte for byte, to one generator fed the whole video (the states are exact; only their merge is ordered).
- * Message = 16-byte header + batch_frames latest states (g1s_latest_size() each, ~27 KB): N x 0.9 MB a round at 4K. */
+ * Message = 24-byte header + batch_frames latest states (g1s_latest_size() each, ~27 KB): N x 0.9 MB a round at 4K.
+ * The header says WHICH of the sending rank's batches the message carries; the root merges by that index (global batch =
+ * local batch * N + rank), so ranks that have fed different numbers of batches -- the idle rank of a short last round is
+ * one feed behind -- may send different local batches in the same round: a batch that arrives before its predecessors
+ * waits inside the fold, and g1s_fold_finish refuses (G1S_ERR_STATE) while one is still missing. */
 size_t g1s_shard_msg_size(uint32_t ar_coeff_lag, uint32_t batch_frames);
 /* This rank's message of the round: the latest states of ONE batch -- the oldest one not sent yet among those fed before
  * the two most recent feeds (flush = 0: the same batch index on every rank, however far each runs ahead; waits for it)
  * or among all (flush = 1: drains the generator first) -- or an empty message.  records_only = 2 generators. */
 int g1s_shard_pack(g1s_diff_t *, int flush, void *msg, size_t cap_bytes);
-/* A message from latest states made elsewhere (g1s_latest_from_record): n <= batch_frames. */
+/* A message from latest states made elsewhere (g1s_latest_from_record): n <= batch_frames.  Without a batch index: the
+ * root merges such messages as they come (rounds in order, ranks in order) -- the caller keeps its ranks in lock step. */
 int g1s_shard_msg_from_latest(const void *blobs, size_t n, uint32_t ar_coeff_lag, uint32_t batch_frames, void *msg, size_t cap_bytes);
+/* The same with the index of the batch among the sending rank's batches (0, 1, ...; G1S_SHARD_NO_INDEX: none). */
+#define G1S_SHARD_NO_INDEX UINT64_MAX
+int g1s_shard_msg_from_latest_at(const void *blobs, size_t n, uint32_t ar_coeff_lag, uint32_t batch_frames, uint64_t local_batch,
+                                 void *msg, size_t cap_bytes);
 size_t g1s_latest_size(uint32_t ar_coeff_lag);
 /* The per-frame half of the fold on the host: record -> latest state.  Thread-safe.  A frame
  * that fails (not enough flat blocks, singular system) yields a blob that carries the error;
@@ -193,8 +202,8 @@ int g1s_fold_push(g1s_fold_t *, const void *record, size_t size_bytes);
 int g1s_fold_push_many(g1s_fold_t *, const void *records, size_t stride_bytes, size_t n);
 /* n latest states, stride_bytes apart, in frame order: the ordered half only. */
 int g1s_fold_push_latest(g1s_fold_t *, const void *blobs, size_t stride_bytes, size_t n);
-/* Rank 0: the `world` gathered messages of one round, stride_bytes apart, rank order -> the ordered merge.  Rounds must
- * be merged in order. */
+/* Rank 0: the `world` gathered messages of one round, stride_bytes apart, rank order -> the ordered merge (by the batch
+ * index the messages carry; messages without one: rounds must be merged in order). */
 int g1s_shard_merge(g1s_fold_t *, const void *msgs, size_t stride_bytes, uint32_t world);
 /* Same contract as g1s_diff_finish: G1S_ERR_CAPACITY leaves the segments in place for a second call. */
 int g1s_fold_finish(g1s_fold_t *, g1s_segment_t *out, size_t cap, size_t *n_out);

@@ -1,8 +1,10 @@
 """python -m tests.dist_gpu_worker OUT.tbl -- one rank of a frame-shard job (tests/test_gpu_parity.py launches two of these on ONE
 device with the gloo backend, the way G1S_BENCH_SHARE_GPU=1 runs bench.py --gpus N on a single-GPU box).
 
-The job: 10 frame pairs in batches of 2 -> FIVE batches for two ranks (rank 0: batches 0, 2, 4; rank 1: batches 1, 3 and an
-idle round), a scene cut at frame 5, i.e. inside batch 2.  Rank 0 writes the table."""
+The job: G1S_TEST_BATCHES (default 5) batches of 2 frame pairs; with an odd count rank 1 sits out the last round (five batches:
+rank 0: batches 0, 2, 4; rank 1: batches 1, 3 and an idle round) and is from then on one feed behind rank 0 -- with 7 or 9
+batches the ranks then send different local batches in the same round and the root must order by the index the
+messages carry.  A scene cut in the middle of the video, inside a batch.  Rank 0 writes the table."""
 import os
 import sys
 from fractions import Fraction
@@ -17,8 +19,16 @@ from grav1synth_amd.synth import SynthSpec, make_pair
 FPS = Fraction(30000, 1001)
 A = SynthSpec(320, 192, 8)
 B = SynthSpec(320, 192, 8, gain_scale=3)
-SPECS = [A] * 5 + [B] * 5
 BATCH = 2
+
+
+def specs(nbatches: int = 5):
+    """nbatches batches of BATCH frame pairs; the scene changes in the middle of the video, inside a batch"""
+    n = nbatches * BATCH
+    return [A] * (n // 2) + [B] * (n - n // 2)
+
+
+SPECS = specs(int(os.environ.get("G1S_TEST_BATCHES", "5")))
 
 
 def main(out_path):

@@ -107,3 +107,33 @@ def test_front_door_refusals(tmp_path, caplog):
         assert caplog.records[-1].getMessage() == cli.NOT_OVERWRITING and caplog.records[-1].levelname == "WARNING"
         assert open(out).read() == "keep me"
     assert cli.main(["diff", a, a, "-o", out]) == 0  # a refusal is not a failure (`return Ok(())`)
+
+
+def test_front_door_compares_paths_like_pathbuf_and_fails_without_a_terminal(tmp_path, monkeypatch):
+    """ADVICE r02: the reference compares PathBuf values (src/main.rs:354, :362): `a//b`, `a/./b`, `a/b/` are the path `a/b`;
+    and dialoguer's Confirm::interact()? is an error without a terminal -- a non-zero exit, not a quiet refusal."""
+    import io
+
+    from grav1synth_amd import cli
+
+    d = str(tmp_path)
+    assert cli._same_path(d + "/a.y4m", d + "//a.y4m") and cli._same_path(d + "/./a.y4m", d + "/a.y4m")
+    assert cli._same_path("x/y/", "x/y") and not cli._same_path("./x", "x") and not cli._same_path("x/../x", "x")
+    assert cli.diff_command(d + "/a.y4m", d + "/b.y4m", d + "//a.y4m") == -1
+    assert cli.diff_command(d + "/a.y4m", d + "/./a.y4m", d + "/o.tbl") == -1
+    out = str(tmp_path / "o.tbl")
+    open(out, "w").write("keep me")
+    monkeypatch.setattr("sys.stdin", io.StringIO(""))  # not a terminal
+    assert cli.main(["diff", d + "/a.y4m", d + "/b.y4m", "-o", out]) == 1
+    assert cli.main(["estimate", d + "/a.y4m", "-o", out]) == 1
+    assert open(out).read() == "keep me"
+
+
+def test_crop_amounts_that_would_wrap_a_sum_are_refused():
+    """`crop:left=18446744073709551615,right=1` must not pass the bounds check by wrapping to 0."""
+    y = np.zeros((64, 96), np.uint8)
+    for chain in ("crop:left=18446744073709551615,right=1", "crop:top=18446744073709551615,bottom=1",
+                  "crop:left=96", "crop:right=18446744073709551615"):
+        with pytest.raises(FilterError, match="leaves nothing"):
+            FilterChain(chain).apply(Frame([y], 1, 1))
+    assert FilterChain("crop:left=95").apply(Frame([y], 1, 1)).planes[0].shape == (64, 1)

@@ -94,17 +94,21 @@ def test_records_and_table_match_oracle(case):
     assert mine == tbl
 
 
-def test_two_ranks_stream_a_sharded_job_on_one_device(tmp_path):
-    """StreamingShardedDiff -- the class `bench.py --gpus N` runs -- with TWO ranks (gloo, both on this one GPU): five
-    batches dealt round-robin (an odd count: rank 1 sits out the last round), a scene cut inside a batch, the
-    lock-step exchange of latest states, the ordered merge on rank 0.  The table must be the single generator's and
-    the oracle's, byte for byte."""
+@pytest.mark.parametrize("nbatches,no_defer", [(5, False), (7, False), (9, False), (5, True), (8, False)])
+def test_two_ranks_stream_a_sharded_job_on_one_device(tmp_path, nbatches, no_defer):
+    """StreamingShardedDiff -- the class `bench.py --gpus N` runs -- with TWO ranks (gloo, both on this one GPU): batches
+    dealt round-robin (an odd count: rank 1 sits out the last round and is one feed behind from then on -- with 7 and 9
+    batches, and with 5 under G1S_NO_DEFER, the ranks send different local batches in the same round: the root orders by
+    the batch index in the message), a scene cut inside a batch, the exchange of latest states, the ordered merge on
+    rank 0.  The table must be the single generator's and the oracle's, byte for byte."""
     import os
     import socket
     import subprocess
     import sys
 
     from tests import dist_gpu_worker as w
+
+    SPECS = w.specs(nbatches)
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -114,7 +118,9 @@ def test_two_ranks_stream_a_sharded_job_on_one_device(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   G1S_FOLD_THREADS="4")
+                   G1S_FOLD_THREADS="4", G1S_TEST_BATCHES=str(nbatches))
+        if no_defer:
+            env["G1S_NO_DEFER"] = "1"
         procs.append(subprocess.Popen([sys.executable, "-m", "tests.dist_gpu_worker", out], env=env, cwd=root,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -127,10 +133,10 @@ def test_two_ranks_stream_a_sharded_job_on_one_device(tmp_path):
             raise
         logs.append(o)
     assert all(p.returncode == 0 for p in procs), "\n".join(x[-1500:] for x in logs)
-    want, segs = oracle_run(w.A, range(len(w.SPECS)), fps=w.FPS, specs_per_frame=w.SPECS)
+    want, segs = oracle_run(w.A, range(len(SPECS)), fps=w.FPS, specs_per_frame=SPECS)
     assert len(segs) >= 2
     g = DiffGenerator(w.FPS, 8, 8, batch_frames=w.BATCH)
-    for k, sp in enumerate(w.SPECS):
+    for k, sp in enumerate(SPECS):
         s, d = make_pair(sp, k, device="cuda")
         g.diff_frame(s, d, 1, 1)
     single = format_tbl(g.finish())
@@ -252,23 +258,44 @@ def test_cropped_device_frames_equal_the_oracle():
 
 
 def test_pinned_host_frames_are_copied_asynchronously_and_give_the_same_table():
-    """N2: on_device = 2 (pinned host planes): g1s_diff_frame queues the copies and returns; g1s_diff_frames_copied
-    says when the planes may be reused; the table is the oracle's."""
+    """N2: on_device = 2 (pinned host planes, Frame(..., async_host=True)): g1s_diff_frame queues the copies and returns;
+    g1s_diff_frames_copied says when the planes may be reused; the table is the oracle's."""
     spec = SynthSpec(322, 190, 10)
     want, _ = oracle_run(spec, range(5))
     g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=2)
-    L = g._L
     for k in range(5):
         s, d = np_pair(spec, k)
         ps = [torch.from_numpy(p).pin_memory() for p in s]
         pd = [torch.from_numpy(p).pin_memory() for p in d]
-        f = Frame(ps, spec.xdec, spec.ydec)
+        f = Frame(ps, spec.xdec, spec.ydec, async_host=True)
         assert f.to_c([]).on_device == 2
-        g.diff_frame(f, Frame(pd, spec.xdec, spec.ydec))
-        assert L.g1s_diff_frames_copied(g._h, 0) <= k + 1
-        assert L.g1s_diff_frames_copied(g._h, k + 1) == k + 1  # wait for this frame: now its planes may be overwritten
+        g.diff_frame(f, Frame(pd, spec.xdec, spec.ydec, async_host=True))
+        assert g.frames_copied() <= k + 1
+        assert g.frames_copied(k + 1) == k + 1  # wait for this frame: now its planes may be overwritten
         for p in ps + pd:
             p.fill_(0)
+    assert format_tbl(g.finish()) == want
+
+
+def test_pinned_staging_buffers_can_be_refilled_right_after_diff_frame():
+    """a pinned tensor is usually a staging buffer its owner refills; without async_host the planes are
+    copied before diff_frame returns (the `&Frame` borrow), so ONE pair of pinned buffers can carry every frame."""
+    spec = SynthSpec(322, 190, 10)
+    want, _ = oracle_run(spec, range(5))
+    g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=2)
+    s0, d0 = np_pair(spec, 0)
+    ps = [torch.from_numpy(p.copy()).pin_memory() for p in s0]
+    pd = [torch.from_numpy(p.copy()).pin_memory() for p in d0]
+    assert Frame(ps, spec.xdec, spec.ydec).to_c([]).on_device == 0
+    with pytest.raises(ValueError):
+        Frame([p.numpy() for p in ps], spec.xdec, spec.ydec, async_host=True).to_c([])
+    for k in range(5):
+        s, d = np_pair(spec, k)
+        for t, p in zip(ps + pd, list(s) + list(d)):
+            t.copy_(torch.from_numpy(p))
+        g.diff_frame(Frame(ps, spec.xdec, spec.ydec), Frame(pd, spec.xdec, spec.ydec))
+        for t in ps + pd:
+            t.fill_(0)
     assert format_tbl(g.finish()) == want
 
 

@@ -9,7 +9,7 @@ from fractions import Fraction
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from grav1synth_amd.diff import DiffGenerator
+from grav1synth_amd.diff import DiffGenerator, Frame
 from grav1synth_amd.ingest import diff_y4m_files, write_y4m
 from grav1synth_amd.synth import SynthSpec, make_pair
 
@@ -39,7 +39,7 @@ for rep in range(2):
     t0 = time.perf_counter()
     for k in range(n):
         s, d = pinned[k % 8]
-        g.diff_frame(s, d, 1, 1)
+        g.diff_frame(Frame(s, 1, 1, async_host=True), Frame(d, 1, 1, async_host=True))
     g.finish()
     dt = time.perf_counter() - t0
     g.close()
