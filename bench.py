@@ -98,7 +98,7 @@ def main() -> None:
 
     # ---- synthetic frame pairs, resident in HBM before any timed region ----
     # N > 1: the video is dealt to the ranks batch by batch (global batch j -> rank j % N)
-    B = max(1, min(args.batch, 32))
+    B = max(1, args.batch)  # (frames per launch, the same at any N; what the line reports as config.batch_frames)
     frames = []
     for k in range(F):
         gid = ((k // B) * world + rank) * B + (k % B) if world > 1 else k
@@ -195,6 +195,9 @@ def main() -> None:
 
     def own_bytes(name):
         """algorithmic bytes one launch of this kernel exists to read, per frame pair (None: not a pixel kernel)"""
+        if name.startswith("k3s_fused"):
+            t = [x.strip(" >") for x in name.split("<")[1].split(",")]
+            return 2 * bps * W * H if t[3] == "0" else 2 * bps * 2 * cpx
         if name.startswith("k3f_fused"):
             t = [x.strip(" >") for x in name.split("<")[1].split(",")]
             if t[4] == "1":  # staging the int8 planes of the pixel pass
@@ -244,7 +247,8 @@ def main() -> None:
             "frames_per_rank_per_step": FJ,
             "resident_frames_per_rank": F,
             "batch_frames": args.batch,
-            "accumulation": {"fused": "exact int8 SYRK on the matrix cores (v_mfma_i32_32x32x32_i8), residual fused into the consumer -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01",
+            "accumulation": {"stream": "exact int8 SYRK on the matrix cores (v_mfma_i32_16x16x64_i8 on operand pairs, one LDS operand read per 64 samples), residual fused into the consumer, two tile buffers -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01",
+                             "fused": "exact int8 SYRK on the matrix cores (v_mfma_i32_32x32x32_i8), residual fused into the consumer -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01",
                              "planes": "pixel pass K0 -> int8 planes -> exact int8 SYRK on the matrix cores",
                              "dot4": "round 1: pixel pass K0 -> int8 planes -> lag-structured v_dot4 kernels"}[os.environ.get("G1S_K3", "fused")],
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,

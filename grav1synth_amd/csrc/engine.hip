@@ -29,6 +29,7 @@
 #include "k3q.hip.h"
 #include "k3m.hip.h"
 #include "k3f.hip.h"
+#include "k3s.hip.h"
 #include "record.h"
 
 using namespace g1s;
@@ -59,13 +60,15 @@ int k3_mode() {
     const char *e = getenv("G1S_K3");
     if (e && std::strcmp(e, "dot4") == 0) return 0;
     if (e && std::strcmp(e, "planes") == 0) return 2;
+    if (e && std::strcmp(e, "stream") == 0) return 3;
     return 1;
   }();
   return v;
 }
 bool use_mfma() { return k3_mode() != 0; }
-bool use_k0() { return k3_mode() != 1; }
+bool use_k0() { return k3_mode() == 0 || k3_mode() == 2; }
 bool use_planes() { return k3_mode() == 2; }
+bool use_stream() { return k3_mode() == 3; }  // k3s.hip.h: the second-generation fused pass
 constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per CU, one round
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
 int m_wgs_per_frame(int nunits, int B) {
@@ -560,7 +563,7 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
   // L plane of a frame: block rows x chunk columns at chroma resolution (+ a slack row)
   m_lpitch = g.nplanes == 3 ? (uint32_t)((((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * kMUnitBlocks * (kBlock >> g.xdec) + 15) & ~15) : 0u;
   m_lframe = m_lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec) + 1);
-  const size_t lplane_bytes = k3_mode() == 1 ? (size_t)m_lframe * batch : 0;
+  const size_t lplane_bytes = (k3_mode() == 1 || k3_mode() == 3) ? (size_t)m_lframe * batch : 0;
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
                      partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes, mpart_bytes, lplane_bytes,
                      g.W, g.H, g.xdec, g.ydec, g.nplanes};
@@ -1046,7 +1049,9 @@ int g1s_diff::launch_back(int si) {
     { const char *e = getenv("G1S_F_REUSE"); fq.reuse = e ? atoi(e) : 1; }  // test / tuning aid (0: every halo word is read)
     fq.planes = sl.d_k0;
     fq.ps = ps;
-    const bool planes = use_planes();
+    static const int s_dbg = getenv("G1S_S_DBG") ? atoi(getenv("G1S_S_DBG")) : 0;  // timing experiments: parts of k3s_fused left out (wrong results)
+    fq.dbg = s_dbg;
+    const bool planes = use_planes(), stream_mode = use_stream();
     const dim3 gr((uint32_t)G * B);
     const int bpsm = g.src_bps == g.den_bps ? g.src_bps : 0;  // bytes per sample at compile time unless the depths are mixed
     // two launches: the luma plane (which leaves L behind), then the two chroma planes
@@ -1058,12 +1063,18 @@ int g1s_diff::launch_back(int si) {
     static const hipError_t attr_rp = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, 1, PL, 1>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
     (void)attr_rp;                                                                                                   \
-    const size_t lds = std::min((size_t)f_lds_bytes(CW, CH, PL) + lds_pad, (size_t)144 * 1024);                     \
+    static const hipError_t attr_rs = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3s_fused<CW, CH, BP, PL>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
+    (void)attr_rs;                                                                                                   \
+    const size_t lds = std::min((size_t)(stream_mode ? s_lds_bytes(CW, CH, PL) : f_lds_bytes(CW, CH, PL)) + lds_pad, \
+                                (size_t)144 * 1024);                                                                 \
     char kn_[64];                                                                                                    \
-    snprintf(kn_, sizeof(kn_), "k3f_fused<%d, %d, %d, %d, %d>", CW, CH, planes ? 1 : BP, PL, planes ? 1 : 0);        \
+    if (stream_mode) snprintf(kn_, sizeof(kn_), "k3s_fused<%d, %d, %d, %d>", CW, CH, BP, PL);                        \
+    else snprintf(kn_, sizeof(kn_), "k3f_fused<%d, %d, %d, %d, %d>", CW, CH, planes ? 1 : BP, PL, planes ? 1 : 0);   \
     kmark(sl, stream, kn_);                                                                                          \
     fq.phase_cycles = phases == PL + 1 ? phase_buf : nullptr;                                                        \
-    if (planes) hipLaunchKernelGGL((k3f_fused<CW, CH, 1, PL, 1>), gr, dim3(kFThreads), lds, stream, g, fq);          \
+    if (stream_mode) hipLaunchKernelGGL((k3s_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);       \
+    else if (planes) hipLaunchKernelGGL((k3f_fused<CW, CH, 1, PL, 1>), gr, dim3(kFThreads), lds, stream, g, fq);     \
     else hipLaunchKernelGGL((k3f_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);                   \
   } while (0)
 #define G1S_FS(CW, CH, PL)                 \
