@@ -83,6 +83,33 @@ __host__ __device__ constexpr int s_lds_bytes(int CBW, int CBH, int PL) { return
 
 typedef int v4i32s __attribute__((ext_vector_type(4)));
 
+// timing experiments (FParams::dbg, G1S_S_DBG): parts of the kernel left out -- only in builds with -DG1S_S_DBG_BUILD (a
+// wave-uniform test costs the hot loop three instructions a time)
+#ifdef G1S_S_DBG_BUILD
+#define G1S_S_DBGBIT(bit) ((dbg & (bit)) != 0)
+#else
+#define G1S_S_DBGBIT(bit) false
+#endif
+
+// a raw 8-sample word -> packed 16-bit pairs 0x00vv00vv of the narrowed samples (f_narrow with plain 32-bit shifts: what the
+// shift drags from the upper sample into the lower one is masked away)
+template <int BPS>
+__device__ __forceinline__ void s_narrow(const u32x4 &v, int rbps, int shift, uint32_t (&h)[4]) {
+  if (f_bps<BPS>(rbps) == 2) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = (w[k] >> shift) & 0x00ff00ffu;
+  } else {
+    f_narrow<BPS>(v, rbps, shift, h);
+  }
+}
+// residuals of a word; acc |= (d + 128) of every residual: some d outside -128 .. 127 <=> (acc & 0xff00ff00) != 0
+__device__ __forceinline__ void s_residual(const uint32_t (&hs)[4], const uint32_t (&hv)[4], uint32_t (&d16)[4], uint32_t &acc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) d16[q] = pk_sub(hs[q], hv[q]);
+  acc = acc | pk_add(d16[0], 0x00800080u) | pk_add(d16[1], 0x00800080u);
+  acc = acc | pk_add(d16[2], 0x00800080u) | pk_add(d16[3], 0x00800080u);
+}
 // NSTEP steps of RS rows from lane address a0 (the P operand of the first step), pitch P.  MASKED: `rm` bit j * RS says
 // whether the lane's sample row of step j lies inside its block's window rows (a sample outside contributes nothing: both
 // operands of the step are zeroed for the lane's k-group -- copies of them, the tile rows stay what they are for the next step)
@@ -138,8 +165,6 @@ __device__ __forceinline__ uint32_t s_flag_bits(int wd, int WB) {
   if (wd - b * WB <= 1 && b >= 1) r |= 1u << (b - 1);
   return r;
 }
-// running max (>= 0) / min (<= 0) of packed i16 -> packed max |v|: some |v| > 127 <=> (result & 0xff80ff80) != 0
-__device__ __forceinline__ uint32_t s_range_word(uint32_t mx, uint32_t mn) { return pk_max(mx, pk_sub(0u, mn)); }
 
 // control word of iteration k (one LDS read for everything uniform the iteration needs):
 //   .x  unit k + 3: chunk | block row << 12 | fast << 29 | right neighbour follows << 30 | left neighbour precedes << 31
@@ -206,6 +231,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
   // aligned, no word straddling the right plane edge)
   const bool reuse = LUMA && fpar.reuse && vec_all && (g.W & 7) == 0;
   const int dbg = fpar.dbg;
+  (void)dbg;
 
   // ---- this lane's operand address inside a buffer ----
   const int mi = lane & 15, mg = lane >> 4;
@@ -341,23 +367,25 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
 
   // ux: the unit's control .x (chunk, block row, fast, right, left)
   auto request = [&](uint32_t ux) __attribute__((always_inline)) {
-    if (dbg & 1) return;
+    if (G1S_S_DBGBIT(1)) return;
     const int bx0 = kMUnitBlocks * (int)(ux & 0xfffu), by = (int)((ux >> 12) & 0xfffu);
     const int X0y = bx0 * 32 - 8, Y0y = by * kBlock - 4, X0c = bx0 * CW_ - 8, Y0c = by * CH_ - 3;
     if constexpr (CHROMA) {
       if (l_on) lraw = *reinterpret_cast<const uint2 *>(lplane + (size_t)(by * CH_ + l_row) * fpar.lpitch + bx0 * CW_ + 8 * l_wd);
     }
     if (LUMA && y_wave) {
-      const uint8_t *sb = fp.src[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.src_stride[0] + (ptrdiff_t)X0y * sbps);
-      const uint8_t *db = fp.den[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.den_stride[0] + (ptrdiff_t)X0y * dbps);
-      if ((ux >> 29) & 1u) {  // the fast path: every lane loads at its constant offset
+      if ((ux >> 29) & 1u) {  // the fast path: every lane loads at its constant offset (the origin lies inside the plane)
+        const uint8_t *sb = fp.src[0] + ((uint32_t)Y0y * fp.src_stride[0] + (uint32_t)(X0y * sbps));
+        const uint8_t *db = fp.den[0] + ((uint32_t)Y0y * fp.den_stride[0] + (uint32_t)(X0y * dbps));
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          ys_[r] = f_load<BPS>(sb, y_los[r], g.src_bps, true);
-          yd_[r] = f_load<BPS>(db, y_lod[r], g.den_bps, true);
+          ys_[r] = f_load<BPS>(sb, y_los[r], g.src_bps, true);  // (f_load hides the offset from the optimiser: it would turn
+          yd_[r] = f_load<BPS>(db, y_lod[r], g.den_bps, true);  //  base + offset into 64-bit lane addresses, and spill)
         }
         return;
       }
+      const uint8_t *sb = fp.src[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.src_stride[0] + (ptrdiff_t)X0y * sbps);
+      const uint8_t *db = fp.den[0] + ((ptrdiff_t)Y0y * (ptrdiff_t)fp.den_stride[0] + (ptrdiff_t)X0y * dbps);
       // the general path: halo lanes read their words unless a neighbour holds them, everything inside the plane
       const bool aL = (ux >> 31) != 0, aR = ((ux >> 30) & 1u) != 0;
       const bool slow = !vec_all || ((g.W & 7) != 0 && X0y + 8 * SH::WY > g.W);
@@ -412,7 +440,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
   // aL / fast: of unit k.
   auto form = [&](int k, bool aL, bool fast) __attribute__((always_inline)) {
     const int slot = k & 3;
-    if (dbg & 2) {
+    if (G1S_S_DBGBIT(2)) {
       if (LUMA && y_wave) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -428,14 +456,14 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
       return;
     }
     if (LUMA && y_wave) {
-      uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0, d16[2][4];
+      uint32_t racc = 0, lacc = 0, d16[2][4];
       int sd = 0, sd2 = 0, ls = 0;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         uint32_t hs[4], hv[4];
-        f_narrow<BPS>(ys_[r], g.src_bps, g.src_shift, hs);
-        f_narrow<BPS>(yd_[r], g.den_bps, g.den_shift, hv);
-        f_residual(hs, hv, d16[r], mx, mn);
+        s_narrow<BPS>(ys_[r], g.src_bps, g.src_shift, hs);
+        s_narrow<BPS>(yd_[r], g.den_bps, g.den_shift, hv);
+        s_residual(hs, hv, d16[r], racc);
         Dn[r][0] = pk_bytes(d16[r][0], d16[r][1]);
         Dn[r][1] = pk_bytes(d16[r][2], d16[r][3]);
         // (every lane sums; the lanes outside the block's own rows and words drop theirs into a dummy below)
@@ -446,7 +474,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
         ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[0], hs[1]), 0u, (uint32_t)ls);
         ls = (int)__builtin_amdgcn_sad_u8(pk_bytes(hs[2], hs[3]), 0u, (uint32_t)ls);
       }
-      if (!(dbg & 4)) {
+      if (!G1S_S_DBGBIT(4)) {
         // int8 arithmetic: a block that holds a residual outside int8 is redone by the exact kernel, statistics included
         unsigned long long *tgt = &s_sum[slot][y_stat ? 0 : 3][y_bq];
         atomicAdd(tgt, ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)(uint32_t)ls << 19) | (unsigned long long)(uint32_t)(sd + kFBiasY));
@@ -465,34 +493,30 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
           if (sx) {
             const uint32_t p0 = ((uint32_t)pk_dot(v[0], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[1], 0x00010001u, 0) << 16);
             const uint32_t p1 = ((uint32_t)pk_dot(v[2], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[3], 0x00010001u, 0) << 16);
-            lmx = pk_max(lmx, pk_max(p0, p1));
-            lmn = pk_min(lmn, pk_min(p0, p1));
+            lacc = lacc | pk_add(p0, 0x00800080u) | pk_add(p1, 0x00800080u);
             *reinterpret_cast<uint32_t *>(lp) = pk_bytes(p0, p1);
           } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              lmx = pk_max(lmx, v[q]);
-              lmn = pk_min(lmn, v[q]);
-            }
+            lacc = lacc | pk_add(v[0], 0x00800080u) | pk_add(v[1], 0x00800080u);
+            lacc = lacc | pk_add(v[2], 0x00800080u) | pk_add(v[3], 0x00800080u);
             *reinterpret_cast<uint2 *>(lp) = make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
           }
         }
       }
-      // ---- residuals (or L) outside int8: rare; ONE wave-uniform test on the usual way ----
-      const uint32_t rw = s_range_word(mx, mn), rl = CH ? s_range_word(lmx, lmn) : 0u;
-      const bool lane_on = fast ? y_own : (y_own || y_halo);  // (fast path: the other lanes hold copies of a word that is not theirs)
-      const bool some = lane_on && ((rw | (y_stat ? rl : 0u)) & 0xff80ff80u) != 0;
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(some) != 0 || carry_u, 0)) {
+      // ---- residuals (or L) outside int8 (-128 .. 127): rare; ONE wave-uniform test on the usual way (every lane takes part:
+      //      the lanes without a word of their own hold copies of real words, or zeros) ----
+      const uint32_t out = (racc | (y_stat ? lacc : 0u)) & 0xff00ff00u;
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(out != 0) != 0 || carry_u, 0)) {
         // A residual outside int8 flags the blocks whose tile holds it.  A halo word that is not read is a neighbour's own
         // word: the unit before carries the flag of its last word to this unit's first block, and this unit's first word
         // flags the second block of the unit before (whose slot is still open: it is multiplied an iteration after this)
-        const bool badw = lane_on && (rw & 0xff80ff80u) != 0;
+        const bool lane_on = fast ? y_own : (y_own || y_halo);  // (fast path: the other lanes hold copies of a word that is not theirs)
+        const bool badw = lane_on && (racc & 0xff00ff00u) != 0;
         if (badw) atomicOr(&s_badbits[slot], y_flagbits);
         if (aL && carry_y) atomicOr(&s_badbits[slot], 1u);
         if (aL && badw && ywd == 1) atomicOr(&s_badbits[(k - 1) & 3], 1u << (kMUnitBlocks - 1));
         carry_y = badw && ywd == SH::WY - 2;
         carry_u = __builtin_amdgcn_ballot_w64(carry_y) != 0;
-        if (CH && y_stat && (rl & 0xff80ff80u) != 0) atomicOr(&s_badbits[slot], 1u << (kMUnitBlocks + y_bq));
+        if (CH && y_stat && (lacc & 0xff00ff00u) != 0) atomicOr(&s_badbits[slot], 1u << (kMUnitBlocks + y_bq));
       }
     }
     if constexpr (CHROMA) {
@@ -500,13 +524,13 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
       uint32_t rall = 0;
 #pragma unroll
       for (int q = 0; q < CROUNDS; ++q) {
-        uint32_t hs[4], hv[4], d16[4], mx = 0, mn = 0;
-        f_narrow<BPS>(cs_[q], g.src_bps, g.src_shift, hs);
-        f_narrow<BPS>(cd_[q], g.den_bps, g.den_shift, hv);
-        f_residual(hs, hv, d16, mx, mn);
+        uint32_t hs[4], hv[4], d16[4], racc = 0;
+        s_narrow<BPS>(cs_[q], g.src_bps, g.src_shift, hs);
+        s_narrow<BPS>(cd_[q], g.den_bps, g.den_shift, hv);
+        s_residual(hs, hv, d16, racc);
         Cn[q][0] = pk_bytes(d16[0], d16[1]);
         Cn[q][1] = pk_bytes(d16[2], d16[3]);
-        if (!(dbg & 4)) {
+        if (!G1S_S_DBGBIT(4)) {
           int sd = __builtin_amdgcn_sdot4((int)Cn[q][0], 0x01010101, 0, false);
           sd = __builtin_amdgcn_sdot4((int)Cn[q][1], 0x01010101, sd, false);
           int sd2 = __builtin_amdgcn_sdot4((int)Cn[q][0], (int)Cn[q][0], 0, false);
@@ -514,11 +538,10 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
           unsigned long long *tgt = &s_sum[slot][c_stat[q] ? cplane : 3][c_bq];
           atomicAdd(tgt, ((unsigned long long)(uint32_t)sd2 << 37) | (unsigned long long)(uint32_t)(sd + kFBiasC));
         }
-        const uint32_t rw = s_range_word(mx, mn);
-        rall |= cpl[q] ? rw : 0u;
+        rall |= cpl[q] ? racc : 0u;
       }
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64((rall & 0xff80ff80u) != 0) != 0, 0)) {
-        if ((rall & 0xff80ff80u) != 0) atomicOr(&s_badbits[slot], c_flagbits);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64((rall & 0xff00ff00u) != 0) != 0, 0)) {
+        if ((rall & 0xff00ff00u) != 0) atomicOr(&s_badbits[slot], c_flagbits);
       }
     }
   };
@@ -539,7 +562,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
   // neighbour is the unit before it (aL), its right neighbour's first dwords are in Dn when it is the unit after it (aR);
   // otherwise they are in the halo lanes of Dc1 (general path).  wy: the unit's two windows of this launch's plane kind.
   auto write_copies = [&](int k1, bool aL, bool aR, uint32_t wy) __attribute__((always_inline)) {
-    if (dbg & 8) return;
+    if (G1S_S_DBGBIT(8)) return;
     const bool plain = k1 < n_p;
     const uint32_t wins[2] = {wy & 0xffffu, wy >> 16};
     uint8_t *buf = m_smem + (k1 & 1) * BUF;
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
         if (LUMA && CH) defer |= ((badbits >> kMUnitBlocks) & fbits) << kMUnitBlocks;  // L: the chroma launch's business
         if (__builtin_expect((mine & fbits) != 0, 0)) {
           defer |= fbits << (LUMA ? 0 : kMUnitBlocks);
-        } else if (!(dbg & 16)) {
+        } else if (!G1S_S_DBGBIT(16)) {
           const uint8_t *buf = m_smem + (k & 1) * BUF;
           if constexpr (PLAIN) {
             s_multiply<NSTEP, RS, MP, false>(aPP, aPQ, aQQ, buf, m_addr, ~0u);
@@ -663,7 +686,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
         }
       }
       // ---- wave 3: the unit's statistics record (a four-unit ring, stored four at a time), the next unit's L tile ----
-      if (wave == kFWaves - 1 && !(dbg & 32)) {
+      if (wave == kFWaves - 1 && !G1S_S_DBGBIT(32)) {
         auto mine_entry = [](int t) {
           const int b = t >= 7 ? 1 : 0, e = t - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2);
           return t < 14 ? (LUMA ? c == 0 : c != 0) : t == 14 + PL;
@@ -687,8 +710,10 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
         if (k + 1 < nmine) flush_l(ux1, (k + 1) & 3);
       }
       // (the sums and flags of the unit before this one: consumed an iteration ago, written again two iterations on)
-      if (tid >= 64 && tid < 64 + 4 * kMUnitBlocks) (&s_sum[(k + 3) & 3][0][0])[tid - 64] = 0ull;
-      else if (tid == 128) s_badbits[(k + 3) & 3] = 0u;
+      if (wave == kFWaves - 1) {
+        if (lane < 4 * kMUnitBlocks) (&s_sum[(k + 3) & 3][0][0])[lane] = 0ull;
+        else if (lane == 32) s_badbits[(k + 3) & 3] = 0u;
+      }
       ux1 = ux2;
       ux2 = ux3;
       __syncthreads();
