@@ -364,6 +364,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
   const bool l_on = CHROMA && tid < SH::NL;
   constexpr int LWR = kMUnitBlocks * CW_ / 8;  // 8-byte words of an L tile row
   const int l_row = tid / LWR, l_wd = tid - l_row * LWR;
+  const uint32_t l_off = (uint32_t)l_row * fpar.lpitch + (uint32_t)(8 * l_wd);  // this thread's word of a unit's L tile in the L plane
 
   // ux: the unit's control .x (chunk, block row, fast, right, left)
   auto request = [&](uint32_t ux) __attribute__((always_inline)) {
@@ -371,7 +372,13 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
     const int bx0 = kMUnitBlocks * (int)(ux & 0xfffu), by = (int)((ux >> 12) & 0xfffu);
     const int X0y = bx0 * 32 - 8, Y0y = by * kBlock - 4, X0c = bx0 * CW_ - 8, Y0c = by * CH_ - 3;
     if constexpr (CHROMA) {
-      if (l_on) lraw = *reinterpret_cast<const uint2 *>(lplane + (size_t)(by * CH_ + l_row) * fpar.lpitch + bx0 * CW_ + 8 * l_wd);
+      if (l_on) {  // (scalar base + the lane's constant offset)
+        const uint8_t *lb = lplane + ((uint32_t)(by * CH_) * fpar.lpitch + (uint32_t)(bx0 * CW_));
+        uint32_t lo = l_off;
+        asm volatile("" : "+v"(lo));
+        const u32x2 t = *(gptr_u2)(as_global(lb) + lo);
+        lraw = make_uint2(t.x, t.y);
+      }
     }
     if (LUMA && y_wave) {
       if ((ux >> 29) & 1u) {  // the fast path: every lane loads at its constant offset (the origin lies inside the plane)
@@ -414,16 +421,18 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
         }
         return;
       }
-      const uint8_t *sb = c_src + ((ptrdiff_t)Y0c * (ptrdiff_t)c_sst + (ptrdiff_t)X0c * sbps);
-      const uint8_t *db = c_den + ((ptrdiff_t)Y0c * (ptrdiff_t)c_dst + (ptrdiff_t)X0c * dbps);
       const bool inside = X0c >= 0 && X0c + 8 * SH::WC <= cpw && Y0c >= 0 && Y0c + CH_ + 3 <= cph;
       if (inside) {  // (every lane loads: the idle lanes of a round read row 0, unused)
+        const uint8_t *sb = c_src + ((uint32_t)Y0c * c_sst + (uint32_t)(X0c * sbps));
+        const uint8_t *db = c_den + ((uint32_t)Y0c * c_dst + (uint32_t)(X0c * dbps));
 #pragma unroll
         for (int q = 0; q < CROUNDS; ++q) {
           cs_[q] = f_load<BPS>(sb, cso[q], g.src_bps, true);
           cd_[q] = f_load<BPS>(db, cdo[q], g.den_bps, true);
         }
       } else {
+        const uint8_t *sb = c_src + ((ptrdiff_t)Y0c * (ptrdiff_t)c_sst + (ptrdiff_t)X0c * sbps);
+        const uint8_t *db = c_den + ((ptrdiff_t)Y0c * (ptrdiff_t)c_dst + (ptrdiff_t)X0c * dbps);
         const bool xok = X0c + 8 * cwd >= 0 && X0c + 8 * cwd + 8 <= cpw;
 #pragma unroll
         for (int q = 0; q < CROUNDS; ++q) {
@@ -550,11 +559,13 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
     if constexpr (LUMA && CH) {
       const int bx0 = kMUnitBlocks * (int)(ux & 0xfffu), by = (int)((ux >> 12) & 0xfffu);
       constexpr int LW = kMUnitBlocks * CW_ / 8;
+      uint8_t *lb = lplane + ((uint32_t)(by * CH_) * fpar.lpitch + (uint32_t)(bx0 * CW_));
 #pragma unroll
       for (int w0 = 0; w0 < SH::NL; w0 += 64) {
         const int w = w0 + lane, row = w / LW, wd = w - row * LW;
-        if (w < SH::NL)
-          *reinterpret_cast<uint2 *>(lplane + (size_t)(by * CH_ + row) * fpar.lpitch + bx0 * CW_ + 8 * wd) = s_L[slot][w];
+        uint32_t lo = (uint32_t)row * fpar.lpitch + (uint32_t)(8 * wd);
+        asm volatile("" : "+v"(lo));
+        if (w < SH::NL) *reinterpret_cast<uint2 *>(lb + lo) = s_L[slot][w];
       }
     }
   };
