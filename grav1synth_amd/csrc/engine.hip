@@ -272,7 +272,7 @@ std::vector<CachedSlot> g_slot_cache;
 //   upload   the frame tables (72 bytes a frame pair), ahead of everything
 struct StreamSet {
   int device = -1;
-  hipStream_t compute = nullptr, copy = nullptr, flat = nullptr, upload = nullptr;
+  hipStream_t compute = nullptr, copy = nullptr, flat = nullptr, flat2 = nullptr, upload = nullptr;
   hipEvent_t kernels_done[kSlots] = {};
   hipEvent_t mask_done[kSlots] = {};
   hipEvent_t pix_done[kSlots] = {};
@@ -300,6 +300,7 @@ bool acquire_streams(int device, StreamSet &out) {
   bool ok = hipStreamCreateWithPriority(&out.compute, hipStreamNonBlocking, prio_lo) == hipSuccess &&
             hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+            hipStreamCreateWithPriority(&out.flat2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipStreamCreateWithFlags(&out.upload, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < kSlots && ok; ++i)
     ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
@@ -779,7 +780,11 @@ int g1s_diff::launch_front(int si) {
   Geom g = batch_geom(sl);
   static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
   hipStream_t stream = ss.compute;                                        // main stream (shadows the member)
-  hipStream_t fstream = (one_stream || timing || !ss.flat) ? stream : ss.flat;  // per-kernel timing: one stream
+  // Two side streams, a batch's chain on the one of its slot's parity: the latency-bound tail of a chain (certify, the
+  // literal blocks, select, unit lists) then runs next to the moments kernel of the batch after it -- one waits on dependent
+  // loads, the other streams through HBM -- instead of in front of it (G1S_SIDE2=0: one side stream)
+  static const bool side2 = !(getenv("G1S_SIDE2") && atoi(getenv("G1S_SIDE2")) == 0);
+  hipStream_t fstream = (one_stream || timing || !ss.flat) ? stream : ((si & 1) && side2 && ss.flat2 ? ss.flat2 : ss.flat);  // per-kernel timing: one stream
   // the pixel pass of round 1's chain (K0) runs on the main stream; the fused pass has no K0: its only pixel pass before
   // the mask is the finder's luma-source moments kernel, which joins the finder chain on the side stream and runs next to
   // the accumulation of the batch before
@@ -1448,6 +1453,7 @@ void g1s_diff::release() {
   if (ss.compute) (void)hipStreamSynchronize(ss.compute);
   if (ss.copy) (void)hipStreamSynchronize(ss.copy);
   if (ss.flat) (void)hipStreamSynchronize(ss.flat);
+  if (ss.flat2) (void)hipStreamSynchronize(ss.flat2);
   if (ss.upload) (void)hipStreamSynchronize(ss.upload);
   release_streams(ss);
   for (Slot &sl : slots) {

@@ -54,7 +54,7 @@ struct FParams {
   int reuse;              // 1: (luma launch) the left halo word of a unit whose left neighbour was the unit before it in the run is not read
   const uint8_t *planes;  // SRC = 1: the int8 planes of the pixel pass K0 (k0.hip.h), [batch] x ps.frame_bytes
   PlaneSet ps;
-  int dbg;                  // timing experiments (G1S_S_DBG, k3s.hip.h): bit 0 no global loads, 1 no residual arithmetic, 2 no statistics atomics, 3 no copy writes, 4 no multiplies, 5 no statistics / L stores; wrong results
+  int dbg;                  // timing experiments (G1S_S_DBG, k3s.hip.h): bit 0 no global loads, 1 no residual arithmetic, 2 no statistics atomics, 3 no copy writes, 4 no multiplies, 5 no statistics / L stores, 6 no barrier in the loop; wrong results
   long long *phase_cycles;  // profiling aid (built with -DG1S_F_PHASES, run with G1S_F_PHASES=1): [workgroup][wave][8] cycles: tile copies, barrier 2, multiply, barrier 1, wait for the words, residuals, requests, stores; or null
 };
 

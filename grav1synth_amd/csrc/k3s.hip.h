@@ -110,13 +110,22 @@ __device__ __forceinline__ void s_residual(const uint32_t (&hs)[4], const uint32
   acc = acc | pk_add(d16[0], 0x00800080u) | pk_add(d16[1], 0x00800080u);
   acc = acc | pk_add(d16[2], 0x00800080u) | pk_add(d16[3], 0x00800080u);
 }
-// NSTEP steps of RS rows from lane address a0 (the P operand of the first step), pitch P.  MASKED: `rm` bit j * RS says
-// whether the lane's sample row of step j lies inside its block's window rows (a sample outside contributes nothing: both
-// operands of the step are zeroed for the lane's k-group -- copies of them, the tile rows stay what they are for the next step)
+// NSTEP steps of RS rows from lane address a0 (the P operand of the first step), pitch P.
+// The products of a step: P P^T, P Q^T, Q Q^T with Q = the P of the step before -- so Q Q^T of a step IS P P^T of the step
+// before.  Where no step is masked (PLAIN: every row of both blocks inside its window) the wave therefore multiplies
+//   aS += P P^T of steps 0 .. NSTEP - 2   (counts for P P^T and, as the Q Q^T of steps 1 .. NSTEP - 1, for Q Q^T)
+//   aP += P P^T of the last step, aQ += Q Q^T of the first step (the operand read for the renaming), aX += P Q^T:
+// 2 NSTEP + 1 products instead of 3 NSTEP; P P^T = aS + aP and Q Q^T = aS + aQ when the accumulators are written out.
+// MASKED: `rm` bit j * RS says whether the lane's sample row of step j lies inside its block's window rows (a sample outside
+// contributes nothing: both operands of the step are zeroed for the lane's k-group -- copies of them, the tile rows stay what
+// they are for the next step); all three products of every step, into aP, aX, aQ.
 template <int NSTEP, int RS, int P, bool MASKED>
-__device__ __forceinline__ void s_multiply(v4i32s &aPP, v4i32s &aPQ, v4i32s &aQQ, const uint8_t *smem, int a0, uint32_t rm) {
+__device__ __forceinline__ void s_multiply(v4i32s &aS, v4i32s &aP, v4i32s &aX, v4i32s &aQ, const uint8_t *smem, int a0, uint32_t rm) {
   v4i32s q = m_lds16(smem, a0 - RS * P);
-  constexpr int H = NSTEP > 4 ? 4 : NSTEP;  // operand reads in flight
+#ifndef G1S_S_READS
+#define G1S_S_READS 2
+#endif
+  constexpr int H = NSTEP > G1S_S_READS ? G1S_S_READS : NSTEP;  // operand reads in flight (4: the luma launch spills)
 #pragma unroll
   for (int j0 = 0; j0 < NSTEP; j0 += H) {
     v4i32s p[H];
@@ -128,13 +137,14 @@ __device__ __forceinline__ void s_multiply(v4i32s &aPP, v4i32s &aPQ, v4i32s &aQQ
       if constexpr (MASKED) {
         const int m = __builtin_amdgcn_sbfe((int)rm, (j0 + j) * RS, 1);  // 0 or -1
         const v4i32s pm = p[j] & m, qm = q & m;
-        aPP = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, pm, aPP, 0, 0, 0);
-        aPQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, q, aPQ, 0, 0, 0);
-        aQQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(qm, qm, aQQ, 0, 0, 0);
+        aP = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, pm, aP, 0, 0, 0);
+        aX = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, q, aX, 0, 0, 0);
+        aQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(qm, qm, aQ, 0, 0, 0);
       } else {
-        aPP = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], p[j], aPP, 0, 0, 0);
-        aPQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], q, aPQ, 0, 0, 0);
-        aQQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(q, q, aQQ, 0, 0, 0);
+        if (j0 + j == 0) aQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(q, q, aQ, 0, 0, 0);
+        if (j0 + j == NSTEP - 1) aP = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], p[j], aP, 0, 0, 0);
+        else aS = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], p[j], aS, 0, 0, 0);
+        aX = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], q, aX, 0, 0, 0);
       }
       q = p[j];
     }
@@ -175,8 +185,11 @@ __device__ __forceinline__ uint32_t s_flag_bits(int wd, int WB) {
 // k3s_fused<CBW, CBH, BPS, PL>: as k3f_fused (chroma block 32 >> xdec by 32 >> ydec, 0 0: luma only; PL = 0 the luma plane
 // and L, PL = 1 the chroma planes).  grid = frames x workgroups per frame (1-D), block = 256, dynamic LDS = s_lds_bytes.
 // ---------------------------------------------------------------------------------
+#ifndef G1S_S_OCC_C
+#define G1S_S_OCC_C 4  // waves per SIMD the 4:2:0 chroma launch is compiled for (5 = 96 registers: measured 9 % slower, profiles/r03b)
+#endif
 template <int CBW, int CBH, int BPS, int PL>
-__global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParams fpar) {
+__global__ __launch_bounds__(kFThreads, (PL == 1 && CBW == 16 && CBH == 16) ? G1S_S_OCC_C : G1S_F_OCC) void k3s_fused(Geom g, FParams fpar) {
   extern __shared__ __attribute__((aligned(16))) uint8_t m_smem[];
   using SH = SShape<CBW, CBH>;
   constexpr bool CH = SH::CH;
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
   }
   const uint32_t c_flagbits = s_flag_bits(cwd, CW_ / 8) << kMUnitBlocks;
 
-  v4i32s aPP = {0, 0, 0, 0}, aPQ = {0, 0, 0, 0}, aQQ = {0, 0, 0, 0};
+  v4i32s aSS = {0, 0, 0, 0}, aPP = {0, 0, 0, 0}, aPQ = {0, 0, 0, 0}, aQQ = {0, 0, 0, 0};  // (P P^T = aSS + aPP, Q Q^T = aSS + aQQ: s_multiply)
 
   // ---- this workgroup's units: their entries, then the iterations' control words, parked in LDS ----
   const int nmine = n_p + n_g;
@@ -685,13 +698,13 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
         } else if (!G1S_S_DBGBIT(16)) {
           const uint8_t *buf = m_smem + (k & 1) * BUF;
           if constexpr (PLAIN) {
-            s_multiply<NSTEP, RS, MP, false>(aPP, aPQ, aQQ, buf, m_addr, ~0u);
+            s_multiply<NSTEP, RS, MP, false>(aSS, aPP, aPQ, aQQ, buf, m_addr, ~0u);
           } else {
             const MWin w0m = m_unpack(wy0 & 0xffffu, g.lag), w1m = m_unpack(wy0 >> 16, g.lag);
             if (w0m.go || w1m.go) {
               const uint32_t r0 = w0m.go ? m_rowmask(w0m.ys, w0m.ye) : 0u, r1 = w1m.go ? m_rowmask(w1m.ys, w1m.ye) : 0u;
               const uint32_t rm = (m_blk ? r1 : r0) >> (m_y0 + m_rho);
-              s_multiply<NSTEP, RS, MP, true>(aPP, aPQ, aQQ, buf, m_addr, rm);
+              s_multiply<NSTEP, RS, MP, true>(aSS, aPP, aPQ, aQQ, buf, m_addr, rm);
             }
           }
         }
@@ -727,7 +740,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
       }
       ux1 = ux2;
       ux2 = ux3;
-      __syncthreads();
+      if (!G1S_S_DBGBIT(64)) __syncthreads();
     }
   };
   run(std::true_type{}, 0, n_p);
@@ -762,9 +775,9 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3s_fused(Geom g, FParam
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * mg + r;
       const int rP = s_rec_index<TWO_ROW>(0, row, g.lag, g.n, ch), rQ = s_rec_index<TWO_ROW>(1, row, g.lag, g.n, ch);
-      add(rP, cP, aPP[r], false);
+      add(rP, cP, aSS[r] + aPP[r], false);
       add(rP, cQ, aPQ[r], true);
-      add(rQ, cQ, aQQ[r], false);
+      add(rQ, cQ, aSS[r] + aQQ[r], false);
     }
   }
   __syncthreads();
