@@ -41,15 +41,15 @@ thread_local std::string g_global_error;
 constexpr uint32_t kDefaultBatch = 32;
 constexpr int kK3Chunks = 48;
 
-// The AR accumulation is an exact int8 SYRK on the matrix cores (k3f.hip.h). G1S_K3 selects where its bytes come from:
-//   fused (default)   the accumulation kernel reads the source / denoised planes of the flat blocks' tiles itself and takes
-//                     the block statistics on the way: no pixel pass but the finder's moments of the luma source, no
-//                     intermediate planes (HBM traffic below the algorithmic bytes when not every block is flat);
+// The AR accumulation is an exact int8 SYRK on the matrix cores.  G1S_K3 selects the chain:
+//   stream (default)  k3s.hip.h: the accumulation kernel reads the source / denoised planes of the flat blocks' tiles itself and
+//                     takes the block statistics on the way (no pixel pass but the finder's moments of the luma source, no
+//                     intermediate planes); 16x16x64 MFMAs on operand pairs, two tile buffers, a fast path for units in a run;
+//   fused             k3f.hip.h: round 2's form of the same pass (32x32x32 MFMAs, one tile buffer, two barriers a unit);
 //   planes            the pixel pass K0 (k0.hip.h: one streaming pass -> int8 residual and L planes, block statistics,
-//                     the finder's moments) runs first, the accumulation kernel stages K0's planes (a copy);
+//                     the finder's moments) runs first, k3f stages K0's planes (a copy);
 //   dot4              round 1's chain -- K0, then the lag-structured v_dot4 kernels (k3q.hip.h).
-// All three are bit-exact against each other and the oracle (tests/test_gpu_k3_modes.py); fused and planes measure the
-// same on the 4K workload ("What bounds the pass").
+// All four are bit-exact against each other and the oracle (tests/test_gpu_parity.py::test_accumulation_modes_agree).
 // timing experiments: G1S_DBG_SKIP=name[,name...] leaves kernels out (wrong results; never set in tests or bench lines)
 bool dbg_skip(const char *name) {
   static const std::string v = getenv("G1S_DBG_SKIP") ? std::string(",") + getenv("G1S_DBG_SKIP") + "," : std::string();
@@ -60,8 +60,8 @@ int k3_mode() {
     const char *e = getenv("G1S_K3");
     if (e && std::strcmp(e, "dot4") == 0) return 0;
     if (e && std::strcmp(e, "planes") == 0) return 2;
-    if (e && std::strcmp(e, "stream") == 0) return 3;
-    return 1;
+    if (e && std::strcmp(e, "fused") == 0) return 1;
+    return 3;
   }();
   return v;
 }
@@ -782,8 +782,8 @@ int g1s_diff::launch_front(int si) {
   hipStream_t stream = ss.compute;                                        // main stream (shadows the member)
   // Two side streams, a batch's chain on the one of its slot's parity: the latency-bound tail of a chain (certify, the
   // literal blocks, select, unit lists) then runs next to the moments kernel of the batch after it -- one waits on dependent
-  // loads, the other streams through HBM -- instead of in front of it (G1S_SIDE2=0: one side stream)
-  static const bool side2 = !(getenv("G1S_SIDE2") && atoi(getenv("G1S_SIDE2")) == 0);
+  // loads, the other streams through HBM -- instead of in front of it (G1S_SIDE2=1; the timeline shows them overlap either way)
+  static const bool side2 = getenv("G1S_SIDE2") && atoi(getenv("G1S_SIDE2")) != 0;  // (measured: no gain, profiles/r03b; off)
   hipStream_t fstream = (one_stream || timing || !ss.flat) ? stream : ((si & 1) && side2 && ss.flat2 ? ss.flat2 : ss.flat);  // per-kernel timing: one stream
   // the pixel pass of round 1's chain (K0) runs on the main stream; the fused pass has no K0: its only pixel pass before
   // the mask is the finder's luma-source moments kernel, which joins the finder chain on the side stream and runs next to

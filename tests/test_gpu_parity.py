@@ -145,21 +145,26 @@ def test_two_ranks_stream_a_sharded_job_on_one_device(tmp_path, nbatches, no_def
 
 
 def test_accumulation_modes_agree():
-    """G1S_K3 = fused (default: matrix-core accumulation straight from the source planes), planes (pixel pass K0 + the
-    matrix-core kernel on its int8 planes) and dot4 (round 1: K0 + lag-structured v_dot4 kernels) must give the same
-    records and tables, bit for bit -- small odd formats, 12-bit residuals outside int8, the 4K workload."""
+    """G1S_K3 = stream (default: matrix-core accumulation straight from the source planes, k3s.hip.h), fused (round 2's form
+    of the same pass, k3f.hip.h), planes (pixel pass K0 + the matrix-core kernel on its int8 planes) and dot4 (round 1: K0 +
+    lag-structured v_dot4 kernels) must give the same records and tables, bit for bit -- small odd formats, 12-bit residuals
+    outside int8, the 4K workload; the stream chain also without the halo reuse / fast path (G1S_F_REUSE=0)."""
     import json
     import os
     import subprocess
     import sys
 
     lines = {}
-    for mode in ("fused", "planes", "dot4"):
-        env = dict(os.environ, G1S_K3=mode)
+    for mode in ("stream", "fused", "planes", "dot4", "stream-noreuse"):
+        env = dict(os.environ, G1S_K3=mode.split("-")[0])
+        if mode.endswith("noreuse"):
+            env["G1S_F_REUSE"] = "0"
         p = subprocess.run([sys.executable, "-m", "tests.k3_mode_digest"], env=env, capture_output=True, text=True, timeout=600,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert p.returncode == 0, f"{mode}: {p.stderr[-2000:]}"
         lines[mode] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert lines["stream"] == lines["fused"], "stream vs fused"
+    assert lines["stream"] == lines["stream-noreuse"], "stream with vs without the halo reuse"
     assert lines["fused"] == lines["planes"], "fused vs planes"
     assert lines["fused"] == lines["dot4"], "fused vs dot4"
 
@@ -687,6 +692,63 @@ def test_partial_last_column_with_many_units_per_workgroup(lag, monkeypatch):
         S2, Sb2, n2 = r.ar_sums(c)
         assert n == n2 and np.array_equal(S, S2) and np.array_equal(Sb, Sb2), f"plane {c}"
     assert format_tbl(g.finish()) == ofmt(o.finish())
+
+
+def test_int32_accumulators_at_their_ceiling(monkeypatch):
+    """VERDICT r02 #6a: kMMaxUnits = 240 is sized so that a wave's int32 accumulator cannot overflow (240 units x 512
+    samples x 127^2 < 2^31).  Here every workgroup of the accumulation pass walks 220 units (3520 x 1024, 8 workgroups a
+    frame) of a frame whose residual is +-127 on EVERY sample, in a checkerboard -- so the products of a matrix entry all
+    have one sign and the sums go where the bound says they may: |S| up to 220 x 512 x 127^2 = 1.8e9 per wave.  Every block
+    has the same content, hence the same score: the 90th-percentile rule marks them all.  The AR system of such a frame is
+    singular (the fold refuses it): the generator only keeps the records, which must hold the oracle's sums."""
+    from tests.oracle_binding import OracleDiff
+
+    monkeypatch.setenv("G1S_F_WGS", "8")
+    W, H = 3520, 1024
+    yy, xx = np.mgrid[0:H, 0:W]
+    sign = (1 - 2 * ((xx + yy) & 1)).astype(np.int16)
+    den_y = np.full((H, W), 128, np.uint8)
+    src_y = (128 + 127 * sign).astype(np.uint8)
+    den_c = np.full((H // 2, W // 2), 128, np.uint8)
+    src_c = (128 + 127 * sign[: H // 2, : W // 2]).astype(np.uint8)
+    src, den = [src_y, src_c, src_c.copy()], [den_y, den_c, den_c.copy()]
+    o = OracleDiff(24, 1, 8, 8, 3, True)
+    try:
+        o.diff_frame(src, den, 1, 1)
+    except RuntimeError:
+        pass  # (the singular AR system; the sums below were taken before the solve)
+    assert (o.flat_mask() != 0).all()
+    g = DiffGenerator(Fraction(24, 1), 8, 8, batch_frames=1, records_only=True)
+    g.diff_frame(Frame(src, 1, 1), Frame(den, 1, 1))
+    recs, n = g.take_records(W, H, 3, 1)
+    assert n == 1
+    from grav1synth_amd.diff import Record
+
+    r = Record(recs[0])
+    assert np.array_equal(r.flat_mask(), o.flat_mask())
+    S, Sb, nobs = o.ar_sums(0)  # (the oracle stops at the luma solve: its chroma sums of this frame do not exist)
+    S2, Sb2, nobs2 = r.ar_sums(0)
+    assert nobs == nobs2 and nobs > 0
+    assert np.array_equal(S, S2) and np.array_equal(Sb, Sb2)
+    assert np.abs(S).max() == nobs * 127 * 127  # (the diagonal: every product + 127^2)
+    g.close()
+    # the chroma planes at +-127 on every sample under an ordinary luma plane (the chroma solve falls back, no error)
+    spec = SynthSpec(W, H, 8, textured=False)
+    s0, d0 = np_pair(spec, 0)
+    src, den = [s0[0], src_c, src_c.copy()], [d0[0], den_c, den_c.copy()]
+    o = OracleDiff(24, 1, 8, 8, 3, True)
+    o.diff_frame(src, den, 1, 1)
+    g = DiffGenerator(Fraction(24, 1), 8, 8, batch_frames=1, records_only=True)
+    g.diff_frame(Frame(src, 1, 1), Frame(den, 1, 1))
+    recs, n = g.take_records(W, H, 3, 1)
+    r = Record(recs[0])
+    for c in range(3):
+        S, Sb, nobs = o.ar_sums(c)
+        S2, Sb2, nobs2 = r.ar_sums(c)
+        assert nobs == nobs2 and nobs > 0, f"plane {c}"
+        assert np.array_equal(S, S2) and np.array_equal(Sb, Sb2), f"plane {c}"
+    assert np.abs(r.ar_sums(1)[0]).max() >= (r.ar_sums(1)[2] - 1) * 127 * 127 // 2
+    g.close()
 
 
 @pytest.mark.parametrize("spec,nframes", [(SynthSpec(320, 200, 10), 5), (SynthSpec(288, 160, 8, xdec=0, ydec=0), 4)],
