@@ -14,7 +14,7 @@ flat = os.environ.get("FLAT") is not None
 wl = os.environ.get("WL", "4k10")
 W, H, bd, xd, yd = {"4k10": (3840, 2160, 10, 1, 1), "1080p8": (1920, 1080, 8, 1, 1), "8k10_444": (7680, 4320, 10, 0, 0)}[wl]
 spec = SynthSpec(W, H, bd, xdec=xd, ydec=yd, textured=not flat)
-nd = int(os.environ.get("DISTINCT", "16"))
+nd = int(os.environ.get("DISTINCT", "64"))  # (distinct frame pairs: 64 = none shared inside a launch, what a video gives the caches)
 pairs = [make_pair(spec, k, device="cuda") for k in range(nd)]
 torch.cuda.synchronize()
 g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=B)
