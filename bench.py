@@ -50,12 +50,14 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="frame pairs per rank per step (one video chunk per step)")
-    ap.add_argument("--cycles", type=int, default=8,
-                    help="a step feeds the resident frames this many times over: one job of frames x cycles frame pairs")
+    ap.add_argument("--cycles", type=int, default=104,
+                    help="a step feeds the resident frames this many times over: one job of frames x cycles frame pairs "
+                         "(default: a step of about half a second, so that the timed region of --steps 20 is 10 s)")
     ap.add_argument("--batch", type=int, default=64, help="frames per kernel launch group (<= 256)")
     ap.add_argument("--workload", default="4k10", choices=sorted(WORKLOADS))
     ap.add_argument("--flat", action="store_true", help="all-flat stress variant (no textured region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-all-flat", action="store_true", help="skip the all-flat variant's timed-kernels job (roofline.frac_all_flat)")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
 
@@ -118,22 +120,25 @@ def main() -> None:
     last_tbl = None
     window_samples = None  # per plane, of the last frame of the timed-kernels step
 
-    def one_step(timing: bool):
+    def one_step(timing: bool, cycles: int = 0, prep=None):
+        """one job: the resident frames `cycles` times over through a fresh generator, up to the finished table"""
         nonlocal stats_total, last_tbl, window_samples, kernel_times
+        cycles = cycles or args.cycles
+        prep = prep if prep is not None else prepared
         if world > 1:
             # streaming frame shards: per batch one small all-gather of latest states, rank 0 merges in order
             sd = StreamingShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
                                       batch_frames=B, group=dist)
             sd.generator.set_timing(timing)
-            for _ in range(args.cycles):
+            for _ in range(cycles):
                 for pb in prepared_batches:
                     sd.diff_prepared(pb, sync_torch=False)
         else:
             sd = ShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
                              batch_frames=args.batch, group=None)
             sd.generator.set_timing(timing)
-            for _ in range(args.cycles):
-                sd.diff_prepared(prepared, W, H, nplanes, sync_torch=False)
+            for _ in range(cycles):
+                sd.diff_prepared(prep, W, H, nplanes, sync_torch=False)
         segs = sd.finish()  # (exchange +) ordered fold; rank 0 holds the table
         st = sd.generator.stats()
         if timing:
@@ -173,7 +178,9 @@ def main() -> None:
 
     # ---- per-kernel HIP-event timing, in separate (untimed) steps: events between
     # kernels serialise nothing here but we keep them out of the headline number ----
-    st = one_step(True)
+    TC = min(args.cycles, 8)  # (the timed-kernels job: 8 passes over the resident frames are plenty)
+    st = one_step(True, TC)
+    FT = F * TC
     families = {
         "k1_flat_features": (st.ms_flat_features, st.launches_flat_features),
         "k2_flat_select": (st.ms_flat_select, st.launches_flat_select),
@@ -184,7 +191,7 @@ def main() -> None:
     dom = max(kt, key=lambda k: kt[k][0]) if kt else max(families, key=lambda k: families[k][0])
     dom_ms, dom_launches = kt[dom] if kt else families[dom]
     n_batches = max(st.launches_ar_accumulate, 1)
-    frames_per_launch = FJ / n_batches
+    frames_per_launch = FT / n_batches
     # bpp bytes per luma pixel of a frame pair = every source and denoised sample once
     alg_bytes_per_launch = bpp * W * H * frames_per_launch
     # the whole pass over one batch: every kernel from the finder's first to the accumulation's last, alone on the chip
@@ -226,6 +233,32 @@ def main() -> None:
         except Exception:
             traffic = None
 
+    # ---- SURVEY 8(d) asks for both content variants: the timed-kernels job once more on the all-flat stress variant (no
+    #      textured region: every unit of every frame is staged and multiplied), 64 resident frame pairs, rank 0 of N = 1 ----
+    frac_all_flat = flat_fraction_all_flat = batch_ms_all_flat = None
+    if world == 1 and not args.flat and not args.no_all_flat:
+        fl_spec = SynthSpec(W, H, bd, xdec, ydec, textured=False)
+        nfl = min(F, max(args.batch, 64))
+        fl_frames = []
+        for k in range(nfl):
+            s_, d_ = make_pair(fl_spec, k, device=dev)
+            if not chroma:
+                s_, d_ = s_[:1], d_[:1]
+            fl_frames.append((s_, d_))
+        torch.cuda.synchronize()
+        fl_prep = DiffGenerator.prepare_frames(fl_frames, xdec, ydec)
+        keep_kt = dict(kernel_times)
+        one_step(False, 2, fl_prep)  # (warm)
+        fst = one_step(True, 8, fl_prep)
+        fkt = {k: v for k, v in kernel_times.items() if v[1] > 0}
+        kernel_times = keep_kt
+        fb = max(fst.launches_ar_accumulate, 1)
+        batch_ms_all_flat = sum(v[0] for v in fkt.values()) / fb
+        frac_all_flat = (bpp * W * H * (nfl * 8 / fb)) / (batch_ms_all_flat * 1e-3) / 1e9 / HBM_PEAK_GBS
+        flat_fraction_all_flat = (fst.flat_blocks / fst.blocks) if fst.blocks else None
+        del fl_frames, fl_prep
+        torch.cuda.empty_cache()
+
     total_px = float(W) * H * F * args.cycles * args.steps * world
     value = total_px / elapsed / 1e6
     out = {
@@ -253,6 +286,8 @@ def main() -> None:
                              "dot4": "round 1: pixel pass K0 -> int8 planes -> lag-structured v_dot4 kernels"}[os.environ.get("G1S_K3", "stream")],
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
+            "rccl_ranks": (dist.get_world_size() if (world > 1 and not share) else (1 if world == 1 else 0)),
+            "backend": (dist.get_backend() if world > 1 else "none (one process)"),
             "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if world > 1 else "single GPU",
         },
         "hbm_roofline_frac_whole_job": (value * bpp * 1e6 / 1e9) / (HBM_PEAK_GBS * world),
@@ -268,6 +303,11 @@ def main() -> None:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            # the same fraction on the all-flat stress variant (every unit staged and multiplied), its flat fraction, its batch
+            "frac_all_flat": frac_all_flat,
+            "flat_fraction_all_flat": flat_fraction_all_flat,
+            "avg_launch_ms_all_flat": batch_ms_all_flat,
+            "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "avg_launch_ms": batch_ms,
             "alg_bytes_per_launch": alg_bytes_per_launch,
             "frames_per_launch": frames_per_launch,
@@ -280,8 +320,8 @@ def main() -> None:
                 "achieved": (ob * frames_per_launch / (dom_avg_ms * 1e-3) / 1e9) if ob and dom_avg_ms > 0 else None,
             },
             "kernels_us_per_launch": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
-            "families_ms_per_frame": {k: v[0] / FJ for k, v in families.items()},
-            "host_fold_ms_per_frame": st.ms_host_fold / FJ,
+            "families_ms_per_frame": {k: v[0] / FT for k, v in families.items()},
+            "host_fold_ms_per_frame": st.ms_host_fold / FT,
             "accumulation": os.environ.get("G1S_K3", "stream"),
         },
     }

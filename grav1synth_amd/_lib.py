@@ -202,6 +202,9 @@ SYMBOLS = [
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     ("g1s_diff_y4m_files_filtered", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(G1SOpts), C.c_char_p,
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    ("g1s_diff_y4m_files_sharded", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(G1SOpts), C.c_char_p,
+                                              C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_int),
+                                              C.c_char_p, C.c_size_t]),
 ]
 
 _lib = None

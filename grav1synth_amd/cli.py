@@ -66,6 +66,10 @@ def build_parser() -> argparse.ArgumentParser:
                         '"crop:top=42,left=64".  crop: top, bottom, left, right.  resize (width, height, alg) parses like the '
                         "reference's but is not supported here.")
     d.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: the current device)")
+    d.add_argument("--gpus", type=int, default=1,
+                   help="shard the frames over the first N devices of the node (one generator each, batches dealt round-robin, "
+                        "ordered merge on the host: the same table as one device)")
+    d.add_argument("--devices", default=None, help="the same with an explicit list of HIP ordinals, e.g. 0,2,3")
     e = sub.add_parser("estimate", help="Estimates the amount of noise in a source video, frame by frame (y4m input; the reference's "
                                         "`estimate`, feature \"unstable\").")
     e.add_argument("source", help="The source file to inspect.")
@@ -76,7 +80,7 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def diff_command(source: str, denoised: str, output: str, overwrite: bool = False, filters: Optional[str] = None,
-                 device: int = -1, confirm=_confirm) -> int:
+                 device: int = -1, confirm=_confirm, devices: Optional[List[int]] = None) -> int:
     """Returns the number of frame pairs diffed, or -1 when the command refused to run (a logged line, exit 0)."""
     from .filters import FilterChain, FilterError
     from .ingest import diff_y4m_files
@@ -96,7 +100,7 @@ def diff_command(source: str, denoised: str, output: str, overwrite: bool = Fals
     if os.path.exists(output) and not overwrite and not confirm(f"File {output} exists. Overwrite?"):
         log.warning(NOT_OVERWRITING)
         return -1
-    frames, _unequal = diff_y4m_files(source, denoised, output, device=device, filters=filters)  # (logs "Computed diff for N frames")
+    frames, _unequal = diff_y4m_files(source, denoised, output, device=device, filters=filters, devices=devices)  # (logs "Computed diff for N frames")
     log.info("Done, wrote output file to %s", output)
     return frames
 
@@ -122,7 +126,12 @@ def main(argv: Optional[List[str]] = None) -> int:
     logging.basicConfig(level=logging.INFO, format="%(levelname)s %(message)s", stream=sys.stderr)
     if args.command == "diff":
         try:
-            diff_command(args.source, args.denoised, args.output, args.overwrite, args.filters, args.device)
+            devices = None
+            if args.devices:
+                devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
+            elif args.gpus > 1:
+                devices = list(range(args.gpus))
+            diff_command(args.source, args.denoised, args.output, args.overwrite, args.filters, args.device, devices=devices)
         except Exception as e:  # `?` out of main: the error, a non-zero exit
             log.error("%s", e)
             return 1

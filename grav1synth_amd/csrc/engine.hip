@@ -1124,6 +1124,20 @@ int g1s_diff::launch_back(int si) {
                 phases == 1 ? "luma" : "chroma", v, tot[v][0] / (G * B), tot[v][1] / (G * B), tot[v][2] / (G * B), tot[v][4] / (G * B), tot[v][5] / (G * B), tot[v][6] / (G * B),
                 tot[v][7] / (G * B), tot[v][3] / (G * B));
     }
+    {
+      // debugging aid (G1S_DBG_ONLY=1): how many flat blocks the accumulation launches left to the exact kernel
+      static const bool count_only = getenv("G1S_DBG_ONLY") != nullptr;
+      if (count_only) {
+        std::vector<uint8_t> h(m_only_bytes);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), mp.only, m_only_bytes, hipMemcpyDeviceToHost);
+        size_t n[2] = {0, 0};
+        for (uint32_t f = 0; f < B; ++f)
+          for (int kind = 0; kind < 2; ++kind)
+            for (int b = 0; b < g.nblocks; ++b) n[kind] += h[((size_t)f * 2 + kind) * g.nblocks + b] != 0;
+        fprintf(stderr, "deferred to k3_ar_generic: %zu luma, %zu chroma blocks of %u frames x %d blocks\n", n[0], n[1], B, g.nblocks);
+      }
+    }
     kmark(sl, stream, "k3_ar_generic");
     if (!dbg_skip("generic"))
       hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
@@ -1212,6 +1226,10 @@ int g1s_diff::launch_back(int si) {
   HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
   HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, ss.copy));
   HIP_TRY(hipEventRecord(sl.done, ss.copy));
+  // profiling aid (G1S_D2H_SYNC=1, with G1S_ONE_STREAM=1): the records copy has ended before the next batch's first kernel
+  // starts -- under rocprofv3 the copy is a blit kernel that otherwise shares the chip with k1_moments and doubles its time
+  static const bool d2h_sync = getenv("G1S_D2H_SYNC") != nullptr;
+  if (d2h_sync) HIP_TRY(hipStreamSynchronize(ss.copy));
   stats.launches_flat_features++;
   stats.launches_flat_select++;
   stats.launches_ar_accumulate++;

@@ -468,4 +468,150 @@ done:
   return rc;
 }
 
+
+// `grav1synth diff` over several devices (north_star: "frames shard naturally across the GPUs ... so it drops in for that
+// subcommand"; the loop of src/main.rs:414-531).  ONE process: a records_only = 2 generator per entry of `devices` (an
+// ordinal may repeat: two generators on one device), the two readers' frame pairs dealt batch by batch (batch j of the
+// video -> generator j % n), per round one g1s_shard_pack per generator and one g1s_shard_merge -- the round protocol of
+// include/g1s_diff.h with the host as the transport (the messages never leave this process).  The table is the single
+// generator's, byte for byte.
+int g1s_diff_y4m_files_sharded(const char *source_path, const char *denoised_path, const char *out_tbl_path,
+                               const g1s_opts_t *opts, const char *filter_text, const int32_t *devices, uint32_t n_devices,
+                               uint64_t *frames_out, int *unequal_out, char *err, size_t errcap) {
+  if (!devices || n_devices == 0) {
+    set_err(err, errcap, "no devices");
+    return G1S_ERR_INVALID;
+  }
+  g1s_filters_t *filters = nullptr;
+  if (filter_text && *filter_text) {
+    char ferr[256] = "";
+    filters = g1s_filters_new(filter_text, ferr, sizeof(ferr));
+    if (!filters) {
+      set_err(err, errcap, std::string("Invalid filter chain: ") + ferr);
+      return G1S_ERR_INVALID;
+    }
+  }
+  g1s_y4m_t *ys = g1s_y4m_open(source_path, err, errcap);
+  if (!ys) {
+    g1s_filters_free(filters);
+    return G1S_ERR_INVALID;
+  }
+  g1s_y4m_t *yd = g1s_y4m_open(denoised_path, err, errcap);
+  if (!yd) {
+    g1s_y4m_close(ys);
+    g1s_filters_free(filters);
+    return G1S_ERR_INVALID;
+  }
+  const uint32_t N = n_devices;
+  g1s_opts_t o{};
+  o.struct_size = sizeof(g1s_opts_t);
+  if (opts) o = *opts;
+  o.struct_size = sizeof(g1s_opts_t);
+  if (o.ar_coeff_lag == 0) o.ar_coeff_lag = 3;
+  if (o.batch_frames == 0) {  // (the engine's default is sized by the frame: ask one generator what it would take)
+    const uint64_t px = (uint64_t)ys->info.width * ys->info.height;
+    o.batch_frames = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(1, (530ull << 20) / std::max<uint64_t>(px, 1)));
+  }
+  o.records_only = 2;
+  const uint32_t B = o.batch_frames;
+  int rc = G1S_OK;
+  uint64_t frames = 0;
+  int unequal = 0;
+  std::vector<g1s_diff_t *> gen(N, nullptr);
+  g1s_fold_t *fold = nullptr;
+  const size_t msg_bytes = g1s_shard_msg_size(o.ar_coeff_lag, B);
+  std::vector<uint8_t> msgs(msg_bytes * N);
+  std::vector<g1s_segment_t> segs(64);
+  size_t n = 0;
+  bool ended = false;
+  auto round = [&](int flush) -> int {  // every generator's message of the round, merged in global batch order
+    for (uint32_t r = 0; r < N; ++r) {
+      const int prc = g1s_shard_pack(gen[r], flush, msgs.data() + (size_t)r * msg_bytes, msg_bytes);
+      if (prc) {
+        set_err(err, errcap, std::string("generator ") + std::to_string(r) + ": " + g1s_diff_last_error(gen[r]));
+        return prc;
+      }
+    }
+    const int mrc = g1s_shard_merge(fold, msgs.data(), msg_bytes, N);
+    if (mrc) set_err(err, errcap, std::string("merge: ") + g1s_fold_last_error(fold));
+    return mrc;
+  };
+  for (uint32_t r = 0; r < N; ++r) {
+    o.device = devices[r];
+    gen[r] = g1s_diff_new(ys->info.fps_num, ys->info.fps_den, ys->info.bit_depth, yd->info.bit_depth, &o);
+    if (!gen[r]) {
+      set_err(err, errcap, std::string("device ") + std::to_string(devices[r]) + ": " + g1s_last_global_error());
+      rc = G1S_ERR_NO_DEVICE;
+      goto done;
+    }
+  }
+  fold = g1s_fold_new(ys->info.fps_num, ys->info.fps_den, o.ar_coeff_lag);
+  if (!fold) {
+    set_err(err, errcap, "g1s_fold_new failed");
+    rc = G1S_ERR_INVALID;
+    goto done;
+  }
+  // rounds: generator r takes batch (round * N + r) of the video -- B frame pairs read from the two files -- then every
+  // generator packs, the fold merges.  The readers lend host buffers: a frame is copied before g1s_diff_frame returns.
+  while (!ended && rc == G1S_OK) {
+    for (uint32_t r = 0; r < N && !ended && rc == G1S_OK; ++r) {
+      for (uint32_t i = 0; i < B; ++i) {
+        g1s_frame_t s, d;
+        const int rs = g1s_y4m_next(ys, &s), rd = g1s_y4m_next(yd, &d);
+        if (rs < 0 || rd < 0) {
+          rc = rs < 0 ? rs : rd;
+          set_err(err, errcap, "frame " + std::to_string(frames) + ": " + (rs < 0 ? "source" : "denoised") + " reader failed (" +
+                                   (rs < 0 ? ys->error : yd->error) + ")");
+          break;
+        }
+        if (rs == 0 || rd == 0) {  // (None, None), or the warning of src/main.rs:449-455
+          unequal = (rs == 0) != (rd == 0);
+          ended = true;
+          break;
+        }
+        if (filters) {
+          char ferr[320] = "";
+          g1s_frame_t cropped;
+          rc = g1s_filters_apply(filters, &s, &cropped, ferr, sizeof(ferr));
+          if (rc) {
+            set_err(err, errcap, "frame " + std::to_string(frames) + ": " + ferr);
+            break;
+          }
+          s = cropped;
+        }
+        rc = g1s_diff_frame(gen[r], &s, &d);
+        if (rc) {
+          set_err(err, errcap, "frame " + std::to_string(frames) + ": diff_frame: " + g1s_diff_last_error(gen[r]));
+          break;
+        }
+        ++frames;
+      }
+    }
+    if (rc == G1S_OK) rc = round(0);
+  }
+  for (int k = 0; k < 4 && rc == G1S_OK; ++k) rc = round(1);  // what is still in the generators' pipelines
+  if (rc) goto done;
+  rc = g1s_fold_finish(fold, segs.data(), segs.size(), &n);
+  if (rc == G1S_ERR_CAPACITY) {
+    segs.resize(n);
+    rc = g1s_fold_finish(fold, segs.data(), segs.size(), &n);
+  }
+  if (rc) {
+    set_err(err, errcap, g1s_fold_last_error(fold));
+    goto done;
+  }
+  rc = g1s_write_tbl(out_tbl_path, segs.data(), n);
+  if (rc) set_err(err, errcap, std::string("cannot write ") + out_tbl_path);
+done:
+  if (frames_out) *frames_out = frames;
+  if (unequal_out) *unequal_out = unequal;
+  for (g1s_diff_t *g : gen)
+    if (g) g1s_diff_free(g);
+  if (fold) g1s_fold_free(fold);
+  g1s_filters_free(filters);
+  g1s_y4m_close(ys);
+  g1s_y4m_close(yd);
+  return rc;
+}
+
 }  // extern "C"

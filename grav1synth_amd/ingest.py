@@ -84,15 +84,24 @@ class Y4MReader:
 
 
 def diff_y4m_files(source: str, denoised: str, output: str, *, ar_coeff_lag: int = 3, luma_only: bool = False,
-                   batch_frames: int = 0, device: int = -1, filters: Optional[str] = None) -> Tuple[int, bool]:
-    """`grav1synth diff SOURCE DENOISED -o OUTPUT [-f FILTERS]` for .y4m inputs.  Returns (frames, unequal)."""
+                   batch_frames: int = 0, device: int = -1, filters: Optional[str] = None,
+                   devices: Optional[Sequence[int]] = None) -> Tuple[int, bool]:
+    """`grav1synth diff SOURCE DENOISED -o OUTPUT [-f FILTERS]` for .y4m inputs.  Returns (frames, unequal).
+    devices: HIP ordinals of a frame-sharded job (one generator each, the video dealt batch by batch; an ordinal may
+    repeat); None = one generator on `device`."""
     L = _lib.lib()
     opts = G1SOpts(C.sizeof(G1SOpts), device, ar_coeff_lag, int(luma_only), batch_frames, 0)
     frames = C.c_uint64(0)
     unequal = C.c_int(0)
     err = C.create_string_buffer(512)
-    rc = L.g1s_diff_y4m_files_filtered(str(source).encode(), str(denoised).encode(), str(output).encode(), C.byref(opts),
-                                       filters.encode() if filters else None, C.byref(frames), C.byref(unequal), err, len(err))
+    if devices is not None:
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        rc = L.g1s_diff_y4m_files_sharded(str(source).encode(), str(denoised).encode(), str(output).encode(), C.byref(opts),
+                                          filters.encode() if filters else None, devs, len(devices), C.byref(frames),
+                                          C.byref(unequal), err, len(err))
+    else:
+        rc = L.g1s_diff_y4m_files_filtered(str(source).encode(), str(denoised).encode(), str(output).encode(), C.byref(opts),
+                                           filters.encode() if filters else None, C.byref(frames), C.byref(unequal), err, len(err))
     if rc:
         raise RuntimeError(err.value.decode() or f"g1s_diff_y4m_files failed ({rc})")
     if unequal.value:

@@ -332,6 +332,13 @@ int g1s_diff_y4m_files(const char *source, const char *denoised, const char *out
  * G1S_ERR_INVALID and err = "Invalid filter chain: <reason>" (the reference logs that line and exits). */
 int g1s_diff_y4m_files_filtered(const char *source, const char *denoised, const char *out_tbl, const g1s_opts_t *opts,
                                 const char *filters, uint64_t *frames, int *unequal, char *err, size_t errcap);
+/* The same command over several devices (north_star: frames shard across the GPUs of a node; the loop of src/main.rs:414-531):
+ * ONE process, a generator per entry of `devices` (an ordinal may repeat), the two files' frame pairs dealt batch by batch
+ * (batch j -> generator j % n_devices), the frame-shard rounds above with the host as the transport.  Same table, byte for
+ * byte, as one generator; same return values and error texts as g1s_diff_y4m_files_filtered. */
+int g1s_diff_y4m_files_sharded(const char *source, const char *denoised, const char *out_tbl, const g1s_opts_t *opts,
+                               const char *filter_text, const int32_t *devices, uint32_t n_devices, uint64_t *frames_out,
+                               int *unequal_out, char *err, size_t errcap);
 
 /* ---- N4: `grav1synth estimate` (feature "unstable", src/main.rs:534-608): the single-source noise estimator ---- */
 /* av1_grain::estimate_plane_noise(&frame.y_plane, bit_depth) per frame (the port of libaom's

@@ -776,6 +776,37 @@ def test_y4m_files_give_the_table_of_the_in_memory_path_and_of_the_oracle(tmp_pa
     assert by_hand == oracle_tbl
 
 
+@pytest.mark.parametrize("devices,nframes", [([0], 7), ([0, 0], 7), ([0, 0], 9), ([0, 0, 0], 11), ("visible", 13)],
+                         ids=["1gen", "2gen_7", "2gen_9", "3gen_11", "all_visible_devices"])
+def test_sharded_y4m_diff_gives_the_table_of_one_generator(tmp_path, devices, nframes):
+    """`diff --gpus N SOURCE DENOISED -o OUT` (g1s_diff_y4m_files_sharded; the loop of src/main.rs:414-531 dealt over
+    N generators in one process, batches of 2 -> short last batch, idle generators in the last round, a scene cut inside a
+    batch): the same bytes as one generator and as the oracle -- with one generator per visible device (N = 1 on the
+    test box) and with several generators on device 0."""
+    from grav1synth_amd import cli
+    from grav1synth_amd.ingest import diff_y4m_files, write_y4m
+
+    if devices == "visible":
+        devices = list(range(torch.cuda.device_count()))
+    a, b = SynthSpec(320, 200, 10), SynthSpec(320, 200, 10, gain_scale=3)
+    specs = [a] * (nframes // 2) + [b] * (nframes - nframes // 2)
+    pairs = [make_pair(sp, k, device="cpu") for k, sp in enumerate(specs)]
+    fps = Fraction(30000, 1001)
+    write_y4m(str(tmp_path / "src.y4m"), [s for s, _ in pairs], 10, 1, 1, fps)
+    write_y4m(str(tmp_path / "den.y4m"), [d for _, d in pairs], 10, 1, 1, fps)
+    out = tmp_path / "out.tbl"
+    frames, unequal = diff_y4m_files(str(tmp_path / "src.y4m"), str(tmp_path / "den.y4m"), str(out), batch_frames=2, devices=devices)
+    assert (frames, unequal) == (nframes, False)
+    want, segs = oracle_run(a, range(nframes), fps=fps, specs_per_frame=specs)
+    assert len(segs) >= 2
+    assert out.read_bytes() == want
+    # the front door: python -m grav1synth_amd diff ... --devices 0,0
+    out2 = tmp_path / "out2.tbl"
+    assert cli.main(["diff", str(tmp_path / "src.y4m"), str(tmp_path / "den.y4m"), "-o", str(out2), "--devices",
+                     ",".join(str(d) for d in devices)]) == 0
+    assert out2.read_bytes() == want
+
+
 def test_y4m_unequal_frame_counts_stop_at_the_shorter_file(tmp_path):
     """The reference warns and stops when only one reader ends (src/main.rs:449-455): the table then covers
     the common prefix."""
