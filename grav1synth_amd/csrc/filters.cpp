@@ -6,17 +6,22 @@
 //           src/main.rs:615-629).  A crop does not touch a sample: it is extent arithmetic on the frame descriptor
 //           -- plane pointers move by (top, left), width and height shrink -- for host and device frames alike, so
 //           the kernels simply see a smaller frame with the same strides.
-//   resize  parsed and validated exactly like the reference, then REFUSED at apply time with a clear error: the
-//           reference resamples with the video-resize crate's separable kernels (hermite / catmullrom / mitchell /
-//           lanczos / spline36); that arithmetic is a dependency absent from /root/reference and is out of this
-//           path's scope: resize the source before `diff`.
+//   resize  parsed and validated exactly like the reference; applied ON THE DEVICE by resize.hip (the five separable
+//           kernels -- hermite / catmullrom / mitchell / lanczos / spline36 -- of the video-resize crate, a dependency absent
+//           from /root/reference: parity unpinned, the assumptions are listed there).  The resized frame lives in a ring
+//           of device buffers owned by the chain; the frame-pair loop (ingest.cpp) keeps a slot until the generator has
+//           released the frame.  A resize needs the source bit depth (FilterChain::apply's `source_bd`):
+//           g1s_filters_apply_bd.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "../../include/g1s_diff.h"
+#include "resize.h"
 
 namespace {
 
@@ -149,6 +154,8 @@ bool parse_chain(const std::string &text, std::vector<Filter> &out, std::string 
 
 struct g1s_filters {
   std::vector<Filter> filters;
+  // one state per resize filter of the chain (taps, staging, the ring of output frames); made at the first apply
+  mutable std::vector<std::unique_ptr<g1s::ResizeState>> resize;
 };
 
 extern "C" {
@@ -182,15 +189,37 @@ int g1s_filters_get(const g1s_filters_t *f, size_t i, g1s_filter_desc_t *out) {
   return G1S_OK;
 }
 
-int g1s_filters_apply(const g1s_filters_t *f, const g1s_frame_t *in, g1s_frame_t *out, char *err, size_t errcap) {
+// FilterChain::apply(frame, source_bd) (src/filters.rs:112-116).  device: where a resize runs (-1: the current device);
+// slot: which buffer of the resize filters' output rings receives the frame (the caller keeps slot s untouched for as long
+// as it uses the frame that went there).  bit_depth 0: only legal for chains without a resize.
+int g1s_filters_apply_bd(const g1s_filters_t *f, const g1s_frame_t *in, uint32_t bit_depth, int32_t device, uint32_t slot, g1s_frame_t *out,
+                         char *err, size_t errcap) {
   if (!in || !out) return G1S_ERR_INVALID;
   g1s_frame_t fr = *in;
   if (f) {
-    for (const Filter &x : f->filters) {
+    if (f->resize.size() < f->filters.size()) f->resize.resize(f->filters.size());
+    for (size_t fi = 0; fi < f->filters.size(); ++fi) {
+      const Filter &x = f->filters[fi];
       if (x.kind == 1) {
-        set_err(err, errcap, "resize:width=" + std::to_string(x.width) + ",height=" + std::to_string(x.height) + ",alg=" + x.alg +
-                                 " -- the resize filter is not supported here (crop is): resize the source before diff");
-        return G1S_ERR_UNSUPPORTED;
+        if (bit_depth == 0) {
+          set_err(err, errcap, "resize:width=" + std::to_string(x.width) + ",height=" + std::to_string(x.height) + ",alg=" + x.alg +
+                                   " -- a resize needs the source bit depth (g1s_filters_apply_bd)");
+          return G1S_ERR_UNSUPPORTED;
+        }
+        if (x.width > 65535 || x.height > 65535) {
+          set_err(err, errcap, "resize: target larger than 65535 x 65535");
+          return G1S_ERR_INVALID;
+        }
+        if (!f->resize[fi]) f->resize[fi].reset(new g1s::ResizeState(g1s::resize_alg_id(x.alg.c_str())));
+        std::string why;
+        g1s_frame_t resized;
+        const int rc = f->resize[fi]->run(fr, bit_depth, (uint32_t)x.width, (uint32_t)x.height, device, (int)slot, resized, why);
+        if (rc) {
+          set_err(err, errcap, why);
+          return rc;
+        }
+        fr = resized;
+        continue;
       }
       // crop: the frame must keep at least one sample, and with decimated chroma the cut must fall on a chroma sample
       // (each amount on its own: the parser accepts anything up to UINT64_MAX and a sum would wrap)
@@ -216,6 +245,18 @@ int g1s_filters_apply(const g1s_filters_t *f, const g1s_frame_t *in, g1s_frame_t
   }
   *out = fr;
   return G1S_OK;
+}
+
+int g1s_filters_apply(const g1s_filters_t *f, const g1s_frame_t *in, g1s_frame_t *out, char *err, size_t errcap) {
+  // (8-bit samples say their depth; deeper ones need g1s_filters_apply_bd when the chain resizes)
+  return g1s_filters_apply_bd(f, in, in && in->bytes_per_sample == 1 ? 8u : 0u, -1, 0, out, err, errcap);
+}
+
+int g1s_filters_has_resize(const g1s_filters_t *f) {
+  if (f)
+    for (const Filter &x : f->filters)
+      if (x.kind == 1) return 1;
+  return 0;
 }
 
 void g1s_filters_free(g1s_filters_t *f) { delete f; }

@@ -342,6 +342,8 @@ void g1s_y4m_close(g1s_y4m_t *y) {
 
 // (engine.hip) replaces the generator's error text: the loop below prefixes errors with the index of the frame pair
 extern "C" void g1s_diff_set_error_text_(g1s_diff_t *, const char *);
+extern "C" uint32_t g1s_diff_source_bit_depth_(const g1s_diff_t *);
+extern "C" int32_t g1s_diff_device_(const g1s_diff_t *);
 
 int g1s_diff_run_filtered(g1s_diff_t *g, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
                           void *denoised_user, const g1s_filters_t *filters, uint64_t *frames_out, int *unequal_out) {
@@ -349,6 +351,8 @@ int g1s_diff_run_filtered(g1s_diff_t *g, g1s_next_frame_fn source, void *source_
   uint64_t frames = 0;
   int unequal = 0;
   int rc = G1S_OK;
+  const bool resizes = filters && g1s_filters_has_resize(filters);
+  constexpr uint64_t kResizeRing = 512;  // resized frames that may be inside the generator at once (4 batches of <= 128)
   auto note = [&](const std::string &what) {
     g1s_diff_set_error_text_(g, ("frame " + std::to_string(frames) + ": " + what).c_str());
   };
@@ -371,7 +375,20 @@ int g1s_diff_run_filtered(g1s_diff_t *g, g1s_next_frame_fn source, void *source_
     if (filters) {
       char ferr[320] = "";
       g1s_frame_t cropped;
-      rc = g1s_filters_apply(filters, &s, &cropped, ferr, sizeof(ferr));
+      // a resized frame lives in slot (frame index mod ring) of the chain's ring; the generator reads device frames in
+      // place, so a slot is taken again only when the frame that was there has been released
+      uint32_t slot = 0;
+      if (resizes) {
+        slot = (uint32_t)(frames % kResizeRing);
+        if (frames >= kResizeRing && g1s_diff_frames_released(g) + kResizeRing <= frames) {
+          rc = g1s_diff_sync(g);
+          if (rc) {
+            note(std::string("diff_frame: ") + g1s_diff_last_error(g));
+            break;
+          }
+        }
+      }
+      rc = g1s_filters_apply_bd(filters, &s, g1s_diff_source_bit_depth_(g), g1s_diff_device_(g), slot, &cropped, ferr, sizeof(ferr));
       if (rc) {
         note(ferr);
         break;
@@ -572,6 +589,11 @@ int g1s_diff_y4m_files_sharded(const char *source_path, const char *denoised_pat
         if (filters) {
           char ferr[320] = "";
           g1s_frame_t cropped;
+          if (g1s_filters_has_resize(filters)) {  // (one chain, one device: the sharded command does not resize)
+            rc = G1S_ERR_UNSUPPORTED;
+            set_err(err, errcap, "frame " + std::to_string(frames) + ": the resize filter is served on one device only (drop --gpus / --devices)");
+            break;
+          }
           rc = g1s_filters_apply(filters, &s, &cropped, ferr, sizeof(ferr));
           if (rc) {
             set_err(err, errcap, "frame " + std::to_string(frames) + ": " + ferr);

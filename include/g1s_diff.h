@@ -42,7 +42,7 @@ enum {
   G1S_ERR_HIP = -6,           /* a HIP runtime call failed (see last_error) */
   G1S_ERR_STATE = -7,         /* call not legal in this state (e.g. after finish) */
   G1S_ERR_CAPACITY = -8,      /* output buffer too small */
-  G1S_ERR_UNSUPPORTED = -9    /* valid request this path does not serve (the resize filter) */
+  G1S_ERR_UNSUPPORTED = -9    /* valid request this path does not serve (a resize of deep samples without their bit depth) */
 };
 
 /* One decoded frame == v_frame::Frame<T> as produced by
@@ -295,6 +295,21 @@ int g1s_filters_get(const g1s_filters_t *, size_t i, g1s_filter_desc_t *out);
  * (G1S_ERR_INVALID otherwise).  A chain with a resize filter parses but is refused here: G1S_ERR_UNSUPPORTED, with
  * the filter named in err.  filters == NULL: *out = *in. */
 int g1s_filters_apply(const g1s_filters_t *, const g1s_frame_t *in, g1s_frame_t *out, char *err, size_t errcap);
+/* FilterChain::apply(frame, source_bd) (src/filters.rs:112-116) with the resize filter served: crop as above; resize
+ * (src/filters.rs:150-178: hermite / catmullrom / mitchell / lanczos / spline36) runs ON THE DEVICE `device` (-1: the
+ * current one; host planes are staged there) and the resized frame comes back as device planes (on_device = 1) inside
+ * buffer `slot` of a ring the chain owns -- valid until the chain is applied with the same slot again, or freed.  No CPU
+ * fallback.  bit_depth = the source bit depth (8..16).  g1s_filters_apply = this with bit_depth 8 for 8-bit samples and a
+ * refusal (G1S_ERR_UNSUPPORTED) for deeper ones when the chain resizes. */
+int g1s_filters_apply_bd(const g1s_filters_t *, const g1s_frame_t *in, uint32_t bit_depth, int32_t device, uint32_t slot,
+                         g1s_frame_t *out, char *err, size_t errcap);
+int g1s_filters_has_resize(const g1s_filters_t *);
+/* The taps of one axis of a resize (test / documentation aid): output i = sum over k < *taps of coef[i * taps + k] *
+ * in[idx[i * taps + k]], k ascending, in f32 without fused multiply-adds; cap = entries idx / coef hold (dst * taps). */
+int g1s_resize_plan(const char *alg, uint32_t src, uint32_t dst, uint32_t *taps, int32_t *idx, float *coef, size_t cap);
+/* One frame (host or device planes) through the device resize, result into host planes (tests, the Python FilterChain). */
+int g1s_resize_frame_to_host(const char *alg, const g1s_frame_t *in, uint32_t bit_depth, uint32_t out_w, uint32_t out_h,
+                             int32_t device, void *const out_planes[3], const size_t out_stride_bytes[3], char *err, size_t errcap);
 void g1s_filters_free(g1s_filters_t *);
 /* g1s_diff_run with get_filtered_frame_pair's filter step (src/main.rs:615-629): the chain is applied to every SOURCE
  * frame before the pair is handed to diff_frame; the denoised frame is taken as it comes.  A frame index goes with

@@ -75,12 +75,17 @@ def lib():
     if not os.path.exists(_LIB_PATH):
         build()
     L = C.CDLL(_LIB_PATH)
-    if not hasattr(L, "orc_estimate_plane_noise"):  # a library from before the estimator was added
+    if not hasattr(L, "orc_estimate_plane_noise") or not hasattr(L, "orc_resize_plane"):  # a library from before these were added
         del L
         build()
         L = C.CDLL(_LIB_PATH)
     L.orc_estimate_plane_noise.restype = C.c_double
     L.orc_estimate_plane_noise.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.orc_resize_plan.restype = C.c_int
+    L.orc_resize_plan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orc_resize_plane.restype = C.c_int
+    L.orc_resize_plane.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                   C.c_int]
     L.orc_diff_new.restype = C.c_void_p
     L.orc_diff_new.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_diff_frame.restype = C.c_int
@@ -111,6 +116,32 @@ def estimate_plane_noise(plane: np.ndarray, bit_depth: int) -> Optional[float]:
     assert p.dtype == (np.uint8 if bit_depth == 8 else np.uint16)
     v = lib().orc_estimate_plane_noise(p.ctypes.data, p.strides[0], p.shape[1], p.shape[0], bit_depth)
     return None if v == -1.0 else float(v)
+
+
+def resize_plan(alg: str, src: int, dst: int):
+    """taps of one axis as oracle/resize_oracle.c forms them: (idx[dst, taps], coef[dst, taps])"""
+    L = lib()
+    taps = L.orc_resize_plan(alg.encode(), src, dst, None, None, 0)
+    assert taps > 0
+    idx = np.zeros((dst, taps), np.int32)
+    coef = np.zeros((dst, taps), np.float32)
+    assert L.orc_resize_plan(alg.encode(), src, dst, idx.ctypes.data, coef.ctypes.data, idx.size) == taps
+    return idx, coef
+
+
+def resize_planes(planes: Sequence[np.ndarray], xdec: int, ydec: int, width: int, height: int, bit_depth: int, alg: str = "catmullrom"):
+    """video_resize::resize as restated in oracle/resize_oracle.c: every plane, chroma to (width >> xdec, height >> ydec)."""
+    L = lib()
+    out = []
+    for c, p in enumerate(planes):
+        p = np.ascontiguousarray(p)
+        dw, dh = (width >> xdec, height >> ydec) if c else (width, height)
+        o = np.zeros((dh, dw), p.dtype)
+        rc = L.orc_resize_plane(alg.encode(), p.ctypes.data, p.dtype.itemsize, p.strides[0], p.shape[1], p.shape[0], o.ctypes.data, o.strides[0],
+                                dw, dh, bit_depth)
+        assert rc == 0
+        out.append(o)
+    return out
 
 
 def _np_frame(planes: Sequence[np.ndarray], xdec: int, ydec: int) -> OrcFrame:

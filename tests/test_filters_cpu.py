@@ -81,10 +81,52 @@ def test_crop_must_fall_on_chroma_samples_and_leave_something():
         FilterChain("crop:top=32,bottom=32").apply(Frame([y, u, u], 1, 1))
 
 
-def test_resize_parses_but_is_refused_at_apply():
-    y = np.zeros((64, 96), np.uint8)
-    with pytest.raises(FilterError, match="resize filter is not supported"):
-        FilterChain("resize:width=48,height=32").apply(Frame([y], 1, 1))
+def test_resize_taps_are_the_oracles_and_sum_to_one():
+    """N3: the taps of an axis (g1s_resize_plan: host code of csrc/resize.hip, no device needed) are the ones
+    oracle/resize_oracle.c forms -- the five kernels, up and down, mirrored edges -- and every output sample's taps sum to 1."""
+    import ctypes as C
+
+    from grav1synth_amd import _lib
+    from tests.oracle_binding import resize_plan
+
+    L = _lib.lib()
+    for alg in ("hermite", "catmullrom", "mitchell", "lanczos", "spline36"):
+        for src, dst in ((96, 48), (48, 96), (100, 37), (37, 100), (64, 64), (7, 50), (1920, 1280)):
+            want_idx, want_coef = resize_plan(alg, src, dst)
+            taps = C.c_uint32()
+            idx = np.zeros(want_idx.shape, np.int32)
+            coef = np.zeros(want_coef.shape, np.float32)
+            assert L.g1s_resize_plan(alg.encode(), src, dst, C.byref(taps), idx.ctypes.data, coef.ctypes.data, idx.size) == 0
+            assert taps.value == want_idx.shape[1] == 2 * int(np.ceil((2 if alg in ("hermite", "catmullrom", "mitchell") else 3) / min(dst / src, 1.0)))
+            assert np.array_equal(idx, want_idx) and np.array_equal(coef.view(np.uint32), want_coef.view(np.uint32)), (alg, src, dst)
+            assert np.allclose(coef.astype(np.float64).sum(axis=1), 1.0, atol=1e-6)
+            assert idx.min() >= 0 and idx.max() <= src - 1
+    assert L.g1s_resize_plan(b"bilinear", 8, 8, C.byref(C.c_uint32()), None, None, 0) != 0
+
+
+def test_resize_oracle_properties():
+    """oracle/resize_oracle.c on what must hold for any separable resampler with normalised taps: a constant plane stays
+    constant, the same size with an interpolating kernel is the identity, values stay inside the bit depth, a horizontal
+    ramp stays monotone when enlarged with a non-negative kernel."""
+    from tests.oracle_binding import resize_planes
+
+    rng = np.random.default_rng(5)
+    const = np.full((40, 56), 700, np.uint16)
+    for alg in ("hermite", "catmullrom", "mitchell", "lanczos", "spline36"):
+        out = resize_planes([const], 0, 0, 84, 26, 10, alg)[0]
+        assert out.shape == (26, 84) and (out == 700).all(), alg
+    noise = rng.integers(0, 1024, (40, 56), dtype=np.uint16)
+    for alg in ("hermite", "catmullrom", "lanczos", "spline36"):  # (interpolating kernels: 1 at 0, 0 at the other integers)
+        assert np.array_equal(resize_planes([noise], 0, 0, 56, 40, 10, alg)[0], noise), alg
+    hot = np.where(rng.random((40, 56)) < 0.5, 0, 1023).astype(np.uint16)  # (overshoot is clamped to the bit depth)
+    out = resize_planes([hot], 0, 0, 112, 80, 10, "lanczos")[0]
+    assert out.max() <= 1023
+    ramp = np.tile(np.arange(64, dtype=np.uint8) * 4, (8, 1))
+    out = resize_planes([ramp], 0, 0, 256, 8, 8, "hermite")[0].astype(int)
+    assert (np.diff(out, axis=1) >= 0).all()
+    y, u = np.zeros((64, 96), np.uint8), np.zeros((32, 48), np.uint8)
+    o = resize_planes([y, u, u], 1, 1, 48, 32, 8)
+    assert [p.shape for p in o] == [(32, 48), (16, 24), (16, 24)]
 
 
 def test_front_door_refusals(tmp_path, caplog):

@@ -239,9 +239,62 @@ def test_front_door_with_a_cropped_source_equals_the_oracle_on_the_cropped_plane
     from grav1synth_amd.ingest import diff_y4m_files
     with pytest.raises(RuntimeError, match=r"frame 0: .*dimensions do not match"):
         diff_y4m_files(a, b, out)
-    # a resize in the chain parses and is refused when the first frame arrives
-    with pytest.raises(RuntimeError, match=r"frame 0: resize:width=320,height=200,alg=catmullrom -- the resize filter is not supported"):
-        diff_y4m_files(a, b, out, filters="resize:width=320,height=200")
+
+
+@pytest.mark.parametrize("alg", ["hermite", "catmullrom", "mitchell", "lanczos", "spline36"])
+def test_device_resize_equals_the_oracle_plane_for_plane(alg):
+    """N3: the resize filter on the device (csrc/resize.hip) against oracle/resize_oracle.c, bit for bit: up and down, odd
+    sizes whose windows mirror at the edges, 8- and 10-bit, 4:2:0 and 4:4:4 chroma planes, host and device input."""
+    from grav1synth_amd.filters import FilterChain
+    from tests.oracle_binding import resize_planes
+
+    rng = np.random.default_rng(11)
+    for (w, h, bd, xd, yd, tw, th, on_dev) in [(96, 64, 8, 1, 1, 48, 40, False), (100, 38, 10, 1, 1, 146, 90, False), (64, 48, 10, 0, 0, 37, 29, True),
+                                               (90, 70, 8, 0, 0, 90, 70, True), (320, 200, 10, 1, 1, 480, 304, True)]:
+        dt = np.uint8 if bd == 8 else np.uint16
+        planes = [rng.integers(0, 1 << bd, (h >> (yd if c else 0), w >> (xd if c else 0)), dtype=dt) for c in range(3)]
+        planes[0][: h // 4] = (1 << bd) - 1  # (saturated and empty areas: the clamp)
+        planes[0][h // 4: h // 2, : w // 3] = 0
+        want = resize_planes(planes, xd, yd, tw, th, bd, alg)
+        src = [torch.from_numpy(p).cuda() for p in planes] if on_dev else planes
+        got = FilterChain(f"resize:width={tw},height={th},alg={alg}").apply(Frame(src, xd, yd), bd).planes
+        for c in range(3):
+            assert got[c].shape == want[c].shape and np.array_equal(got[c], want[c]), f"{w}x{h} -> {tw}x{th} {bd}b plane {c}"
+
+
+@pytest.mark.parametrize("bd,alg", [(8, "catmullrom"), (10, "lanczos")])
+def test_front_door_with_a_resized_source_equals_the_oracle_on_the_oracles_resized_planes(tmp_path, bd, alg):
+    """N3 + the front door: `diff SOURCE DENOISED -o OUT -y -f resize:width=..,height=..,alg=..` (src/filters.rs:150-178 applied
+    to the source only, src/main.rs:615-629) on a source file of another size: the table is, byte for byte, the oracle's table
+    for the source planes resized by the oracle's restatement; and crop and resize in one chain."""
+    from grav1synth_amd import cli
+    from grav1synth_amd.ingest import write_y4m
+    from tests.oracle_binding import OracleDiff, format_tbl as ofmt, resize_planes
+
+    spec = SynthSpec(320, 200, bd)
+    nframes = 3
+    fps = Fraction(30000, 1001)
+    big, den = [], []
+    for k in range(nframes):
+        s, d = np_pair(spec, k)
+        big.append(resize_planes(s, 1, 1, 480, 304, bd, "spline36"))  # (a larger source: 480 x 304)
+        den.append(d)
+    a, b, out = str(tmp_path / "source.y4m"), str(tmp_path / "denoised.y4m"), str(tmp_path / "out.tbl")
+    write_y4m(a, big, bd, 1, 1, fps)
+    write_y4m(b, den, bd, 1, 1, fps)
+    o = OracleDiff(fps.numerator, fps.denominator, bd, bd, 3, True)
+    for k in range(nframes):
+        o.diff_frame(resize_planes(big[k], 1, 1, 320, 200, bd, alg), den[k], 1, 1)
+    want = ofmt(o.finish())
+    assert cli.diff_command(a, b, out, overwrite=True, filters=f"resize:width=320,height=200,alg={alg}") == nframes
+    assert open(out, "rb").read() == want
+    # crop first, then resize what is left
+    o = OracleDiff(fps.numerator, fps.denominator, bd, bd, 3, True)
+    for k in range(nframes):
+        cropped = [p[(8 >> (1 if c else 0)):, (16 >> (1 if c else 0)):] for c, p in enumerate(big[k])]
+        o.diff_frame(resize_planes(cropped, 1, 1, 320, 200, bd, alg), den[k], 1, 1)
+    assert cli.diff_command(a, b, out, overwrite=True, filters=f"crop:top=8,left=16;resize:width=320,height=200,alg={alg}") == nframes
+    assert open(out, "rb").read() == ofmt(o.finish())
 
 
 def test_cropped_device_frames_equal_the_oracle():
