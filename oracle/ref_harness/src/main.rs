@@ -2,14 +2,17 @@
 //!
 //! The reference's `diff` arithmetic without its ffmpeg front end: av1_grain::DiffGenerator (the crate
 //! grav1synth 0.4.x pins) driven exactly as grav1synth's src/main.rs:414-529 drives it -- new(fps, source bit
-//! depth, denoised bit depth), diff_frame per frame pair in order, finish(), then the table writer.  The Y4M
+//! depth, denoised bit depth), diff_frame per frame pair in order, finish(), then the table in GRAV1SYNTH'S OWN text
+//! layout (its src/main.rs:525-529 and write_film_grain_segment, :631-696 -- "filmgrn1", two spaces after "sY n", one after
+//! "sCb n" / "sCr n" -- restated below, not av1_grain::write_grain_table: a byte that differs from the committed tables is
+//! then arithmetic, not whitespace).  The Y4M
 //! reader below is this harness's own (8 / 10 / 12-bit, 4:2:0 / 4:2:2 / 4:4:4 / mono), so the binary needs
 //! no video libraries.  Test infrastructure: it produces golden tables for tests/test_reference_pin.py and is
 //! never linked into or called by the product.
-use std::io::{BufRead, BufReader, Read};
+use std::io::{BufRead, BufReader, BufWriter, Read, Write};
 
 use anyhow::{anyhow, bail, Result};
-use av1_grain::{write_grain_table, DiffGenerator};
+use av1_grain::{DiffGenerator, GrainTableSegment};
 use num_rational::Rational64;
 use v_frame::{frame::Frame, pixel::{ChromaSampling, Pixel}};
 
@@ -67,8 +70,45 @@ fn run<T: Pixel, U: Pixel>(mut s: Y4m, mut d: Y4m, out: &str) -> Result<()> {
         }
         frames += 1;
     }
-    write_grain_table(out, &differ.finish())?;
+    write_tbl(out, &differ.finish())?;
     eprintln!("Computed diff for {frames} frames");
+    Ok(())
+}
+
+/// The `.tbl` text as grav1synth writes it after `diff` (reference src/main.rs:525-529, 631-696): the fields of
+/// av1_grain::GrainTableSegment in the order of its `From` impl (src/parser/grain.rs:108-133).
+fn write_tbl(path: &str, segments: &[GrainTableSegment]) -> Result<()> {
+    let mut o = BufWriter::new(std::fs::File::create(path)?);
+    writeln!(o, "filmgrn1")?;
+    for s in segments {
+        writeln!(o, "E {} {} 1 {} 1", s.start_time, s.end_time, s.random_seed)?;
+        writeln!(
+            o,
+            "\tp {} {} {} {} {} {} {} {} {} {} {} {}",
+            s.ar_coeff_lag, s.ar_coeff_shift, s.grain_scale_shift, s.scaling_shift,
+            u8::from(s.chroma_scaling_from_luma), u8::from(s.overlap_flag),
+            s.cb_mult, s.cb_luma_mult, s.cb_offset, s.cr_mult, s.cr_luma_mult, s.cr_offset
+        )?;
+        write!(o, "\tsY {} ", s.scaling_points_y.len())?; // (a space here AND one before every point: two after the count)
+        for p in &s.scaling_points_y { write!(o, " {} {}", p[0], p[1])?; }
+        writeln!(o)?;
+        write!(o, "\tsCb {}", s.scaling_points_cb.len())?;
+        for p in &s.scaling_points_cb { write!(o, " {} {}", p[0], p[1])?; }
+        writeln!(o)?;
+        write!(o, "\tsCr {}", s.scaling_points_cr.len())?;
+        for p in &s.scaling_points_cr { write!(o, " {} {}", p[0], p[1])?; }
+        writeln!(o)?;
+        write!(o, "\tcY")?;
+        for c in &s.ar_coeffs_y { write!(o, " {}", *c)?; }
+        writeln!(o)?;
+        write!(o, "\tcCb")?;
+        for c in &s.ar_coeffs_cb { write!(o, " {}", *c)?; }
+        writeln!(o)?;
+        write!(o, "\tcCr")?;
+        for c in &s.ar_coeffs_cr { write!(o, " {}", *c)?; }
+        writeln!(o)?;
+    }
+    o.flush()?;
     Ok(())
 }
 
