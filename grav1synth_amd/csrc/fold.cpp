@@ -7,6 +7,7 @@
 #include "fold.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -562,6 +563,20 @@ int NoiseFold::push_latest(FrameLatest &fl) {
   return G1S_OK;
 }
 
+namespace {
+struct FoldProfile {  // G1S_FOLD_PROFILE=1: where the ordered merge's time goes (printed when the process ends)
+  bool on = getenv("G1S_FOLD_PROFILE") != nullptr;
+  double prefix = 0, solves = 0, commit = 0;
+  size_t frames = 0;
+  ~FoldProfile() {
+    if (on && frames)
+      fprintf(stderr, "ordered merge, us per frame: prefix sums %.2f, solves %.2f, in-order commit %.2f (%zu frames)\n", prefix * 1e6 / frames,
+              solves * 1e6 / frames, commit * 1e6 / frames, frames);
+  }
+} g_fold_profile;
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pfor) {
   constexpr size_t kWindow = 64;
   if (snap_.size() < kWindow) {
@@ -571,6 +586,7 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
   size_t i = 0;
   while (i < n) {
     // ---- prefix sums of the luma systems over a window of frames (no segment cut assumed) ----
+    const double t_a = g_fold_profile.on ? now_s() : 0;
     size_t W = std::min(kWindow, n - i);
     for (size_t j = 0; j < W; ++j) {
       if (fl[i + j].status != G1S_OK) {  // an error frame ends the window; it is reported when reached
@@ -592,6 +608,7 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       return fl[i].status;
     }
     // ---- the solves, independent of each other ----
+    const double t_b = g_fold_profile.on ? now_s() : 0;
     const std::function<void(int)> solve_one = [&](int j) {
       const bool a = ar_solve(snap_[j], false);
       const bool b = snap_[j].strength.solve_x_only();
@@ -608,6 +625,7 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       for (size_t j = 0; j < W; ++j) solve_one((int)j);
     }
     // ---- in order: the is_different() tests, commits, segment cuts ----
+    const double t_c = g_fold_profile.on ? now_s() : 0;
     size_t done = W;
     for (size_t j = 0; j < W; ++j) {
       FrameLatest &f = fl[i + j];
@@ -641,6 +659,13 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       frame_count_ += 1;
     }
     i += done;
+    if (g_fold_profile.on) {
+      const double t_d = now_s();
+      g_fold_profile.prefix += t_b - t_a;
+      g_fold_profile.solves += t_c - t_b;
+      g_fold_profile.commit += t_d - t_c;
+      g_fold_profile.frames += done;
+    }
   }
   return G1S_OK;
 }

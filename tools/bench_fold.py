@@ -39,5 +39,22 @@ f.push_latest_many(big)
 merge = (time.perf_counter() - t0) / len(big)
 f.finish()
 f.close()
-print(json.dumps({"frame": f"{w}x{h} 10-bit 4:2:0 lag 3", "record_bytes": int(R.shape[1]), "latest_bytes": int(blobs.shape[1]),
-                  "per_frame_half_cpu_us": round(per_frame * 1e6, 1), "ordered_merge_cpu_us": round(merge * 1e6, 2)}))
+out = {"frame": f"{w}x{h} 10-bit 4:2:0 lag 3", "record_bytes": int(R.shape[1]), "latest_bytes": int(blobs.shape[1]),
+       "per_frame_half_cpu_us": round(per_frame * 1e6, 1), "ordered_merge_cpu_us": round(merge * 1e6, 2), "hw_threads": os.cpu_count()}
+# the ordered merge with its pool (the solves of a window of frames run on the merge pool, the rest is serial): wall time per
+# frame, what rank 0 of an N-rank job has to stay under (1 / (N x frames/s of a rank)).  A fresh process per pool size
+# (the pool is made once per process).
+if len(sys.argv) <= 2:
+    import subprocess
+
+    out["ordered_merge_wall_us_by_threads"] = {}
+    for t in (1, 4, 8, 16, 32, 64):
+        if t > (os.cpu_count() or 1):
+            break
+        r = subprocess.run([sys.executable, __file__, f"{w}x{h}", "merge-only"], env=dict(os.environ, G1S_FOLD_THREADS=str(t)),
+                           capture_output=True, text=True)
+        try:
+            out["ordered_merge_wall_us_by_threads"][str(t)] = json.loads(r.stdout.strip().splitlines()[-1])["ordered_merge_cpu_us"]
+        except Exception:
+            out["ordered_merge_wall_us_by_threads"][str(t)] = None
+print(json.dumps(out))
