@@ -578,35 +578,65 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }  // namespace
 
 int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pfor) {
-  constexpr size_t kWindow = 64;
+  constexpr size_t kWindow = 256;  // (frames per speculative window: a dispatch to the merge pool costs tens of microseconds)
   if (snap_.size() < kWindow) {
     snap_.resize(kWindow);
     snap_ok_.resize(kWindow);
   }
+  // one frame's chroma plane into a running combined state (what push_latest does for c > 0, in frame order)
+  auto chroma_add = [](PlaneState &com, const PlaneState &lat) {
+    com.num_observations += lat.num_observations;
+    com.ar.add(lat.ar);
+    com.strength.add(lat.strength);
+    com.strength.apply_regularisation_to_b();
+  };
   size_t i = 0;
   while (i < n) {
-    // ---- prefix sums of the luma systems over a window of frames (no segment cut assumed) ----
+    // ---- a window of frames, no segment cut assumed ----
     const double t_a = g_fold_profile.on ? now_s() : 0;
     size_t W = std::min(kWindow, n - i);
-    for (size_t j = 0; j < W; ++j) {
+    for (size_t j = 0; j < W; ++j)
       if (fl[i + j].status != G1S_OK) {  // an error frame ends the window; it is reported when reached
         W = j;
         break;
       }
-      PlaneState &s = snap_[j];
-      const PlaneState &prev = j ? snap_[j - 1] : combined_[0];
-      const PlaneState &lat = fl[i + j].st[0];
-      s.ar.set_sum(prev.ar, lat.ar);
-      s.strength.eq.set_sum(prev.strength.eq, lat.strength.eq);
-      s.strength.num_equations = prev.strength.num_equations + lat.strength.num_equations;
-      s.strength.total = prev.strength.total + lat.strength.total;
-      s.num_observations = prev.num_observations + lat.num_observations;
-      s.strength.apply_regularisation_to_b();  // (the first half of StrengthSolver::solve)
-    }
     if (W == 0) {
       err_ = fl[i].err;
       return fl[i].status;
     }
+    // Three running sums, each sequential in frame order (the additions happen in the reference's order: same bits), each
+    // on data of its own -- so they run next to each other: task 0 the prefix sums of the luma systems (one state per
+    // frame: the solves below need them all), tasks 1, 2 the combined Cb / Cr states after the window's last frame (nothing
+    // reads a chroma state between segment boundaries).  The serial commit below then only swaps pointers: the frames'
+    // states were parsed on other cores, and every byte the serial stage does not touch is a cache miss it does not wait for.
+    uint32_t cplanes = fl[i].nplanes;
+    for (size_t j = 1; j < W; ++j) cplanes = std::min(cplanes, fl[i + j].nplanes);
+    const std::function<void(int)> sums = [&](int t) {
+      if (t == 0) {
+        for (size_t j = 0; j < W; ++j) {
+          PlaneState &s = snap_[j];
+          const PlaneState &prev = j ? snap_[j - 1] : combined_[0];
+          const PlaneState &lat = fl[i + j].st[0];
+          s.ar.set_sum(prev.ar, lat.ar);
+          s.strength.eq.set_sum(prev.strength.eq, lat.strength.eq);
+          s.strength.num_equations = prev.strength.num_equations + lat.strength.num_equations;
+          s.strength.total = prev.strength.total + lat.strength.total;
+          s.num_observations = prev.num_observations + lat.num_observations;
+          s.strength.apply_regularisation_to_b();  // (the first half of StrengthSolver::solve)
+        }
+      } else if ((uint32_t)t < cplanes) {
+        PlaneState &acc = csum_[t];
+        acc.num_observations = combined_[t].num_observations;
+        acc.ar.assign(combined_[t].ar);
+        acc.strength.eq.assign(combined_[t].strength.eq);
+        acc.strength.num_equations = combined_[t].strength.num_equations;
+        acc.strength.total = combined_[t].strength.total;
+        for (size_t j = 0; j < W; ++j) chroma_add(acc, fl[i + j].st[t]);
+      }
+    };
+    if (pfor && W > 8) pfor(3, sums);
+    else
+      for (int t = 0; t < 3; ++t) sums(t);
     // ---- the solves, independent of each other ----
     const double t_b = g_fold_profile.on ? now_s() : 0;
     const std::function<void(int)> solve_one = [&](int j) {
@@ -615,7 +645,7 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       snap_ok_[j] = (uint8_t)((a ? 1 : 0) | (b ? 2 : 0));
     };
     if (pfor && W > 1) {
-      // a few tasks of several solves each: a solve is ~3 us, waking a thread costs about as much
+      // a few tasks of several solves each: a solve is ~2 us, waking a thread costs more
       const int T = (int)std::min<size_t>(W, 8);
       const std::function<void(int)> range = [&](int t) {
         for (size_t j = W * t / T; j < W * (t + 1) / T; ++j) solve_one((int)j);
@@ -627,16 +657,25 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
     // ---- in order: the is_different() tests, commits, segment cuts ----
     const double t_c = g_fold_profile.on ? now_s() : 0;
     size_t done = W;
+    bool cut = false;
     for (size_t j = 0; j < W; ++j) {
       FrameLatest &f = fl[i + j];
       for (int c = 0; c < 3; ++c) std::swap(latest_[c], f.st[c]);
       if (combined_[0].strength.num_equations > 0 && is_different()) {
+        // a new segment starts with this frame: the chroma planes of the frames before it, in order, into the combined
+        // model that ends here (their states are back in fl[..].st: the swaps below undo themselves pairwise)
+        for (size_t q = 0; q < j; ++q)
+          for (int c = 1; c < (int)fl[i + q].nplanes; ++c) {
+            chroma_add(combined_[c], held_[q * 2 + (c - 1)]);
+            chroma_dirty_ = true;
+          }
         const uint64_t cur = frame_count_ * 10000000ULL * (uint64_t)fps_den_ / (uint64_t)fps_num_;
         table_.push_back(grain_parameters(prev_timestamp_, cur));
         save_latest();
         prev_timestamp_ = cur;
         frame_count_ += 1;
         done = j + 1;  // the states behind the cut were built on a combined model that is gone
+        cut = true;
         break;
       }
       if (!(snap_ok_[j] & 1)) {
@@ -648,15 +687,22 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
         return G1S_ERR_SOLVE;
       }
       std::swap(combined_[0], snap_[j]);
-      for (int c = 1; c < (int)f.nplanes; ++c) {
-        PlaneState &com = combined_[c];
-        com.num_observations += latest_[c].num_observations;
-        com.ar.add(latest_[c].ar);
-        com.strength.add(latest_[c].strength);
-        com.strength.apply_regularisation_to_b();
+      // (the frame's chroma states stay reachable until the window is committed: a cut later in the window needs them)
+      if (held_.size() < 2 * kWindow) held_.resize(2 * kWindow);
+      for (int c = 1; c < 3; ++c) std::swap(held_[j * 2 + (c - 1)], latest_[c]);
+      frame_count_ += 1;
+    }
+    if (!cut) {  // the window went through: the combined chroma states are the running sums
+      for (uint32_t c = 1; c < cplanes; ++c) {
+        std::swap(combined_[c].ar, csum_[c].ar);
+        std::swap(combined_[c].strength.eq, csum_[c].strength.eq);
+        combined_[c].strength.num_equations = csum_[c].strength.num_equations;
+        combined_[c].strength.total = csum_[c].strength.total;
+        combined_[c].num_observations = csum_[c].num_observations;
         chroma_dirty_ = true;
       }
-      frame_count_ += 1;
+      // (frames with fewer planes than the window's minimum do not exist: cplanes is the minimum; a frame with MORE planes
+      //  than another cannot happen inside one generator)
     }
     i += done;
     if (g_fold_profile.on) {

@@ -123,6 +123,8 @@ class NoiseFold {
   std::string err_;
   std::vector<PlaneState> snap_;  // push_latest_many: speculative combined luma states
   std::vector<uint8_t> snap_ok_;
+  PlaneState csum_[3];            // ... the combined chroma states after the window (running sums)
+  std::vector<PlaneState> held_;  // ... the window's chroma states (a segment cut inside the window adds them one by one)
 };
 
 long format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap);
