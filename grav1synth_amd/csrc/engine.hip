@@ -183,7 +183,8 @@ Pool *merge_pool() {
   static Pool *p = [] {
     unsigned hw = std::thread::hardware_concurrency();
     if (const char *e = getenv("G1S_FOLD_THREADS")) hw = (unsigned)atoi(e);
-    const unsigned n = std::min(8u, hw / 4);
+    unsigned n = std::min(8u, hw / 4);
+    if (const char *e = getenv("G1S_MERGE_POOL")) n = (unsigned)atoi(e);  // (measurement: the pool's size itself)
     return n > 1 ? new Pool(n - 1) : nullptr;
   }();
   return p;
@@ -1909,7 +1910,7 @@ int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, 
   };
   std::vector<int> prc(n, G1S_OK);
   {
-    const int T = (int)std::min<size_t>(n, 8);
+    const int T = (int)std::min<size_t>((n + 7) / 8, 32);
     pfor(T, [&](int t) {
       for (size_t i = n * t / T; i < n * (t + 1) / T; ++i)
         prc[i] = latest_from_blob(base + i * stride_bytes, stride_bytes, f->lag, f->latest[i]);

@@ -259,8 +259,10 @@ void chroma_fallback(PlaneState &s) {
   if (std::fabs(s.ar.A[last * nc + last]) > 1e-6) s.ar.x[last] = s.ar.b[last] / s.ar.A[last * nc + last];
 }
 
-bool NoiseFold::is_different() const {
-  const LinearSystem &l = latest_[0].ar, &c = combined_[0].ar;
+bool NoiseFold::is_different() const { return differs(latest_[0], combined_[0]); }
+
+bool NoiseFold::differs(const PlaneState &latest, const PlaneState &combined) {
+  const LinearSystem &l = latest.ar, &c = combined.ar;
   double dot = 0, l2 = 0, c2 = 0;
   for (int i = 0; i < c.n; ++i) {
     l2 += l.x[i] * l.x[i];
@@ -270,7 +272,7 @@ bool NoiseFold::is_different() const {
   const double corr = dot / (std::sqrt(l2) * std::sqrt(c2));
   if (corr < 0.9) return true;
   const double dx = 1.0 / kNumBins;
-  const LinearSystem &ls = latest_[0].strength.eq, &cs = combined_[0].strength.eq;
+  const LinearSystem &ls = latest.strength.eq, &cs = combined.strength.eq;
   double diff = 0, total_weight = 0;
   for (int j = 0; j < ls.n; ++j) {
     double weight = 0;
@@ -604,95 +606,99 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       err_ = fl[i].err;
       return fl[i].status;
     }
-    // Three running sums, each sequential in frame order (the additions happen in the reference's order: same bits), each
-    // on data of its own -- so they run next to each other: task 0 the prefix sums of the luma systems (one state per
-    // frame: the solves below need them all), tasks 1, 2 the combined Cb / Cr states after the window's last frame (nothing
-    // reads a chroma state between segment boundaries).  The serial commit below then only swaps pointers: the frames'
+    // Six running sums, each sequential in frame order (the additions happen in the reference's order: same bits), each
+    // on data of its own -- so they run next to each other: tasks 0, 1 the prefix sums of the luma AR and strength systems
+    // (one state per frame: the solves below need them all), tasks 2..5 the combined Cb / Cr states after the window's last
+    // frame (nothing reads a chroma state between segment boundaries).  The serial commit below then only swaps pointers: the frames'
     // states were parsed on other cores, and every byte the serial stage does not touch is a cache miss it does not wait for.
     uint32_t cplanes = fl[i].nplanes;
     for (size_t j = 1; j < W; ++j) cplanes = std::min(cplanes, fl[i + j].nplanes);
     const std::function<void(int)> sums = [&](int t) {
-      if (t == 0) {
+      const int plane = t >> 1;
+      const bool ar_half = !(t & 1);  // (a plane's AR system and its strength system never meet before the solves)
+      if (plane == 0) {
         for (size_t j = 0; j < W; ++j) {
           PlaneState &s = snap_[j];
           const PlaneState &prev = j ? snap_[j - 1] : combined_[0];
           const PlaneState &lat = fl[i + j].st[0];
-          s.ar.set_sum(prev.ar, lat.ar);
-          s.strength.eq.set_sum(prev.strength.eq, lat.strength.eq);
-          s.strength.num_equations = prev.strength.num_equations + lat.strength.num_equations;
-          s.strength.total = prev.strength.total + lat.strength.total;
-          s.num_observations = prev.num_observations + lat.num_observations;
-          s.strength.apply_regularisation_to_b();  // (the first half of StrengthSolver::solve)
+          if (ar_half) {
+            s.ar.set_sum(prev.ar, lat.ar);
+            s.num_observations = prev.num_observations + lat.num_observations;
+          } else {
+            s.strength.eq.set_sum(prev.strength.eq, lat.strength.eq);
+            s.strength.num_equations = prev.strength.num_equations + lat.strength.num_equations;
+            s.strength.total = prev.strength.total + lat.strength.total;
+            s.strength.apply_regularisation_to_b();  // (the first half of StrengthSolver::solve)
+          }
         }
-      } else if ((uint32_t)t < cplanes) {
-        PlaneState &acc = csum_[t];
-        acc.num_observations = combined_[t].num_observations;
-        acc.ar.assign(combined_[t].ar);
-        acc.strength.eq.assign(combined_[t].strength.eq);
-        acc.strength.num_equations = combined_[t].strength.num_equations;
-        acc.strength.total = combined_[t].strength.total;
-        for (size_t j = 0; j < W; ++j) chroma_add(acc, fl[i + j].st[t]);
+      } else if ((uint32_t)plane < cplanes) {
+        PlaneState &acc = csum_[plane];
+        if (ar_half) {
+          acc.num_observations = combined_[plane].num_observations;
+          acc.ar.assign(combined_[plane].ar);
+          for (size_t j = 0; j < W; ++j) {
+            acc.num_observations += fl[i + j].st[plane].num_observations;
+            acc.ar.add(fl[i + j].st[plane].ar);
+          }
+        } else {
+          acc.strength.eq.assign(combined_[plane].strength.eq);
+          acc.strength.num_equations = combined_[plane].strength.num_equations;
+          acc.strength.total = combined_[plane].strength.total;
+          for (size_t j = 0; j < W; ++j) {
+            acc.strength.add(fl[i + j].st[plane].strength);
+            acc.strength.apply_regularisation_to_b();
+          }
+        }
       }
     };
-    if (pfor && W > 8) pfor(3, sums);
+    if (pfor && W > 8) pfor(6, sums);
     else
-      for (int t = 0; t < 3; ++t) sums(t);
-    // ---- the solves, independent of each other ----
+      for (int t = 0; t < 6; ++t) sums(t);
+    // ---- the solves, independent of each other; and the is_different() test of every frame whose predecessor's state the
+    //      same task solved (frame j is tested against the combined model after frame j - 1: snap_[j - 1]) ----
     const double t_b = g_fold_profile.on ? now_s() : 0;
-    const std::function<void(int)> solve_one = [&](int j) {
-      const bool a = ar_solve(snap_[j], false);
-      const bool b = snap_[j].strength.solve_x_only();
-      snap_ok_[j] = (uint8_t)((a ? 1 : 0) | (b ? 2 : 0));
+    if (snap_cut_.size() < kWindow) snap_cut_.resize(kWindow);
+    auto test_one = [&](size_t j) {
+      const PlaneState &before = j ? snap_[j - 1] : combined_[0];
+      snap_cut_[j] = (uint8_t)(before.strength.num_equations > 0 && differs(fl[i + j].st[0], before));
     };
-    if (pfor && W > 1) {
-      // a few tasks of several solves each: a solve is ~2 us, waking a thread costs more
-      const int T = (int)std::min<size_t>(W, 8);
-      const std::function<void(int)> range = [&](int t) {
-        for (size_t j = W * t / T; j < W * (t + 1) / T; ++j) solve_one((int)j);
-      };
-      pfor(T, range);
-    } else {
-      for (size_t j = 0; j < W; ++j) solve_one((int)j);
-    }
-    // ---- in order: the is_different() tests, commits, segment cuts ----
+    const int T = pfor && W > 1 ? (int)std::min<size_t>((W + 7) / 8, 32) : 1;  // tasks of 8+ solves each: a solve is ~2 us,
+                                                                    // waking a thread costs more
+    const std::function<void(int)> range = [&](int t) {
+      const size_t a = W * t / T, b = W * (t + 1) / T;
+      for (size_t j = a; j < b; ++j) {
+        const bool ok_ar = ar_solve(snap_[j], false);
+        const bool ok_st = snap_[j].strength.solve_x_only();
+        snap_ok_[j] = (uint8_t)((ok_ar ? 1 : 0) | (ok_st ? 2 : 0));
+        if (j > a) test_one(j);
+      }
+    };
+    if (T > 1) pfor(T, range);
+    else range(0);
+    // ---- in order: the first segment cut or failed solve of the window, then one commit for the frames before it ----
     const double t_c = g_fold_profile.on ? now_s() : 0;
-    size_t done = W;
+    for (int t = 0; t < T; ++t) test_one(W * t / T);  // (the first frame of each task's range: its predecessor is solved now)
+    size_t m = W;  // frames that go into the combined model as assumed
+    int failed = 0;
     bool cut = false;
     for (size_t j = 0; j < W; ++j) {
-      FrameLatest &f = fl[i + j];
-      for (int c = 0; c < 3; ++c) std::swap(latest_[c], f.st[c]);
-      if (combined_[0].strength.num_equations > 0 && is_different()) {
-        // a new segment starts with this frame: the chroma planes of the frames before it, in order, into the combined
-        // model that ends here (their states are back in fl[..].st: the swaps below undo themselves pairwise)
-        for (size_t q = 0; q < j; ++q)
-          for (int c = 1; c < (int)fl[i + q].nplanes; ++c) {
-            chroma_add(combined_[c], held_[q * 2 + (c - 1)]);
-            chroma_dirty_ = true;
-          }
-        const uint64_t cur = frame_count_ * 10000000ULL * (uint64_t)fps_den_ / (uint64_t)fps_num_;
-        table_.push_back(grain_parameters(prev_timestamp_, cur));
-        save_latest();
-        prev_timestamp_ = cur;
-        frame_count_ += 1;
-        done = j + 1;  // the states behind the cut were built on a combined model that is gone
+      if (snap_cut_[j]) {
+        m = j;
         cut = true;
         break;
       }
-      if (!(snap_ok_[j] & 1)) {
-        set_error(err_, "Solving combined noise equation system failed %d!", 0);
-        return G1S_ERR_SOLVE;
+      if ((snap_ok_[j] & 3) != 3) {
+        m = j;
+        failed = (snap_ok_[j] & 1) ? 2 : 1;
+        break;
       }
-      if (!(snap_ok_[j] & 2)) {
-        set_error(err_, "Solving combined noise strength failed!");
-        return G1S_ERR_SOLVE;
-      }
-      std::swap(combined_[0], snap_[j]);
-      // (the frame's chroma states stay reachable until the window is committed: a cut later in the window needs them)
-      if (held_.size() < 2 * kWindow) held_.resize(2 * kWindow);
-      for (int c = 1; c < 3; ++c) std::swap(held_[j * 2 + (c - 1)], latest_[c]);
-      frame_count_ += 1;
     }
-    if (!cut) {  // the window went through: the combined chroma states are the running sums
+    if (m > 0) {
+      std::swap(combined_[0], snap_[m - 1]);
+      frame_count_ += m;
+    }
+    size_t done = m;
+    if (m == W) {  // the window went through: the combined chroma states are the running sums
       for (uint32_t c = 1; c < cplanes; ++c) {
         std::swap(combined_[c].ar, csum_[c].ar);
         std::swap(combined_[c].strength.eq, csum_[c].strength.eq);
@@ -703,6 +709,26 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       }
       // (frames with fewer planes than the window's minimum do not exist: cplanes is the minimum; a frame with MORE planes
       //  than another cannot happen inside one generator)
+    } else {  // the chroma planes of the frames before the stop, in order, into the combined model that ends there
+      for (size_t q = 0; q < m; ++q)
+        for (int c = 1; c < (int)fl[i + q].nplanes; ++c) {
+          chroma_add(combined_[c], fl[i + q].st[c]);
+          chroma_dirty_ = true;
+        }
+    }
+    if (failed) {
+      if (failed == 1) set_error(err_, "Solving combined noise equation system failed %d!", 0);
+      else set_error(err_, "Solving combined noise strength failed!");
+      return G1S_ERR_SOLVE;
+    }
+    if (cut) {  // a new segment starts with frame m; the states behind it were built on a combined model that is gone
+      for (int c = 0; c < 3; ++c) std::swap(latest_[c], fl[i + m].st[c]);
+      const uint64_t cur = frame_count_ * 10000000ULL * (uint64_t)fps_den_ / (uint64_t)fps_num_;
+      table_.push_back(grain_parameters(prev_timestamp_, cur));
+      save_latest();
+      prev_timestamp_ = cur;
+      frame_count_ += 1;
+      done = m + 1;
     }
     i += done;
     if (g_fold_profile.on) {

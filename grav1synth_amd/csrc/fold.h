@@ -108,6 +108,7 @@ class NoiseFold {
 
  private:
   bool is_different() const;
+  static bool differs(const PlaneState &latest, const PlaneState &combined);
   void finalize_chroma() const;
   void save_latest();
   g1s_segment_t grain_parameters(uint64_t start_ts, uint64_t end_ts) const;
@@ -124,7 +125,7 @@ class NoiseFold {
   std::vector<PlaneState> snap_;  // push_latest_many: speculative combined luma states
   std::vector<uint8_t> snap_ok_;
   PlaneState csum_[3];            // ... the combined chroma states after the window (running sums)
-  std::vector<PlaneState> held_;  // ... the window's chroma states (a segment cut inside the window adds them one by one)
+  std::vector<uint8_t> snap_cut_;  // ... whether frame j starts a new segment, given no cut before it
 };
 
 long format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap);

@@ -1,0 +1,11 @@
+#!/bin/bash
+# the ordered merge on the GPU box's host cores, by pool size, with the stage timers
+mkdir -p gpurun_out
+{
+for t in 1 8 32 64 256; do
+  echo "== G1S_FOLD_THREADS=$t"
+  G1S_FOLD_PROFILE=1 G1S_FOLD_THREADS=$t python tools/bench_fold.py 3840x2160 merge-only 2>&1 | tail -2
+done
+} > gpurun_out/r3_fold.txt 2>&1
+cat gpurun_out/r3_fold.txt
+python -m pytest tests -m gpu -x -q -k "two_ranks or scene or sharded or records_and_table" 2>&1 | tail -3
