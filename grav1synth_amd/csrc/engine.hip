@@ -183,7 +183,7 @@ Pool *merge_pool() {
   static Pool *p = [] {
     unsigned hw = std::thread::hardware_concurrency();
     if (const char *e = getenv("G1S_FOLD_THREADS")) hw = (unsigned)atoi(e);
-    unsigned n = std::min(8u, hw / 4);
+    unsigned n = std::min(16u, hw / 2);
     if (const char *e = getenv("G1S_MERGE_POOL")) n = (unsigned)atoi(e);  // (measurement: the pool's size itself)
     return n > 1 ? new Pool(n - 1) : nullptr;
   }();
@@ -1844,6 +1844,7 @@ struct g1s_fold {
   std::vector<g1s_segment_t> final_segs;  // what finish() returned (kept: a too-small buffer can be retried)
   Pool *pool = nullptr;
   std::vector<FrameLatest> latest;
+  std::vector<FrameView> views;  // g1s_fold_push_latest: the blobs of a pass, read in place
   // g1s_shard_merge: indexed batches that arrived ahead of the next one in the global order (global batch -> its states)
   std::map<uint64_t, std::vector<uint8_t>> early;
   uint64_t next_batch = 0;
@@ -1898,7 +1899,6 @@ int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, 
     }
     return G1S_OK;
   }
-  if (f->latest.size() < n) f->latest.resize(n);
   const uint8_t *base = (const uint8_t *)blobs;
   const NoiseFold::ParallelFor pfor = [&](int m, const std::function<void(int)> &fn) {
     if (mp && m > 1) {
@@ -1908,29 +1908,48 @@ int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, 
       for (int i = 0; i < m; ++i) fn(i);
     }
   };
-  std::vector<int> prc(n, G1S_OK);
-  {
-    const int T = (int)std::min<size_t>((n + 7) / 8, 32);
-    pfor(T, [&](int t) {
-      for (size_t i = n * t / T; i < n * (t + 1) / T; ++i)
-        prc[i] = latest_from_blob(base + i * stride_bytes, stride_bytes, f->lag, f->latest[i]);
-    });
-  }
+  static struct ParseProfile {  // G1S_FOLD_PROFILE=1: the whole call next to the fold's own stage timers
+    bool on = getenv("G1S_FOLD_PROFILE") != nullptr;
+    double s = 0, all = 0;
+    size_t frames = 0;
+    ~ParseProfile() {
+      if (on && frames) fprintf(stderr, "ordered merge, us per frame: blob headers %.2f, whole call %.2f (%zu frames)\n", s * 1e6 / frames, all * 1e6 / frames, frames);
+    }
+  } pp;
+  const auto t_p0 = std::chrono::steady_clock::now();
+  // The blobs are read where they lie (fold.h, FrameView); only a caller's unaligned buffer is copied first.
+  const bool in_place = !((reinterpret_cast<uintptr_t>(base) | stride_bytes) & 7);
+  if (f->views.size() < n) f->views.resize(n);
+  if (!in_place && f->latest.size() < n) f->latest.resize(n);
   size_t good = n;
+  int bad_rc = G1S_OK;
   for (size_t i = 0; i < n; ++i) {
-    if (prc[i]) {
+    int rc = G1S_OK;
+    if (in_place) rc = view_of_blob(base + i * stride_bytes, stride_bytes, f->lag, f->views[i]);
+    else {
+      rc = latest_from_blob(base + i * stride_bytes, stride_bytes, f->lag, f->latest[i]);
+      if (!rc) view_of(f->latest[i], f->views[i]);
+    }
+    if (rc) {
       good = i;
+      bad_rc = rc;
       break;
     }
   }
-  const int rc = f->fold.push_latest_many(f->latest.data(), good, pfor);  // (the frames before a bad blob still count)
+  const auto t_p1 = std::chrono::steady_clock::now();
+  const int rc = f->fold.push_latest_many(f->views.data(), good, pfor);  // (the frames before a bad blob still count)
+  if (pp.on) {
+    pp.s += std::chrono::duration<double>(t_p1 - t_p0).count();
+    pp.all += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count();
+    pp.frames += good;
+  }
   if (rc) {
     f->err = f->fold.error();
     return rc;
   }
   if (good < n) {
     f->err = "bad latest blob";
-    return prc[good];
+    return bad_rc;
   }
   return G1S_OK;
 }

@@ -86,15 +86,17 @@ G1S_HOST_CLONES void sum_into(double *__restrict dst, const double *__restrict a
                                                                         const double *__restrict b, int n) {
   for (int i = 0; i < n; ++i) dst[i] = a[i] + b[i];
 }
-void LinearSystem::add(const LinearSystem &o) {
-  add_into(A.data(), o.A.data(), n * n);
-  add_into(b.data(), o.b.data(), n);
+void LinearSystem::add(const LinearSystem &o) { add(o.A.data(), o.b.data()); }
+void LinearSystem::add(const double *oA, const double *ob) {
+  add_into(A.data(), oA, n * n);
+  add_into(b.data(), ob, n);
 }
 // this = a + b (elementwise on A and b; x is left alone): one pass instead of assign + add
-void LinearSystem::set_sum(const LinearSystem &a, const LinearSystem &bb) {
+void LinearSystem::set_sum(const LinearSystem &a, const LinearSystem &bb) { set_sum(a, bb.A.data(), bb.b.data()); }
+void LinearSystem::set_sum(const LinearSystem &a, const double *A2, const double *b2) {
   if (n != a.n) resize(a.n);
-  sum_into(A.data(), a.A.data(), bb.A.data(), n * n);
-  sum_into(b.data(), a.b.data(), bb.b.data(), n);
+  sum_into(A.data(), a.A.data(), A2, n * n);
+  sum_into(b.data(), a.b.data(), b2, n);
 }
 void LinearSystem::assign(const LinearSystem &o) {
   n = o.n;
@@ -120,6 +122,11 @@ void StrengthSolver::add(const StrengthSolver &o) {
   eq.add(o.eq);
   num_equations += o.num_equations;
   total += o.total;
+}
+void StrengthSolver::add(const double *oA, const double *ob, int o_num_equations, double o_total) {
+  eq.add(oA, ob);
+  num_equations += o_num_equations;
+  total += o_total;
 }
 double StrengthSolver::bin_index(double value) {
   const double val = clampd(value, 0.0, 255.0);
@@ -259,26 +266,63 @@ void chroma_fallback(PlaneState &s) {
   if (std::fabs(s.ar.A[last * nc + last]) > 1e-6) s.ar.x[last] = s.ar.b[last] / s.ar.A[last * nc + last];
 }
 
-bool NoiseFold::is_different() const { return differs(latest_[0], combined_[0]); }
+static PlaneView view_of_plane(const PlaneState &s) {
+  PlaneView v;
+  v.A = s.ar.A.data();
+  v.b = s.ar.b.data();
+  v.x = s.ar.x.data();
+  v.sA = s.strength.eq.A.data();
+  v.sb = s.strength.eq.b.data();
+  v.sx = s.strength.eq.x.data();
+  v.n = s.ar.n;
+  v.num_observations = s.num_observations;
+  v.ar_gain = s.ar_gain;
+  v.num_equations = s.strength.num_equations;
+  v.total = s.strength.total;
+  return v;
+}
+void view_of(const FrameLatest &fl, FrameView &out) {
+  for (int c = 0; c < 3; ++c) out.st[c] = view_of_plane(fl.st[c]);
+  out.nplanes = fl.nplanes;
+  out.status = fl.status;
+  out.err = fl.err.c_str();
+}
+static void load_plane(PlaneState &s, const PlaneView &v) {
+  if (s.ar.n != v.n) s.ar.resize(v.n);
+  std::memcpy(s.ar.A.data(), v.A, sizeof(double) * v.n * v.n);
+  std::memcpy(s.ar.b.data(), v.b, sizeof(double) * v.n);
+  std::memcpy(s.ar.x.data(), v.x, sizeof(double) * v.n);
+  std::memcpy(s.strength.eq.A.data(), v.sA, sizeof(double) * kNumBins * kNumBins);
+  std::memcpy(s.strength.eq.b.data(), v.sb, sizeof(double) * kNumBins);
+  std::memcpy(s.strength.eq.x.data(), v.sx, sizeof(double) * kNumBins);
+  s.num_observations = v.num_observations;
+  s.ar_gain = v.ar_gain;
+  s.strength.num_equations = v.num_equations;
+  s.strength.total = v.total;
+}
 
-bool NoiseFold::differs(const PlaneState &latest, const PlaneState &combined) {
-  const LinearSystem &l = latest.ar, &c = combined.ar;
+bool NoiseFold::is_different() const { return differs(view_of_plane(latest_[0]), combined_[0]); }
+
+bool NoiseFold::differs(const PlaneView &latest, const PlaneState &combined) {
+  const LinearSystem &c = combined.ar;
+  const double *lx = latest.x;
   double dot = 0, l2 = 0, c2 = 0;
   for (int i = 0; i < c.n; ++i) {
-    l2 += l.x[i] * l.x[i];
+    l2 += lx[i] * lx[i];
     c2 += c.x[i] * c.x[i];
-    dot += l.x[i] * c.x[i];
+    dot += lx[i] * c.x[i];
   }
   const double corr = dot / (std::sqrt(l2) * std::sqrt(c2));
   if (corr < 0.9) return true;
   const double dx = 1.0 / kNumBins;
-  const LinearSystem &ls = latest.strength.eq, &cs = combined.strength.eq;
+  const LinearSystem &cs = combined.strength.eq;
+  const int sn = kNumBins;
   double diff = 0, total_weight = 0;
-  for (int j = 0; j < ls.n; ++j) {
+  for (int j = 0; j < sn; ++j) {
     double weight = 0;
-    for (int i = 0; i < ls.n; ++i) weight += ls.A[i * ls.n + j];
+    for (int i = 0; i < sn; ++i) weight += latest.sA[i * sn + j];
     weight = std::sqrt(weight);
-    diff += weight * std::fabs(ls.x[j] - cs.x[j]);
+    diff += weight * std::fabs(latest.sx[j] - cs.x[j]);
     total_weight += weight;
   }
   return diff * dx / total_weight > 0.005;
@@ -525,6 +569,37 @@ int latest_from_blob(const uint8_t *blob, size_t size, uint32_t lag, FrameLatest
   return G1S_OK;
 }
 
+int view_of_blob(const uint8_t *blob, size_t size, uint32_t lag, FrameView &out) {
+  if (size < sizeof(LatestHeader) || (reinterpret_cast<uintptr_t>(blob) & 7)) return G1S_ERR_INVALID;
+  const LatestHeader *h = reinterpret_cast<const LatestHeader *>(blob);
+  if (h->magic != kLatestMagic || h->lag != lag || h->size_bytes != latest_blob_size(lag) || h->size_bytes > size || h->nplanes > 3)
+    return G1S_ERR_INVALID;
+  if (!memchr(h->err, 0, sizeof(h->err))) return G1S_ERR_INVALID;
+  out.nplanes = h->nplanes;
+  out.status = h->status;
+  out.err = h->err;
+  const int n = (int)num_coeffs(lag), ncm = n + 1;
+  for (int c = 0; c < 3; ++c) {
+    const uint8_t *p = blob + sizeof(LatestHeader) + c * plane_blob_bytes(ncm);
+    const LatestPlaneHead *ph = reinterpret_cast<const LatestPlaneHead *>(p);
+    PlaneView &v = out.st[c];
+    v.num_observations = ph->num_observations;
+    v.ar_gain = ph->ar_gain;
+    v.num_equations = ph->num_equations;
+    v.total = ph->total;
+    v.n = n + (c > 0);
+    const double *d = reinterpret_cast<const double *>(p + sizeof(*ph));
+    v.A = d;
+    v.b = d + ncm * ncm;
+    v.x = d + ncm * ncm + ncm;
+    const double *q = d + ncm * ncm + 2 * ncm;
+    v.sA = q;
+    v.sb = q + kNumBins * kNumBins;
+    v.sx = q + kNumBins * kNumBins + kNumBins;
+  }
+  return G1S_OK;
+}
+
 int NoiseFold::push_latest(FrameLatest &fl) {
   if (fl.status != G1S_OK) {
     err_ = fl.err;
@@ -580,16 +655,22 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }  // namespace
 
 int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pfor) {
+  if (views_.size() < n) views_.resize(n);
+  for (size_t i = 0; i < n; ++i) view_of(fl[i], views_[i]);
+  return push_latest_many(views_.data(), n, pfor);
+}
+
+int NoiseFold::push_latest_many(const FrameView *fl, size_t n, const ParallelFor &pfor) {
   constexpr size_t kWindow = 256;  // (frames per speculative window: a dispatch to the merge pool costs tens of microseconds)
   if (snap_.size() < kWindow) {
     snap_.resize(kWindow);
     snap_ok_.resize(kWindow);
   }
   // one frame's chroma plane into a running combined state (what push_latest does for c > 0, in frame order)
-  auto chroma_add = [](PlaneState &com, const PlaneState &lat) {
+  auto chroma_add = [](PlaneState &com, const PlaneView &lat) {
     com.num_observations += lat.num_observations;
-    com.ar.add(lat.ar);
-    com.strength.add(lat.strength);
+    com.ar.add(lat.A, lat.b);
+    com.strength.add(lat.sA, lat.sb, lat.num_equations, lat.total);
     com.strength.apply_regularisation_to_b();
   };
   size_t i = 0;
@@ -606,54 +687,96 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       err_ = fl[i].err;
       return fl[i].status;
     }
-    // Six running sums, each sequential in frame order (the additions happen in the reference's order: same bits), each
-    // on data of its own -- so they run next to each other: tasks 0, 1 the prefix sums of the luma AR and strength systems
-    // (one state per frame: the solves below need them all), tasks 2..5 the combined Cb / Cr states after the window's last
-    // frame (nothing reads a chroma state between segment boundaries).  The serial commit below then only swaps pointers: the frames'
+    // Running sums, each element's sequential in frame order (the additions happen in the reference's order: same bits),
+    // elements independent of each other -- so slices of the systems run next to each other: for luma the prefix sums (one
+    // state per frame: the solves below need them all), for Cb / Cr the combined state after the window's last frame (nothing
+    // reads a chroma state between segment boundaries).  The serial commit below then only swaps pointers: the frames'
     // states were parsed on other cores, and every byte the serial stage does not touch is a cache miss it does not wait for.
     uint32_t cplanes = fl[i].nplanes;
     for (size_t j = 1; j < W; ++j) cplanes = std::min(cplanes, fl[i + j].nplanes);
+    // (task t: plane t / 5; parts 0..2 = thirds of the AR matrix, part 0 with b and the observation count; parts 3, 4 = halves
+    //  of the strength matrix, part 3 with b, the equation count, the total and the regularisation term they give)
+    // (a task's slice of frame j + 4 is asked for while frame j is added: the slices lie a blob apart, no hardware
+    //  prefetcher follows that, and the blobs arrive cold)
+    auto ahead = [](const double *p, int count) {
+      for (int k = 0; k < count; k += 8) __builtin_prefetch(p + k, 0, 0);
+    };
     const std::function<void(int)> sums = [&](int t) {
-      const int plane = t >> 1;
-      const bool ar_half = !(t & 1);  // (a plane's AR system and its strength system never meet before the solves)
+      const int plane = t / 5, part = t % 5;
+      if (plane > 0 && (uint32_t)plane >= cplanes) return;
+      const bool ar_part = part < 3;
+      const int nn = ar_part ? combined_[plane].ar.n * combined_[plane].ar.n : kNumBins * kNumBins;
+      const int lo = ar_part ? nn * part / 3 : nn * (part - 3) / 2, hi = ar_part ? nn * (part + 1) / 3 : nn * (part - 2) / 2;
+      const bool head = part == 0 || part == 3;
       if (plane == 0) {
         for (size_t j = 0; j < W; ++j) {
           PlaneState &s = snap_[j];
           const PlaneState &prev = j ? snap_[j - 1] : combined_[0];
-          const PlaneState &lat = fl[i + j].st[0];
-          if (ar_half) {
-            s.ar.set_sum(prev.ar, lat.ar);
-            s.num_observations = prev.num_observations + lat.num_observations;
+          const PlaneView &lat = fl[i + j].st[0];
+          if (j + 4 < W) ahead((ar_part ? fl[i + j + 4].st[0].A : fl[i + j + 4].st[0].sA) + lo, hi - lo);
+          if (ar_part) {
+            sum_into(s.ar.A.data() + lo, prev.ar.A.data() + lo, lat.A + lo, hi - lo);
+            if (head) {
+              sum_into(s.ar.b.data(), prev.ar.b.data(), lat.b, s.ar.n);
+              s.num_observations = prev.num_observations + lat.num_observations;
+            }
           } else {
-            s.strength.eq.set_sum(prev.strength.eq, lat.strength.eq);
-            s.strength.num_equations = prev.strength.num_equations + lat.strength.num_equations;
-            s.strength.total = prev.strength.total + lat.strength.total;
-            s.strength.apply_regularisation_to_b();  // (the first half of StrengthSolver::solve)
+            sum_into(s.strength.eq.A.data() + lo, prev.strength.eq.A.data() + lo, lat.sA + lo, hi - lo);
+            if (head) {
+              sum_into(s.strength.eq.b.data(), prev.strength.eq.b.data(), lat.sb, kNumBins);
+              s.strength.num_equations = prev.strength.num_equations + lat.num_equations;
+              s.strength.total = prev.strength.total + lat.total;
+              s.strength.apply_regularisation_to_b();  // (the first half of StrengthSolver::solve)
+            }
           }
         }
-      } else if ((uint32_t)plane < cplanes) {
+      } else {
         PlaneState &acc = csum_[plane];
-        if (ar_half) {
-          acc.num_observations = combined_[plane].num_observations;
-          acc.ar.assign(combined_[plane].ar);
+        const PlaneState &com = combined_[plane];
+        if (ar_part) {
+          std::memcpy(acc.ar.A.data() + lo, com.ar.A.data() + lo, sizeof(double) * (hi - lo));
+          if (head) {
+            acc.ar.b = com.ar.b;
+            acc.num_observations = com.num_observations;
+          }
           for (size_t j = 0; j < W; ++j) {
-            acc.num_observations += fl[i + j].st[plane].num_observations;
-            acc.ar.add(fl[i + j].st[plane].ar);
+            const PlaneView &lat = fl[i + j].st[plane];
+            if (j + 4 < W) ahead(fl[i + j + 4].st[plane].A + lo, hi - lo);
+            add_into(acc.ar.A.data() + lo, lat.A + lo, hi - lo);
+            if (head) {
+              add_into(acc.ar.b.data(), lat.b, acc.ar.n);
+              acc.num_observations += lat.num_observations;
+            }
           }
         } else {
-          acc.strength.eq.assign(combined_[plane].strength.eq);
-          acc.strength.num_equations = combined_[plane].strength.num_equations;
-          acc.strength.total = combined_[plane].strength.total;
+          std::memcpy(acc.strength.eq.A.data() + lo, com.strength.eq.A.data() + lo, sizeof(double) * (hi - lo));
+          if (head) {
+            acc.strength.eq.b = com.strength.eq.b;
+            acc.strength.num_equations = com.strength.num_equations;
+            acc.strength.total = com.strength.total;
+          }
           for (size_t j = 0; j < W; ++j) {
-            acc.strength.add(fl[i + j].st[plane].strength);
-            acc.strength.apply_regularisation_to_b();
+            const PlaneView &lat = fl[i + j].st[plane];
+            if (j + 4 < W) ahead(fl[i + j + 4].st[plane].sA + lo, hi - lo);
+            add_into(acc.strength.eq.A.data() + lo, lat.sA + lo, hi - lo);
+            if (head) {
+              add_into(acc.strength.eq.b.data(), lat.sb, kNumBins);
+              acc.strength.num_equations += lat.num_equations;
+              acc.strength.total += lat.total;
+              acc.strength.apply_regularisation_to_b();
+            }
           }
         }
       }
     };
-    if (pfor && W > 8) pfor(6, sums);
+    // (sizes settled before the tasks share the states)
+    for (size_t j = 0; j < W; ++j)
+      if (snap_[j].ar.n != combined_[0].ar.n) snap_[j].ar.resize(combined_[0].ar.n);
+    for (int c = 1; c < 3; ++c)
+      if (csum_[c].ar.n != combined_[c].ar.n) csum_[c].ar.resize(combined_[c].ar.n);
+    if (pfor && W > 8) pfor(15, sums);
     else
-      for (int t = 0; t < 6; ++t) sums(t);
+      for (int t = 0; t < 15; ++t) sums(t);
     // ---- the solves, independent of each other; and the is_different() test of every frame whose predecessor's state the
     //      same task solved (frame j is tested against the combined model after frame j - 1: snap_[j - 1]) ----
     const double t_b = g_fold_profile.on ? now_s() : 0;
@@ -722,7 +845,7 @@ int NoiseFold::push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pf
       return G1S_ERR_SOLVE;
     }
     if (cut) {  // a new segment starts with frame m; the states behind it were built on a combined model that is gone
-      for (int c = 0; c < 3; ++c) std::swap(latest_[c], fl[i + m].st[c]);
+      for (int c = 0; c < 3; ++c) load_plane(latest_[c], fl[i + m].st[c]);
       const uint64_t cur = frame_count_ * 10000000ULL * (uint64_t)fps_den_ / (uint64_t)fps_num_;
       table_.push_back(grain_parameters(prev_timestamp_, cur));
       save_latest();

@@ -27,7 +27,9 @@ struct LinearSystem {
   void resize(int n_);
   void clear();
   void add(const LinearSystem &o);
+  void add(const double *oA, const double *ob);  // (the other system where it lies: n x n and n doubles)
   void set_sum(const LinearSystem &a, const LinearSystem &b);
+  void set_sum(const LinearSystem &a, const double *A2, const double *b2);
   void assign(const LinearSystem &o);
   bool solve();  // works on copies of A and b; writes x
 };
@@ -44,6 +46,7 @@ struct StrengthSolver {
   StrengthSolver();
   void clear();
   void add(const StrengthSolver &o);
+  void add(const double *oA, const double *ob, int o_num_equations, double o_total);
   static double bin_index(double value);
   double value_at(double x) const;
   void add_measurement(double block_mean, double noise_std);
@@ -85,6 +88,27 @@ size_t latest_blob_size(uint32_t lag);
 void latest_to_blob(const FrameLatest &fl, uint32_t lag, uint8_t *blob);
 int latest_from_blob(const uint8_t *blob, size_t size, uint32_t lag, FrameLatest &out);
 
+// A frame's latest state where it lies (in a FrameLatest, or in a blob as it arrived): what the ordered merge reads.
+// The merge reads each of a frame's systems exactly once; copying a blob into a FrameLatest first was a second pass over
+// 27 KB per frame, and the larger share of the merge's time.
+struct PlaneView {
+  const double *A = nullptr, *b = nullptr, *x = nullptr;     // AR system (n x n, n, n)
+  const double *sA = nullptr, *sb = nullptr, *sx = nullptr;  // strength system (kNumBins)
+  int n = 0;
+  int64_t num_observations = 0;
+  double ar_gain = 1.0;
+  int num_equations = 0;
+  double total = 0.0;
+};
+struct FrameView {
+  PlaneView st[3];
+  uint32_t nplanes = 0;
+  int status = 0;
+  const char *err = "";  // (points into the blob / the FrameLatest)
+};
+void view_of(const FrameLatest &fl, FrameView &out);
+int view_of_blob(const uint8_t *blob, size_t size, uint32_t lag, FrameView &out);  // header checked, nothing copied (blob 8-aligned)
+
 class NoiseFold {
  public:
   NoiseFold(int64_t fps_num, int64_t fps_den, uint32_t lag);
@@ -101,6 +125,7 @@ class NoiseFold {
   // a segment cut discards the speculative states behind it.  Every solve sees exactly the operands
   // push_latest() would give it: results are identical bit for bit.
   using ParallelFor = std::function<void(int, const std::function<void(int)> &)>;
+  int push_latest_many(const FrameView *fl, size_t n, const ParallelFor &pfor);
   int push_latest_many(FrameLatest *fl, size_t n, const ParallelFor &pfor);
   void finish(std::vector<g1s_segment_t> &out);
   const std::string &error() const { return err_; }
@@ -108,7 +133,7 @@ class NoiseFold {
 
  private:
   bool is_different() const;
-  static bool differs(const PlaneState &latest, const PlaneState &combined);
+  static bool differs(const PlaneView &latest, const PlaneState &combined);
   void finalize_chroma() const;
   void save_latest();
   g1s_segment_t grain_parameters(uint64_t start_ts, uint64_t end_ts) const;
@@ -126,6 +151,7 @@ class NoiseFold {
   std::vector<uint8_t> snap_ok_;
   PlaneState csum_[3];            // ... the combined chroma states after the window (running sums)
   std::vector<uint8_t> snap_cut_;  // ... whether frame j starts a new segment, given no cut before it
+  std::vector<FrameView> views_;
 };
 
 long format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap);
