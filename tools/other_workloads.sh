@@ -10,6 +10,7 @@ print(round(j['value']), 'Mpx/s  frac', round(r['frac'],4), ' frames/launch', r[
 echo "bench.py --workload W --steps 5 --warmup 2 --no-cpu-baseline: value, roofline.frac, per-kernel us per launch (HIP events, one stream)"
 for w in 1080p8_lag2_luma 1080p8 8k10_444; do echo "== $w"; one --workload $w; done
 echo "== 4k10 --flat"; one --flat
+echo "== 4k10 G1S_K3=fused (round 2 kernel)"; G1S_K3=fused one
 echo "== 4k10 G1S_K3=planes"; G1S_K3=planes one
 echo "== 4k10 G1S_K3=dot4"; G1S_K3=dot4 one
 echo "== 4k10 --batch 32"; one --batch 32
