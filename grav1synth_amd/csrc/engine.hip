@@ -30,6 +30,7 @@
 #include "k3m.hip.h"
 #include "k3f.hip.h"
 #include "k3s.hip.h"
+#include "latest_dev.h"
 #include "record.h"
 
 using namespace g1s;
@@ -191,6 +192,7 @@ Pool *merge_pool() {
 }
 std::mutex g_merge_pool_mutex;
 
+constexpr bool kDeviceLatestDefault = false;
 constexpr int kSlots = 4;  // batches in flight: pixel pass + finder, accumulation, D2H + fold, being filled
 
 struct Slot {
@@ -208,6 +210,9 @@ struct Slot {
   long long *d_mpart = nullptr;    // MFMA path: partial systems of the accumulation workgroups
   uint8_t *d_lplane = nullptr;     // MFMA path: L at chroma resolution, int8 (luma launch -> chroma launch)
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
+  // the per-frame half of the fold on the device (latest.hip): the frames' latest-state blobs and the kernel's scratch
+  uint8_t *d_latest = nullptr, *h_latest = nullptr /* pinned */, *d_lscratch = nullptr;
+  size_t latest_cap = 0, lscratch_cap = 0;
   size_t stage_bytes_per_frame = 0;
   hipEvent_t done = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: finder start, k2 start, k3 start, k3 end, k0 end, k0 start
@@ -235,6 +240,9 @@ static void free_slot(Slot &sl) {
   if (sl.d_mpart) (void)hipFree(sl.d_mpart);
   if (sl.d_lplane) (void)hipFree(sl.d_lplane);
   if (sl.d_stage) (void)hipFree(sl.d_stage);
+  if (sl.d_latest) (void)hipFree(sl.d_latest);
+  if (sl.h_latest) (void)hipHostFree(sl.h_latest);
+  if (sl.d_lscratch) (void)hipFree(sl.d_lscratch);
   if (sl.done) (void)hipEventDestroy(sl.done);
   for (auto &e : sl.ev)
     if (e) (void)hipEventDestroy(e);
@@ -352,6 +360,7 @@ struct g1s_diff {
   uint32_t lag, n;
   bool luma_only, records_only;
   bool latest_only = false;  // keep the per-frame latest states (blobs) instead of folding them here
+  bool device_latest = false;  // the per-frame half of the fold runs on the device (k4_latest): blobs come back, not records
   uint32_t batch;
   bool batch_auto = false;  // no batch size asked for: sized to the frames at the first frame pair
   int device = 0;
@@ -383,6 +392,7 @@ struct g1s_diff {
   std::condition_variable cv_fold;
   bool folder_stop = false;
   std::vector<FrameLatest> latest_s[kSlots];  // per slot: two batches are in the fold at a time
+  std::vector<FrameView> views_s[kSlots];     // device_latest: the slot's blobs, read where the copy put them
   std::vector<uint32_t> nflat_s[kSlots];
   std::vector<uint8_t> stage_s[kSlots];
   double ms_fold_front = 0, ms_fold_back = 0;  // (one writer each)
@@ -1225,7 +1235,56 @@ int g1s_diff::launch_back(int si) {
   // records D2H on the copy stream (behind the tail kernels): the main stream goes straight on to the next batch
   HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
   HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
-  HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, ss.copy));
+  if (device_latest) {
+    // the per-frame half of the fold where the records lie: the host gets 27 KB of latest state a frame instead of the record
+    // (the batch's last record still comes back: g1s_diff_last_record)
+    const size_t blob = latest_blob_size(lag), scr = latest_scratch_bytes((uint32_t)L.nblocks);
+    if (sl.latest_cap < blob * batch) {
+      if (sl.d_latest) (void)hipFree(sl.d_latest);
+      if (sl.h_latest) (void)hipHostFree(sl.h_latest);
+      sl.d_latest = sl.h_latest = nullptr;
+      sl.latest_cap = 0;
+      HIP_TRY(hipMalloc((void **)&sl.d_latest, blob * batch));
+      HIP_TRY(hipHostMalloc((void **)&sl.h_latest, blob * batch, hipHostMallocDefault));
+      sl.latest_cap = blob * batch;
+    }
+    if (sl.lscratch_cap < scr * batch) {
+      if (sl.d_lscratch) (void)hipFree(sl.d_lscratch);
+      sl.d_lscratch = nullptr;
+      sl.lscratch_cap = 0;
+      HIP_TRY(hipMalloc((void **)&sl.d_lscratch, scr * batch));
+      sl.lscratch_cap = scr * batch;
+    }
+    LatestJob job{};
+    job.records = sl.d_records;
+    job.L = L;
+    job.blobs = sl.d_latest;
+    job.blob_bytes = blob;
+    job.scratch = sl.d_lscratch;
+    job.scratch_bytes = scr;
+    job.lag = (int)lag;
+    job.n = (int)n;
+    job.nplanes = g.nplanes;
+    job.W = g.W;
+    job.H = g.H;
+    job.xdec = g.xdec;
+    job.ydec = g.ydec;
+    job.nbw = g.nbw;
+    job.nbh = g.nbh;
+    if (sl.timed) {  // (per-kernel timing: everything on the one stream)
+      kmark(sl, stream, latest_kernel_name());
+      HIP_TRY(launch_latest(job, B, stream));
+      kmark(sl, stream, nullptr);
+      HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
+      HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
+    } else {
+      HIP_TRY(launch_latest(job, B, ss.copy));
+    }
+    HIP_TRY(hipMemcpyAsync(sl.h_latest, sl.d_latest, blob * B, hipMemcpyDeviceToHost, ss.copy));
+    HIP_TRY(hipMemcpyAsync(sl.h_records + L.size * (B - 1), sl.d_records + L.size * (B - 1), L.size, hipMemcpyDeviceToHost, ss.copy));
+  } else {
+    HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, ss.copy));
+  }
   HIP_TRY(hipEventRecord(sl.done, ss.copy));
   // profiling aid (G1S_D2H_SYNC=1, with G1S_ONE_STREAM=1): the records copy has ended before the next batch's first kernel
   // starts -- under rocprofv3 the copy is a blit kernel that otherwise shares the chip with k1_moments and doubles its time
@@ -1346,7 +1405,7 @@ int g1s_diff::drain_front(int si) {
   // ---- per-frame half, concurrent: header, symmetric mirror, latest noise state ----
   const size_t blob = latest_only ? latest_blob_size(lag) : 0;
   if (latest_only) latest_stage.resize(blob * sl.count);
-  auto per_frame = [&](int i) {
+  auto finish_record = [&](int i) {
     uint8_t *rec = sl.h_records + L.size * i;
     RecHeader h{};
     h.magic = kRecMagic;
@@ -1373,6 +1432,32 @@ int g1s_diff::drain_front(int si) {
       for (int a = 0; a < nc; ++a)
         for (int b = a + 1; b < nc; ++b) S[b * nc + a] = S[a * nc + b];
     }
+    return rec;
+  };
+  if (device_latest) {
+    // the latest states were computed on the device (k4_latest): nothing per frame is left but reading the headers
+    const size_t bl = latest_blob_size(lag);
+    std::vector<FrameView> &views = views_s[si];
+    if (views.size() < sl.count) views.resize(sl.count);
+    int rc = G1S_OK;
+    for (uint32_t i = 0; i < sl.count; ++i) {
+      uint8_t *b = sl.h_latest + bl * i;
+      LatestHeader *h = reinterpret_cast<LatestHeader *>(b);
+      nflat_v[i] = h->reserved;
+      h->reserved = 0;  // (the kernel's note to this function; the blob a rank sends is the blob the host half would make)
+      if (!latest_only && view_of_blob(b, bl, lag, views[i]) != G1S_OK) rc = G1S_ERR_INVALID;
+    }
+    if (latest_only) latest_stage.assign(sl.h_latest, sl.h_latest + bl * sl.count);
+    if (sl.count) finish_record((int)sl.count - 1);
+    ms_fold_front += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc) {
+      std::lock_guard<std::mutex> lk(dm);
+      err = "k4_latest wrote a blob the fold does not recognise";
+    }
+    return rc;
+  }
+  auto per_frame = [&](int i) {
+    uint8_t *rec = finish_record(i);
     if (!records_only) compute_latest(rec, L.size, lag, latest[i]);
     if (latest_only) latest_to_blob(latest[i], lag, latest_stage.data() + (size_t)i * blob);
   };
@@ -1425,7 +1510,7 @@ int g1s_diff::drain_back(int si) {
         for (int i = 0; i < m; ++i) fn(i);
       }
     };
-    rc = fold->push_latest_many(latest.data(), sl.count, pfor);
+    rc = device_latest ? fold->push_latest_many(views_s[si].data(), sl.count, pfor) : fold->push_latest_many(latest.data(), sl.count, pfor);
     if (rc) {
       std::lock_guard<std::mutex> lk(dm);
       err = fold->error();
@@ -1564,6 +1649,12 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   g->luma_only = luma_only;
   g->records_only = records_only;
   g->latest_only = latest_only;
+  {
+    // G1S_LATEST=host|device: where the per-frame half of the fold runs (records_only generators hand out records: host)
+    const char *e = getenv("G1S_LATEST");
+    const bool dev = e ? std::string(e) == "device" : kDeviceLatestDefault;
+    g->device_latest = dev && !records_only;
+  }
   g->batch = batch;
   g->batch_auto = batch_auto;
   g->device = device;

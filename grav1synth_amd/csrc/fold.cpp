@@ -479,25 +479,6 @@ void NoiseFold::finalize_chroma() const {
 }
 
 // ---- FrameLatest <-> blob ----
-namespace {
-constexpr uint32_t kLatestMagic = 0x4c315347u;  // "GS1L"
-struct LatestHeader {
-  uint32_t magic, lag, nplanes;
-  int32_t status;
-  uint32_t size_bytes, reserved;
-  char err[104];
-};
-struct LatestPlaneHead {
-  int64_t num_observations;
-  double ar_gain;
-  int32_t num_equations, reserved;
-  double total;
-};
-inline size_t plane_blob_bytes(int nc_max) {
-  return sizeof(LatestPlaneHead) + sizeof(double) * ((size_t)nc_max * nc_max + 2 * (size_t)nc_max + (size_t)kNumBins * kNumBins + 2 * kNumBins);
-}
-}  // namespace
-
 size_t latest_blob_size(uint32_t lag) { return sizeof(LatestHeader) + 3 * plane_blob_bytes((int)num_coeffs(lag) + 1); }
 
 void latest_to_blob(const FrameLatest &fl, uint32_t lag, uint8_t *blob) {

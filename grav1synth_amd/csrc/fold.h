@@ -84,6 +84,24 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
 // A FrameLatest as a flat, fixed-size blob (what frame-shard ranks exchange instead of the ~10x larger
 // records: the per-frame half of the fold runs where the frame was processed, only the ordered half
 // runs on rank 0).  Doubles are copied bit for bit.
+// (the blob's layout, shared with the device kernel that writes the same bytes: latest.hip)
+constexpr uint32_t kLatestMagic = 0x4c315347u;  // "GS1L"
+struct LatestHeader {
+  uint32_t magic, lag, nplanes;
+  int32_t status;
+  uint32_t size_bytes, reserved;
+  char err[104];
+};
+struct LatestPlaneHead {
+  int64_t num_observations;
+  double ar_gain;
+  int32_t num_equations, reserved;
+  double total;
+};
+// per plane: head, AR A (nc x nc packed at the front of an ncm x ncm field), b (ncm), x (ncm), strength A, b, x
+constexpr size_t plane_blob_bytes(int nc_max) {
+  return sizeof(LatestPlaneHead) + sizeof(double) * ((size_t)nc_max * nc_max + 2 * (size_t)nc_max + (size_t)kNumBins * kNumBins + 2 * kNumBins);
+}
 size_t latest_blob_size(uint32_t lag);
 void latest_to_blob(const FrameLatest &fl, uint32_t lag, uint8_t *blob);
 int latest_from_blob(const uint8_t *blob, size_t size, uint32_t lag, FrameLatest &out);

@@ -958,3 +958,93 @@ def test_streaming_shards_over_rccl_with_one_rank():
                MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+# ---- the per-frame half of the fold on the device (csrc/latest.hip, G1S_LATEST=device) ------------------------------------
+_LATEST_CASES = [
+    (SynthSpec(320, 192, 8), 3, True),
+    (SynthSpec(326, 198, 8), 3, True),                       # partial edge blocks in both directions
+    (SynthSpec(352, 208, 10), 3, True),
+    (SynthSpec(320, 192, 10, xdec=1, ydec=0), 3, True),      # 4:2:2
+    (SynthSpec(256, 160, 10, xdec=0, ydec=0), 2, True),      # 4:4:4, lag 2
+    (SynthSpec(320, 192, 8), 2, False),                      # luma only
+    (SynthSpec(300, 180, 8, textured=False), 1, True),       # all flat, lag 1
+    (SynthSpec(1920, 1080, 8), 3, True),
+    (SynthSpec(3840, 2160, 10), 3, True),                    # the bench workload
+]
+
+
+def _latest_blobs(monkeypatch, where, spec, lag, chroma, frames, batch):
+    monkeypatch.setenv("G1S_LATEST", where)
+    g = DiffGenerator(Fraction(24, 1), spec.bit_depth, spec.bit_depth, ar_coeff_lag=lag, luma_only=not chroma,
+                      batch_frames=batch, records_only=2)
+    for k in frames:
+        s, d = make_pair(spec, k, device="cuda")
+        g.diff_frame(s, d, spec.xdec, spec.ydec)
+    blobs = g.take_latest(len(frames) + 8, sync=True).copy()
+    g.close()
+    return blobs
+
+
+@pytest.mark.parametrize("case", _LATEST_CASES, ids=lambda c: f"{c[0].width}x{c[0].height}_{c[0].bit_depth}b_{c[0].xdec}{c[0].ydec}_lag{c[1]}_{'yuv' if c[2] else 'y'}")
+def test_device_latest_states_are_the_host_halfs_bytes(monkeypatch, case):
+    """k4_latest (AR solve, block measurements, strength solve of every frame on the device) must write the blob the host
+    half makes from the same record -- every f64 bit of every system, solution, gain and total, and the header."""
+    spec, lag, chroma = case
+    frames = list(range(5)) if spec.width < 3000 else [0, 1, 2]
+    host = _latest_blobs(monkeypatch, "host", spec, lag, chroma, frames, 3)
+    dev = _latest_blobs(monkeypatch, "device", spec, lag, chroma, frames, 3)
+    assert host.shape == dev.shape and host.shape[0] == len(frames)
+    for i in range(len(frames)):
+        if not np.array_equal(host[i], dev[i]):
+            bad = np.flatnonzero(host[i] != dev[i])
+            raise AssertionError(f"frame {i}: {bad.size} bytes differ, first at {bad[0]} (of {host.shape[1]})")
+
+
+def test_device_latest_reports_the_host_halfs_failures(monkeypatch):
+    """Frames the per-frame half refuses -- one block only ("Not enough flat blocks ..."), a constant frame (singular luma
+    system) -- give the same blob (status, message, the state as far as it got) and the same error from a folding generator."""
+    from grav1synth_amd._lib import G1SError
+
+    one_block = [np.full((32, 32), 9, np.uint8), np.full((16, 16), 9, np.uint8), np.full((16, 16), 9, np.uint8)]
+    constant = [np.full((64, 64), 7, np.uint8), np.full((32, 32), 7, np.uint8), np.full((32, 32), 7, np.uint8)]
+    for planes, code in ((one_block, -3), (constant, -4)):
+        blobs = {}
+        for where in ("host", "device"):
+            monkeypatch.setenv("G1S_LATEST", where)
+            g = DiffGenerator(Fraction(24, 1), 8, 8, batch_frames=1, records_only=2)
+            g.diff_frame(planes, planes)
+            blobs[where] = g.take_latest(4, sync=True).copy()
+            g.close()
+            g = DiffGenerator(Fraction(24, 1), 8, 8, batch_frames=1)
+            with pytest.raises(G1SError) as e:
+                g.diff_frame(planes, planes)
+                g.sync()
+            assert e.value.code == code
+            blobs[where + "_msg"] = e.value.message
+            g.close()
+        assert np.array_equal(blobs["host"], blobs["device"])
+        assert blobs["host_msg"] == blobs["device_msg"]
+        assert int(np.frombuffer(blobs["host"][0].tobytes()[12:16], np.int32)[0]) == code
+
+
+@pytest.mark.parametrize("spec,lag", [(SynthSpec(320, 192, 8), 3), (SynthSpec(352, 208, 10), 2), (SynthSpec(1920, 1080, 10), 3)])
+def test_device_latest_gives_the_oracles_table(monkeypatch, spec, lag):
+    """The whole front door with the per-frame half on the device: table == oracle, a scene cut inside a batch included,
+    and the statistics the host half used to count."""
+    monkeypatch.setenv("G1S_LATEST", "device")
+    ks = [0, 1, 2, 50, 51, 3, 4] if spec.width < 1000 else [0, 1, 2]
+    tbl, _ = oracle_run(spec, ks, lag)
+    g = DiffGenerator(Fraction(24, 1), spec.bit_depth, spec.bit_depth, ar_coeff_lag=lag, batch_frames=3)
+    g.set_timing(True)
+    for k in ks:
+        s, d = make_pair(spec, k, device="cuda")
+        g.diff_frame(s, d, spec.xdec, spec.ydec)
+    out = format_tbl(g.finish())
+    st = g.stats()
+    kt = g.kernel_times()
+    g.close()
+    assert out == tbl
+    assert st.frames == len(ks) and st.flat_blocks > 0
+    assert "k4_latest" in kt and kt["k4_latest"][1] == (len(ks) + 2) // 3, kt  # (the kernel did run: one launch a batch)
+    print({k: round(v[0] / v[1] * 1e3, 1) for k, v in kt.items()})
