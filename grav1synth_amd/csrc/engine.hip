@@ -282,6 +282,7 @@ std::vector<CachedSlot> g_slot_cache;
 struct StreamSet {
   int device = -1;
   hipStream_t compute = nullptr, copy = nullptr, flat = nullptr, flat2 = nullptr, upload = nullptr;
+  hipStream_t latest = nullptr;  // k4_latest and the blobs' D2H (the copy stream carries the accumulation's tail kernels)
   hipEvent_t kernels_done[kSlots] = {};
   hipEvent_t mask_done[kSlots] = {};
   hipEvent_t pix_done[kSlots] = {};
@@ -310,7 +311,8 @@ bool acquire_streams(int device, StreamSet &out) {
             hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_hi) == hipSuccess &&
             hipStreamCreateWithPriority(&out.flat2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
-            hipStreamCreateWithFlags(&out.upload, hipStreamNonBlocking) == hipSuccess;
+            hipStreamCreateWithFlags(&out.upload, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&out.latest, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < kSlots && ok; ++i)
     ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess &&
@@ -1278,14 +1280,17 @@ int g1s_diff::launch_back(int si) {
       HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
       HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
     } else {
-      HIP_TRY(launch_latest(job, B, ss.copy));
+      HIP_TRY(hipStreamWaitEvent(ss.latest, ss.kernels_done[si], 0));
+      HIP_TRY(launch_latest(job, B, ss.latest));
     }
-    HIP_TRY(hipMemcpyAsync(sl.h_latest, sl.d_latest, blob * B, hipMemcpyDeviceToHost, ss.copy));
-    HIP_TRY(hipMemcpyAsync(sl.h_records + L.size * (B - 1), sl.d_records + L.size * (B - 1), L.size, hipMemcpyDeviceToHost, ss.copy));
+    hipStream_t ls = sl.timed ? ss.copy : ss.latest;
+    HIP_TRY(hipMemcpyAsync(sl.h_latest, sl.d_latest, blob * B, hipMemcpyDeviceToHost, ls));
+    HIP_TRY(hipMemcpyAsync(sl.h_records + L.size * (B - 1), sl.d_records + L.size * (B - 1), L.size, hipMemcpyDeviceToHost, ls));
+    HIP_TRY(hipEventRecord(sl.done, ls));
   } else {
     HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, ss.copy));
+    HIP_TRY(hipEventRecord(sl.done, ss.copy));
   }
-  HIP_TRY(hipEventRecord(sl.done, ss.copy));
   // profiling aid (G1S_D2H_SYNC=1, with G1S_ONE_STREAM=1): the records copy has ended before the next batch's first kernel
   // starts -- under rocprofv3 the copy is a blit kernel that otherwise shares the chip with k1_moments and doubles its time
   static const bool d2h_sync = getenv("G1S_D2H_SYNC") != nullptr;
@@ -1556,6 +1561,7 @@ void g1s_diff::release() {
   }
   if (ss.compute) (void)hipStreamSynchronize(ss.compute);
   if (ss.copy) (void)hipStreamSynchronize(ss.copy);
+  if (ss.latest) (void)hipStreamSynchronize(ss.latest);
   if (ss.flat) (void)hipStreamSynchronize(ss.flat);
   if (ss.flat2) (void)hipStreamSynchronize(ss.flat2);
   if (ss.upload) (void)hipStreamSynchronize(ss.upload);
