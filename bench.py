@@ -288,6 +288,7 @@ def main() -> None:
             "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
             "rccl_ranks": (dist.get_world_size() if (world > 1 and not share) else (1 if world == 1 else 0)),
             "backend": (dist.get_backend() if world > 1 else "none (one process)"),
+            "per_frame_fold_half": ("device (k4_latest)" if os.environ.get("G1S_LATEST") == "device" else "host pool"),
             "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if world > 1 else "single GPU",
         },
         "hbm_roofline_frac_whole_job": (value * bpp * 1e6 / 1e9) / (HBM_PEAK_GBS * world),

@@ -31,6 +31,10 @@ FULL_SIZE = {
     "oracle_full_1920x1080_8b_lag2_luma.tbl": dict(spec=SynthSpec(1920, 1080, 8), frames=3, lag=2, chroma=False),
     "oracle_full_1920x1080_8b_420_lag3.tbl": dict(spec=SynthSpec(1920, 1080, 8), frames=3, lag=3, chroma=True),
     "oracle_full_7680x4320_10b_444_lag3.tbl": dict(spec=SynthSpec(7680, 4320, 10, xdec=0, ydec=0), frames=2, lag=3, chroma=True),
+    # configs[0] as BASELINE.json states it: 1080p 8-bit 4:2:0, 30 frames, lag 3, chroma
+    "oracle_full_1920x1080_8b_420_lag3_30frames.tbl": dict(spec=SynthSpec(1920, 1080, 8), frames=30, lag=3, chroma=True),
+    # configs[2]'s format with a scene cut (the noise gain triples from frame 4 on): is_different at the bench workload's size
+    "oracle_full_3840x2160_10b_420_lag3_cut.tbl": dict(spec=SynthSpec(3840, 2160, 10), frames=8, lag=3, chroma=True, cut=4, fps=(24, 1)),
 }
 
 
@@ -42,13 +46,16 @@ def generate(name):
     if "cut" in g:
         b = SynthSpec(spec.width, spec.height, spec.bit_depth, gain_scale=3)
         specs = [spec if k < g["cut"] else b for k in range(g["frames"])]
-        fps = Fraction(30000, 1001)
+        fps = Fraction(*g.get("fps", (30000, 1001)))
     tbl, _ = oracle_run(spec, range(g["frames"]), g["lag"], g["chroma"], fps=fps, specs_per_frame=specs)
     return tbl
 
 
 if __name__ == "__main__":
-    for name in (FULL_SIZE if sys.argv[1:] == ["full"] else GOLDEN):
+    names = FULL_SIZE if sys.argv[1:2] == ["full"] else GOLDEN
+    if len(sys.argv) > 2:  # `full NAME ...`: only those
+        names = sys.argv[2:]
+    for name in names:
         with open(os.path.join(HERE, name), "wb") as f:
             f.write(generate(name))
         print("wrote", name)

@@ -170,11 +170,13 @@ def test_accumulation_modes_agree():
 
 
 @pytest.mark.parametrize("name", ["oracle_full_1920x1080_8b_lag2_luma.tbl", "oracle_full_1920x1080_8b_420_lag3.tbl",
-                                  "oracle_full_7680x4320_10b_444_lag3.tbl"])
+                                  "oracle_full_7680x4320_10b_444_lag3.tbl", "oracle_full_1920x1080_8b_420_lag3_30frames.tbl",
+                                  "oracle_full_3840x2160_10b_420_lag3_cut.tbl"])
 def test_full_size_tables_match_the_committed_oracle_goldens(name):
     """BASELINE.json's configurations at their FULL sizes -- 1080p 8-bit lag 2 luma-only (configs[1]), 1080p 8-bit 4:2:0
-    lag 3, 8K 10-bit 4:4:4 lag 3 (configs[4]'s format) -- against tables the oracle wrote for the same seeded frames
-    (tests/golden/make_golden.py full: minutes of CPU time, committed as data): byte-identical."""
+    lag 3 (3 frames, and configs[0] as stated: 30 frames), 8K 10-bit 4:4:4 lag 3 (configs[4]'s format), 4K 10-bit 4:2:0 lag 3
+    (configs[2]'s format) with a scene cut after four of eight frames -- against tables the oracle wrote for the same seeded
+    frames (tests/golden/make_golden.py full: minutes of CPU time, committed as data): byte-identical."""
     import os
 
     from tests.golden import make_golden
@@ -183,14 +185,21 @@ def test_full_size_tables_match_the_committed_oracle_goldens(name):
     spec, lag, chroma = gd["spec"], gd["lag"], gd["chroma"]
     with open(os.path.join(os.path.dirname(__file__), "golden", name), "rb") as f:
         want = f.read()
-    g = DiffGenerator(Fraction(24, 1), spec.bit_depth, spec.bit_depth, ar_coeff_lag=lag, luma_only=not chroma, batch_frames=2)
+    fps = Fraction(*gd.get("fps", (24, 1))) if "cut" in gd else Fraction(24, 1)
+    g = DiffGenerator(fps, spec.bit_depth, spec.bit_depth, ar_coeff_lag=lag, luma_only=not chroma, batch_frames=2 if gd["frames"] < 8 else 5)
     for k in range(gd["frames"]):
-        s, d = make_pair(spec, k, device="cuda")
+        sp = spec
+        if "cut" in gd and k >= gd["cut"]:
+            sp = SynthSpec(spec.width, spec.height, spec.bit_depth, gain_scale=3)
+        s, d = make_pair(sp, k, device="cuda")
         if not chroma:
             s, d = s[:1], d[:1]
         g.diff_frame(Frame(s, spec.xdec, spec.ydec), Frame(d, spec.xdec, spec.ydec))
         del s, d
-    assert format_tbl(g.finish()) == want
+    got = format_tbl(g.finish())
+    assert got == want
+    if "cut" in gd:
+        assert got.count(b"E ") == 2 if isinstance(got, bytes) else got.count("E ") == 2  # (the cut is there: two segments)
 
 
 def _padded(planes, spec, top, bottom, left, right, fill):
