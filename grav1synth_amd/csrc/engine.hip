@@ -71,12 +71,19 @@ bool use_k0() { return k3_mode() == 0 || k3_mode() == 2; }
 bool use_planes() { return k3_mode() == 2; }
 bool use_stream() { return k3_mode() == 3; }  // k3s.hip.h: the second-generation fused pass
 constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per CU, one round
-// workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32
-int m_wgs_per_frame(int nunits, int B) {
+// workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32.
+// kind 0: the luma launch, 1: the chroma launch.  The luma launch likes workgroups of ~64 units of the list (4 096 - 6 144
+// workgroups for 64 4K frames: 518 / 510 us against 534 at 2 048), the chroma launch 2 048 (372 us against 377 - 383 at 4 096):
+// profiles/r03_wgs_sweep.txt.
+int m_wgs_per_frame(int nunits, int B, int kind = 1) {
   const int gmin = (nunits + (kMMaxUnits - 16) - 1) / (kMMaxUnits - 16);  // (two lists, each dealt with its own rounding)
   const char *e = getenv("G1S_F_WGS");  // tuning / test aid (read at every call: a test sets it for its own generator)
+  const char *el = kind == 0 ? getenv("G1S_F_WGS_L") : nullptr;  // ... the luma launch alone
   // (at least 32 workgroups to a frame: 64-frame launches are two resident rounds)
-  const int target = e ? std::max(8, atoi(e)) : std::max(kMTargetWgs, 32 * B);
+  int target = std::max(kMTargetWgs, 32 * B);
+  if (kind == 0) target = std::max(target, std::min(64 * B, (int)((long long)B * nunits / 64)));
+  if (e) target = std::max(8, atoi(e));
+  if (el) target = std::max(8, atoi(el));
   return (std::max(gmin, (target + B - 1) / std::max(B, 1)) + 7) & ~7;  // (a multiple of 8: workgroup b of a frame on XCD b % 8)
 }
 
@@ -572,7 +579,8 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
                                             sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
   // one partial system per accumulation workgroup and plane: the most workgroups a launch of 1 .. batch frames asks for
   m_wg_cap = 0;
-  for (uint32_t b = 1; b <= batch; ++b) m_wg_cap = std::max(m_wg_cap, (size_t)b * m_wgs_per_frame(m_nunits, (int)b));
+  for (uint32_t b = 1; b <= batch; ++b)
+    m_wg_cap = std::max(m_wg_cap, (size_t)b * std::max(m_wgs_per_frame(m_nunits, (int)b, 0), m_wgs_per_frame(m_nunits, (int)b, 1)));
   const size_t mpart_bytes = !use_mfma() ? 0 : sizeof(long long) * 3 * kMRec * m_wg_cap;
   // L plane of a frame: block rows x chunk columns at chroma resolution (+ a slack row)
   m_lpitch = g.nplanes == 3 ? (uint32_t)((((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * kMUnitBlocks * (kBlock >> g.xdec) + 15) & ~15) : 0u;
@@ -1041,8 +1049,11 @@ int g1s_diff::launch_back(int si) {
     fq.partials = mp.partials;
     fq.ustats = reinterpret_cast<int32_t *>(mp.only + m_only_bytes);
     fq.nunits = m_nunits;
-    int G = m_wgs_per_frame(m_nunits, (int)B);
-    if ((size_t)G * B > m_wg_cap) G = m_wgs_per_frame(m_nunits, 1 << 20);  // (G1S_F_WGS raised after the slots were sized: the fewest that hold the units)
+    int G_kind[2] = {m_wgs_per_frame(m_nunits, (int)B, 0), m_wgs_per_frame(m_nunits, (int)B, 1)};  // luma launch, chroma launch
+    for (int &Gk : G_kind)
+      if ((size_t)Gk * B > m_wg_cap) Gk = m_wgs_per_frame(m_nunits, 1 << 20);  // (G1S_F_WGS raised after the slots were sized: the fewest that hold the units)
+    const int G_cap = std::max(G_kind[0], G_kind[1]);
+    int G = G_kind[0];
     // profiling aid: G1S_F_PHASES=1 prints, per batch, the cycles the accumulation waves spent in each phase
     // (G1S_F_PHASES=1: the luma launch, 2: the chroma launch)
     static const int phases = getenv("G1S_F_PHASES") ? atoi(getenv("G1S_F_PHASES")) : 0;
@@ -1060,6 +1071,7 @@ int g1s_diff::launch_back(int si) {
     static const size_t lds_pad = getenv("G1S_F_LDS_PAD") ? (size_t)atoi(getenv("G1S_F_LDS_PAD")) : 0;  // tuning aid: fewer workgroups to a CU
     fq.frames = (int)B;
     fq.wgs = G;
+    fq.wg_cap = G_cap;
     // units to workgroups: contiguous runs of the lists (measured +2..4 % over round-robin in the pipelined job, although a
     // kernel alone on the chip is 5 % slower: the runs' loads disturb the kernels next to it less)
     static const int deal_env = getenv("G1S_F_DEAL") ? atoi(getenv("G1S_F_DEAL")) : 1;  // tuning aid
@@ -1070,7 +1082,7 @@ int g1s_diff::launch_back(int si) {
     static const int s_dbg = getenv("G1S_S_DBG") ? atoi(getenv("G1S_S_DBG")) : 0;  // timing experiments: parts of k3s_fused left out (wrong results)
     fq.dbg = s_dbg;
     const bool planes = use_planes(), stream_mode = use_stream();
-    const dim3 gr((uint32_t)G * B);
+    dim3 gr((uint32_t)G * B);
     const int bpsm = g.src_bps == g.den_bps ? g.src_bps : 0;  // bytes per sample at compile time unless the depths are mixed
     // two launches: the luma plane (which leaves L behind), then the two chroma planes
 #define G1S_F(CW, CH, BP, PL)                                                                                        \
@@ -1090,6 +1102,9 @@ int g1s_diff::launch_back(int si) {
     if (stream_mode) snprintf(kn_, sizeof(kn_), "k3s_fused<%d, %d, %d, %d>", CW, CH, BP, PL);                        \
     else snprintf(kn_, sizeof(kn_), "k3f_fused<%d, %d, %d, %d, %d>", CW, CH, planes ? 1 : BP, PL, planes ? 1 : 0);   \
     kmark(sl, stream, kn_);                                                                                          \
+    G = G_kind[PL];                                                                                                  \
+    fq.wgs = G;                                                                                                      \
+    gr = dim3((uint32_t)G * B);                                                                                      \
     fq.phase_cycles = phases == PL + 1 ? phase_buf : nullptr;                                                        \
     if (stream_mode) hipLaunchKernelGGL((k3s_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);       \
     else if (planes) hipLaunchKernelGGL((k3f_fused<CW, CH, 1, PL, 1>), gr, dim3(kFThreads), lds, stream, g, fq);     \
@@ -1122,7 +1137,7 @@ int g1s_diff::launch_back(int si) {
 #undef G1S_FS
 #undef G1S_F
     kmark(sl, stream, "k3m_finish");
-    if (!dbg_skip("finish")) hipLaunchKernelGGL(k3m_finish, dim3(kMFinishParts * g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G,
+    if (!dbg_skip("finish")) hipLaunchKernelGGL(k3m_finish, dim3(kMFinishParts * g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G_kind[0], G_kind[1], G_cap,
                        planes ? (const int32_t *)nullptr : (const int32_t *)fq.ustats, sl.d_records);
     if (phase_buf) {
       std::vector<long long> hc((size_t)G * B * kFWaves * 8);

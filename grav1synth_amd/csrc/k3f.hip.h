@@ -50,6 +50,7 @@ struct FParams {
   uint8_t *lplane;        // [batch][lrows][lpitch]  L (sum of the co-located luma residuals) at chroma resolution, int8
   uint32_t lpitch, lframe_bytes;
   int frames, wgs;        // the launch: frames x workgroups per frame, as a 1-D grid (see the kernel)
+  int wg_cap;             // workgroups per frame the partial systems are laid out for (>= wgs: the luma and the chroma launch may differ)
   int deal;               // units to workgroups: 0 round-robin, 1 contiguous runs
   int reuse;              // 1: (luma launch) the left halo word of a unit whose left neighbour was the unit before it in the run is not read
   const uint8_t *planes;  // SRC = 1: the int8 planes of the pixel pass K0 (k0.hip.h), [batch] x ps.frame_bytes
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
   flush(accA, PL0);
   if (CHROMA) flush(accB, 2);
   __syncthreads();
-  long long *out = fpar.partials + (((size_t)frame * G + wg) * 3 + PL0) * kMRec;
+  long long *out = fpar.partials + (((size_t)frame * fpar.wg_cap + wg) * 3 + PL0) * kMRec;
   for (int k = tid; k < NPL * kMRec; k += kFThreads) out[k] = s_S[k];
 }
 

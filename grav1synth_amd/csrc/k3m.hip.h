@@ -347,7 +347,7 @@ __device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const ui
 constexpr int kMStatInts = 16, kMFinishWgs = 12, kMFinishParts = 3;
 static_assert(kMFinishParts * 256 >= 26 * 26 + 26, "k3m_finish: one entry per thread");
 // ustats == nullptr: a pixel pass took the statistics and the deferrals (K0 + k3m_units): only the systems and nobs.
-__global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, const int32_t *__restrict__ ustats,
+__global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G_luma, int G_chroma, int G_cap, const int32_t *__restrict__ ustats,
                                                   uint8_t *__restrict__ records) {
   const int frame = g.frame0 + (int)blockIdx.y;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G, con
     const int k = ((int)blockIdx.x - c * kMFinishParts) * 256 + (int)threadIdx.x;
     if (k >= nc * nc + nc) return;
     long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
-    const long long *p = mp.partials + (size_t)frame * G * 3 * kMRec + (size_t)c * kMRec + k;
+    const int G = c == 0 ? G_luma : G_chroma;  // (workgroups a frame of the launch that made this plane's partial systems)
+    const long long *p = mp.partials + (size_t)frame * G_cap * 3 * kMRec + (size_t)c * kMRec + k;
     long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int w = 0;
     for (; w + 4 <= G; w += 4) {  // (independent loads in flight)

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(kFThreads, (PL == 1 && CBW == 16 && CBH == 16) ? G1
     }
   }
   __syncthreads();
-  long long *out = fpar.partials + (((size_t)frame * G + wg) * 3 + PL0) * kMRec;
+  long long *out = fpar.partials + (((size_t)frame * fpar.wg_cap + wg) * 3 + PL0) * kMRec;
   for (int k = tid; k < NPL * kMRec; k += kFThreads) out[k] = s_S[k];
 }
 
