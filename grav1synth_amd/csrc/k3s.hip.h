@@ -119,13 +119,10 @@ __device__ __forceinline__ void s_residual(const uint32_t (&hs)[4], const uint32
 // MASKED: `rm` bit j * RS says whether the lane's sample row of step j lies inside its block's window rows (a sample outside
 // contributes nothing: both operands of the step are zeroed for the lane's k-group -- copies of them, the tile rows stay what
 // they are for the next step); all three products of every step, into aP, aX, aQ.
-template <int NSTEP, int RS, int P, bool MASKED>
+template <int NSTEP, int RS, int P, bool MASKED, int READS>
 __device__ __forceinline__ void s_multiply(v4i32s &aS, v4i32s &aP, v4i32s &aX, v4i32s &aQ, const uint8_t *smem, int a0, uint32_t rm) {
   v4i32s q = m_lds16(smem, a0 - RS * P);
-#ifndef G1S_S_READS
-#define G1S_S_READS 2
-#endif
-  constexpr int H = NSTEP > G1S_S_READS ? G1S_S_READS : NSTEP;  // operand reads in flight (4: the luma launch spills)
+  constexpr int H = NSTEP > READS ? READS : NSTEP;  // operand reads in flight
 #pragma unroll
   for (int j0 = 0; j0 < NSTEP; j0 += H) {
     v4i32s p[H];
@@ -151,6 +148,9 @@ __device__ __forceinline__ void s_multiply(v4i32s &aS, v4i32s &aP, v4i32s &aX, v
   }
 }
 
+#ifndef G1S_S_READS
+#define G1S_S_READS 2  // operand reads in flight in the multiplies (4: the 4:2:0 luma launch spills)
+#endif
 template <int CBW, int CBH>
 struct SShape {
   static constexpr bool CH = CBW != 0;
@@ -188,8 +188,18 @@ __device__ __forceinline__ uint32_t s_flag_bits(int wd, int WB) {
 #ifndef G1S_S_OCC_C
 #define G1S_S_OCC_C 4  // waves per SIMD the 4:2:0 chroma launch is compiled for (5 = 96 registers: measured 9 % slower, profiles/r03b)
 #endif
+// workgroups a CU holds (= waves a SIMD holds) for an instantiation: what its LDS leaves room for, at most G1S_F_OCC.  The
+// kernel is compiled for that many -- 4:4:4 planes (70 KB of tiles a chroma workgroup: two to a CU; 46 KB a luma workgroup:
+// three) get 256 / 168 registers instead of 128 and no longer spill.
+__host__ __device__ constexpr int s_occupancy(int CBW, int CBH, int PL) {
+  const int nl = (PL == 0 && CBW != 0) ? CBH * kMUnitBlocks * CBW / 8 : 0;      // words of the luma launch's L tile
+  const int fixed = 4400 + (nl ? 8 * (nl + 1) * 4 : 0);                          // static LDS (control words, rings, L tiles)
+  const int fit = (160 * 1024) / (s_lds_bytes(CBW, CBH, PL) + fixed);
+  const int want = (PL == 1 && CBW == 16 && CBH == 16) ? G1S_S_OCC_C : G1S_F_OCC;
+  return fit < 1 ? 1 : (fit < want ? fit : want);
+}
 template <int CBW, int CBH, int BPS, int PL>
-__global__ __launch_bounds__(kFThreads, (PL == 1 && CBW == 16 && CBH == 16) ? G1S_S_OCC_C : G1S_F_OCC) void k3s_fused(Geom g, FParams fpar) {
+__global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fused(Geom g, FParams fpar) {
   extern __shared__ __attribute__((aligned(16))) uint8_t m_smem[];
   using SH = SShape<CBW, CBH>;
   constexpr bool CH = SH::CH;
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(kFThreads, (PL == 1 && CBW == 16 && CBH == 16) ? G1
   // the entries (+ 5 empty ones behind the last): needed until the control words exist and the prologue has read its own --
   // they live where the tiles will
   uint4 *s_ent = reinterpret_cast<uint4 *>(m_smem);
-  static_assert((kMMaxUnits + 5) * 16 <= 2 * s_buf_bytes(CBW, CBH, PL), "the parked entries fit the tile buffers");
+  static_assert((kMMaxUnits + 5) * 16 <= s_lds_bytes(CBW, CBH, PL), "the parked entries fit the tile buffers");
 
   const int G = fpar.wgs, frame = g.frame0 + (int)blockIdx.x % fpar.frames, wg = (int)blockIdx.x / fpar.frames;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -698,13 +708,13 @@ __global__ __launch_bounds__(kFThreads, (PL == 1 && CBW == 16 && CBH == 16) ? G1
         } else if (!G1S_S_DBGBIT(16)) {
           const uint8_t *buf = m_smem + (k & 1) * BUF;
           if constexpr (PLAIN) {
-            s_multiply<NSTEP, RS, MP, false>(aSS, aPP, aPQ, aQQ, buf, m_addr, ~0u);
+            s_multiply<NSTEP, RS, MP, false, G1S_S_READS>(aSS, aPP, aPQ, aQQ, buf, m_addr, ~0u);
           } else {
             const MWin w0m = m_unpack(wy0 & 0xffffu, g.lag), w1m = m_unpack(wy0 >> 16, g.lag);
             if (w0m.go || w1m.go) {
               const uint32_t r0 = w0m.go ? m_rowmask(w0m.ys, w0m.ye) : 0u, r1 = w1m.go ? m_rowmask(w1m.ys, w1m.ye) : 0u;
               const uint32_t rm = (m_blk ? r1 : r0) >> (m_y0 + m_rho);
-              s_multiply<NSTEP, RS, MP, true>(aSS, aPP, aPQ, aQQ, buf, m_addr, rm);
+              s_multiply<NSTEP, RS, MP, true, G1S_S_READS>(aSS, aPP, aPQ, aQQ, buf, m_addr, rm);
             }
           }
         }
