@@ -136,6 +136,11 @@ def main() -> None:
         else:
             sd = ShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
                              batch_frames=args.batch, group=None)
+            if timing:
+                # (one untimed pass first: the first batch of a generator carries one-off costs -- 1.3 ms in the last kernel
+                #  of its chain -- that are not the kernels')
+                sd.generator.set_timing(False)
+                sd.diff_prepared(prep, W, H, nplanes, sync_torch=False)
             sd.generator.set_timing(timing)
             for _ in range(cycles):
                 sd.diff_prepared(prep, W, H, nplanes, sync_torch=False)
@@ -190,7 +195,7 @@ def main() -> None:
     kt = {k: v for k, v in kernel_times.items() if v[1] > 0}
     dom = max(kt, key=lambda k: kt[k][0]) if kt else max(families, key=lambda k: families[k][0])
     dom_ms, dom_launches = kt[dom] if kt else families[dom]
-    n_batches = max(st.launches_ar_accumulate, 1)
+    n_batches = max(dom_launches if kt else st.launches_ar_accumulate, 1)  # (the timed batches: the job's first pass is not)
     frames_per_launch = FT / n_batches
     # bpp bytes per luma pixel of a frame pair = every source and denoised sample once
     alg_bytes_per_launch = bpp * W * H * frames_per_launch
@@ -322,7 +327,7 @@ def main() -> None:
             },
             "kernels_us_per_launch": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
             "families_ms_per_frame": {k: v[0] / FT for k, v in families.items()},
-            "host_fold_ms_per_frame": st.ms_host_fold / FT,
+            "host_fold_ms_per_frame": st.ms_host_fold / (F * (TC + (1 if world == 1 else 0))),  # (every frame the job fed, its untimed first pass too)
             "accumulation": os.environ.get("G1S_K3", "stream"),
         },
     }

@@ -191,7 +191,7 @@ Pool *merge_pool() {
   static Pool *p = [] {
     unsigned hw = std::thread::hardware_concurrency();
     if (const char *e = getenv("G1S_FOLD_THREADS")) hw = (unsigned)atoi(e);
-    unsigned n = std::min(16u, hw / 2);
+    unsigned n = std::min(8u, hw / 2);  // (8: 1.5 - 1.6 us a frame, steady; 16 reaches 1.0 but swings to 2 - 8 on a busy host: profiles/r03_fold_budget.txt)
     if (const char *e = getenv("G1S_MERGE_POOL")) n = (unsigned)atoi(e);  // (measurement: the pool's size itself)
     return n > 1 ? new Pool(n - 1) : nullptr;
   }();
