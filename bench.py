@@ -119,10 +119,11 @@ def main() -> None:
     kernel_times = {}
     last_tbl = None
     window_samples = None  # per plane, of the last frame of the timed-kernels step
+    exchange_s, exchange_rounds = 0.0, 0  # N > 1: the feeding thread's time in the rounds' exchange
 
     def one_step(timing: bool, cycles: int = 0, prep=None):
         """one job: the resident frames `cycles` times over through a fresh generator, up to the finished table"""
-        nonlocal stats_total, last_tbl, window_samples, kernel_times
+        nonlocal stats_total, last_tbl, window_samples, kernel_times, exchange_s, exchange_rounds
         cycles = cycles or args.cycles
         prep = prep if prep is not None else prepared
         if world > 1:
@@ -145,6 +146,9 @@ def main() -> None:
             for _ in range(cycles):
                 sd.diff_prepared(prep, W, H, nplanes, sync_torch=False)
         segs = sd.finish()  # (exchange +) ordered fold; rank 0 holds the table
+        if world > 1 and not timing:
+            exchange_s += sd.exchange_s
+            exchange_rounds += cycles * len(prepared_batches) + sd.PIPELINE_BATCHES
         st = sd.generator.stats()
         if timing:
             kernel_times = sd.generator.kernel_times()
@@ -293,6 +297,7 @@ def main() -> None:
             "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
             "rccl_ranks": (dist.get_world_size() if (world > 1 and not share) else (1 if world == 1 else 0)),
             "backend": (dist.get_backend() if world > 1 else "none (one process)"),
+            "exchange_ms_per_round": (exchange_s * 1e3 / exchange_rounds) if exchange_rounds else None,  # (N > 1: pack + gather + hand-over, on the feeding thread of this rank)
             "per_frame_fold_half": ("device (k4_latest)" if os.environ.get("G1S_LATEST") == "device" else "host pool"),
             "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if world > 1 else "single GPU",
         },

@@ -10,6 +10,7 @@ integers, so the result does not depend on the number of ranks.
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 from fractions import Fraction
@@ -93,6 +94,87 @@ def gather_msgs(msg: np.ndarray, dist, device: Optional[torch.device] = None) ->
     return host
 
 
+_RCCL_ROUNDS = {}
+
+
+class _RcclRounds:
+    """The transport of the rounds over RCCL, with nothing allocated and nothing waited for on the feeding thread: the rank's
+    message is packed into one of a ring of pinned buffers, copied to the device on a copy stream and gathered to rank 0 (send /
+    recv over xGMI) on a collective stream; on rank 0 the gathered rows go to one of a ring of pinned host buffers and the MERGER
+    thread waits for that copy.  The feeding thread waits only when the collective stream is RING rounds behind.
+    (The first form of this class' job -- gather_msgs per round -- allocated, copied through pageable memory and ended in a
+    blocking `.cpu()` of world x 1.7 MB on rank 0's feeding thread: comparable to a batch's kernel time at eight ranks.  The
+    second had one stream: the next round's message waited behind the last round's gather kernel, which itself waits for a
+    free workgroup slot next to the accumulation launches: 0.4 - 0.6 ms a round.)"""
+
+    RING = 4
+
+    def __init__(self, dist, device: torch.device, msg_bytes: int):
+        self.dist = dist
+        self.dev = device
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.coll_stream = torch.cuda.Stream(device=device)
+        self.send_host = [torch.zeros(msg_bytes, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self.send_dev = [torch.zeros(msg_bytes, dtype=torch.uint8, device=device) for _ in range(self.RING)]
+        self.gathered = [None] * self.RING  # event: the gather that read send_dev[i] has run
+        self.round = 0
+        self.rooted = True
+        self.recv_dev = None
+        if self.rank == 0:
+            self.recv_dev = torch.zeros((self.world, msg_bytes), dtype=torch.uint8, device=device)
+            self.recv_host = [torch.zeros((self.world, msg_bytes), dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+            self.free = queue.Queue()
+            for k in range(self.RING):
+                self.free.put(k)
+
+    def pack_buffer(self) -> np.ndarray:
+        """where this round's message is packed (the round RING rounds ago has left it)"""
+        i = self.round % self.RING
+        if self.gathered[i] is not None:
+            self.gathered[i].synchronize()
+        return self.send_host[i].numpy()
+
+    def exchange(self):
+        """the packed message -> rank 0.  Returns (ring index, event) on rank 0 -- the rows are in recv_host[index] once the
+        event has passed; release(index) hands the buffer back -- and None elsewhere."""
+        i = self.round % self.RING
+        self.round += 1
+        with torch.cuda.stream(self.copy_stream):
+            self.send_dev[i].copy_(self.send_host[i], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.copy_stream)
+        out = None
+        with torch.cuda.stream(self.coll_stream):
+            self.coll_stream.wait_event(copied)
+            if self.rooted:
+                try:
+                    parts = [self.recv_dev[r] for r in range(self.world)] if self.rank == 0 else None
+                    self.dist.gather(self.send_dev[i], gather_list=parts, dst=0)
+                except (RuntimeError, NotImplementedError):  # raised on every rank alike, before any traffic
+                    self.rooted = False
+            if not self.rooted:
+                if self.recv_dev is None:
+                    self.recv_dev = torch.zeros((self.world, self.send_dev[i].numel()), dtype=torch.uint8, device=self.dev)
+                self.dist.all_gather_into_tensor(self.recv_dev, self.send_dev[i])
+            done = torch.cuda.Event()
+            done.record(self.coll_stream)
+            self.gathered[i] = done
+            if self.rank == 0:
+                k = self.free.get()  # (blocks only if the merger is RING rounds behind)
+                self.recv_host[k].copy_(self.recv_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.coll_stream)
+                out = (k, ev)
+        return out
+
+    def rows(self, k: int) -> np.ndarray:
+        return self.recv_host[k].numpy()
+
+    def release(self, k: int) -> None:
+        self.free.put(k)
+
+
 class StreamingShardedDiff:
     """Frame-shard mode with the fold streamed: the video is dealt to the ranks batch by batch
     (global batch j goes to rank j % N), every rank runs the kernels AND the per-frame half of the
@@ -126,21 +208,55 @@ class StreamingShardedDiff:
         self._dev = None
         if torch.cuda.is_available():
             self._dev = torch.device("cuda", device if device >= 0 else torch.cuda.current_device())
+        self._rccl = None
+        if group is not None and self._dev is not None and group.get_backend() == "nccl":
+            # (the pinned rings and streams are made once per process and message size: pinning memory costs milliseconds)
+            key = (id(group), str(self._dev), self._msg_bytes)
+            if key not in _RCCL_ROUNDS:
+                _RCCL_ROUNDS[key] = _RcclRounds(group, self._dev, self.ROUNDS_PER_GATHER * self._msg_bytes)
+            self._rccl = _RCCL_ROUNDS[key]
+        self._group_buf, self._group_n = None, 0
+        self.exchange_s = 0.0  # seconds the feeding thread spent in the rounds' exchange (bench.py prints it)
 
     # batches that can still be inside a generator when the last frame has been queued: being filled,
     # pixel pass queued, accumulation queued, draining (csrc/engine.hip, kSlots)
     PIPELINE_BATCHES = 4
 
+    # Rounds per gather: every rank packs one message a round (the library's protocol, unchanged), the transport moves
+    # ROUNDS_PER_GATHER of them at a time.  A collective next to the accumulation launches costs the GPU ~0.2 ms whatever it
+    # moves (its kernel waits for a workgroup slot and holds it): one per round took 11 % off a rank's throughput, one per four
+    # rounds 3 % (tools/rccl_round_cost.py).  The merge orders by the batch index in the messages, so grouping changes nothing
+    # but when the states reach rank 0.
+    ROUNDS_PER_GATHER = int(os.environ.get("G1S_ROUNDS_PER_GATHER", "4"))
+
     def _exchange_one(self, flush: bool = False) -> None:
-        """One fixed-size round.  The protocol is the library's (g1s_shard_pack: which batch goes out, the message;
-        g1s_shard_merge: the root's order); this class only moves the bytes -- one gather to rank 0."""
+        """One round: this rank's message (g1s_shard_pack decides which batch goes out) into the group's buffer; every
+        ROUNDS_PER_GATHER-th round the buffer goes to rank 0 in one gather and on to g1s_shard_merge there."""
+        import time as _time
+
+        t0 = _time.perf_counter()
         L = self.generator._L
-        msg = np.zeros(self._msg_bytes, dtype=np.uint8)
-        self.generator._check(L.g1s_shard_pack(self.generator._h, int(flush), msg.ctypes.data, msg.nbytes))
-        gathered = gather_msgs(msg, self.dist, self._dev)
-        if self._fold is not None:
-            # the merge itself runs on a thread of its own (the C call drops the GIL): this thread goes back to feeding its GPU
-            self._merge_q.put(gathered)
+        R, mb = self.ROUNDS_PER_GATHER, self._msg_bytes
+        if self._group_buf is None:
+            self._group_buf = self._rccl.pack_buffer() if self._rccl is not None else np.zeros(R * mb, dtype=np.uint8)
+        slot = self._group_buf[self._group_n * mb:(self._group_n + 1) * mb]
+        self.generator._check(L.g1s_shard_pack(self.generator._h, int(flush), slot.ctypes.data, mb))
+        self._group_n += 1
+        if self._group_n == R:
+            self._group_n = 0
+            buf, self._group_buf = self._group_buf, None
+            if os.environ.get("G1S_ROUNDS_LOCAL") and self.dist.get_world_size() == 1:  # measurement: the rounds without a transport
+                self._merge_q.put(buf.reshape(1, R * mb))
+            elif self._rccl is not None:
+                got = self._rccl.exchange()
+                if self._fold is not None:
+                    self._merge_q.put(got)  # (ring index, event): the merger waits for the copy, merges, hands the buffer back
+            else:
+                gathered = gather_msgs(buf, self.dist, self._dev)
+                if self._fold is not None:
+                    # the merge itself runs on a thread of its own (the C call drops the GIL): this thread goes back to feeding its GPU
+                    self._merge_q.put(gathered)
+        self.exchange_s += _time.perf_counter() - t0
 
     def _merge_main(self) -> None:
         L = self.generator._L
@@ -148,11 +264,22 @@ class StreamingShardedDiff:
             item = self._merge_q.get()
             if item is None:
                 return
-            if self._merge_err is None:
-                rc = L.g1s_shard_merge(self._fold._h, item.ctypes.data, item.strides[0], item.shape[0])
+            ring = None
+            if isinstance(item, tuple):  # RCCL rounds: the gathered rows are on their way into a pinned ring buffer
+                ring, ev = item
+                ev.synchronize()
+                item = self._rccl.rows(ring)
+            # item: [ranks, ROUNDS_PER_GATHER x message]: the messages of one round sit a row apart (the row index IS the rank: the
+            # merge computes a batch's place in the video from it)
+            for j in range(item.shape[1] // self._msg_bytes):
+                if self._merge_err is not None:
+                    break
+                rc = L.g1s_shard_merge(self._fold._h, item.ctypes.data + j * self._msg_bytes, item.strides[0], item.shape[0])
                 if rc:  # surfaces in finish()
                     from ._lib import G1SError
                     self._merge_err = G1SError(rc, L.g1s_fold_last_error(self._fold._h).decode())
+            if ring is not None:
+                self._rccl.release(ring)
 
     def diff_prepared(self, prepared, sync_torch: bool = True) -> None:
         """Feeds ONE batch (this rank's next batch in the global order)."""
@@ -173,6 +300,8 @@ class StreamingShardedDiff:
         if self.dist is None:
             return self.generator.finish()
         for _ in range(self.PIPELINE_BATCHES):
+            self._exchange_one(flush=True)
+        while self._group_n:  # (the last group goes out full: empty messages behind the last states)
             self._exchange_one(flush=True)
         if self._fold is None:
             return None
