@@ -1904,27 +1904,21 @@ int g1s_shard_pack(g1s_diff_t *g, int flush, void *msg, size_t cap_bytes) {
   if (!g->latest_only) return g->fail(G1S_ERR_STATE, "not a latest_only generator (records_only = 2)");
   const size_t total = g1s_shard_msg_size(g->lag, g->batch), bs = latest_blob_size(g->lag);
   if (cap_bytes < total) return g->fail(G1S_ERR_CAPACITY, "shard message buffer too small");
-  uint64_t limit;  // batches that may go out by now: a function of the call sequence only (lock step across ranks)
+  // flush = 0: whatever is ready goes out, nothing is waited for -- the root orders by the batch index in the message, so the
+  // ranks need not send the same batch in the same round (they did, and waited for it, when the root merged by arrival: the
+  // feeding thread then ran at most two batches ahead of the drain, 3.5 % of a rank's throughput).  A rank is never more than
+  // the generator's four slots behind with its messages: a round sends nothing only when every unsent batch is still in a slot.
   if (flush) {
     const int rc = g1s_diff_sync(g);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g->dm);
-    limit = g->submitted;
   } else {
-    {
-      std::lock_guard<std::mutex> lk(g->dm);
-      limit = g->submitted >= 2 ? g->submitted - 2 : 0;
-    }
-    g->wait_drained(limit);
-    {
-      const int pending = take_deferred(g);
-      if (pending) return pending;
-    }
+    const int pending = take_deferred(g);
+    if (pending) return pending;
   }
   std::lock_guard<std::mutex> lk(g->dm);
   size_t n = 0;
   uint64_t local_batch = G1S_SHARD_NO_INDEX;
-  if (g->delivered < limit && !g->latest_batches.empty()) {  // ONE batch a round, the oldest not sent yet
+  if (!g->latest_batches.empty()) {  // ONE batch a round, the oldest not sent yet
     n = g->latest_batches.front();
     g->latest_batches.pop_front();
     local_batch = g->delivered;  // (the message says which one: the root orders by it)

@@ -174,9 +174,9 @@ int g1s_diff_take_latest(g1s_diff_t *, int sync, void *buf, size_t cap_bytes, si
  * one feed behind -- may send different local batches in the same round: a batch that arrives before its predecessors
  * waits inside the fold, and g1s_fold_finish refuses (G1S_ERR_STATE) while one is still missing. */
 size_t g1s_shard_msg_size(uint32_t ar_coeff_lag, uint32_t batch_frames);
-/* This rank's message of the round: the latest states of ONE batch -- the oldest one not sent yet among those fed before
- * the two most recent feeds (flush = 0: the same batch index on every rank, however far each runs ahead; waits for it)
- * or among all (flush = 1: drains the generator first) -- or an empty message.  records_only = 2 generators. */
+/* This rank's message of the round: the latest states of ONE batch -- the oldest one not sent yet among those the generator
+ * has finished (flush = 0: never waits; the message is empty when every unsent batch is still in the pipeline, which holds
+ * at most four) or among all (flush = 1: drains the generator first) -- or an empty message.  records_only = 2 generators. */
 int g1s_shard_pack(g1s_diff_t *, int flush, void *msg, size_t cap_bytes);
 /* A message from latest states made elsewhere (g1s_latest_from_record): n <= batch_frames.  Without a batch index: the
  * root merges such messages as they come (rounds in order, ranks in order) -- the caller keeps its ranks in lock step. */
