@@ -838,6 +838,47 @@ def test_y4m_files_give_the_table_of_the_in_memory_path_and_of_the_oracle(tmp_pa
     assert by_hand == oracle_tbl
 
 
+def test_diff_command_takes_two_decoders_output_from_pipes(tmp_path):
+    """No libav here: the stand-in for the reference's two `BitstreamReader`s is two decoders piping YUV4MPEG2 in
+    (`ffmpeg -i source.mkv -f yuv4mpegpipe - > fifo_a`, likewise the denoised file).  The whole command over two FIFOs fed by
+    two writer threads, the streams ending at different times as decoders do: table == the files' table."""
+    import os
+    import threading
+
+    from grav1synth_amd.ingest import diff_y4m_files, write_y4m
+
+    spec = SynthSpec(640, 360, 10)
+    nframes = 9
+    pairs = [make_pair(spec, k, device="cpu") for k in range(nframes)]
+    fps = Fraction(24, 1)
+    files = {"src": tmp_path / "src.y4m", "den": tmp_path / "den.y4m"}
+    write_y4m(str(files["src"]), [s for s, _ in pairs], spec.bit_depth, spec.xdec, spec.ydec, fps)
+    write_y4m(str(files["den"]), [d for _, d in pairs], spec.bit_depth, spec.xdec, spec.ydec, fps)
+    want = tmp_path / "files.tbl"
+    assert diff_y4m_files(str(files["src"]), str(files["den"]), str(want), batch_frames=4) == (nframes, False)
+    fifos = {k: tmp_path / f"{k}.pipe" for k in files}
+    for f in fifos.values():
+        os.mkfifo(f)
+
+    def feed(name, chunk):
+        with open(files[name], "rb") as src, open(fifos[name], "wb") as dst:
+            while True:
+                b = src.read(chunk)
+                if not b:
+                    break
+                dst.write(b)
+
+    ts = [threading.Thread(target=feed, args=("src", 1 << 16), daemon=True), threading.Thread(target=feed, args=("den", 12345), daemon=True)]
+    for t in ts:
+        t.start()
+    got = tmp_path / "pipes.tbl"
+    assert diff_y4m_files(str(fifos["src"]), str(fifos["den"]), str(got), batch_frames=4) == (nframes, False)
+    for t in ts:
+        t.join(timeout=20)
+        assert not t.is_alive()
+    assert got.read_bytes() == want.read_bytes() and len(want.read_bytes()) > 100
+
+
 @pytest.mark.parametrize("devices,nframes", [([0], 7), ([0, 0], 7), ([0, 0], 9), ([0, 0, 0], 11), ("visible", 13)],
                          ids=["1gen", "2gen_7", "2gen_9", "3gen_11", "all_visible_devices"])
 def test_sharded_y4m_diff_gives_the_table_of_one_generator(tmp_path, devices, nframes):

@@ -88,3 +88,40 @@ def test_malformed_files_are_reported(tmp_path):
     with pytest.raises(ValueError, match="truncated frame 1"):
         r.get_frame()
     r.close()
+
+
+def test_reader_takes_a_stream_from_a_pipe(tmp_path):
+    """No libav in the image: what stands in for the reference's decoder is a decoder's output piped in --
+    `ffmpeg -i in.mkv -f yuv4mpegpipe - > fifo`.  The reader must therefore work on something it cannot seek in or take the
+    size of: a FIFO, written by another thread frame by frame, big frames included (the positional-read path needs a file)."""
+    import os
+    import threading
+
+    for (w, h, bd) in ((64, 48, 8), (2048, 1024, 10)):
+        frames = _frames(5, w, h, bd, 1, 1, 3, seed=11)
+        plain = tmp_path / f"plain_{w}.y4m"
+        write_y4m(str(plain), frames, bd, 1, 1, Fraction(24, 1))
+        fifo = tmp_path / f"pipe_{w}.y4m"
+        os.mkfifo(fifo)
+
+        def feed():
+            with open(plain, "rb") as src, open(fifo, "wb") as dst:  # (opening the FIFO blocks until the reader opens it)
+                while True:
+                    chunk = src.read(1 << 16)
+                    if not chunk:
+                        break
+                    dst.write(chunk)
+
+        t = threading.Thread(target=feed, daemon=True)
+        t.start()
+        r = Y4MReader(str(fifo))
+        assert (r.details.width, r.details.height, r.details.bit_depth) == (w, h, bd)
+        for want in frames:
+            got = r.get_frame()
+            assert got is not None
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b)
+        assert r.get_frame() is None
+        r.close()
+        t.join(timeout=10)
+        assert not t.is_alive()
