@@ -50,7 +50,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="frame pairs per rank per step (one video chunk per step)")
-    ap.add_argument("--cycles", type=int, default=104,
+    ap.add_argument("--cycles", type=int, default=120,
                     help="a step feeds the resident frames this many times over: one job of frames x cycles frame pairs "
                          "(default: a step of about half a second, so that the timed region of --steps 20 is 10 s)")
     ap.add_argument("--batch", type=int, default=64, help="frames per kernel launch group (<= 256)")
