@@ -387,7 +387,7 @@ struct g1s_diff {
   uint32_t m_lpitch = 0, m_lframe = 0;  // MFMA path: L plane geometry
   int m_nunits = 0;          // MFMA path: chunks per frame
   size_t m_wg_cap = 0;       // ... workgroups (partial systems) the slots hold
-  size_t m_only_bytes = 0;   // ... deferred-block flags [batch][2][nblocks], 16-byte rounded
+  size_t m_only_bytes = 0;   // ... deferred-block flags [batch][3][nblocks] (one list a plane), 16-byte rounded
   MParams make_mparams(const Slot &sl) const;
   SlotKey slot_key{};
   Slot slots[kSlots];
@@ -571,7 +571,7 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
     pgl_bytes = sizeof(uint32_t) * ((size_t)batch * 2 * pg_cap + (size_t)batch * 2);
   }
   m_nunits = ((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * g.nbh;
-  m_only_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
+  m_only_bytes = ((size_t)g.nblocks * 3 * batch + 15) & ~size_t(15);
   // [units][unit counts][any-deferred flags][deferred-block flags]
   // ... [per-unit statistics records]
   const size_t mu_bytes = !use_mfma() ? 0
@@ -1159,11 +1159,11 @@ int g1s_diff::launch_back(int si) {
         std::vector<uint8_t> h(m_only_bytes);
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h.data(), mp.only, m_only_bytes, hipMemcpyDeviceToHost);
-        size_t n[2] = {0, 0};
+        size_t n[3] = {0, 0, 0};
         for (uint32_t f = 0; f < B; ++f)
-          for (int kind = 0; kind < 2; ++kind)
-            for (int b = 0; b < g.nblocks; ++b) n[kind] += h[((size_t)f * 2 + kind) * g.nblocks + b] != 0;
-        fprintf(stderr, "deferred to k3_ar_generic: %zu luma, %zu chroma blocks of %u frames x %d blocks\n", n[0], n[1], B, g.nblocks);
+          for (int c = 0; c < 3; ++c)
+            for (int b = 0; b < g.nblocks; ++b) n[c] += h[((size_t)f * 3 + c) * g.nblocks + b] != 0;
+        fprintf(stderr, "deferred to k3_ar_generic: %zu luma, %zu Cb, %zu Cr blocks of %u frames x %d blocks\n", n[0], n[1], n[2], B, g.nblocks);
       }
     }
     kmark(sl, stream, "k3_ar_generic");

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(kFThreads, G1S_F_OCC) void k3f_fused(Geom g, FParam
           const MWin wc = m_unpack(wins[kMUnitBlocks + b], g.lag);
           constexpr int RPC = CH_ / kFWaves;
           if (flat_b && (__builtin_amdgcn_readfirstlane(s_bad[par][1][b]) || ((lbad >> b) & 1u))) {
-            defer |= 1u << (kMUnitBlocks + b);
+            defer |= (1u << (kMUnitBlocks + b)) | (1u << (2 * kMUnitBlocks + b));  // (both chroma planes: k3m_finish reads them per plane)
           } else if (PLAIN || wc.go) {
             const uint32_t rm = PLAIN ? ~0u : m_rowmask(wc.ys, wc.ye) >> (wave * RPC);
             if constexpr (CW_ == 32) m_rows_two<RPC, SH::PC>(accA, accB, m_smem, addr_cb + CW_ * b, addr_cr + CW_ * b, rm, ZOFF);

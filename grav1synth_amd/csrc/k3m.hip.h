@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
         }
     }
     if (defer) {
-      mp.only[((size_t)frame * 2 + kind) * g.nblocks + by * g.nbw + bx] = 1;
+      // (the exact kernel's lists are per plane: a chroma deferral of this chain concerns both chroma planes)
+      mp.only[((size_t)frame * 3 + kind) * g.nblocks + by * g.nbw + bx] = 1;
+      if (kind) mp.only[((size_t)frame * 3 + 2) * g.nblocks + by * g.nbw + bx] = 1;
       mp.only_any[frame] = 1u;
       plain = false;
     } else {
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G_luma
   const int32_t *us = ustats + (size_t)frame * mp.nunits * kMStatInts;
   const int part = (int)blockIdx.x - kMFinishParts * g.nplanes;
   const bool chroma = g.nplanes == 3;
-  long long n_y = 0, n_c = 0;  // observations: the windows of the blocks that were multiplied (go and not deferred)
+  long long n_y = 0, n_cb = 0, n_cr = 0;  // observations: the windows of the blocks that were multiplied (go and not deferred)
   for (uint32_t v = part * 256 + threadIdx.x; v < cnt; v += kMFinishWgs * 256) {
     const uint32_t u = upos(v);
     const uint4 e = *reinterpret_cast<const uint4 *>(units + (size_t)u * kMUnitDwords);
@@ -395,12 +397,16 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G_luma
 #pragma unroll
       for (int q = 0; q < kMStatInts; ++q) rv[q] = 0;
     }
-    const uint32_t defer = (uint32_t)rv[14] | (chroma ? (uint32_t)rv[15] : 0u);  // (the luma and the chroma launch)
+    // deferrals, per PLANE: entry 14 (the luma launch): bits 0, 1 the luma plane of block b, bits 2, 3 L outside int8 (both
+    // chroma planes); entry 15 (the chroma launch(es)): bits 2, 3 Cb, bits 4, 5 Cr
+    const uint32_t r14 = (uint32_t)rv[14], r15 = chroma ? (uint32_t)rv[15] : 0u;
+    const uint32_t dpl[3] = {r14 & 3u, ((r14 | r15) >> kMUnitBlocks) & 3u, ((r14 >> kMUnitBlocks) | (r15 >> (2 * kMUnitBlocks))) & 3u};
 #pragma unroll
     for (int b = 0; b < kMUnitBlocks; ++b) {
       const MWin wy = m_unpack((e.y >> (16 * b)) & 0xffffu, g.lag), wc = m_unpack((e.z >> (16 * b)) & 0xffffu, g.lag);
-      if (wy.go && !((defer >> b) & 1u)) n_y += (long long)(wy.xe - wy.xs) * (wy.ye - wy.ys);
-      if (wc.go && !((defer >> (kMUnitBlocks + b)) & 1u)) n_c += (long long)(wc.xe - wc.xs) * (wc.ye - wc.ys);
+      if (wy.go && !((dpl[0] >> b) & 1u)) n_y += (long long)(wy.xe - wy.xs) * (wy.ye - wy.ys);
+      if (wc.go && !((dpl[1] >> b) & 1u)) n_cb += (long long)(wc.xe - wc.xs) * (wc.ye - wc.ys);
+      if (wc.go && !((dpl[2] >> b) & 1u)) n_cr += (long long)(wc.xe - wc.xs) * (wc.ye - wc.ys);
       if (!ustats || !((e0 >> (24 + b)) & 1u)) continue;
       const int blk = by * g.nbw + bx0 + b;
       reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = rv[7 * b + 0];
@@ -413,27 +419,29 @@ __global__ __launch_bounds__(256) void k3m_finish(Geom g, MParams mp, int G_luma
         reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)rv[7 * b + 6];
       }
 #pragma unroll
-      for (int kind = 0; kind < 2; ++kind)
-        if ((defer >> (kind * kMUnitBlocks + b)) & 1u) {
-          mp.only[((size_t)frame * 2 + kind) * g.nblocks + blk] = 1;
+      for (int c = 0; c < 3; ++c)
+        if ((dpl[c] >> b) & 1u) {
+          mp.only[((size_t)frame * 3 + c) * g.nblocks + blk] = 1;
           mp.only_any[frame] = 1u;
         }
     }
   }
-  __shared__ long long s_n[2][4];
+  __shared__ long long s_n[3][4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     n_y += __shfl_xor(n_y, o, 64);
-    n_c += __shfl_xor(n_c, o, 64);
+    n_cb += __shfl_xor(n_cb, o, 64);
+    n_cr += __shfl_xor(n_cr, o, 64);
   }
   if ((threadIdx.x & 63) == 0) {
     s_n[0][threadIdx.x >> 6] = n_y;
-    s_n[1][threadIdx.x >> 6] = n_c;
+    s_n[1][threadIdx.x >> 6] = n_cb;
+    s_n[2][threadIdx.x >> 6] = n_cr;
   }
   __syncthreads();
   if ((int)threadIdx.x < g.nplanes) {
     const int c = threadIdx.x, nc = g.n + (c > 0);
-    const long long n = c ? s_n[1][0] + s_n[1][1] + s_n[1][2] + s_n[1][3] : s_n[0][0] + s_n[0][1] + s_n[0][2] + s_n[0][3];
+    const long long n = s_n[c][0] + s_n[c][1] + s_n[c][2] + s_n[c][3];
     if (n) atomicAdd(reinterpret_cast<unsigned long long *>(rec + g.off_ar[c]) + (nc * nc + nc), (unsigned long long)n);
   }
 }

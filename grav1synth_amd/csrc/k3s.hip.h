@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
         const uint32_t mine = LUMA ? badbits & 3u : ((badbits >> kMUnitBlocks) | lbad) & 3u;
         if (LUMA && CH) defer |= ((badbits >> kMUnitBlocks) & fbits) << kMUnitBlocks;  // L: the chroma launch's business
         if (__builtin_expect((mine & fbits) != 0, 0)) {
-          defer |= fbits << (LUMA ? 0 : kMUnitBlocks);
+          defer |= LUMA ? fbits : (fbits << kMUnitBlocks) | (fbits << (2 * kMUnitBlocks));  // (chroma: both planes, read per plane by k3m_finish)
         } else if (!G1S_S_DBGBIT(16)) {
           const uint8_t *buf = m_smem + (k & 1) * BUF;
           if constexpr (PLAIN) {

@@ -542,7 +542,7 @@ __device__ __forceinline__ int block_reduce_sum(int v, int *scratch) {
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
-// `only` (optional): per-frame block lists [batch][2][nblocks] (luma, chroma); when given, only the
+// `only` (optional): per-frame block lists [batch][3][nblocks] (one per plane); when given, only the
 // blocks marked there are processed (the blocks the lag-3 fast kernel deferred
 // because |d| > 127), and frames with only_any[frame] == 0 exit at once.
 __global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FrameTable ft, Geom g,
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FrameTable ft,
   const int c = blockIdx.y;
   const int frame = blockIdx.z;
   if (only_any && only_any[frame] == 0) return;
-  const uint8_t *only_f = only ? only + ((size_t)frame * 2 + (c > 0 ? 1 : 0)) * g.nblocks : nullptr;
+  const uint8_t *only_f = only ? only + ((size_t)frame * 3 + c) * g.nblocks : nullptr;
   const FramePlanes fp = ft.f[frame];
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint8_t *mask = rec + g.off_mask;
