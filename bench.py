@@ -213,7 +213,7 @@ def main() -> None:
         """algorithmic bytes one launch of this kernel exists to read, per frame pair (None: not a pixel kernel)"""
         if name.startswith("k3s_fused"):
             t = [x.strip(" >") for x in name.split("<")[1].split(",")]
-            return 2 * bps * W * H if t[3] == "0" else 2 * bps * 2 * cpx
+            return 2 * bps * W * H if t[3] == "0" else 2 * bps * (2 if t[3] == "1" else 1) * cpx  # (launch 2 / 3: one chroma plane)
         if name.startswith("k3f_fused"):
             t = [x.strip(" >") for x in name.split("<")[1].split(",")]
             if t[4] == "1":  # staging the int8 planes of the pixel pass

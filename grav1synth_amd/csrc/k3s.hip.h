@@ -76,8 +76,9 @@ __host__ __device__ constexpr int s_copy_stride(int BW, int BH) {
   return slots * 16;
 }
 // one buffer: luma launch 7 copies; chroma launch [Cb: 7 copies][L: an eighth "copy" of the Cb tile][Cr: 7 copies]
+// (PL = 2 / 3: the Cb / the Cr plane alone: [plane: 7 copies][L])
 __host__ __device__ constexpr int s_buf_bytes(int CBW, int CBH, int PL) {
-  return PL == 0 ? kMCopies * s_copy_stride(32, kBlock) : 15 * s_copy_stride(CBW, CBH);
+  return PL == 0 ? kMCopies * s_copy_stride(32, kBlock) : (PL == 1 ? 15 : 8) * s_copy_stride(CBW, CBH);
 }
 __host__ __device__ constexpr int s_lds_bytes(int CBW, int CBH, int PL) { return 2 * s_buf_bytes(CBW, CBH, PL); }
 
@@ -203,9 +204,12 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
   extern __shared__ __attribute__((aligned(16))) uint8_t m_smem[];
   using SH = SShape<CBW, CBH>;
   constexpr bool CH = SH::CH;
-  constexpr bool LUMA = PL == 0, CHROMA = PL == 1;
+  // PL: 0 the luma plane (and L); 1 both chroma planes (Cb on waves 0-1, Cr on waves 2-3); 2 / 3 the Cb / the Cr plane alone on
+  // all four waves -- for 4:4:4, where two planes' tiles (70 KB) leave room for two workgroups on a CU and one plane's for four
+  constexpr bool LUMA = PL == 0, CHROMA = PL >= 1, SINGLE = PL >= 2;
   static_assert(LUMA || CH, "the chroma launch needs chroma planes");
-  constexpr int CW_ = SH::CW_, CH_ = SH::CH_, CROUNDS = CHROMA ? SH::CROUNDS : 0, NCR = CROUNDS > 0 ? CROUNDS : 1;
+  constexpr int CPW = SINGLE ? kFWaves : kFWaves / 2;  // waves that stage and multiply a chroma plane
+  constexpr int CW_ = SH::CW_, CH_ = SH::CH_, CROUNDS = CHROMA ? (SH::RC + CPW * SH::RPW - 1) / (CPW * SH::RPW) : 0, NCR = CROUNDS > 0 ? CROUNDS : 1;
   constexpr int BUF = s_buf_bytes(CBW, CBH, PL);
   constexpr int OFF_CB = 0, OFF_L = 7 * SH::CSC, OFF_CR = 8 * SH::CSC;
   // per-unit side data, slot = unit & 3: written when the unit's residuals are formed (two iterations before it is
@@ -267,15 +271,15 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
   const int m_blk = TWO_ROW ? (mg & 1) : (mg >> 1);          // the block its 16 samples belong to
   const int m_xo = TWO_ROW ? 16 * (mg & 1) : 16 * mg;
   const int m_ro = TWO_ROW ? m_rho - mu : -2 * mu;           // tile row of the lane's bytes, relative to the step's first sample row
-  constexpr int WPP = LUMA ? kFWaves : kFWaves / 2;          // waves per plane
+  constexpr int WPP = LUMA ? kFWaves : CPW;                  // waves per plane
   constexpr int RS = TWO_ROW ? 2 : 1;
   constexpr int NSTEP = MBH / RS / WPP;
-  const int m_plane = LUMA ? 0 : 1 + (wave >> 1);            // plane this wave multiplies
-  const int m_y0 = (LUMA ? wave : (wave & 1)) * NSTEP * RS;  // its first sample row
+  const int m_plane = LUMA ? 0 : (SINGLE ? PL - 1 : 1 + (wave >> 1));  // plane this wave multiplies
+  const int m_y0 = ((LUMA || SINGLE) ? wave : (wave & 1)) * NSTEP * RS;  // its first sample row
   int m_addr;
   {
     const int s_eff = (LUMA && ms == 7) ? 6 : ms;  // luma launch: the spare rows read what row s = 6 reads (a broadcast)
-    int base = (CHROMA && m_plane == 2) ? OFF_CR : OFF_CB;
+    int base = (CHROMA && !SINGLE && m_plane == 2) ? OFF_CR : OFF_CB;
     int so = s_eff * MCS;
     if (CHROMA && ms == 7) { base = 0; so = OFF_L; }  // L: an eighth copy of the Cb tile (both planes' waves)
     m_addr = base + so + (m_y0 + 4 + m_ro) * MP + m_xo;
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
   const int y_lrow = ypair - 2;  // chroma row of the pair (vertically subsampled chroma)
   // chroma: waves 0, 1 stage Cb, waves 2, 3 Cr; round k, row (2 k + (wave & 1)) * RPW + lane / WC of the rows -3 .. CH - 1
   const int cwd = lane % SH::WC;
-  const int cplane = 1 + (wave >> 1);
+  const int cplane = SINGLE ? PL - 1 : 1 + (wave >> 1);
   const uint8_t *c_src = cplane == 2 ? fp.src[2] : fp.src[1], *c_den = cplane == 2 ? fp.den[2] : fp.den[1];
   const uint32_t c_sst = cplane == 2 ? fp.src_stride[2] : fp.src_stride[1], c_dst = cplane == 2 ? fp.den_stride[2] : fp.den_stride[1];
   const bool c_interior = cwd >= 1 && cwd <= SH::WC - 2;
@@ -320,13 +324,13 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
   bool c_stat[NCR];
 #pragma unroll
   for (int k = 0; k < CROUNDS; ++k) {
-    const int rr = (2 * k + (wave & 1)) * SH::RPW + lane / SH::WC;
+    const int rr = (CPW * k + (SINGLE ? wave : (wave & 1))) * SH::RPW + lane / SH::WC;
     const bool on = lane / SH::WC < SH::RPW && rr < SH::RC;
     cpl[k] = on ? cplane : 0;
     ctr[k] = on ? rr : 0;
     cso[k] = (uint32_t)ctr[k] * c_sst + (uint32_t)(8 * cwd * sbps);
     cdo[k] = (uint32_t)ctr[k] * c_dst + (uint32_t)(8 * cwd * dbps);
-    c_wa[k] = (on && c_interior) ? (cplane == 2 ? OFF_CR : OFF_CB) + (ctr[k] + 1) * SH::PC + c_xw : 8 * (lane & (SH::PC / 8 - 1));
+    c_wa[k] = (on && c_interior) ? ((cplane == 2 && !SINGLE) ? OFF_CR : OFF_CB) + (ctr[k] + 1) * SH::PC + c_xw : 8 * (lane & (SH::PC / 8 - 1));
     c_stat[k] = on && c_interior && rr >= 3;
   }
   const uint32_t c_flagbits = s_flag_bits(cwd, CW_ / 8) << kMUnitBlocks;
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
         if ((a & 0xfff000u) == (here & 0xfff000u) && (a & 0xfffu) + 1u == (here & 0xfffu)) e.x |= 1u << 31;
       }
       e.w = CHROMA ? (uint32_t)ustats[(size_t)upos(tid) * kMStatInts + 14] : 0u;  // the luma launch's deferral bits
+      if (PL == 3) e.y = (uint32_t)ustats[(size_t)upos(tid) * kMStatInts + 15];   // the Cb launch's (a chroma launch has no use for the luma windows)
     }
     s_ent[tid] = e;
   }
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
     c.y = LUMA ? e1.y : e1.z;
     c.z = LUMA ? e0.y : e0.z;
     c.w = ((e0.x >> 24) & 3u) | (((e0.w >> kMUnitBlocks) & 3u) << 2) | ((e1.x >> 31) << 4) | ((s_ent[tid + 2].x >> 31) << 5);
+    if (PL == 3) c.w |= (e0.y & 0xffu) << 8;  // what the Cb launch wrote into the unit's deferral entry: kept
     s_ctl[tid] = c;
   }
   // what the prologue needs of the entries (the tiles take their place)
@@ -704,7 +710,8 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
         const uint32_t mine = LUMA ? badbits & 3u : ((badbits >> kMUnitBlocks) | lbad) & 3u;
         if (LUMA && CH) defer |= ((badbits >> kMUnitBlocks) & fbits) << kMUnitBlocks;  // L: the chroma launch's business
         if (__builtin_expect((mine & fbits) != 0, 0)) {
-          defer |= LUMA ? fbits : (fbits << kMUnitBlocks) | (fbits << (2 * kMUnitBlocks));  // (chroma: both planes, read per plane by k3m_finish)
+          // (chroma: bits 2, 3 Cb, bits 4, 5 Cr: k3m_finish reads them per plane)
+          defer |= LUMA ? fbits : (PL == 1 ? (fbits << kMUnitBlocks) | (fbits << (2 * kMUnitBlocks)) : fbits << ((PL - 1) * kMUnitBlocks));
         } else if (!G1S_S_DBGBIT(16)) {
           const uint8_t *buf = m_smem + (k & 1) * BUF;
           if constexpr (PLAIN) {
@@ -723,11 +730,11 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
       if (wave == kFWaves - 1 && !G1S_S_DBGBIT(32)) {
         auto mine_entry = [](int t) {
           const int b = t >= 7 ? 1 : 0, e = t - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2);
-          return t < 14 ? (LUMA ? c == 0 : c != 0) : t == 14 + PL;
+          return t < 14 ? (LUMA ? c == 0 : (SINGLE ? c == PL - 1 : c != 0)) : t == (LUMA ? 14 : 15);
         };
         if (lane < kMStatInts && mine_entry(lane)) {
           const int b = lane >= 7 ? 1 : 0, e = lane - 7 * b, c = e < 3 ? 0 : (e < 5 ? 1 : 2), f = e < 3 ? e : (e - 3) & 1;
-          int val = (int)defer;
+          int val = (int)(PL == 3 ? defer | ((cw >> 8) & 0xffu) : defer);
           if (lane < 14) {
             const unsigned long long pk = s_sum[slot][c][b];
             const int bias = c == 0 ? kFBiasY * 16 * 4 : kFBiasC * CH_ * (CW_ / 8);
@@ -757,7 +764,7 @@ __global__ __launch_bounds__(kFThreads, s_occupancy(CBW, CBH, PL)) void k3s_fuse
   run(std::false_type{}, n_p, nmine);
 
   // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
-  constexpr int NPL = LUMA ? 1 : 2, PL0 = LUMA ? 0 : 1;
+  constexpr int NPL = (LUMA || SINGLE) ? 1 : 2, PL0 = LUMA ? 0 : (SINGLE ? PL - 1 : 1);
   long long *s_S = reinterpret_cast<long long *>(m_smem);
   __syncthreads();
   for (int k = tid; k < NPL * kMRec; k += kFThreads) s_S[k] = 0;

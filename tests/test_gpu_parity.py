@@ -974,6 +974,52 @@ def test_tuning_switches_do_not_change_results():
         assert run(extra) == ref, extra
 
 
+def test_one_chroma_plane_a_launch_gives_the_same_records():
+    """G1S_F_SPLIT444=1: at 4:4:4 the chroma launch as two launches of one plane each (k3s_fused<32,32,.,2> / <.,3>), with
+    deferrals to the exact kernel per plane: a frame whose Cb plane alone, and one whose Cr plane alone, holds residuals
+    outside int8 must give the records and the table of the two-plane launch (itself held to the oracle above)."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import hashlib, numpy as np\n"
+        "from fractions import Fraction\n"
+        "from grav1synth_amd.diff import DiffGenerator, format_tbl\n"
+        "from grav1synth_amd.synth import SynthSpec, make_pair\n"
+        "h = hashlib.sha256()\n"
+        "for bd, w, hh in ((10, 352, 224), (8, 288, 160)):\n"
+        "    spec = SynthSpec(w, hh, bd, xdec=0, ydec=0, textured=False)\n"
+        "    pairs = []\n"
+        "    for k in range(4):\n"
+        "        s, d = make_pair(spec, k, device='cpu')\n"
+        "        s = [np.array(p) for p in s]; d = [np.array(p) for p in d]\n"
+        "        if k in (1, 3): d[1][40:44, 70:75] = 0 if bd == 8 else 3   # Cb far off: |d| > 127 after narrowing\n"
+        "        if k in (2, 3): d[2][100:103, 200:204] = (255 if bd == 8 else 1020)\n"
+        "        pairs.append((s, d))\n"
+        "    g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=2, records_only=True)\n"
+        "    for s, d in pairs: g.diff_frame(s, d, 0, 0)\n"
+        "    recs, n = g.take_records(w, hh, 3, 4); g.close(); h.update(recs.tobytes())\n"
+        "    g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=2)\n"
+        "    for s, d in pairs: g.diff_frame(s, d, 0, 0)\n"
+        "    h.update(format_tbl(g.finish())); g.close()\n"
+        "print(h.hexdigest())\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.strip().splitlines()[-1]
+
+    ref = run({})
+    assert len(ref) == 64
+    assert run({"G1S_F_SPLIT444": "1"}) == ref
+    assert run({"G1S_F_SPLIT444": "1", "G1S_F_REUSE": "0"}) == ref
+    assert run({"G1S_K3": "fused"}) == ref   # (round 2's kernel writes the per-plane deferral bits too)
+
+
 def test_streaming_shards_over_rccl_with_one_rank():
     """The frame-shard exchange on the real backend ("nccl" = RCCL), world size 1 (two ranks on one device are
     refused by RCCL; the 2-rank logic is covered over gloo in tests/test_dist_cpu.py): device-side message,
