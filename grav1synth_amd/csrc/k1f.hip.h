@@ -54,12 +54,15 @@ __global__ __launch_bounds__(256) void k1_moments(const FrameTable ft, Geom g, i
   }
   int32_t s[14];
   row_moments(pk, pu, pd, yi, s);
-  // sum over the 32 rows of the block
-  half_sums_dpp<14>(s);
-  if (live && yi == kBlock - 1) {
+  // sum over the 32 rows of the block: the last four lanes of the block hold the fourteen totals between them
+  int x[4];
+  half_sums_split14(s, x);
+  if (live && yi >= kBlock - 4) {
     int32_t *out = mom + ((size_t)frame * g.nblocks + blk) * kMomInts;
+    const int c = yi & 3;
 #pragma unroll
-    for (int i = 0; i < 14; ++i) out[i] = s[i];
+    for (int j = 0; j < 3; ++j) out[4 * j + c] = x[j];
+    if (c < 2) out[12 + c] = x[3];
   }
 }
 
