@@ -30,6 +30,7 @@
 #include "k3m.hip.h"
 #include "k3f.hip.h"
 #include "k3s.hip.h"
+#include "k3w.hip.h"
 #include "latest_dev.h"
 #include "record.h"
 
@@ -62,14 +63,16 @@ int k3_mode() {
     if (e && std::strcmp(e, "dot4") == 0) return 0;
     if (e && std::strcmp(e, "planes") == 0) return 2;
     if (e && std::strcmp(e, "fused") == 0) return 1;
-    return 3;
+    if (e && std::strcmp(e, "stream") == 0) return 3;
+    return 4;
   }();
   return v;
 }
 bool use_mfma() { return k3_mode() != 0; }
 bool use_k0() { return k3_mode() == 0 || k3_mode() == 2; }
 bool use_planes() { return k3_mode() == 2; }
-bool use_stream() { return k3_mode() == 3; }  // k3s.hip.h: the second-generation fused pass
+bool use_stream() { return k3_mode() >= 3; }  // k3s.hip.h: the second-generation fused pass (also what `wide` falls back on)
+bool use_wide() { return k3_mode() == 4; }    // k3w.hip.h: wide units (the default; formats it does not serve run the stream chain)
 constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per CU, one round
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32.
 // kind 0: the luma launch, 1: the chroma launch.  The luma launch likes workgroups of ~64 units of the list (4 096 - 6 144
@@ -85,6 +88,17 @@ int m_wgs_per_frame(int nunits, int B, int kind = 1) {
   if (e) target = std::max(8, atoi(e));
   if (el) target = std::max(8, atoi(el));
   return (std::max(gmin, (target + B - 1) / std::max(B, 1)) + 7) & ~7;  // (a multiple of 8: workgroup b of a frame on XCD b % 8)
+}
+
+// the wide chain: workgroups per frame.  A workgroup walks a contiguous slice of the frame's raster-ordered list and forms a
+// ghost unit at either end: longer slices, fewer ghosts; at least one resident round (4 to a CU) a launch
+int w_wgs_per_frame(int ncell, int B, int kind) {
+  const int cap = kind == 1 ? kWMaxUnits / 2 : kWMaxUnits;
+  const int gmin = (ncell + cap - 1) / cap;
+  const char *e = getenv(kind ? "G1S_W_WGS_C" : "G1S_W_WGS");  // tuning / test aid
+  int target = std::max(kMTargetWgs, (kind ? 16 : 32) * B);
+  if (e) target = std::max(8, atoi(e));
+  return (std::max(gmin, (target + B - 1) / std::max(B, 1)) + 7) & ~7;
 }
 
 #define HIP_TRY(expr)                                                                      \
@@ -216,6 +230,7 @@ struct Slot {
   uint8_t *d_mu = nullptr;         // MFMA path: unit lists [batch][nunits], unit counts, deferred-block flags
   long long *d_mpart = nullptr;    // MFMA path: partial systems of the accumulation workgroups
   uint8_t *d_lplane = nullptr;     // MFMA path: L at chroma resolution, int8 (luma launch -> chroma launch)
+  uint8_t *d_wu = nullptr;         // wide chain: unit lists, counts, per-unit statistics records, L-outside-int8 flags
   uint8_t *d_stage = nullptr;  // device copies of host-resident frames
   // the per-frame half of the fold on the device (latest.hip): the frames' latest-state blobs and the kernel's scratch
   uint8_t *d_latest = nullptr, *h_latest = nullptr /* pinned */, *d_lscratch = nullptr;
@@ -246,6 +261,7 @@ static void free_slot(Slot &sl) {
   if (sl.d_mu) (void)hipFree(sl.d_mu);
   if (sl.d_mpart) (void)hipFree(sl.d_mpart);
   if (sl.d_lplane) (void)hipFree(sl.d_lplane);
+  if (sl.d_wu) (void)hipFree(sl.d_wu);
   if (sl.d_stage) (void)hipFree(sl.d_stage);
   if (sl.d_latest) (void)hipFree(sl.d_latest);
   if (sl.h_latest) (void)hipHostFree(sl.h_latest);
@@ -388,6 +404,11 @@ struct g1s_diff {
   int m_nunits = 0;          // MFMA path: chunks per frame
   size_t m_wg_cap = 0;       // ... workgroups (partial systems) the slots hold
   size_t m_only_bytes = 0;   // ... deferred-block flags [batch][3][nblocks] (one list a plane), 16-byte rounded
+  // the wide chain (k3w.hip.h): blocks a chroma unit, cells a block row / a frame per kind, L geometry, layout of Slot::d_wu
+  int w_ub_c = 4, w_gx[2] = {0, 0}, w_ncell[2] = {0, 0};
+  uint32_t w_lpitch = 0, w_lframe = 0;
+  size_t w_off_units[2] = {0, 0}, w_off_count = 0, w_off_stats[2] = {0, 0}, w_off_lbad = 0, w_lbad_bytes = 0, w_bytes = 0;
+  bool wide_ok(const Geom &g) const;
   MParams make_mparams(const Slot &sl) const;
   SlotKey slot_key{};
   Slot slots[kSlots];
@@ -581,13 +602,35 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
   m_wg_cap = 0;
   for (uint32_t b = 1; b <= batch; ++b)
     m_wg_cap = std::max(m_wg_cap, (size_t)b * std::max(m_wgs_per_frame(m_nunits, (int)b, 0), m_wgs_per_frame(m_nunits, (int)b, 1)));
-  const size_t mpart_bytes = !use_mfma() ? 0 : sizeof(long long) * 3 * kMRec * m_wg_cap;
   // L plane of a frame: block rows x chunk columns at chroma resolution (+ a slack row)
   m_lpitch = g.nplanes == 3 ? (uint32_t)((((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * kMUnitBlocks * (kBlock >> g.xdec) + 15) & ~15) : 0u;
   m_lframe = m_lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec) + 1);
-  const size_t lplane_bytes = (k3_mode() == 1 || k3_mode() == 3) ? (size_t)m_lframe * batch : 0;
+  // the wide chain (k3w.hip.h): its own lists, statistics records and L geometry
+  w_ub_c = g.nplanes == 3 ? (kWUnitW / (kBlock >> g.xdec)) : 4;
+  w_gx[0] = (g.nbw + 3) / 4;
+  w_gx[1] = (g.nbw + w_ub_c - 1) / w_ub_c;
+  w_ncell[0] = w_gx[0] * g.nbh;
+  w_ncell[1] = g.nplanes == 3 ? w_gx[1] * g.nbh : 0;
+  w_lpitch = g.nplanes == 3 ? (uint32_t)((std::max(w_gx[0] * 4 * (kBlock >> g.xdec), w_gx[1] * kWUnitW) + 15) & ~15) : 0u;
+  w_lframe = w_lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec) + 1);
+  {
+    size_t o = 0;
+    w_off_units[0] = o, o += sizeof(uint32_t) * (size_t)batch * w_ncell[0] * kWEntry;
+    w_off_units[1] = o, o += sizeof(uint32_t) * (size_t)batch * w_ncell[1] * kWEntry;
+    w_off_count = o, o += sizeof(uint32_t) * 2 * (size_t)batch;
+    o = (o + 15) & ~size_t(15);
+    w_off_stats[0] = o, o += sizeof(int32_t) * (size_t)batch * w_ncell[0] * kWStatY;
+    w_off_stats[1] = o, o += sizeof(int32_t) * (size_t)batch * w_ncell[1] * kWStatC;
+    w_off_lbad = o, w_lbad_bytes = ((size_t)batch * w_ncell[0] + 15) & ~size_t(15), o += w_lbad_bytes;
+    w_bytes = use_wide() ? o : 0;
+  }
+  if (use_wide())
+    for (uint32_t b = 1; b <= batch; ++b)
+      m_wg_cap = std::max(m_wg_cap, (size_t)b * std::max(w_wgs_per_frame(w_ncell[0], (int)b, 0), w_wgs_per_frame(std::max(w_ncell[1], 1), (int)b, 1)));
+  const size_t mpart_bytes2 = !use_mfma() ? 0 : sizeof(long long) * 3 * kMRec * m_wg_cap;
+  const size_t lplane_bytes = (k3_mode() == 1 || k3_mode() >= 3) ? (size_t)std::max(m_lframe, use_wide() ? w_lframe : 0u) * batch : 0;
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
-                     partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes, mpart_bytes, lplane_bytes,
+                     partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes + w_bytes, mpart_bytes2, lplane_bytes,
                      g.W, g.H, g.xdec, g.ydec, g.nplanes};
   for (Slot &sl : slots) {
     {
@@ -617,7 +660,8 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
     }
     if (pgl_bytes) HIP_TRY(hipMalloc((void **)&sl.d_pgl, pgl_bytes));
     if (mu_bytes) HIP_TRY(hipMalloc((void **)&sl.d_mu, mu_bytes));
-    if (mpart_bytes) HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes));
+    if (mpart_bytes2) HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes2));
+    if (w_bytes) HIP_TRY(hipMalloc((void **)&sl.d_wu, w_bytes));
     if (lplane_bytes) HIP_TRY(hipMalloc((void **)&sl.d_lplane, lplane_bytes));
     HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
@@ -851,6 +895,10 @@ int g1s_diff::launch_front(int si) {
       z.ptr[4] = sl.d_pgl + (size_t)batch * 2 * pg_cap;  // partial-group list counts
       z.ndw[4] = (uint32_t)batch * 2;
     }
+    if (use_wide() && sl.d_wu) {
+      z.ptr[6] = reinterpret_cast<uint32_t *>(sl.d_wu + w_off_lbad);  // luma units whose L left int8
+      z.ndw[6] = (uint32_t)(w_lbad_bytes / 4);
+    }
     z.ptr[5] = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * (kMomInts + 1);  // literal-list counts
     z.ndw[5] = (uint32_t)batch;
     // (on the upload stream too: the slot is free, its buffers can be zeroed while the main stream is still busy
@@ -961,8 +1009,22 @@ int g1s_diff::launch_front(int si) {
   if (fast_ok && use_mfma()) {
     // the unit lists (chunks with a flat block) need the flat mask
     const MParams mp = make_mparams(sl);
-    kmark(sl, fstream, "k3m_units");
-    hipLaunchKernelGGL(k3m_units, dim3((m_nunits + 255) / 256, B), dim3(256), 0, fstream, g, (const uint8_t *)sl.d_records, mp);
+    if (wide_ok(g)) {
+      WUnitParams up;
+      for (int k = 0; k < 2; ++k) {
+        up.units[k] = reinterpret_cast<uint32_t *>(sl.d_wu + w_off_units[k]);
+        up.ncell[k] = w_ncell[k];
+        up.gx[k] = w_gx[k];
+      }
+      up.count = reinterpret_cast<uint32_t *>(sl.d_wu + w_off_count);
+      up.ub[0] = 4;
+      up.ub[1] = w_ub_c;
+      kmark(sl, fstream, "k3w_units");
+      hipLaunchKernelGGL(k3w_units, dim3(2, B), dim3(1024), 0, fstream, g, (const uint8_t *)sl.d_records, up);
+    } else {
+      kmark(sl, fstream, "k3m_units");
+      hipLaunchKernelGGL(k3m_units, dim3((m_nunits + 255) / 256, B), dim3(256), 0, fstream, g, (const uint8_t *)sl.d_records, mp);
+    }
   } else if (fast_ok) {
     // the window bit planes and the area lists need the flat mask: small kernels after K2
     const QParams qp = make_qparams(sl);
@@ -1003,6 +1065,21 @@ QParams g1s_diff::make_qparams(const Slot &sl) const {
   return qp;
 }
 
+// the wide chain serves: equal sample widths, every plane's rows 16-byte aligned, whole 8-sample words in every plane,
+// 4:2:0 or luma only (the other formats, unaligned planes and mixed depths run the stream chain)
+bool g1s_diff::wide_ok(const Geom &g) const {
+  if (!use_wide()) return false;
+  static const bool off = getenv("G1S_W_OFF") != nullptr;  // debugging aid
+  if (off) return false;
+  if (g.src_bps != g.den_bps || g.lag < 1) return false;
+  const int need = g.nplanes == 3 ? 0x3f : 0x09;
+  if ((g.vec_mask & need) != need) return false;
+  if ((g.W & 7) != 0 || (g.nplanes == 3 && ((g.W >> g.xdec) & 7) != 0)) return false;
+  if (g.nplanes == 3 && !(g.xdec == 1 && g.ydec == 1)) return false;
+  if (g.nbw > 1023 * 4 || g.nbh > 4095) return false;
+  return true;
+}
+
 MParams g1s_diff::make_mparams(const Slot &sl) const {
   MParams mp;
   // (the fused pass finds the residuals outside int8 itself; K0 flags them per block)
@@ -1037,7 +1114,80 @@ int g1s_diff::launch_back(int si) {
   FrameTable ft;
   ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);  // (uploaded by the front half)
   const bool fast_ok = use_mfma() || !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
-  if (use_mfma()) {
+  if (use_mfma() && wide_ok(g)) {
+    // the wide chain (k3w.hip.h): luma launch (leaves L behind), chroma launch, the reducer, the exact kernel for deferred blocks
+    const MParams mp = make_mparams(sl);
+    const bool chroma = g.nplanes == 3;
+    WParams wq;
+    wq.ft = ft;
+    wq.partials = mp.partials;
+    wq.lbad = sl.d_wu + w_off_lbad;
+    wq.lplane = sl.d_lplane;
+    wq.lpitch = w_lpitch;
+    wq.lframe_bytes = w_lframe;
+    wq.ncell_y = w_ncell[0];
+    wq.gx_y = w_gx[0];
+    wq.frames = (int)B;
+    int Gk[2] = {w_wgs_per_frame(w_ncell[0], (int)B, 0), w_wgs_per_frame(std::max(w_ncell[1], 1), (int)B, 1)};
+    for (int k = 0; k < 2; ++k)
+      if ((size_t)Gk[k] * B > m_wg_cap) Gk[k] = (int)(m_wg_cap / B) & ~7;  // (the environment changed after the slots were sized)
+    const int G_cap = std::max(Gk[0], Gk[1]);
+    wq.wg_cap = G_cap;
+    auto set_kind = [&](int k) {
+      wq.units = reinterpret_cast<const uint32_t *>(sl.d_wu + w_off_units[k]);
+      wq.count = reinterpret_cast<const uint32_t *>(sl.d_wu + w_off_count) + k;  // (stride 2: see the kernel)
+      wq.stats = reinterpret_cast<int32_t *>(sl.d_wu + w_off_stats[k]);
+      wq.ncell = w_ncell[k];
+      wq.wgs = Gk[k];
+    };
+#define G1S_W(KIND, BP, SX, SY)                                                                                        \
+  do {                                                                                                                 \
+    constexpr int lds_ = w_lds_bytes(KIND, WShape<KIND, SX, SY>::BH);                                                  \
+    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3w_pass<KIND, BP, SX, SY>),   \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_);             \
+    (void)attr_;                                                                                                       \
+    char kn_[64];                                                                                                      \
+    snprintf(kn_, sizeof(kn_), "k3w_pass<%d, %d, %d, %d>", KIND, BP, SX, SY);                                          \
+    kmark(sl, stream, kn_);                                                                                            \
+    set_kind(KIND);                                                                                                    \
+    hipLaunchKernelGGL((k3w_pass<KIND, BP, SX, SY>), dim3((uint32_t)Gk[KIND] * B), dim3(kWThreads), lds_, stream, g, wq); \
+  } while (0)
+    if (!chroma) {
+      if (g.src_bps == 2) G1S_W(0, 2, -1, -1);
+      else G1S_W(0, 1, -1, -1);
+    } else {
+      if (g.src_bps == 2) G1S_W(0, 2, 1, 1);
+      else G1S_W(0, 1, 1, 1);
+      static const bool chroma_aside = getenv("G1S_F_SERIAL") == nullptr;  // tuning aid
+      if (side && chroma_aside) {  // the chroma launch and what follows: next to the luma launch of the batch after
+        HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
+        HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
+        stream = ss.copy;
+      }
+      if (g.src_bps == 2) G1S_W(1, 2, 1, 1);
+      else G1S_W(1, 1, 1, 1);
+    }
+#undef G1S_W
+    WFinishParams fpn;
+    for (int k = 0; k < 2; ++k) {
+      fpn.units[k] = reinterpret_cast<const uint32_t *>(sl.d_wu + w_off_units[k]);
+      fpn.stats[k] = reinterpret_cast<const int32_t *>(sl.d_wu + w_off_stats[k]);
+      fpn.ncell[k] = w_ncell[k];
+      fpn.G[k] = Gk[k];
+    }
+    fpn.ub[0] = 4;
+    fpn.ub[1] = w_ub_c;
+    fpn.count = reinterpret_cast<const uint32_t *>(sl.d_wu + w_off_count);
+    fpn.partials = mp.partials;
+    fpn.wg_cap = G_cap;
+    fpn.only = mp.only;
+    fpn.only_any = mp.only_any;
+    kmark(sl, stream, "k3w_finish");
+    hipLaunchKernelGGL(k3w_finish, dim3(kMFinishParts * g.nplanes + kWFinishWgs, B), dim3(256), 0, stream, g, fpn, sl.d_records);
+    kmark(sl, stream, "k3_ar_generic");
+    hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
+                       sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
+  } else if (use_mfma()) {
     // the fused pass: planes of the flat blocks' tiles -> residuals, block statistics, exact int8 SYRK on the matrix
     // cores, one partial system per workgroup; the reducer; then the exact int32 kernel for the few blocks next to a
     // residual outside int8

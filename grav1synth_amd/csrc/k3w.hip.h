@@ -1,0 +1,876 @@
+// k3w.hip.h -- the accumulation pass, third generation (G1S_K3=wide): WIDE units, one tile buffer, windows at multiply time.
+//
+// Same job as k3s.hip.h: source / denoised planes of the flat blocks' tiles -> int8 residual tiles in LDS (7 shifted copies)
+// -> exact int8 SYRK on the matrix cores (add_block_observations of av1-grain diff/solver.rs == libaom noise_model.c) -> one
+// partial system per workgroup and plane; block statistics, the chroma regressor L and out-of-int8 deferrals on the way.
+// What changed, and the measurement behind each change (profiles/r04_issue_probe.txt, profiles/r03_sq_counters_final.txt):
+//
+//  * A unit is 128 samples wide (4 luma blocks; 8 chroma blocks of 16): a row of a unit is ONE row of 16 lanes (one DPP row),
+//    every staging lane holds a word of its own (k3s: 48 of 64), the per-unit costs (entry, branches, barriers, halo
+//    exchange) are paid once per 4 096 samples instead of once per 2 048, and a row of a 10-bit unit is two whole 128-byte
+//    lines (a chroma row of k3s's units was half a line).
+//  * The unit entries are read with SCALAR loads straight into SGPRs (constant address space): no parking in LDS, no
+//    control words, no v_readfirstlane.
+//  * Observation windows are applied when the tile is MULTIPLIED, as a byte mask on the A operand only
+//    (S = sum_p m(p) v(p) v(p)^T = (M V) V^T): a k-group's 16 samples sit in fixed columns, so the column window of a block
+//    is one 16-byte lane constant per unit and a row outside the window rows zeroes it for that step.  The staging code
+//    therefore writes the copies unmasked, always (k3s: 14 v_and per word and a second code path).
+//  * Residual arithmetic in plain 32-bit SWAR on 16-bit lanes (v_and / v_sub / v_add / v_lshrrev issue in ~2.6 cycles a
+//    wave, packed-16 / perm / DPP / VOP3 forms in ~4.6): t = ((s >> sh) & 0xff00ff) + 0x800080 - ((v >> sh) & 0xff00ff) holds
+//    d + 128 in each half; "some d outside int8" is ONE OR-accumulated test of the high bytes (a borrow between the halves
+//    happens only when the low half is out of range, i.e. when the unit is deferred anyway); the bytes are packed with
+//    one v_perm per four samples and flipped to two's complement with one v_xor.
+//  * No halo words are ever loaded: the left / right halo dwords of a unit are the neighbouring unit's own dwords, taken
+//    from the registers of the unit before / after it in the workgroup's run (a DPP row rotation); the list is in raster
+//    order (k3w_units compacts it deterministically), a neighbour that exists is therefore adjacent in the list, and the
+//    one in front of / behind the workgroup's slice is formed as a GHOST (loads and residuals only).
+//  * ONE tile buffer (two barriers a unit): 32 KB a luma workgroup, four to a CU.
+//
+// Exactness: int8 x int8 -> int32 products, int32 accumulators (a workgroup's slice is bounded so that they cannot
+// overflow), int64 partial systems: every sum is the reference's own sum of integers, in another order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "k3m.hip.h"
+#include "kernels.hip.h"
+
+namespace g1s {
+
+constexpr int kWThreads = 256, kWWaves = 4;
+constexpr int kWUnitW = 128;       // samples a unit row
+constexpr int kWEntry = 8;         // dwords a list entry
+constexpr int kWStatY = 16;        // ints a luma unit's statistics record: per block sum d, sum d^2, sum src8; [12] deferral
+constexpr int kWStatC = 36;        // ints a chroma unit's: per block Cb sum d, sum d^2, Cr sum d, sum d^2; [32] deferral bits (1 Cb, 2 Cr)
+constexpr int kWMaxUnits = 100;    // units a workgroup: 100 units * 16 steps * 64 samples * 128^2 < 2^31 (32-row chroma planes: 32 steps, 50)
+
+
+// entry: .x = c | by << 10 | aL << 22 | aR << 23 | plain << 24 | interior << 25 | top << 26;  .y = flat bits;  .z = grid index;
+//        [4 .. 7] = the windows of the unit's blocks, 16 bits each (m_unpack's format)
+struct WParams {
+  FrameTable ft;
+  const uint32_t *units;    // [batch][ncell][kWEntry]  this launch's list (k3w_units), raster order
+  const uint32_t *count;    // [batch]
+  long long *partials;      // [batch][wg_cap][3][kMRec]
+  int32_t *stats;           // [batch][ncell][kWStatY | kWStatC]  per-unit block statistics + deferral bits, by grid cell
+  uint8_t *lbad;            // [batch][ncell_y]  luma unit whose L left int8 (zeroed per batch); the chroma launch reads it
+  uint8_t *lplane;          // [batch][lrows][lpitch]  L at chroma resolution, int8
+  uint32_t lpitch, lframe_bytes;
+  int ncell, ncell_y;       // grid cells a frame of this launch's kind / of the luma kind
+  int gx_y;                 // luma cells a block row
+  int frames, wgs, wg_cap;
+};
+
+// ---- matrix rows (as k3s.hip.h): lane l of an operand holds 16 bytes of row i = l & 15 for the k-group l >> 4.
+// i -> (u, s): u = which of the operand's two `a`, s = 0..6 the copy (cx = s - 3), s = 7 the chroma regressor L (u = 0 of P)
+// or a spare.  P = {a = 0, 2}, Q = {a = 1, 3}; the Q operand of a step is the P operand of the step before.
+__device__ __forceinline__ void w_row(int i, int &u, int &s) {
+  if (i < 4) { u = 0; s = i; }
+  else if (i < 12) { u = 1; s = i - 4; }
+  else { u = 0; s = i - 8; }
+}
+__device__ __forceinline__ int w_rec_index(int op, int i, int lag, int n, bool chroma) {
+  int u, s;
+  w_row(i, u, s);
+  const int a = 2 * u + op;
+  if (s == 7) return (a == 0 && chroma) ? n : -1;
+  const int cx = s - 3;
+  if (a == 0 && cx == 0) return n + (chroma ? 1 : 0);
+  if (a == 0 && cx > 0) return -1;
+  if (a > lag || cx < -lag || cx > lag) return -1;
+  return (lag - a) * (2 * lag + 1) + (cx + lag);
+}
+
+// ---- tile geometry: rows t = 0 .. BH + 3 (t = block row + 4; rows 1 .. 3 the halo rows, row 0 unused), 128 bytes a row ----
+__host__ __device__ constexpr int w_copy_stride(int BH) {
+  int slots = (BH + 4) * (kWUnitW / 16);
+  while ((slots & 15) != 2) ++slots;  // copies 2 (mod 16) 16-byte slots apart: conflict-free operand reads
+  return slots * 16;
+}
+// luma: 7 copies; chroma: [Cb: 7 copies][L: an eighth copy][Cr: 7 copies]
+__host__ __device__ constexpr int w_lds_bytes(int KIND, int BH) { return (KIND == 0 ? 7 : 15) * w_copy_stride(BH); }
+
+typedef int w_v4 __attribute__((ext_vector_type(4)));
+typedef uint32_t w_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t w_u2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) w_u4 *w_cptr4;  // constant address space: uniform indices become scalar loads
+
+__device__ __forceinline__ uint32_t w_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
+
+// ---------------------------------------------------------------------------------
+// k3w_units: the raster-ordered unit list of a frame and plane kind.  grid = (2 kinds, batch), block = 1024.
+// ---------------------------------------------------------------------------------
+struct WUnitParams {
+  uint32_t *units[2];   // [batch][ncell[k]][kWEntry]
+  uint32_t *count;      // [batch][2]
+  int ncell[2], gx[2], ub[2];  // cells a frame, cells a block row, blocks a unit
+};
+__global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restrict__ records, WUnitParams up) {
+  const int kind = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;
+  if (kind == 1 && g.nplanes != 3) return;
+  const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
+  const int UB = up.ub[kind], gx = up.gx[kind], ncell = up.ncell[kind];
+  const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
+  const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
+  uint32_t *out = up.units[kind] + (size_t)frame * ncell * kWEntry;
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  auto at = [&](int x, int y) { return (x >= 0 && x < g.nbw && y >= 0 && y < g.nbh) ? (int)mask[y * g.nbw + x] : 0; };
+  auto cell_bits = [&](int c, int by) {
+    uint32_t b = 0;
+    if (c < 0 || c >= gx) return b;
+    for (int k = 0; k < UB; ++k) b |= at(c * UB + k, by) ? 1u << k : 0u;
+    return b;
+  };
+  for (int base = 0; base < ncell; base += 1024) {
+    const int idx = base + (int)threadIdx.x;
+    uint32_t bits = 0, e[kWEntry] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (idx < ncell) {
+      const int by = idx / gx, c = idx - by * gx;
+      bits = cell_bits(c, by);
+      if (bits) {
+        const bool aL = cell_bits(c - 1, by) != 0, aR = cell_bits(c + 1, by) != 0;
+        bool plain = bits == (1u << UB) - 1u, top = false;
+        for (int k = 0; k < UB; ++k) {
+          if (!((bits >> k) & 1u)) continue;
+          const int bx = c * UB + k;
+          const int left = at(bx - 1, by), right = at(bx + 1, by), upm = at(bx, by - 1);
+          const int ys = upm ? 0 : g.lag, xs = left ? 0 : g.lag;
+          const int ye = min(ph - by * bh, bh), xe = min(pw - bx * bw - g.lag, right ? bw : (bw - g.lag));
+          const bool go = xe > xs && ye > ys;
+          if (!go || xs != 0 || ys != 0 || xe != bw || ye != bh) plain = false;
+          if (!go) continue;
+          if (ys == 0) top = true;
+          const uint32_t wc = (uint32_t)xe | ((uint32_t)ye << 6) | (ys ? 1u << 13 : 0u) | (xs ? 1u << 14 : 0u) | (1u << 15);
+          e[4 + (k >> 1)] |= wc << (16 * (k & 1));
+        }
+        const bool interior = by >= 1 && (by + 1) * bh <= ph && (c + 1) * kWUnitW <= pw;
+        e[0] = (uint32_t)c | ((uint32_t)by << 10) | (aL ? 1u << 22 : 0u) | (aR ? 1u << 23 : 0u) | (plain ? 1u << 24 : 0u) |
+               (interior ? 1u << 25 : 0u) | (top ? 1u << 26 : 0u);
+        e[1] = bits;
+        e[2] = (uint32_t)idx;
+      }
+    }
+    // ordered compaction: ballot inside the wave, prefix over the 16 waves
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long vote = __ballot(bits != 0);
+    if (lane == 0) s_wave[wv] = (uint32_t)__popcll(vote);
+    __syncthreads();
+    uint32_t before = s_base;
+    for (int k = 0; k < wv; ++k) before += s_wave[k];
+    if (bits) {
+      const uint32_t pos = before + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
+      uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)pos * kWEntry);
+      dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
+      dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = s_base;
+      for (int k = 0; k < 16; ++k) t += s_wave[k];
+      s_base = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) up.count[2 * frame + kind] = s_base;
+}
+
+// ---------------------------------------------------------------------------------
+// residual arithmetic of one row word (8 samples): raw source / denoised words -> T[4], 16-bit halves holding d + 128
+//   BPS 2: T[q] = samples (2 q, 2 q + 1);  BPS 1: T[0] = (0, 2), T[1] = (1, 3), T[2] = (4, 6), T[3] = (5, 7).
+// acc |= every T (some d outside int8 <=> (acc & 0xff00ff00) != 0); ssum += the narrowed source halves.
+// ---------------------------------------------------------------------------------
+template <int BPS>
+__device__ __forceinline__ void w_residual(const w_u4 &s, const w_u4 &v, int ssh, int dsh, uint32_t (&T)[4], uint32_t &acc, uint32_t &ssum) {
+  constexpr uint32_t K = 0x00ff00ffu, B = 0x00800080u;
+  if (BPS == 2) {
+    const uint32_t ws[4] = {s.x, s.y, s.z, s.w}, wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t a = (ws[q] >> ssh) & K, b = (wv[q] >> dsh) & K;
+      ssum += a;
+      T[q] = (a + B) - b;
+      acc |= T[q];
+    }
+  } else {
+    const uint32_t ws[2] = {s.x, s.y}, wv[2] = {v.x, v.y};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t a0 = ws[q] & K, b0 = wv[q] & K, a1 = (ws[q] >> 8) & K, b1 = (wv[q] >> 8) & K;
+      ssum += a0;
+      ssum += a1;
+      T[2 * q] = (a0 + B) - b0;
+      T[2 * q + 1] = (a1 + B) - b1;
+      acc |= T[2 * q];
+      acc |= T[2 * q + 1];
+    }
+  }
+}
+// T -> the word's 8 residual bytes (two's complement)
+template <int BPS>
+__device__ __forceinline__ void w_pack(const uint32_t (&T)[4], uint32_t &d0, uint32_t &d1) {
+  constexpr uint32_t sel = BPS == 2 ? 0x06040200u : 0x06020400u;
+  d0 = __builtin_amdgcn_perm(T[1], T[0], sel) ^ 0x80808080u;
+  d1 = __builtin_amdgcn_perm(T[3], T[2], sel) ^ 0x80808080u;
+}
+
+// 7 shifted copies of a row word -> LDS (copy s at dst + s * CS): 9 alignbytes, 7 ds_write_b64 with immediate offsets
+template <int CS>
+__device__ __forceinline__ void w_write_copies(uint8_t *dst, uint32_t prev1, uint32_t d0, uint32_t d1, uint32_t next0) {
+  const uint32_t a1 = __builtin_amdgcn_alignbyte(d1, d0, 1), a2 = __builtin_amdgcn_alignbyte(d1, d0, 2), a3 = __builtin_amdgcn_alignbyte(d1, d0, 3);
+  const uint32_t b1 = __builtin_amdgcn_alignbyte(d0, prev1, 1), b2 = __builtin_amdgcn_alignbyte(d0, prev1, 2), b3 = __builtin_amdgcn_alignbyte(d0, prev1, 3);
+  const uint32_t c1 = __builtin_amdgcn_alignbyte(next0, d1, 1), c2 = __builtin_amdgcn_alignbyte(next0, d1, 2), c3 = __builtin_amdgcn_alignbyte(next0, d1, 3);
+  *reinterpret_cast<uint2 *>(dst + 0 * CS) = make_uint2(b1, a1);  // cx = -3
+  *reinterpret_cast<uint2 *>(dst + 1 * CS) = make_uint2(b2, a2);
+  *reinterpret_cast<uint2 *>(dst + 2 * CS) = make_uint2(b3, a3);
+  *reinterpret_cast<uint2 *>(dst + 3 * CS) = make_uint2(d0, d1);
+  *reinterpret_cast<uint2 *>(dst + 4 * CS) = make_uint2(a1, c1);  // cx = +1
+  *reinterpret_cast<uint2 *>(dst + 5 * CS) = make_uint2(a2, c2);
+  *reinterpret_cast<uint2 *>(dst + 6 * CS) = make_uint2(a3, c3);
+}
+
+// ---- the multiplies of a chain of NSTEP one-row steps from lane address a0 (the P operand of the first step), pitch 128 ----
+// PLAIN: 2 NSTEP + 1 products (Q Q^T of a step is P P^T of the step before: aS counts for both; k3s.hip.h s_multiply).
+// MASKED: cm = the lane's 16-byte column mask, rm bit j = the lane's sample row of step j lies inside its window rows: the A
+// operand of all three products of a step is masked, the B operand is not.
+template <int NSTEP, bool MASKED>
+__device__ __forceinline__ void w_multiply(w_v4 &aS, w_v4 &aP, w_v4 &aX, w_v4 &aQ, const uint8_t *smem, int a0, w_v4 cm, uint32_t rm) {
+  constexpr int P = kWUnitW;
+  w_v4 q = *reinterpret_cast<const w_v4 *>(smem + a0 - P);
+#pragma unroll
+  for (int j0 = 0; j0 < NSTEP; j0 += 2) {
+    w_v4 p[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) p[j] = *reinterpret_cast<const w_v4 *>(smem + a0 + (j0 + j) * P);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (MASKED) {
+        const int m = __builtin_amdgcn_sbfe((int)rm, j0 + j, 1);  // 0 or -1
+        const w_v4 cmj = cm & m;
+        const w_v4 pm = p[j] & cmj, qm = q & cmj;
+        aP = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, p[j], aP, 0, 0, 0);
+        aX = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, q, aX, 0, 0, 0);
+        aQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(qm, q, aQ, 0, 0, 0);
+      } else {
+        if (j0 + j == 0) aQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(q, q, aQ, 0, 0, 0);
+        if (j0 + j == NSTEP - 1) aP = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], p[j], aP, 0, 0, 0);
+        else aS = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], p[j], aS, 0, 0, 0);
+        aX = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], q, aX, 0, 0, 0);
+      }
+      q = p[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k3w_pass<KIND, BPS, SX, SY>
+//   KIND 0: the luma plane (blocks 32 x 32, 4 to a unit); leaves L behind when the frame has chroma planes
+//           (SX, SY = the chroma subsampling; -1, -1: no chroma planes);
+//   KIND 1: both chroma planes (blocks 32 >> SX by 32 >> SY, 128 / width to a unit), Cb on waves 0-1, Cr on waves 2-3, the L
+//           tile from the luma launch's L plane.
+// grid = frames x workgroups per frame (1-D, frame = blockIdx % frames), block = 256, dynamic LDS = w_lds_bytes.
+// ---------------------------------------------------------------------------------
+template <int KIND, int SX, int SY>
+struct WShape {
+  static constexpr bool CHR = KIND == 1;
+  static constexpr int BW = CHR ? (32 >> SX) : 32, BH = CHR ? (32 >> SY) : 32;
+  static constexpr int UB = kWUnitW / BW;            // blocks a unit
+  static constexpr int WPB = BW / 8;                 // words a block row
+  static constexpr int CS = w_copy_stride(BH);
+  static constexpr int NPL = CHR ? 2 : 1;
+  static constexpr int NOWN = NPL * BH / 32;         // own iterations (8 rows) a wave: 1, or 2 for 32-row chroma planes
+  static constexpr int NSTEP = NPL * BH * 2 / kWWaves;  // steps of a wave's chain: 16, or 32
+  static constexpr int OFF_L = 7 * CS, OFF_P1 = 8 * CS;
+  static constexpr bool LOUT = KIND == 0 && SX >= 0;
+  static constexpr int LBW = LOUT ? (32 >> SX) : 32, LBH = LOUT ? (32 >> SY) : 32;
+};
+
+template <int KIND, int BPS, int SX, int SY>
+__global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w_pass(Geom g, WParams wp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t w_smem[];
+  using SH = WShape<KIND, SX, SY>;
+  constexpr bool CHR = SH::CHR, LOUT = SH::LOUT;
+  constexpr int BW = SH::BW, BH = SH::BH, UB = SH::UB, CS = SH::CS, NPL = SH::NPL, NOWN = SH::NOWN, NSTEP = SH::NSTEP;
+  // per-unit side data, slot = (sequence position + 1) & 3
+  __shared__ unsigned long long s_sum[4][NPL][UB];  // block statistics, one 64-bit LDS atomic a lane and iteration
+  __shared__ uint32_t s_bad[4];                     // bit 0: a residual outside int8 somewhere in the unit's tile rows (plane 0); 1: in word 0; 2: in word 15; 3: L (luma launch)
+                                                    // chroma: bits 4 .. 6 the same for plane 1
+  __shared__ uint4 s_up[17], s_dn[17];              // byte masks: s_up[k] = bytes < k, s_dn[k] = bytes >= k
+
+  const int G = wp.wgs, frame = g.frame0 + (int)blockIdx.x % wp.frames, wg = (int)blockIdx.x / wp.frames;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t cnt = wp.count[2 * frame];  // ([batch][2 kinds]: the pointer is this kind's)
+  const uint32_t first = (uint32_t)((unsigned long long)cnt * (uint32_t)wg / (uint32_t)G);
+  const int nmine = (int)((uint32_t)((unsigned long long)cnt * (uint32_t)(wg + 1) / (uint32_t)G) - first);
+  w_cptr4 ents = (w_cptr4)(uintptr_t)(wp.units + ((size_t)frame * wp.ncell + first) * kWEntry);
+  int32_t *stats = wp.stats + (size_t)frame * wp.ncell * (CHR ? kWStatC : kWStatY);
+  const FramePlanes fp = wp.ft.f[frame];
+  constexpr int sxc = CHR ? SX : 0, syc = CHR ? SY : 0;
+  const int pw = g.W >> sxc, ph = g.H >> syc;
+  const int ssh = g.src_shift, dsh = g.den_shift;
+
+  // ---- this lane's staging work: pair p (two tile rows), word w ----
+  const int p = lane >> 4, w = lane & 15;
+  const int s_plane = CHR ? (wave >> 1) : 0;  // plane of this wave's own rows and of its chain
+  const uint8_t *psrc = CHR ? (s_plane ? fp.src[2] : fp.src[1]) : fp.src[0];
+  const uint8_t *pden = CHR ? (s_plane ? fp.den[2] : fp.den[1]) : fp.den[0];
+  const uint32_t sst = CHR ? (s_plane ? fp.src_stride[2] : fp.src_stride[1]) : fp.src_stride[0];
+  const uint32_t dst_ = CHR ? (s_plane ? fp.den_stride[2] : fp.den_stride[1]) : fp.den_stride[0];
+  // own iteration i: tile rows t = 4 + own_row0 + 8 i + 2 p + r
+  const int own_row0 = CHR ? (wave & 1) * (BH / 2) : 8 * wave;
+  // the halo rows (tile rows 0 .. 3) of a plane: one more iteration on the plane's last wave, lanes p & 1 -> rows 2 (p & 1) + r
+  // (the upper half of the wave repeats the lower half: same loads, same stores)
+  const bool h_wave = CHR ? (wave & 1) == 1 : wave == kWWaves - 1;
+  // constants of the lane: ONE load offset per input (tile row 4 + own_row0 + 2 p, word w, from the unit's origin = tile row 0,
+  // word 0); the second row of the pair, the further own iterations and the halo iteration move the SCALAR base instead.
+  // Halo iteration: pair p -> tile rows 2 p + r; only p < 2 (rows 0 .. 3) is wanted: the upper half of the wave sits out.
+  const uint32_t lo_s = (uint32_t)(4 + own_row0 + 2 * p) * sst + (uint32_t)(8 * w * BPS);
+  const uint32_t lo_v = (uint32_t)(4 + own_row0 + 2 * p) * dst_ + (uint32_t)(8 * w * BPS);
+  const bool h_lane = lane < 32;
+
+  // the L plane of the frame; this thread's word(s) of a unit's L tile (chroma launch) / this lane's L bytes (luma launch)
+  uint8_t *lframe = wp.lplane + (size_t)frame * wp.lframe_bytes;
+  uint32_t l_off[CHR ? (BH / 16) : NOWN];
+  if (CHR) {
+#pragma unroll
+    for (int q = 0; q < BH / 16; ++q) l_off[q] = (uint32_t)(16 * q + (tid >> 4)) * wp.lpitch + (uint32_t)(8 * (tid & 15));
+  } else if (LOUT) {
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) l_off[i] = (uint32_t)((own_row0 + 8 * i + 2 * p) >> (SY > 0 ? 1 : 0)) * wp.lpitch + (uint32_t)(8 * w >> (SX > 0 ? 1 : 0));
+  }
+  (void)l_off;
+
+  // ---- this lane's operand address: row i = lane & 15 -> (u, s); k-group g4 = lane >> 4 ----
+  const int mi = lane & 15, mg = lane >> 4;
+  int mu, ms;
+  w_row(mi, mu, ms);
+  const int m_strip = wave & 1;
+  const int m_row0 = CHR ? 0 : 16 * (wave >> 1);  // first sample row of this wave's chain
+  int m_addr;
+  {
+    const int s_eff = (!CHR && ms == 7) ? 6 : ms;  // luma: the spare rows read what row s = 6 reads
+    int base = CHR ? (s_plane ? SH::OFF_P1 : 0) : 0;
+    int so = s_eff * CS;
+    if (CHR && ms == 7) { base = 0; so = SH::OFF_L; }
+    m_addr = base + so + (m_row0 + 4 - 2 * mu) * kWUnitW + 64 * m_strip + 16 * mg;
+  }
+  const int m_blk = (64 * m_strip + 16 * mg) / BW, m_xo = (64 * m_strip + 16 * mg) % BW;
+
+  w_v4 aSS = {0, 0, 0, 0}, aPP = {0, 0, 0, 0}, aPQ = {0, 0, 0, 0}, aQQ = {0, 0, 0, 0};
+
+  if (tid < 17) {
+    uint32_t u[4], d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = tid - 4 * j;
+      u[j] = k <= 0 ? 0u : (k >= 4 ? ~0u : (1u << (8 * k)) - 1u);
+      d[j] = ~u[j];
+    }
+    s_up[tid] = make_uint4(u[0], u[1], u[2], u[3]);
+    s_dn[tid] = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+  if (tid < 4 * NPL * UB) (&s_sum[0][0][0])[tid] = 0ull;
+  if (tid < 4) s_bad[tid] = 0u;
+  __syncthreads();
+
+  // ---- pipeline registers ----
+  w_u4 rs[NOWN][2], rv[NOWN][2];                      // raw words in flight: own iterations
+  w_u4 hs[2] = {}, hv[2] = {};                        // ... halo iteration (the lanes that sit it out keep zeros)
+  uint32_t Dc[NOWN][2][2] = {}, Dn[NOWN][2][2] = {}, Dl[NOWN][2] = {};   // residual words: unit k, unit k + 1; last dwords of unit k - 1
+  uint32_t Hc[2][2] = {}, Hn[2][2] = {}, Hl[2] = {};
+
+  auto entry_x = [&](int j) -> uint32_t { return ents[(ptrdiff_t)j * 2].x; };
+
+  // the raw words of the unit with entry word ex, into rs / rv (and hs / hv)
+  auto load8 = [&](const uint8_t *base, uint32_t off) __attribute__((always_inline)) -> w_u4 {
+    w_u4 r = {0u, 0u, 0u, 0u};
+    asm volatile("" : "+v"(off));  // (opaque: scalar base + 32-bit lane offset, not a 64-bit lane address)
+    if (BPS == 2) {
+      r = *(gptr_u4)(as_global(base) + off);
+    } else {
+      const u32x2 a = *(gptr_u2)(as_global(base) + off);
+      r.x = a.x, r.y = a.y;
+    }
+    return r;
+  };
+  auto request = [&](uint32_t ex) __attribute__((always_inline)) {
+    const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
+    const int X0 = c * kWUnitW, Y0 = by * BH - 4;
+    // (scalar origin + the lane's constant offset)
+    const uint8_t *sb = psrc + ((ptrdiff_t)Y0 * (ptrdiff_t)sst + (ptrdiff_t)(X0 * BPS));
+    const uint8_t *vb = pden + ((ptrdiff_t)Y0 * (ptrdiff_t)dst_ + (ptrdiff_t)(X0 * BPS));
+    const uint8_t *hsb = sb - (ptrdiff_t)(4 + own_row0) * (ptrdiff_t)sst, *hvb = vb - (ptrdiff_t)(4 + own_row0) * (ptrdiff_t)dst_;
+    if ((ex >> 25) & 1u) {  // every row and word of the tile inside the plane
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          rs[i][r] = load8(sb + (size_t)(8 * i + r) * sst, lo_s);
+          rv[i][r] = load8(vb + (size_t)(8 * i + r) * dst_, lo_v);
+        }
+      if (h_wave && h_lane) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          hs[r] = load8(hsb + (size_t)r * sst, lo_s);
+          hv[r] = load8(hvb + (size_t)r * dst_, lo_v);
+        }
+      }
+    } else {
+      const bool xok = X0 + 8 * w + 8 <= pw;
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int t = 4 + own_row0 + 8 * i + 2 * p + r;
+          rs[i][r] = w_u4{0u, 0u, 0u, 0u};
+          rv[i][r] = w_u4{0u, 0u, 0u, 0u};
+          if (xok && Y0 + t < ph) {
+            rs[i][r] = load8(sb + (size_t)(8 * i + r) * sst, lo_s);
+            rv[i][r] = load8(vb + (size_t)(8 * i + r) * dst_, lo_v);
+          }
+        }
+      if (h_wave) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int t = 2 * p + r;
+          hs[r] = w_u4{0u, 0u, 0u, 0u};
+          hv[r] = w_u4{0u, 0u, 0u, 0u};
+          if (h_lane && xok && Y0 + t >= 0 && Y0 + t < ph) {
+            hs[r] = load8(hsb + (size_t)r * sst, lo_s);
+            hv[r] = load8(hvb + (size_t)r * dst_, lo_v);
+          }
+        }
+      }
+    }
+  };
+  // chroma launch: this thread's words of the unit's L tile (BH rows of 128 bytes, one 8-byte word a thread and 16 rows)
+  w_u2 Lc[CHR ? (BH / 16) : 1];
+  (void)Lc;
+  auto load_L = [&](uint32_t ex) __attribute__((always_inline)) {
+    if constexpr (CHR) {
+      const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
+      const uint8_t *lb = lframe + ((size_t)(by * BH) * wp.lpitch + (size_t)(c * kWUnitW));
+#pragma unroll
+      for (int q = 0; q < BH / 16; ++q) {
+        uint32_t o = l_off[q];
+        asm volatile("" : "+v"(o));
+        Lc[q] = *(gptr_u2)(as_global(lb) + o);
+      }
+    }
+  };
+
+  // raw words -> residual words of the unit at sequence position j (D = Dn, H = Hn); REAL: statistics, L, flags of a unit
+  // of this workgroup's own (a ghost leaves nothing behind but its words and its edge flags)
+  auto form = [&](int j, uint32_t ex, bool real) __attribute__((always_inline)) {
+    const int slot = (j + 1) & 3;
+    uint32_t racc = 0, lacc = 0;
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+      uint32_t T[2][4], ssum = 0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        w_residual<BPS>(rs[i][r], rv[i][r], ssh, dsh, T[r], racc, ssum);
+        w_pack<BPS>(T[r], Dn[i][r][0], Dn[i][r][1]);
+      }
+      if (real) {
+        int sd = 0, sd2 = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          sd = __builtin_amdgcn_sdot4((int)Dn[i][r][0], 0x01010101, sd, false);
+          sd = __builtin_amdgcn_sdot4((int)Dn[i][r][1], 0x01010101, sd, false);
+          sd2 = __builtin_amdgcn_sdot4((int)Dn[i][r][0], (int)Dn[i][r][0], sd2, false);
+          sd2 = __builtin_amdgcn_sdot4((int)Dn[i][r][1], (int)Dn[i][r][1], sd2, false);
+        }
+        unsigned long long pk;
+        if (!CHR) {
+          const uint32_t ls = (ssum & 0xffffu) + (ssum >> 16);
+          pk = ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)ls << 19) | (unsigned long long)(uint32_t)(sd + 16 * 128);
+        } else {
+          pk = ((unsigned long long)(uint32_t)sd2 << 32) | (unsigned long long)(uint32_t)(sd + 16 * 128);
+        }
+        atomicAdd(&s_sum[slot][s_plane][w / SH::WPB], pk);
+        if constexpr (LOUT) {
+          // ---- the chroma regressor L of this lane's samples -> the L plane ----
+          const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
+          uint32_t lo_ = l_off[i];
+          asm volatile("" : "+v"(lo_));
+          uint8_t *lp = lframe + ((size_t)(by * SH::LBH) * wp.lpitch + (size_t)(c * (kWUnitW >> (SX > 0 ? 1 : 0)))) + lo_;
+          if (SX == 0 && SY == 0) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) *reinterpret_cast<uint2 *>(lp + (size_t)r * wp.lpitch) = make_uint2(Dn[i][r][0], Dn[i][r][1]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < (SY ? 1 : 2); ++r) {
+              uint32_t V[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) V[q] = SY ? T[0][q] + T[1][q] : T[r][q];
+              constexpr uint32_t bias1 = SY ? 256u : 128u;
+              if (SX) {
+                uint32_t x01, x23;
+                if (BPS == 2) {
+                  uint32_t h[4];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) h[q] = V[q] + (V[q] >> 16);
+                  x01 = __builtin_amdgcn_perm(h[1], h[0], 0x05040100u);
+                  x23 = __builtin_amdgcn_perm(h[3], h[2], 0x05040100u);
+                } else {
+                  x01 = V[0] + V[1];
+                  x23 = V[2] + V[3];
+                }
+                constexpr uint32_t add = (640u - 2u * bias1) * 0x00010001u;
+                const uint32_t y01 = x01 + add, y23 = x23 + add;  // halves: L + 640; inside int8 <=> high byte 2
+                lacc |= (y01 ^ 0x02000200u) | (y23 ^ 0x02000200u);
+                *reinterpret_cast<uint32_t *>(lp + (size_t)r * wp.lpitch) = __builtin_amdgcn_perm(y23, y01, 0x06040200u) ^ 0x80808080u;
+              } else {
+                // (SY = 1, SX = 0: eight values a row pair, laid out like T)
+                constexpr uint32_t add = (640u - bias1) * 0x00010001u;
+                uint32_t y[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  y[q] = V[q] + add;
+                  lacc |= y[q] ^ 0x02000200u;
+                }
+                constexpr uint32_t sel = BPS == 2 ? 0x06040200u : 0x06020400u;
+                *reinterpret_cast<uint2 *>(lp + (size_t)r * wp.lpitch) =
+                    make_uint2(__builtin_amdgcn_perm(y[1], y[0], sel) ^ 0x80808080u, __builtin_amdgcn_perm(y[3], y[2], sel) ^ 0x80808080u);
+              }
+            }
+          }
+        }
+      }
+    }
+    uint32_t hacc = 0;
+    if (h_wave) {
+      uint32_t T[4], dummy = 0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        w_residual<BPS>(hs[r], hv[r], ssh, dsh, T, hacc, dummy);
+        w_pack<BPS>(T, Hn[r][0], Hn[r][1]);
+      }
+    }
+    // ---- residuals (or L) outside int8: rare; one wave-uniform test on the usual way ----
+    const uint32_t out = (racc | hacc | lacc) & 0xff00ff00u;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(out != 0) != 0, 0)) {
+      const int sh0 = CHR ? 4 * s_plane : 0;
+      uint32_t bits = 0;
+      if ((racc & 0xff00ff00u) != 0) bits |= (1u | (w == 0 ? 2u : 0u) | (w == 15 ? 4u : 0u)) << sh0;
+      if ((lacc & 0xff00ff00u) != 0) bits |= 8u;
+      if ((hacc & 0xff00ff00u) != 0) bits |= (1u | (w == 0 ? 2u : 0u) | (w == 15 ? 4u : 0u)) << sh0;
+      if (!real) bits &= ~(1u | 16u | 8u);  // a ghost: only what its edge words mean to the neighbour
+      if (bits) atomicOr(&s_bad[slot], bits);
+    }
+  };
+
+  // the copies of unit k (Dc / Hc; left halo dwords Dl / Hl, right halo dwords in Dn / Hn) -> the tile buffer.
+  // The dword left of word w is word w - 1's second dword (row_shr:1; lane 0 of the row keeps what the first move put there: the
+  // unit before's last dword, rotated in from lane 15), the dword right of it word w + 1's first (row_shl:1; lane 15 likewise).
+  auto neighbours = [&](uint32_t dl, uint32_t d0, uint32_t d1, uint32_t dn0, uint32_t mL, uint32_t mR, uint32_t &prev1, uint32_t &next0)
+                        __attribute__((always_inline)) {
+    const int hl = __builtin_amdgcn_mov_dpp((int)(dl & mL), 0x121, 0xf, 0xf, true);   // row_ror:1:  lane 0 <- lane 15
+    const int hr = __builtin_amdgcn_mov_dpp((int)(dn0 & mR), 0x12f, 0xf, 0xf, true);  // row_ror:15: lane 15 <- lane 0
+    prev1 = (uint32_t)__builtin_amdgcn_update_dpp(hl, (int)d1, 0x111, 0xf, 0xf, false);  // row_shr:1
+    next0 = (uint32_t)__builtin_amdgcn_update_dpp(hr, (int)d0, 0x101, 0xf, 0xf, false);  // row_shl:1
+  };
+  auto write_copies = [&](uint32_t ex) __attribute__((always_inline)) {
+    const uint32_t mL = ((ex >> 22) & 1u) ? ~0u : 0u, mR = ((ex >> 23) & 1u) ? ~0u : 0u;
+    uint8_t *base = w_smem + (CHR && s_plane ? SH::OFF_P1 : 0) + 2 * p * kWUnitW + 8 * w;
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        uint32_t prev1, next0;
+        neighbours(Dl[i][r], Dc[i][r][0], Dc[i][r][1], Dn[i][r][0], mL, mR, prev1, next0);
+        w_write_copies<CS>(base + (4 + own_row0 + 8 * i + r) * kWUnitW, prev1, Dc[i][r][0], Dc[i][r][1], next0);
+      }
+    if (h_wave) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        uint32_t prev1, next0;
+        neighbours(Hl[r], Hc[r][0], Hc[r][1], Hn[r][0], mL, mR, prev1, next0);
+        if (h_lane) w_write_copies<CS>(base + r * kWUnitW, prev1, Hc[r][0], Hc[r][1], next0);
+      }
+    }
+  };
+  // unit k <- unit k + 1
+  auto advance = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        Dl[i][r] = Dc[i][r][1];
+        Dc[i][r][0] = Dn[i][r][0];
+        Dc[i][r][1] = Dn[i][r][1];
+      }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      Hl[r] = Hc[r][1];
+      Hc[r][0] = Hn[r][0];
+      Hc[r][1] = Hn[r][1];
+    }
+  };
+
+  // ---- prologue: the ghost in front of the slice (when the first unit has a left neighbour), unit 0 ----
+  if (nmine > 0) {
+    const uint32_t e0 = entry_x(0);
+    if ((e0 >> 22) & 1u) {
+      const uint32_t eg = entry_x(-1);
+      request(eg);
+      form(-1, eg, false);
+      advance();  // (the ghost -> the k registers)
+    }
+    request(e0);
+    form(0, e0, true);
+    advance();  // ghost (or zeros) -> the k - 1 registers, unit 0 -> the k registers
+    load_L(e0);
+    // the words of unit 1 (or of the ghost behind a one-unit slice)
+    if (nmine > 1 || ((e0 >> 23) & 1u)) request(entry_x(1));
+  }
+  __syncthreads();
+
+  // entries in SGPRs, loaded an iteration (two, for the unit to request) ahead of their use: entry k, .x of entries k + 1, k + 2
+  w_u4 ea = ents[0], eb = ents[1];
+  uint32_t x1 = entry_x(1), x2 = entry_x(2);
+  for (int k = 0; k < nmine; ++k) {
+    const w_u4 na = ents[(ptrdiff_t)(k + 1) * 2], nb = ents[(ptrdiff_t)(k + 1) * 2 + 1];
+    const uint32_t x3 = entry_x(k + 3);
+    const uint32_t ex = ea.x;
+    const bool last = k + 1 == nmine;
+    // ---- the next unit's residual words (its raw words have had an iteration to land); the unit after it is requested ----
+    if (!last || ((ex >> 23) & 1u)) {
+      form(k + 1, x1, !last);
+      if (!last) {
+        if (k + 2 < nmine || ((x1 >> 23) & 1u)) request(x2);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) Dn[i][r][0] = Dn[i][r][1] = 0u;
+      Hn[0][0] = Hn[0][1] = Hn[1][0] = Hn[1][1] = 0u;
+    }
+    // ---- this unit's copies -> the tile buffer (free since the barrier at the end of the iteration before) ----
+    write_copies(ex);
+    if constexpr (CHR) {
+#pragma unroll
+      for (int q = 0; q < BH / 16; ++q) {
+        const int row = 16 * q + (tid >> 4);
+        *reinterpret_cast<uint2 *>(w_smem + SH::OFF_L + (row + 4) * kWUnitW + 8 * (tid & 15)) = make_uint2(Lc[q].x, Lc[q].y);
+      }
+      if (!last) load_L(x1);  // (the next unit's, an iteration ahead)
+    }
+    __syncthreads();
+    // ------------------------------- multiply unit k -------------------------------
+    const int slot = (k + 1) & 3;
+    const uint32_t b0 = __builtin_amdgcn_readfirstlane(s_bad[slot]), bl = __builtin_amdgcn_readfirstlane(s_bad[k & 3]),
+                   br = __builtin_amdgcn_readfirstlane(s_bad[(k + 2) & 3]);
+    uint32_t defer;  // bit pl: plane pl of this launch is left to the exact kernel; luma bit 3: L left int8
+    {
+      const uint32_t aL = (ex >> 22) & 1u, aR = (ex >> 23) & 1u;
+      const uint32_t d0 = (b0 & 1u) | (aL & (bl >> 2)) | (aR & (br >> 1));
+      defer = d0 & 1u;
+      if (CHR) defer |= (((b0 >> 4) & 1u) | (aL & (bl >> 6)) | (aR & (br >> 5))) << 1;
+      if (LOUT) defer |= b0 & 8u;
+    }
+    if constexpr (CHR) {
+      // L outside int8 in one of the luma units under this unit: both planes
+      const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
+      constexpr int LPU = UB / 4;  // luma units under a chroma unit
+      uint32_t lb = 0;
+#pragma unroll
+      for (int q = 0; q < LPU; ++q) {
+        const int cy = c * LPU + q;
+        if (cy < wp.gx_y) lb |= wp.lbad[(size_t)frame * wp.ncell_y + (size_t)by * wp.gx_y + cy];
+      }
+      if (__builtin_amdgcn_readfirstlane(lb)) defer |= 3u;
+    }
+    const bool mine_deferred = ((defer >> (CHR ? s_plane : 0)) & 1u) != 0;
+    if (!mine_deferred) {
+      if ((ex >> 24) & 1u) {
+        w_multiply<NSTEP, false>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, w_v4{0, 0, 0, 0}, 0u);
+      } else {
+        // this lane's window: block m_blk of the unit
+        const uint32_t wsel[4] = {eb.x, eb.y, eb.z, eb.w};
+        uint32_t wd = wsel[0];
+#pragma unroll
+        for (int q = 1; q < (UB + 1) / 2; ++q) wd = (m_blk >> 1) == q ? wsel[q] : wd;
+        const MWin mw = m_unpack((wd >> (16 * (m_blk & 1))) & 0xffffu, g.lag);
+        const int lo = mw.go ? min(max(mw.xs - m_xo, 0), 16) : 0, hi = mw.go ? min(max(mw.xe - m_xo, 0), 16) : 0;
+        const uint4 mu4 = s_up[hi], md4 = s_dn[lo];
+        const w_v4 cm = {(int)(mu4.x & md4.x), (int)(mu4.y & md4.y), (int)(mu4.z & md4.z), (int)(mu4.w & md4.w)};
+        const uint32_t rm = mw.go ? m_rowmask(mw.ys, mw.ye) >> m_row0 : 0u;
+        w_multiply<NSTEP, true>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, cm, rm);
+      }
+    }
+    // ---- the unit's statistics record and deferral bits; the side data of the unit before it is zeroed ----
+    if (tid < NPL * UB) {
+      const int pl = tid / UB, b = tid - pl * UB;
+      const unsigned long long pk = s_sum[slot][pl][b];
+      s_sum[slot][pl][b] = 0ull;
+      int32_t *r = stats + (size_t)ea.z * (CHR ? kWStatC : kWStatY);
+      if (!CHR) {
+        const int samples = 32 * 32;
+        r[3 * b + 0] = (int)(pk & 0x7ffffu) - samples * 128;
+        r[3 * b + 1] = (int)(pk >> 37);
+        r[3 * b + 2] = (int)((pk >> 19) & 0x3ffffu);
+      } else {
+        const int samples = BW * BH;
+        r[4 * b + 2 * pl + 0] = (int)(uint32_t)(pk & 0xffffffffu) - samples * 128;
+        r[4 * b + 2 * pl + 1] = (int)(pk >> 32);
+      }
+    }
+    if (tid == 64) {
+      stats[(size_t)ea.z * (CHR ? kWStatC : kWStatY) + (CHR ? 32 : 12)] = (int)defer;
+      if (LOUT && (defer & 8u)) wp.lbad[(size_t)frame * wp.ncell_y + ea.z] = 1;
+      s_bad[(k + 3) & 3] = 0u;  // (the slot of unit k - 2 = of unit k + 2: dead since the iteration before, written again in the next)
+    }
+    advance();
+    ea = na;
+    eb = nb;
+    x1 = x2;
+    x2 = x3;
+    // (opaque: the entries stay in their SGPRs -- reloading them where they are used would put a scalar-load latency in every
+    //  iteration's path)
+    asm volatile("" : "+s"(ea.x), "+s"(ea.y), "+s"(ea.z), "+s"(eb.x), "+s"(eb.y), "+s"(eb.z), "+s"(eb.w), "+s"(x1), "+s"(x2));
+    __syncthreads();
+  }
+
+  // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
+  long long *s_S = reinterpret_cast<long long *>(w_smem);
+  for (int k = tid; k < NPL * kMRec; k += kWThreads) s_S[k] = 0;
+  __syncthreads();
+  {
+    const bool ch = CHR;
+    const int nc = g.n + (ch ? 1 : 0);
+    long long *dst = s_S + (CHR ? s_plane : 0) * kMRec;
+    auto add = [&](int er, int ec, int v, bool cross) {
+      if (er < 0 || ec < 0 || v == 0) return;
+      if (cross && er == nc) {  // (the sample itself sits in P: as a row of P Q^T it is the `b` entry of the Q row)
+        const int t = er;
+        er = ec;
+        ec = t;
+      }
+      if (er == nc) return;
+      int idx = -1;
+      if (ec == nc) idx = nc * nc + er;
+      else if (cross) idx = min(er, ec) * nc + max(er, ec);
+      else if (er <= ec) idx = er * nc + ec;
+      if (idx >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(&dst[idx]), (unsigned long long)(long long)v);
+    };
+    const int cP = w_rec_index(0, mi, g.lag, g.n, ch), cQ = w_rec_index(1, mi, g.lag, g.n, ch);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * mg + r;
+      const int rP = w_rec_index(0, row, g.lag, g.n, ch), rQ = w_rec_index(1, row, g.lag, g.n, ch);
+      add(rP, cP, aSS[r] + aPP[r], false);
+      add(rP, cQ, aPQ[r], true);
+      add(rQ, cQ, aSS[r] + aQQ[r], false);
+    }
+  }
+  __syncthreads();
+  long long *outp = wp.partials + (((size_t)frame * wp.wg_cap + wg) * 3 + (CHR ? 1 : 0)) * kMRec;
+  for (int k = tid; k < NPL * kMRec; k += kWThreads) outp[k] = s_S[k];
+}
+
+// ---------------------------------------------------------------------------------
+// k3w_finish: what the accumulation workgroups left behind -> the frame's record (as k3m_finish, for the wide lists).
+//   x < 3 * nplanes:  a third of the G partial systems of plane x / 3, summed;
+//   x >= 3 * nplanes: the lists' statistics records -> block statistics of the flat blocks, `only` flags of the deferred
+//                 ones, nobs of the blocks that were multiplied.
+// grid = (3 * nplanes + kWFinishWgs, batch), block = 256.
+// ---------------------------------------------------------------------------------
+constexpr int kWFinishWgs = 8;
+struct WFinishParams {
+  const uint32_t *units[2];
+  const uint32_t *count;     // [batch][2]
+  const int32_t *stats[2];
+  int ncell[2], ub[2];
+  const long long *partials;
+  int wg_cap, G[2];
+  uint8_t *only;             // [batch][3][nblocks]
+  uint32_t *only_any;        // [batch]
+};
+__global__ __launch_bounds__(256) void k3w_finish(Geom g, WFinishParams fp, uint8_t *__restrict__ records) {
+  const int frame = g.frame0 + (int)blockIdx.y;
+  uint8_t *rec = records + (size_t)frame * g.rec_size;
+  if ((int)blockIdx.x < kMFinishParts * g.nplanes) {
+    const int c = (int)blockIdx.x / kMFinishParts, nc = g.n + (c > 0);
+    const int k = ((int)blockIdx.x - c * kMFinishParts) * 256 + (int)threadIdx.x;
+    if (k >= nc * nc + nc) return;
+    long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
+    const int G = c == 0 ? fp.G[0] : fp.G[1];
+    const long long *p = fp.partials + (size_t)frame * fp.wg_cap * 3 * kMRec + (size_t)c * kMRec + k;
+    long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int w = 0;
+    for (; w + 4 <= G; w += 4) {
+      s0 += p[(size_t)(w + 0) * 3 * kMRec];
+      s1 += p[(size_t)(w + 1) * 3 * kMRec];
+      s2 += p[(size_t)(w + 2) * 3 * kMRec];
+      s3 += p[(size_t)(w + 3) * 3 * kMRec];
+    }
+    for (; w < G; ++w) s0 += p[(size_t)w * 3 * kMRec];
+    ar[k] += (s0 + s1) + (s2 + s3);
+    return;
+  }
+  const int part = (int)blockIdx.x - kMFinishParts * g.nplanes;
+  long long nobs[3] = {0, 0, 0};
+  const int kinds = g.nplanes == 3 ? 2 : 1;
+  for (int kind = 0; kind < kinds; ++kind) {
+    const uint32_t cnt = fp.count[2 * frame + kind];
+    const int UB = fp.ub[kind], SI = kind ? kWStatC : kWStatY;
+    const uint32_t *units = fp.units[kind] + (size_t)frame * fp.ncell[kind] * kWEntry;
+    const int32_t *st = fp.stats[kind] + (size_t)frame * fp.ncell[kind] * SI;
+    for (uint32_t v = part * 256 + threadIdx.x; v < cnt; v += kWFinishWgs * 256) {
+      const uint4 ea = *reinterpret_cast<const uint4 *>(units + (size_t)v * kWEntry);
+      const uint4 eb = *reinterpret_cast<const uint4 *>(units + (size_t)v * kWEntry + 4);
+      const uint32_t wins[4] = {eb.x, eb.y, eb.z, eb.w};
+      const int c = (int)(ea.x & 0x3ffu), by = (int)((ea.x >> 10) & 0xfffu);
+      const int32_t *r = st + (size_t)ea.z * SI;
+      const uint32_t defer = (uint32_t)r[kind ? 32 : 12];
+      for (int b = 0; b < UB; ++b) {
+        if (!((ea.y >> b) & 1u)) continue;
+        const int blk = by * g.nbw + c * UB + b;
+        const MWin w = m_unpack((wins[b >> 1] >> (16 * (b & 1))) & 0xffffu, g.lag);
+        const long long area = w.go ? (long long)(w.xe - w.xs) * (w.ye - w.ys) : 0;
+        if (kind == 0) {
+          reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = r[3 * b + 0];
+          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)r[3 * b + 1];
+          reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)r[3 * b + 2];
+          if (defer & 1u) {
+            fp.only[((size_t)frame * 3 + 0) * g.nblocks + blk] = 1, fp.only_any[frame] = 1u;
+          } else {
+            nobs[0] += area;
+          }
+        } else {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            reinterpret_cast<int32_t *>(rec + g.off_sum_d[1 + pl])[blk] = r[4 * b + 2 * pl + 0];
+            reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1 + pl])[blk] = (uint32_t)r[4 * b + 2 * pl + 1];
+            if ((defer >> pl) & 1u) {
+              fp.only[((size_t)frame * 3 + 1 + pl) * g.nblocks + blk] = 1, fp.only_any[frame] = 1u;
+            } else {
+              nobs[1 + pl] += area;
+            }
+          }
+        }
+      }
+    }
+  }
+  __shared__ long long s_n[3][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nobs[c] += __shfl_xor(nobs[c], o, 64);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s_n[c][threadIdx.x >> 6] = nobs[c];
+  __syncthreads();
+  if ((int)threadIdx.x < g.nplanes) {
+    const int c = threadIdx.x, nc = g.n + (c > 0);
+    const long long n = s_n[c][0] + s_n[c][1] + s_n[c][2] + s_n[c][3];
+    if (n) atomicAdd(reinterpret_cast<unsigned long long *>(rec + g.off_ar[c]) + (nc * nc + nc), (unsigned long long)n);
+  }
+}
+
+}  // namespace g1s
