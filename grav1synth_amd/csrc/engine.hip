@@ -1128,6 +1128,8 @@ int g1s_diff::launch_back(int si) {
     wq.ncell_y = w_ncell[0];
     wq.gx_y = w_gx[0];
     wq.frames = (int)B;
+    static const int w_dbg = getenv("G1S_W_DBG") ? atoi(getenv("G1S_W_DBG")) : 0;  // timing experiments (a -DG1S_W_DBG_BUILD library)
+    wq.dbg = w_dbg;
     int Gk[2] = {w_wgs_per_frame(w_ncell[0], (int)B, 0), w_wgs_per_frame(std::max(w_ncell[1], 1), (int)B, 1)};
     for (int k = 0; k < 2; ++k)
       if ((size_t)Gk[k] * B > m_wg_cap) Gk[k] = (int)(m_wg_cap / B) & ~7;  // (the environment changed after the slots were sized)
@@ -1184,6 +1186,20 @@ int g1s_diff::launch_back(int si) {
     fpn.only_any = mp.only_any;
     kmark(sl, stream, "k3w_finish");
     hipLaunchKernelGGL(k3w_finish, dim3(kMFinishParts * g.nplanes + kWFinishWgs, B), dim3(256), 0, stream, g, fpn, sl.d_records);
+    {
+      // debugging aid (G1S_DBG_ONLY=1): how many flat blocks the accumulation launches left to the exact kernel
+      static const bool count_only = getenv("G1S_DBG_ONLY") != nullptr;
+      if (count_only) {
+        std::vector<uint8_t> h(m_only_bytes);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), mp.only, m_only_bytes, hipMemcpyDeviceToHost);
+        size_t n[3] = {0, 0, 0};
+        for (uint32_t f = 0; f < B; ++f)
+          for (int c = 0; c < 3; ++c)
+            for (int b = 0; b < g.nblocks; ++b) n[c] += h[((size_t)f * 3 + c) * g.nblocks + b] != 0;
+        fprintf(stderr, "deferred to k3_ar_generic: %zu luma, %zu Cb, %zu Cr blocks of %u frames x %d blocks\n", n[0], n[1], n[2], B, g.nblocks);
+      }
+    }
     kmark(sl, stream, "k3_ar_generic");
     hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                        sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);

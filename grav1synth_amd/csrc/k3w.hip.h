@@ -59,7 +59,13 @@ struct WParams {
   int ncell, ncell_y;       // grid cells a frame of this launch's kind / of the luma kind
   int gx_y;                 // luma cells a block row
   int frames, wgs, wg_cap;
+  int dbg;                  // timing experiments (G1S_W_DBG, builds with -DG1S_W_DBG_BUILD only): 1 no global loads, 2 no residual arithmetic, 4 no statistics / L, 8 no copy writes, 16 no multiplies, 32 no barriers in the loop; wrong results
 };
+#ifdef G1S_W_DBG_BUILD
+#define G1S_W_DBGBIT(bit) ((wp.dbg & (bit)) != 0)
+#else
+#define G1S_W_DBGBIT(bit) false
+#endif
 
 // ---- matrix rows (as k3s.hip.h): lane l of an operand holds 16 bytes of row i = l & 15 for the k-group l >> 4.
 // i -> (u, s): u = which of the operand's two `a`, s = 0..6 the copy (cx = s - 3), s = 7 the chroma regressor L (u = 0 of P)
@@ -232,27 +238,36 @@ __device__ __forceinline__ void w_write_copies(uint8_t *dst, uint32_t prev1, uin
 }
 
 // ---- the multiplies of a chain of NSTEP one-row steps from lane address a0 (the P operand of the first step), pitch 128 ----
-// PLAIN: 2 NSTEP + 1 products (Q Q^T of a step is P P^T of the step before: aS counts for both; k3s.hip.h s_multiply).
-// MASKED: cm = the lane's 16-byte column mask, rm bit j = the lane's sample row of step j lies inside its window rows: the A
-// operand of all three products of a step is masked, the B operand is not.
-template <int NSTEP, bool MASKED>
+// MODE 0 (plain): 2 NSTEP + 1 products (Q Q^T of a step is P P^T of the step before: aS counts for both; k3s.hip.h s_multiply).
+// MODE 1 (column windows only: every sample row of the chain inside its window rows): the same 2 NSTEP + 1 products with the
+//   A operand under the lane's 16-byte column mask cm -- the mask does not change from step to step, so the renaming still holds.
+// MODE 2 (general): rm bit j = the lane's sample row of step j lies inside its window rows: all three products of every step,
+//   the A operand under cm and the row bit, the B operand as it is.
+template <int NSTEP, int MODE>
 __device__ __forceinline__ void w_multiply(w_v4 &aS, w_v4 &aP, w_v4 &aX, w_v4 &aQ, const uint8_t *smem, int a0, w_v4 cm, uint32_t rm) {
   constexpr int P = kWUnitW;
   w_v4 q = *reinterpret_cast<const w_v4 *>(smem + a0 - P);
+  if constexpr (MODE == 1) aQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(q & cm, q, aQ, 0, 0, 0);
+  constexpr int H = MODE == 2 ? 1 : 2;  // operand reads in flight (the general form holds three masked copies besides)
 #pragma unroll
-  for (int j0 = 0; j0 < NSTEP; j0 += 2) {
-    w_v4 p[2];
+  for (int j0 = 0; j0 < NSTEP; j0 += H) {
+    w_v4 p[H];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) p[j] = *reinterpret_cast<const w_v4 *>(smem + a0 + (j0 + j) * P);
+    for (int j = 0; j < H; ++j) p[j] = *reinterpret_cast<const w_v4 *>(smem + a0 + (j0 + j) * P);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if constexpr (MASKED) {
+    for (int j = 0; j < H; ++j) {
+      if constexpr (MODE == 2) {
         const int m = __builtin_amdgcn_sbfe((int)rm, j0 + j, 1);  // 0 or -1
         const w_v4 cmj = cm & m;
         const w_v4 pm = p[j] & cmj, qm = q & cmj;
         aP = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, p[j], aP, 0, 0, 0);
         aX = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, q, aX, 0, 0, 0);
         aQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(qm, q, aQ, 0, 0, 0);
+      } else if constexpr (MODE == 1) {
+        const w_v4 pm = p[j] & cm;
+        if (j0 + j == NSTEP - 1) aP = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, p[j], aP, 0, 0, 0);
+        else aS = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, p[j], aS, 0, 0, 0);
+        aX = __builtin_amdgcn_mfma_i32_16x16x64_i8(pm, q, aX, 0, 0, 0);
       } else {
         if (j0 + j == 0) aQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(q, q, aQ, 0, 0, 0);
         if (j0 + j == NSTEP - 1) aP = __builtin_amdgcn_mfma_i32_16x16x64_i8(p[j], p[j], aP, 0, 0, 0);
@@ -396,6 +411,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     return r;
   };
   auto request = [&](uint32_t ex) __attribute__((always_inline)) {
+    if (G1S_W_DBGBIT(1)) return;
     const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
     const int X0 = c * kWUnitW, Y0 = by * BH - 4;
     // (scalar origin + the lane's constant offset)
@@ -466,6 +482,15 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   auto form = [&](int j, uint32_t ex, bool real) __attribute__((always_inline)) {
     const int slot = (j + 1) & 3;
     uint32_t racc = 0, lacc = 0;
+    if (G1S_W_DBGBIT(2)) {
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) Dn[i][r][0] = rs[i][r].x ^ rv[i][r].x, Dn[i][r][1] = rs[i][r].y ^ rv[i][r].y;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) Hn[r][0] = hs[r].x ^ hv[r].x, Hn[r][1] = hs[r].y ^ hv[r].y;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NOWN; ++i) {
       uint32_t T[2][4], ssum = 0;
@@ -474,7 +499,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
         w_residual<BPS>(rs[i][r], rv[i][r], ssh, dsh, T[r], racc, ssum);
         w_pack<BPS>(T[r], Dn[i][r][0], Dn[i][r][1]);
       }
-      if (real) {
+      if (real && !G1S_W_DBGBIT(4)) {
         int sd = 0, sd2 = 0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -574,6 +599,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     next0 = (uint32_t)__builtin_amdgcn_update_dpp(hr, (int)d0, 0x101, 0xf, 0xf, false);  // row_shl:1
   };
   auto write_copies = [&](uint32_t ex) __attribute__((always_inline)) {
+    if (G1S_W_DBGBIT(8)) return;
     const uint32_t mL = ((ex >> 22) & 1u) ? ~0u : 0u, mR = ((ex >> 23) & 1u) ? ~0u : 0u;
     uint8_t *base = w_smem + (CHR && s_plane ? SH::OFF_P1 : 0) + 2 * p * kWUnitW + 8 * w;
 #pragma unroll
@@ -660,7 +686,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       }
       if (!last) load_L(x1);  // (the next unit's, an iteration ahead)
     }
-    __syncthreads();
+    if (!G1S_W_DBGBIT(32)) __syncthreads();
     // ------------------------------- multiply unit k -------------------------------
     const int slot = (k + 1) & 3;
     const uint32_t b0 = __builtin_amdgcn_readfirstlane(s_bad[slot]), bl = __builtin_amdgcn_readfirstlane(s_bad[k & 3]),
@@ -686,9 +712,9 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       if (__builtin_amdgcn_readfirstlane(lb)) defer |= 3u;
     }
     const bool mine_deferred = ((defer >> (CHR ? s_plane : 0)) & 1u) != 0;
-    if (!mine_deferred) {
+    if (!mine_deferred && !G1S_W_DBGBIT(16)) {
       if ((ex >> 24) & 1u) {
-        w_multiply<NSTEP, false>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, w_v4{0, 0, 0, 0}, 0u);
+        w_multiply<NSTEP, 0>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, w_v4{0, 0, 0, 0}, 0u);
       } else {
         // this lane's window: block m_blk of the unit
         const uint32_t wsel[4] = {eb.x, eb.y, eb.z, eb.w};
@@ -699,8 +725,18 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
         const int lo = mw.go ? min(max(mw.xs - m_xo, 0), 16) : 0, hi = mw.go ? min(max(mw.xe - m_xo, 0), 16) : 0;
         const uint4 mu4 = s_up[hi], md4 = s_dn[lo];
         const w_v4 cm = {(int)(mu4.x & md4.x), (int)(mu4.y & md4.y), (int)(mu4.z & md4.z), (int)(mu4.w & md4.w)};
-        const uint32_t rm = mw.go ? m_rowmask(mw.ys, mw.ye) >> m_row0 : 0u;
-        w_multiply<NSTEP, true>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, cm, rm);
+        constexpr uint32_t full = NSTEP >= 32 ? ~0u : (1u << NSTEP) - 1u;
+        const uint32_t rm = mw.go ? (m_rowmask(mw.ys, mw.ye) >> m_row0) & full : 0u;
+        // what the chain needs, wave-uniform: nothing (no window sample in its strip), the plain products (every lane's window
+        // covers its 16 samples and the chain's rows), column masks only, or the general form
+        const bool empty = hi <= lo || rm == 0u;
+        const bool whole = lo == 0 && hi == 16;
+        const bool rows_in = rm == full || empty;
+        if (__builtin_amdgcn_ballot_w64(!empty) != 0) {
+          if (__builtin_amdgcn_ballot_w64(!rows_in) != 0) w_multiply<NSTEP, 2>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, cm, rm);
+          else if (__builtin_amdgcn_ballot_w64(!(whole && !empty)) != 0) w_multiply<NSTEP, 1>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, empty ? w_v4{0, 0, 0, 0} : cm, 0u);
+          else w_multiply<NSTEP, 0>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, w_v4{0, 0, 0, 0}, 0u);
+        }
       }
     }
     // ---- the unit's statistics record and deferral bits; the side data of the unit before it is zeroed ----
@@ -733,7 +769,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     // (opaque: the entries stay in their SGPRs -- reloading them where they are used would put a scalar-load latency in every
     //  iteration's path)
     asm volatile("" : "+s"(ea.x), "+s"(ea.y), "+s"(ea.z), "+s"(eb.x), "+s"(eb.y), "+s"(eb.z), "+s"(eb.w), "+s"(x1), "+s"(x2));
-    __syncthreads();
+    if (!G1S_W_DBGBIT(32)) __syncthreads();
   }
 
   // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
