@@ -93,7 +93,7 @@ int m_wgs_per_frame(int nunits, int B, int kind = 1) {
 // the wide chain: workgroups per frame.  A workgroup walks a contiguous slice of the frame's raster-ordered list and forms a
 // ghost unit at either end: longer slices, fewer ghosts; at least one resident round (4 to a CU) a launch
 int w_wgs_per_frame(int ncell, int B, int kind) {
-  const int cap = kind == 1 ? kWMaxUnits / 2 : kWMaxUnits;
+  const int cap = kind == 1 ? kWMaxUnitsC : kWMaxUnits;
   const int gmin = (ncell + cap - 1) / cap;
   const char *e = getenv(kind ? "G1S_W_WGS_C" : "G1S_W_WGS");  // tuning / test aid
   int target = std::max(kMTargetWgs, (kind ? 16 : 32) * B);
@@ -614,7 +614,7 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
   w_lpitch = g.nplanes == 3 ? (uint32_t)((std::max(w_gx[0] * 4 * (kBlock >> g.xdec), w_gx[1] * kWUnitW) + 15) & ~15) : 0u;
   w_lframe = w_lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec) + 1);
   {
-    size_t o = 0;
+    size_t o = 64;  // (a workgroup parks the entry in front of its slice too)
     w_off_units[0] = o, o += sizeof(uint32_t) * (size_t)batch * w_ncell[0] * kWEntry;
     w_off_units[1] = o, o += sizeof(uint32_t) * (size_t)batch * w_ncell[1] * kWEntry;
     w_off_count = o, o += sizeof(uint32_t) * 2 * (size_t)batch;
@@ -1198,6 +1198,21 @@ int g1s_diff::launch_back(int si) {
           for (int c = 0; c < 3; ++c)
             for (int b = 0; b < g.nblocks; ++b) n[c] += h[((size_t)f * 3 + c) * g.nblocks + b] != 0;
         fprintf(stderr, "deferred to k3_ar_generic: %zu luma, %zu Cb, %zu Cr blocks of %u frames x %d blocks\n", n[0], n[1], n[2], B, g.nblocks);
+        // ... and what the wide lists hold: units, plain units, units off the plane's interior, flat blocks in them
+        for (int k = 0; k < (chroma ? 2 : 1); ++k) {
+          std::vector<uint32_t> cnt(2 * B), ent((size_t)B * w_ncell[k] * kWEntry);
+          (void)hipMemcpy(cnt.data(), sl.d_wu + w_off_count, cnt.size() * 4, hipMemcpyDeviceToHost);
+          (void)hipMemcpy(ent.data(), sl.d_wu + w_off_units[k], ent.size() * 4, hipMemcpyDeviceToHost);
+          size_t units = 0, plain = 0, border = 0, flat = 0, top = 0, runs = 0;
+          for (uint32_t f = 0; f < B; ++f)
+            for (uint32_t u = 0; u < cnt[2 * f + k]; ++u) {
+              const uint32_t *e = &ent[((size_t)f * w_ncell[k] + u) * kWEntry];
+              ++units, plain += (e[0] >> 24) & 1u, border += !((e[0] >> 25) & 1u), top += (e[0] >> 26) & 1u, runs += !((e[0] >> 22) & 1u);
+              flat += (size_t)__builtin_popcount(e[1]);
+            }
+          fprintf(stderr, "wide list %d: %zu units (%zu cells), %zu plain, %zu off the interior, %zu with a top halo, %zu runs, %zu flat blocks\n", k, units,
+                  (size_t)B * w_ncell[k], plain, border, top, runs, flat);
+        }
       }
     }
     kmark(sl, stream, "k3_ar_generic");

@@ -42,7 +42,8 @@ constexpr int kWUnitW = 128;       // samples a unit row
 constexpr int kWEntry = 8;         // dwords a list entry
 constexpr int kWStatY = 16;        // ints a luma unit's statistics record: per block sum d, sum d^2, sum src8; [12] deferral
 constexpr int kWStatC = 36;        // ints a chroma unit's: per block Cb sum d, sum d^2, Cr sum d, sum d^2; [32] deferral bits (1 Cb, 2 Cr)
-constexpr int kWMaxUnits = 100;    // units a workgroup: 100 units * 16 steps * 64 samples * 128^2 < 2^31 (32-row chroma planes: 32 steps, 50)
+constexpr int kWMaxUnits = 100;    // units a workgroup (luma launch): 100 units * 16 steps * 64 samples * 128^2 < 2^31
+constexpr int kWMaxUnitsC = 28;    // ... chroma launch: what fits beside four workgroups' tiles in a CU's LDS (32-row planes: 32 steps a unit, 50 at most)
 
 
 // entry: .x = c | by << 10 | aL << 22 | aR << 23 | plain << 24 | interior << 25 | top << 26;  .y = flat bits;  .z = grid index;
@@ -99,7 +100,6 @@ __host__ __device__ constexpr int w_lds_bytes(int KIND, int BH) { return (KIND =
 typedef int w_v4 __attribute__((ext_vector_type(4)));
 typedef uint32_t w_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t w_u2 __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(4))) w_u4 *w_cptr4;  // constant address space: uniform indices become scalar loads
 
 __device__ __forceinline__ uint32_t w_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
 
@@ -312,14 +312,16 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   __shared__ unsigned long long s_sum[4][NPL][UB];  // block statistics, one 64-bit LDS atomic a lane and iteration
   __shared__ uint32_t s_bad[4];                     // bit 0: a residual outside int8 somewhere in the unit's tile rows (plane 0); 1: in word 0; 2: in word 15; 3: L (luma launch)
                                                     // chroma: bits 4 .. 6 the same for plane 1
-  __shared__ uint4 s_up[17], s_dn[17];              // byte masks: s_up[k] = bytes < k, s_dn[k] = bytes >= k
+  // this workgroup's entries (the ghost's in front, three behind), parked once: a scalar load per iteration costs the launch more
+  // than everything else in the loop (an entry is a cache miss far away; profiles/r04b_elim.txt)
+  constexpr int MAXU = CHR ? kWMaxUnitsC : kWMaxUnits;
+  __shared__ uint4 s_ent[2 * (MAXU + 4)];
 
   const int G = wp.wgs, frame = g.frame0 + (int)blockIdx.x % wp.frames, wg = (int)blockIdx.x / wp.frames;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t cnt = wp.count[2 * frame];  // ([batch][2 kinds]: the pointer is this kind's)
   const uint32_t first = (uint32_t)((unsigned long long)cnt * (uint32_t)wg / (uint32_t)G);
   const int nmine = (int)((uint32_t)((unsigned long long)cnt * (uint32_t)(wg + 1) / (uint32_t)G) - first);
-  w_cptr4 ents = (w_cptr4)(uintptr_t)(wp.units + ((size_t)frame * wp.ncell + first) * kWEntry);
   int32_t *stats = wp.stats + (size_t)frame * wp.ncell * (CHR ? kWStatC : kWStatY);
   const FramePlanes fp = wp.ft.f[frame];
   constexpr int sxc = CHR ? SX : 0, syc = CHR ? SY : 0;
@@ -375,16 +377,9 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
 
   w_v4 aSS = {0, 0, 0, 0}, aPP = {0, 0, 0, 0}, aPQ = {0, 0, 0, 0}, aQQ = {0, 0, 0, 0};
 
-  if (tid < 17) {
-    uint32_t u[4], d[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = tid - 4 * j;
-      u[j] = k <= 0 ? 0u : (k >= 4 ? ~0u : (1u << (8 * k)) - 1u);
-      d[j] = ~u[j];
-    }
-    s_up[tid] = make_uint4(u[0], u[1], u[2], u[3]);
-    s_dn[tid] = make_uint4(d[0], d[1], d[2], d[3]);
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(wp.units + ((size_t)frame * wp.ncell + first) * kWEntry);
+    for (int i = tid; i < 2 * (nmine + 4); i += kWThreads) s_ent[i] = src[i - 2];  // (entry -1: the ghost in front; the engine keeps a pad in front of the first list)
   }
   if (tid < 4 * NPL * UB) (&s_sum[0][0][0])[tid] = 0ull;
   if (tid < 4) s_bad[tid] = 0u;
@@ -396,7 +391,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   uint32_t Dc[NOWN][2][2] = {}, Dn[NOWN][2][2] = {}, Dl[NOWN][2] = {};   // residual words: unit k, unit k + 1; last dwords of unit k - 1
   uint32_t Hc[2][2] = {}, Hn[2][2] = {}, Hl[2] = {};
 
-  auto entry_x = [&](int j) -> uint32_t { return ents[(ptrdiff_t)j * 2].x; };
+  auto entry_x = [&](int j) -> uint32_t { return __builtin_amdgcn_readfirstlane(s_ent[2 * (j + 1)].x); };
 
   // the raw words of the unit with entry word ex, into rs / rv (and hs / hv)
   auto load8 = [&](const uint8_t *base, uint32_t off) __attribute__((always_inline)) -> w_u4 {
@@ -655,12 +650,16 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   }
   __syncthreads();
 
-  // entries in SGPRs, loaded an iteration (two, for the unit to request) ahead of their use: entry k, .x of entries k + 1, k + 2
-  w_u4 ea = ents[0], eb = ents[1];
-  uint32_t x1 = entry_x(1), x2 = entry_x(2);
   for (int k = 0; k < nmine; ++k) {
-    const w_u4 na = ents[(ptrdiff_t)(k + 1) * 2], nb = ents[(ptrdiff_t)(k + 1) * 2 + 1];
-    const uint32_t x3 = entry_x(k + 3);
+    // the entry of unit k and the first words of the next two: LDS -> SGPRs
+    w_u4 ea, eb;
+    {
+      const uint4 ta = s_ent[2 * (k + 1)], tb = s_ent[2 * (k + 1) + 1];
+      ea.x = __builtin_amdgcn_readfirstlane(ta.x), ea.y = __builtin_amdgcn_readfirstlane(ta.y), ea.z = __builtin_amdgcn_readfirstlane(ta.z), ea.w = 0u;
+      eb.x = __builtin_amdgcn_readfirstlane(tb.x), eb.y = __builtin_amdgcn_readfirstlane(tb.y);
+      eb.z = UB > 4 ? __builtin_amdgcn_readfirstlane(tb.z) : 0u, eb.w = UB > 4 ? __builtin_amdgcn_readfirstlane(tb.w) : 0u;
+    }
+    const uint32_t x1 = entry_x(k + 1), x2 = entry_x(k + 2);
     const uint32_t ex = ea.x;
     const bool last = k + 1 == nmine;
     // ---- the next unit's residual words (its raw words have had an iteration to land); the unit after it is requested ----
@@ -723,8 +722,13 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
         for (int q = 1; q < (UB + 1) / 2; ++q) wd = (m_blk >> 1) == q ? wsel[q] : wd;
         const MWin mw = m_unpack((wd >> (16 * (m_blk & 1))) & 0xffffu, g.lag);
         const int lo = mw.go ? min(max(mw.xs - m_xo, 0), 16) : 0, hi = mw.go ? min(max(mw.xe - m_xo, 0), 16) : 0;
-        const uint4 mu4 = s_up[hi], md4 = s_dn[lo];
-        const w_v4 cm = {(int)(mu4.x & md4.x), (int)(mu4.y & md4.y), (int)(mu4.z & md4.z), (int)(mu4.w & md4.w)};
+        // bytes [lo, hi) of the lane's 16
+        w_v4 cm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int hj = min(max(hi - 4 * j, 0), 4), lj = min(max(lo - 4 * j, 0), 4);
+          cm[j] = (int)((uint32_t)((1ull << (8 * hj)) - 1ull) & ~(uint32_t)((1ull << (8 * lj)) - 1ull));
+        }
         constexpr uint32_t full = NSTEP >= 32 ? ~0u : (1u << NSTEP) - 1u;
         const uint32_t rm = mw.go ? (m_rowmask(mw.ys, mw.ye) >> m_row0) & full : 0u;
         // what the chain needs, wave-uniform: nothing (no window sample in its strip), the plain products (every lane's window
@@ -762,13 +766,6 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       s_bad[(k + 3) & 3] = 0u;  // (the slot of unit k - 2 = of unit k + 2: dead since the iteration before, written again in the next)
     }
     advance();
-    ea = na;
-    eb = nb;
-    x1 = x2;
-    x2 = x3;
-    // (opaque: the entries stay in their SGPRs -- reloading them where they are used would put a scalar-load latency in every
-    //  iteration's path)
-    asm volatile("" : "+s"(ea.x), "+s"(ea.y), "+s"(ea.z), "+s"(eb.x), "+s"(eb.y), "+s"(eb.z), "+s"(eb.w), "+s"(x1), "+s"(x2));
     if (!G1S_W_DBGBIT(32)) __syncthreads();
   }
 
