@@ -1066,7 +1066,7 @@ QParams g1s_diff::make_qparams(const Slot &sl) const {
 }
 
 // the wide chain serves: equal sample widths, every plane's rows 16-byte aligned, whole 8-sample words in every plane,
-// 4:2:0 or luma only (the other formats, unaligned planes and mixed depths run the stream chain)
+// (unaligned planes, odd widths and mixed depths run the stream chain)
 bool g1s_diff::wide_ok(const Geom &g) const {
   if (!use_wide()) return false;
   static const bool off = getenv("G1S_W_OFF") != nullptr;  // debugging aid
@@ -1075,7 +1075,6 @@ bool g1s_diff::wide_ok(const Geom &g) const {
   const int need = g.nplanes == 3 ? 0x3f : 0x09;
   if ((g.vec_mask & need) != need) return false;
   if ((g.W & 7) != 0 || (g.nplanes == 3 && ((g.W >> g.xdec) & 7) != 0)) return false;
-  if (g.nplanes == 3 && !(g.xdec == 1 && g.ydec == 1)) return false;
   if (g.nbw > 1023 * 4 || g.nbh > 4095) return false;
   return true;
 }
@@ -1154,21 +1153,32 @@ int g1s_diff::launch_back(int si) {
     set_kind(KIND);                                                                                                    \
     hipLaunchKernelGGL((k3w_pass<KIND, BP, SX, SY>), dim3((uint32_t)Gk[KIND] * B), dim3(kWThreads), lds_, stream, g, wq); \
   } while (0)
+#define G1S_WB(KIND, SX, SY)                   \
+  do {                                         \
+    if (g.src_bps == 2) G1S_W(KIND, 2, SX, SY); \
+    else G1S_W(KIND, 1, SX, SY);               \
+  } while (0)
+#define G1S_WK(KIND)                                 \
+  do {                                               \
+    if (g.xdec == 1 && g.ydec == 1) G1S_WB(KIND, 1, 1); \
+    else if (g.xdec == 1) G1S_WB(KIND, 1, 0);        \
+    else if (g.ydec == 1) G1S_WB(KIND, 0, 1);        \
+    else G1S_WB(KIND, 0, 0);                         \
+  } while (0)
     if (!chroma) {
-      if (g.src_bps == 2) G1S_W(0, 2, -1, -1);
-      else G1S_W(0, 1, -1, -1);
+      G1S_WB(0, -1, -1);
     } else {
-      if (g.src_bps == 2) G1S_W(0, 2, 1, 1);
-      else G1S_W(0, 1, 1, 1);
+      G1S_WK(0);
       static const bool chroma_aside = getenv("G1S_F_SERIAL") == nullptr;  // tuning aid
       if (side && chroma_aside) {  // the chroma launch and what follows: next to the luma launch of the batch after
         HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
         HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
         stream = ss.copy;
       }
-      if (g.src_bps == 2) G1S_W(1, 2, 1, 1);
-      else G1S_W(1, 1, 1, 1);
+      G1S_WK(1);
     }
+#undef G1S_WK
+#undef G1S_WB
 #undef G1S_W
     WFinishParams fpn;
     for (int k = 0; k < 2; ++k) {

@@ -520,6 +520,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
           if (SX == 0 && SY == 0) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) *reinterpret_cast<uint2 *>(lp + (size_t)r * wp.lpitch) = make_uint2(Dn[i][r][0], Dn[i][r][1]);
+            lacc = racc;  // (L is the residual itself: outside int8 exactly where the residual is)
           } else {
 #pragma unroll
             for (int r = 0; r < (SY ? 1 : 2); ++r) {
