@@ -407,7 +407,7 @@ struct g1s_diff {
   // the wide chain (k3w.hip.h): blocks a chroma unit, cells a block row / a frame per kind, L geometry, layout of Slot::d_wu
   int w_ub_c = 4, w_gx[2] = {0, 0}, w_ncell[2] = {0, 0};
   uint32_t w_lpitch = 0, w_lframe = 0;
-  size_t w_off_units[2] = {0, 0}, w_off_count = 0, w_off_stats[2] = {0, 0}, w_off_lbad = 0, w_lbad_bytes = 0, w_bytes = 0;
+  size_t w_off_units[2] = {0, 0}, w_off_count = 0, w_off_lbad = 0, w_lbad_bytes = 0, w_bytes = 0;
   bool wide_ok(const Geom &g) const;
   MParams make_mparams(const Slot &sl) const;
   SlotKey slot_key{};
@@ -619,8 +619,7 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
     w_off_units[1] = o, o += sizeof(uint32_t) * (size_t)batch * w_ncell[1] * kWEntry;
     w_off_count = o, o += sizeof(uint32_t) * 2 * (size_t)batch;
     o = (o + 15) & ~size_t(15);
-    w_off_stats[0] = o, o += sizeof(int32_t) * (size_t)batch * w_ncell[0] * kWStatY;
-    w_off_stats[1] = o, o += sizeof(int32_t) * (size_t)batch * w_ncell[1] * kWStatC;
+    o += 256;  // (a workgroup parks three entries past its slice)
     w_off_lbad = o, w_lbad_bytes = ((size_t)batch * w_ncell[0] + 15) & ~size_t(15), o += w_lbad_bytes;
     w_bytes = use_wide() ? o : 0;
   }
@@ -1119,7 +1118,10 @@ int g1s_diff::launch_back(int si) {
     const bool chroma = g.nplanes == 3;
     WParams wq;
     wq.ft = ft;
+    wq.records = sl.d_records;
     wq.partials = mp.partials;
+    wq.only = mp.only;
+    wq.only_any = mp.only_any;
     wq.lbad = sl.d_wu + w_off_lbad;
     wq.lplane = sl.d_lplane;
     wq.lpitch = w_lpitch;
@@ -1129,6 +1131,7 @@ int g1s_diff::launch_back(int si) {
     wq.frames = (int)B;
     static const int w_dbg = getenv("G1S_W_DBG") ? atoi(getenv("G1S_W_DBG")) : 0;  // timing experiments (a -DG1S_W_DBG_BUILD library)
     wq.dbg = w_dbg;
+    static const int w_rev = getenv("G1S_W_REV") ? atoi(getenv("G1S_W_REV")) : 0;  // tuning aid: bit 0 the luma launch, bit 1 the chroma launch walk the frames last to first
     int Gk[2] = {w_wgs_per_frame(w_ncell[0], (int)B, 0), w_wgs_per_frame(std::max(w_ncell[1], 1), (int)B, 1)};
     for (int k = 0; k < 2; ++k)
       if ((size_t)Gk[k] * B > m_wg_cap) Gk[k] = (int)(m_wg_cap / B) & ~7;  // (the environment changed after the slots were sized)
@@ -1137,7 +1140,6 @@ int g1s_diff::launch_back(int si) {
     auto set_kind = [&](int k) {
       wq.units = reinterpret_cast<const uint32_t *>(sl.d_wu + w_off_units[k]);
       wq.count = reinterpret_cast<const uint32_t *>(sl.d_wu + w_off_count) + k;  // (stride 2: see the kernel)
-      wq.stats = reinterpret_cast<int32_t *>(sl.d_wu + w_off_stats[k]);
       wq.ncell = w_ncell[k];
       wq.wgs = Gk[k];
     };
@@ -1151,6 +1153,7 @@ int g1s_diff::launch_back(int si) {
     snprintf(kn_, sizeof(kn_), "k3w_pass<%d, %d, %d, %d>", KIND, BP, SX, SY);                                          \
     kmark(sl, stream, kn_);                                                                                            \
     set_kind(KIND);                                                                                                    \
+    wq.rev = (w_rev >> KIND) & 1;                                                                                      \
     hipLaunchKernelGGL((k3w_pass<KIND, BP, SX, SY>), dim3((uint32_t)Gk[KIND] * B), dim3(kWThreads), lds_, stream, g, wq); \
   } while (0)
 #define G1S_WB(KIND, SX, SY)                   \
@@ -1180,22 +1183,6 @@ int g1s_diff::launch_back(int si) {
 #undef G1S_WK
 #undef G1S_WB
 #undef G1S_W
-    WFinishParams fpn;
-    for (int k = 0; k < 2; ++k) {
-      fpn.units[k] = reinterpret_cast<const uint32_t *>(sl.d_wu + w_off_units[k]);
-      fpn.stats[k] = reinterpret_cast<const int32_t *>(sl.d_wu + w_off_stats[k]);
-      fpn.ncell[k] = w_ncell[k];
-      fpn.G[k] = Gk[k];
-    }
-    fpn.ub[0] = 4;
-    fpn.ub[1] = w_ub_c;
-    fpn.count = reinterpret_cast<const uint32_t *>(sl.d_wu + w_off_count);
-    fpn.partials = mp.partials;
-    fpn.wg_cap = G_cap;
-    fpn.only = mp.only;
-    fpn.only_any = mp.only_any;
-    kmark(sl, stream, "k3w_finish");
-    hipLaunchKernelGGL(k3w_finish, dim3(kMFinishParts * g.nplanes + kWFinishWgs, B), dim3(256), 0, stream, g, fpn, sl.d_records);
     {
       // debugging aid (G1S_DBG_ONLY=1): how many flat blocks the accumulation launches left to the exact kernel
       static const bool count_only = getenv("G1S_DBG_ONLY") != nullptr;
@@ -1225,9 +1212,11 @@ int g1s_diff::launch_back(int si) {
         }
       }
     }
-    kmark(sl, stream, "k3_ar_generic");
-    hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
-                       sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
+    // (the record's block statistics and AR sums: k3_ar_generic adds to / overwrites what the launches and the reduction wrote,
+    //  and the exact kernel reads the frame number relative to the launch: frame0 is 0 here)
+    kmark(sl, stream, "k3w_tail");
+    hipLaunchKernelGGL(k3w_tail, dim3(kMFinishParts + std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
+                       sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any, (const long long *)mp.partials, G_cap, Gk[0], Gk[1]);
   } else if (use_mfma()) {
     // the fused pass: planes of the flat blocks' tiles -> residuals, block statistics, exact int8 SYRK on the matrix
     // cores, one partial system per workgroup; the reducer; then the exact int32 kernel for the few blocks next to a

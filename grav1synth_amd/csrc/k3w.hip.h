@@ -40,10 +40,8 @@ namespace g1s {
 constexpr int kWThreads = 256, kWWaves = 4;
 constexpr int kWUnitW = 128;       // samples a unit row
 constexpr int kWEntry = 8;         // dwords a list entry
-constexpr int kWStatY = 16;        // ints a luma unit's statistics record: per block sum d, sum d^2, sum src8; [12] deferral
-constexpr int kWStatC = 36;        // ints a chroma unit's: per block Cb sum d, sum d^2, Cr sum d, sum d^2; [32] deferral bits (1 Cb, 2 Cr)
 constexpr int kWMaxUnits = 100;    // units a workgroup (luma launch): 100 units * 16 steps * 64 samples * 128^2 < 2^31
-constexpr int kWMaxUnitsC = 28;    // ... chroma launch: what fits beside four workgroups' tiles in a CU's LDS (32-row planes: 32 steps a unit, 50 at most)
+constexpr int kWMaxUnitsC = 32;    // ... chroma launch: what fits beside four workgroups' tiles in a CU's LDS (32-row planes: 32 steps a unit, 50 at most)
 
 
 // entry: .x = c | by << 10 | aL << 22 | aR << 23 | plain << 24 | interior << 25 | top << 26;  .y = flat bits;  .z = grid index;
@@ -52,15 +50,18 @@ struct WParams {
   FrameTable ft;
   const uint32_t *units;    // [batch][ncell][kWEntry]  this launch's list (k3w_units), raster order
   const uint32_t *count;    // [batch]
-  long long *partials;      // [batch][wg_cap][3][kMRec]
-  int32_t *stats;           // [batch][ncell][kWStatY | kWStatC]  per-unit block statistics + deferral bits, by grid cell
+  uint8_t *records;         // [batch] x g.rec_size: the workgroups scatter the block statistics themselves
+  long long *partials;      // [batch][wg_cap][3][kMRec]  one partial system per workgroup and plane (k3w_tail sums them)
+  uint8_t *only;            // [batch][3][nblocks]  flat blocks left to the exact kernel (zeroed per batch)
+  uint32_t *only_any;       // [batch]
   uint8_t *lbad;            // [batch][ncell_y]  luma unit whose L left int8 (zeroed per batch); the chroma launch reads it
   uint8_t *lplane;          // [batch][lrows][lpitch]  L at chroma resolution, int8
   uint32_t lpitch, lframe_bytes;
   int ncell, ncell_y;       // grid cells a frame of this launch's kind / of the luma kind
   int gx_y;                 // luma cells a block row
   int frames, wgs, wg_cap;
-  int dbg;                  // timing experiments (G1S_W_DBG, builds with -DG1S_W_DBG_BUILD only): 1 no global loads, 2 no residual arithmetic, 4 no statistics / L, 8 no copy writes, 16 no multiplies, 32 no barriers in the loop; wrong results
+  int rev;                  // 1: the launch walks the batch's frames last to first (what the kernel before it touched last is read first)
+  int dbg;                  // timing experiments (G1S_W_DBG, builds with -DG1S_W_DBG_BUILD only): 1 no global loads, 2 no residual arithmetic, 4 no statistics / L, 8 no copy writes, 16 no multiplies, 32 no barriers in the loop, 64 no statistics stores, 128 no L loads; wrong results
 };
 #ifdef G1S_W_DBG_BUILD
 #define G1S_W_DBGBIT(bit) ((wp.dbg & (bit)) != 0)
@@ -317,12 +318,14 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   constexpr int MAXU = CHR ? kWMaxUnitsC : kWMaxUnits;
   __shared__ uint4 s_ent[2 * (MAXU + 4)];
 
-  const int G = wp.wgs, frame = g.frame0 + (int)blockIdx.x % wp.frames, wg = (int)blockIdx.x / wp.frames;
+  const int fi = (int)blockIdx.x % wp.frames;
+  const int G = wp.wgs, frame = g.frame0 + (wp.rev ? wp.frames - 1 - fi : fi), wg = (int)blockIdx.x / wp.frames;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t cnt = wp.count[2 * frame];  // ([batch][2 kinds]: the pointer is this kind's)
   const uint32_t first = (uint32_t)((unsigned long long)cnt * (uint32_t)wg / (uint32_t)G);
   const int nmine = (int)((uint32_t)((unsigned long long)cnt * (uint32_t)(wg + 1) / (uint32_t)G) - first);
-  int32_t *stats = wp.stats + (size_t)frame * wp.ncell * (CHR ? kWStatC : kWStatY);
+  uint8_t *rec = wp.records + (size_t)frame * g.rec_size;
+  uint32_t nobs_acc = 0;  // (statistics threads) observations of the blocks this workgroup multiplied (< 2^32: a slice holds at most kWMaxUnits units)
   const FramePlanes fp = wp.ft.f[frame];
   constexpr int sxc = CHR ? SX : 0, syc = CHR ? SY : 0;
   const int pw = g.W >> sxc, ph = g.H >> syc;
@@ -380,6 +383,23 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(wp.units + ((size_t)frame * wp.ncell + first) * kWEntry);
     for (int i = tid; i < 2 * (nmine + 4); i += kWThreads) s_ent[i] = src[i - 2];  // (entry -1: the ghost in front; the engine keeps a pad in front of the first list)
+  }
+  if constexpr (CHR) {
+    // "L left int8 in a luma unit under this unit" (the luma launch's flags), looked up once: a load in the loop would make the
+    // loop wait for everything in flight.  Parked in the entry's spare word.
+    __syncthreads();
+    if (tid < nmine) {
+      const uint32_t ex = s_ent[2 * (tid + 1)].x;
+      const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
+      constexpr int LPU = UB / 4;  // luma units under a chroma unit
+      uint32_t lb = 0;
+#pragma unroll
+      for (int q = 0; q < LPU; ++q) {
+        const int cy = c * LPU + q;
+        if (cy < wp.gx_y) lb |= wp.lbad[(size_t)frame * wp.ncell_y + (size_t)by * wp.gx_y + cy];
+      }
+      s_ent[2 * (tid + 1)].w = lb;
+    }
   }
   if (tid < 4 * NPL * UB) (&s_sum[0][0][0])[tid] = 0ull;
   if (tid < 4) s_bad[tid] = 0u;
@@ -460,6 +480,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   w_u2 Lc[CHR ? (BH / 16) : 1];
   (void)Lc;
   auto load_L = [&](uint32_t ex) __attribute__((always_inline)) {
+    if (G1S_W_DBGBIT(128)) return;
     if constexpr (CHR) {
       const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
       const uint8_t *lb = lframe + ((size_t)(by * BH) * wp.lpitch + (size_t)(c * kWUnitW));
@@ -493,6 +514,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       for (int r = 0; r < 2; ++r) {
         w_residual<BPS>(rs[i][r], rv[i][r], ssh, dsh, T[r], racc, ssum);
         w_pack<BPS>(T[r], Dn[i][r][0], Dn[i][r][1]);
+        __builtin_amdgcn_sched_barrier(0);  // (row by row: the scheduler would otherwise keep both rows' temporaries alive)
       }
       if (real && !G1S_W_DBGBIT(4)) {
         int sd = 0, sd2 = 0;
@@ -633,6 +655,45 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     }
   };
 
+  // the block statistics of unit j (sequence position) -> the frame's record (flat blocks); its deferred blocks -> the exact
+  // kernel's list; the observation count of the blocks that were multiplied.  Called right behind the loads of the iteration after
+  // the unit's own: global stores share the loads' counter, and a store issued late in an iteration makes the next wait for the
+  // raw words a wait for the store (measured: +130 us on the luma launch).
+  uint32_t defer_prev = 0;
+  auto stats_out = [&](int j, uint32_t dfr) __attribute__((always_inline)) {
+    if (G1S_W_DBGBIT(64)) return;
+    if (tid < NPL * UB) {
+      const int slot = (j + 1) & 3;
+      const int pl = tid / UB, b = tid - pl * UB;
+      const unsigned long long pk = s_sum[slot][pl][b];
+      s_sum[slot][pl][b] = 0ull;
+      const uint4 ta = s_ent[2 * (j + 1)];
+      if ((ta.y >> b) & 1u) {
+        const int c = (int)(ta.x & 0x3ffu), by = (int)((ta.x >> 10) & 0xfffu);
+        const int blk = by * g.nbw + c * UB + b, plane = CHR ? 1 + pl : 0;
+        const int samples = BW * BH;
+        if (!CHR) {
+          reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = (int)(pk & 0x7ffffu) - samples * 128;
+          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)(pk >> 37);
+          reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)((pk >> 19) & 0x3ffffu);
+        } else {
+          // (arithmetic, not an indexed read of the kernel arguments: that is a global load and a wait in the loop)
+          const uint32_t od = g.off_sum_d[1] + (uint32_t)pl * (g.off_sum_d[2] - g.off_sum_d[1]), od2 = g.off_sum_d2[1] + (uint32_t)pl * (g.off_sum_d2[2] - g.off_sum_d2[1]);
+          reinterpret_cast<int32_t *>(rec + od)[blk] = (int)(uint32_t)(pk & 0xffffffffu) - samples * 128;
+          reinterpret_cast<uint32_t *>(rec + od2)[blk] = (uint32_t)(pk >> 32);
+        }
+        if ((dfr >> pl) & 1u) {
+          wp.only[((size_t)frame * 3 + plane) * g.nblocks + blk] = 1;  // (rare)
+          wp.only_any[frame] = 1u;
+        } else {
+          const uint32_t wd = reinterpret_cast<const uint32_t *>(s_ent)[8 * (j + 1) + 4 + (b >> 1)];
+          const MWin mw = m_unpack((wd >> (16 * (b & 1))) & 0xffffu, g.lag);
+          if (mw.go) nobs_acc += (uint32_t)((mw.xe - mw.xs) * (mw.ye - mw.ys));
+        }
+      }
+    }
+  };
+
   // ---- prologue: the ghost in front of the slice (when the first unit has a left neighbour), unit 0 ----
   if (nmine > 0) {
     const uint32_t e0 = entry_x(0);
@@ -656,19 +717,18 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     w_u4 ea, eb;
     {
       const uint4 ta = s_ent[2 * (k + 1)], tb = s_ent[2 * (k + 1) + 1];
-      ea.x = __builtin_amdgcn_readfirstlane(ta.x), ea.y = __builtin_amdgcn_readfirstlane(ta.y), ea.z = __builtin_amdgcn_readfirstlane(ta.z), ea.w = 0u;
+      ea.x = __builtin_amdgcn_readfirstlane(ta.x), ea.y = __builtin_amdgcn_readfirstlane(ta.y), ea.z = __builtin_amdgcn_readfirstlane(ta.z), ea.w = CHR ? __builtin_amdgcn_readfirstlane(ta.w) : 0u;
       eb.x = __builtin_amdgcn_readfirstlane(tb.x), eb.y = __builtin_amdgcn_readfirstlane(tb.y);
       eb.z = UB > 4 ? __builtin_amdgcn_readfirstlane(tb.z) : 0u, eb.w = UB > 4 ? __builtin_amdgcn_readfirstlane(tb.w) : 0u;
     }
     const uint32_t x1 = entry_x(k + 1), x2 = entry_x(k + 2);
+    // (no explicit wait for the loads here: measured, profiles/r04d -- it costs the chroma launch 24 us: it also waits for the
+    //  block-statistics stores of the iteration before, which nothing needs)
     const uint32_t ex = ea.x;
     const bool last = k + 1 == nmine;
     // ---- the next unit's residual words (its raw words have had an iteration to land); the unit after it is requested ----
     if (!last || ((ex >> 23) & 1u)) {
       form(k + 1, x1, !last);
-      if (!last) {
-        if (k + 2 < nmine || ((x1 >> 23) & 1u)) request(x2);
-      }
     } else {
 #pragma unroll
       for (int i = 0; i < NOWN; ++i)
@@ -676,16 +736,22 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
         for (int r = 0; r < 2; ++r) Dn[i][r][0] = Dn[i][r][1] = 0u;
       Hn[0][0] = Hn[0][1] = Hn[1][0] = Hn[1][1] = 0u;
     }
-    // ---- this unit's copies -> the tile buffer (free since the barrier at the end of the iteration before) ----
-    write_copies(ex);
+    // (every wait for memory is behind us: what follows only issues -- the L tile of this unit into the buffer, the stores of the
+    //  unit before, the loads of the units ahead -- and nothing in the rest of the iteration waits for a load or a store)
     if constexpr (CHR) {
 #pragma unroll
       for (int q = 0; q < BH / 16; ++q) {
         const int row = 16 * q + (tid >> 4);
         *reinterpret_cast<uint2 *>(w_smem + SH::OFF_L + (row + 4) * kWUnitW + 8 * (tid & 15)) = make_uint2(Lc[q].x, Lc[q].y);
       }
-      if (!last) load_L(x1);  // (the next unit's, an iteration ahead)
     }
+    if (!last) load_L(x1);  // (the next unit's L tile, an iteration ahead)
+    if (!last && (k + 2 < nmine || ((x1 >> 23) & 1u))) request(x2);
+    // (the stores BEHIND the loads: the compiler guards the loads' destination registers with a wait that would take the stores
+    //  with it; the next wait for memory, form's in the next iteration, is a whole iteration away)
+    if (k > 0) stats_out(k - 1, defer_prev);
+    // ---- this unit's copies -> the tile buffer (free since the barrier at the end of the iteration before) ----
+    write_copies(ex);
     if (!G1S_W_DBGBIT(32)) __syncthreads();
     // ------------------------------- multiply unit k -------------------------------
     const int slot = (k + 1) & 3;
@@ -699,18 +765,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       if (CHR) defer |= (((b0 >> 4) & 1u) | (aL & (bl >> 6)) | (aR & (br >> 5))) << 1;
       if (LOUT) defer |= b0 & 8u;
     }
-    if constexpr (CHR) {
-      // L outside int8 in one of the luma units under this unit: both planes
-      const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
-      constexpr int LPU = UB / 4;  // luma units under a chroma unit
-      uint32_t lb = 0;
-#pragma unroll
-      for (int q = 0; q < LPU; ++q) {
-        const int cy = c * LPU + q;
-        if (cy < wp.gx_y) lb |= wp.lbad[(size_t)frame * wp.ncell_y + (size_t)by * wp.gx_y + cy];
-      }
-      if (__builtin_amdgcn_readfirstlane(lb)) defer |= 3u;
-    }
+    if (CHR && ea.w) defer |= 3u;  // L outside int8 in a luma unit under this unit: both planes
     const bool mine_deferred = ((defer >> (CHR ? s_plane : 0)) & 1u) != 0;
     if (!mine_deferred && !G1S_W_DBGBIT(16)) {
       if ((ex >> 24) & 1u) {
@@ -744,31 +799,15 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
         }
       }
     }
-    // ---- the unit's statistics record and deferral bits; the side data of the unit before it is zeroed ----
-    if (tid < NPL * UB) {
-      const int pl = tid / UB, b = tid - pl * UB;
-      const unsigned long long pk = s_sum[slot][pl][b];
-      s_sum[slot][pl][b] = 0ull;
-      int32_t *r = stats + (size_t)ea.z * (CHR ? kWStatC : kWStatY);
-      if (!CHR) {
-        const int samples = 32 * 32;
-        r[3 * b + 0] = (int)(pk & 0x7ffffu) - samples * 128;
-        r[3 * b + 1] = (int)(pk >> 37);
-        r[3 * b + 2] = (int)((pk >> 19) & 0x3ffffu);
-      } else {
-        const int samples = BW * BH;
-        r[4 * b + 2 * pl + 0] = (int)(uint32_t)(pk & 0xffffffffu) - samples * 128;
-        r[4 * b + 2 * pl + 1] = (int)(pk >> 32);
-      }
-    }
     if (tid == 64) {
-      stats[(size_t)ea.z * (CHR ? kWStatC : kWStatY) + (CHR ? 32 : 12)] = (int)defer;
       if (LOUT && (defer & 8u)) wp.lbad[(size_t)frame * wp.ncell_y + ea.z] = 1;
       s_bad[(k + 3) & 3] = 0u;  // (the slot of unit k - 2 = of unit k + 2: dead since the iteration before, written again in the next)
     }
     advance();
+    defer_prev = defer;
     if (!G1S_W_DBGBIT(32)) __syncthreads();
   }
+  if (nmine > 0) stats_out(nmine - 1, defer_prev);
 
   // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
   long long *s_S = reinterpret_cast<long long *>(w_smem);
@@ -803,108 +842,48 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     }
   }
   __syncthreads();
-  long long *outp = wp.partials + (((size_t)frame * wp.wg_cap + wg) * 3 + (CHR ? 1 : 0)) * kMRec;
-  for (int k = tid; k < NPL * kMRec; k += kWThreads) outp[k] = s_S[k];
+  // the partial systems: plain stores (k3w_tail sums a frame's; atomics into the record were measured: 32 workgroups adding to
+  // the same 41 lines cost the launch 70 us); the observation counts: one atomic per statistics thread
+  {
+    long long *outp = wp.partials + (((size_t)frame * wp.wg_cap + wg) * 3 + (CHR ? 1 : 0)) * kMRec;
+    for (int k = tid; k < NPL * kMRec; k += kWThreads) outp[k] = s_S[k];
+    const int nc0 = g.n + (CHR ? 1 : 0), ne = nc0 * nc0 + nc0;
+    if (tid < NPL * UB && nobs_acc != 0)
+      atomicAdd(reinterpret_cast<unsigned long long *>(rec + g.off_ar[CHR ? 1 + tid / UB : 0]) + ne, (unsigned long long)nobs_acc);
+  }
 }
 
 // ---------------------------------------------------------------------------------
-// k3w_finish: what the accumulation workgroups left behind -> the frame's record (as k3m_finish, for the wide lists).
-//   x < 3 * nplanes:  a third of the G partial systems of plane x / 3, summed;
-//   x >= 3 * nplanes: the lists' statistics records -> block statistics of the flat blocks, `only` flags of the deferred
-//                 ones, nobs of the blocks that were multiplied.
-// grid = (3 * nplanes + kWFinishWgs, batch), block = 256.
+// k3w_tail: the launch behind the accumulation launches.  x < kMFinishParts: a third of the G partial systems of plane y of the
+// frame, summed into its record; x >= kMFinishParts: the exact kernel (k3_ar_generic's body) on the blocks the launches deferred
+// -- on most frames none: it returns at once.  grid = (kMFinishParts + chunks, nplanes, batch), block = kK3Threads (256).
 // ---------------------------------------------------------------------------------
-constexpr int kWFinishWgs = 8;
-struct WFinishParams {
-  const uint32_t *units[2];
-  const uint32_t *count;     // [batch][2]
-  const int32_t *stats[2];
-  int ncell[2], ub[2];
-  const long long *partials;
-  int wg_cap, G[2];
-  uint8_t *only;             // [batch][3][nblocks]
-  uint32_t *only_any;        // [batch]
-};
-__global__ __launch_bounds__(256) void k3w_finish(Geom g, WFinishParams fp, uint8_t *__restrict__ records) {
-  const int frame = g.frame0 + (int)blockIdx.y;
-  uint8_t *rec = records + (size_t)frame * g.rec_size;
-  if ((int)blockIdx.x < kMFinishParts * g.nplanes) {
-    const int c = (int)blockIdx.x / kMFinishParts, nc = g.n + (c > 0);
-    const int k = ((int)blockIdx.x - c * kMFinishParts) * 256 + (int)threadIdx.x;
+static_assert(kK3Threads == 256, "k3w_tail: one entry per thread");
+__global__ __launch_bounds__(kK3Threads) void k3w_tail(const FrameTable ft, Geom g, uint8_t *__restrict__ records, const uint8_t *__restrict__ only,
+                                                       const uint32_t *__restrict__ only_any, const long long *__restrict__ partials, int wg_cap, int G_luma,
+                                                       int G_chroma) {
+  const int c = blockIdx.y, frame = g.frame0 + (int)blockIdx.z;
+  if ((int)blockIdx.x < kMFinishParts) {
+    const int nc = g.n + (c > 0), k = (int)blockIdx.x * 256 + (int)threadIdx.x;
     if (k >= nc * nc + nc) return;
-    long long *ar = reinterpret_cast<long long *>(rec + g.off_ar[c]);
-    const int G = c == 0 ? fp.G[0] : fp.G[1];
-    const long long *p = fp.partials + (size_t)frame * fp.wg_cap * 3 * kMRec + (size_t)c * kMRec + k;
+    long long *ar = reinterpret_cast<long long *>(records + (size_t)frame * g.rec_size + g.off_ar[c]);
+    const int G = c == 0 ? G_luma : G_chroma;
+    const long long *p = partials + (size_t)frame * wg_cap * 3 * kMRec + (size_t)c * kMRec + k;
     long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int w = 0;
-    for (; w + 4 <= G; w += 4) {
+    for (; w + 4 <= G; w += 4) {  // (independent loads in flight)
       s0 += p[(size_t)(w + 0) * 3 * kMRec];
       s1 += p[(size_t)(w + 1) * 3 * kMRec];
       s2 += p[(size_t)(w + 2) * 3 * kMRec];
       s3 += p[(size_t)(w + 3) * 3 * kMRec];
     }
     for (; w < G; ++w) s0 += p[(size_t)w * 3 * kMRec];
-    ar[k] += (s0 + s1) + (s2 + s3);
+    // (an atomic: the exact kernel's workgroups of this launch add to the same entries)
+    const long long tot = (s0 + s1) + (s2 + s3);
+    if (tot != 0) atomicAdd(reinterpret_cast<unsigned long long *>(ar) + k, (unsigned long long)tot);
     return;
   }
-  const int part = (int)blockIdx.x - kMFinishParts * g.nplanes;
-  long long nobs[3] = {0, 0, 0};
-  const int kinds = g.nplanes == 3 ? 2 : 1;
-  for (int kind = 0; kind < kinds; ++kind) {
-    const uint32_t cnt = fp.count[2 * frame + kind];
-    const int UB = fp.ub[kind], SI = kind ? kWStatC : kWStatY;
-    const uint32_t *units = fp.units[kind] + (size_t)frame * fp.ncell[kind] * kWEntry;
-    const int32_t *st = fp.stats[kind] + (size_t)frame * fp.ncell[kind] * SI;
-    for (uint32_t v = part * 256 + threadIdx.x; v < cnt; v += kWFinishWgs * 256) {
-      const uint4 ea = *reinterpret_cast<const uint4 *>(units + (size_t)v * kWEntry);
-      const uint4 eb = *reinterpret_cast<const uint4 *>(units + (size_t)v * kWEntry + 4);
-      const uint32_t wins[4] = {eb.x, eb.y, eb.z, eb.w};
-      const int c = (int)(ea.x & 0x3ffu), by = (int)((ea.x >> 10) & 0xfffu);
-      const int32_t *r = st + (size_t)ea.z * SI;
-      const uint32_t defer = (uint32_t)r[kind ? 32 : 12];
-      for (int b = 0; b < UB; ++b) {
-        if (!((ea.y >> b) & 1u)) continue;
-        const int blk = by * g.nbw + c * UB + b;
-        const MWin w = m_unpack((wins[b >> 1] >> (16 * (b & 1))) & 0xffffu, g.lag);
-        const long long area = w.go ? (long long)(w.xe - w.xs) * (w.ye - w.ys) : 0;
-        if (kind == 0) {
-          reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = r[3 * b + 0];
-          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)r[3 * b + 1];
-          reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)r[3 * b + 2];
-          if (defer & 1u) {
-            fp.only[((size_t)frame * 3 + 0) * g.nblocks + blk] = 1, fp.only_any[frame] = 1u;
-          } else {
-            nobs[0] += area;
-          }
-        } else {
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-            reinterpret_cast<int32_t *>(rec + g.off_sum_d[1 + pl])[blk] = r[4 * b + 2 * pl + 0];
-            reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1 + pl])[blk] = (uint32_t)r[4 * b + 2 * pl + 1];
-            if ((defer >> pl) & 1u) {
-              fp.only[((size_t)frame * 3 + 1 + pl) * g.nblocks + blk] = 1, fp.only_any[frame] = 1u;
-            } else {
-              nobs[1 + pl] += area;
-            }
-          }
-        }
-      }
-    }
-  }
-  __shared__ long long s_n[3][4];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) nobs[c] += __shfl_xor(nobs[c], o, 64);
-  if ((threadIdx.x & 63) == 0)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) s_n[c][threadIdx.x >> 6] = nobs[c];
-  __syncthreads();
-  if ((int)threadIdx.x < g.nplanes) {
-    const int c = threadIdx.x, nc = g.n + (c > 0);
-    const long long n = s_n[c][0] + s_n[c][1] + s_n[c][2] + s_n[c][3];
-    if (n) atomicAdd(reinterpret_cast<unsigned long long *>(rec + g.off_ar[c]) + (nc * nc + nc), (unsigned long long)n);
-  }
+  k3_ar_generic_body(ft, g, records, only, only_any, (int)blockIdx.x - kMFinishParts, (int)gridDim.x - kMFinishParts, c, (int)blockIdx.z);
 }
 
 }  // namespace g1s

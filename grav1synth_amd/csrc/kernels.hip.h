@@ -545,14 +545,12 @@ __device__ __forceinline__ int block_reduce_sum(int v, int *scratch) {
 // `only` (optional): per-frame block lists [batch][3][nblocks] (one per plane); when given, only the
 // blocks marked there are processed (the blocks the lag-3 fast kernel deferred
 // because |d| > 127), and frames with only_any[frame] == 0 exit at once.
-__global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FrameTable ft, Geom g,
-                                                            uint8_t *__restrict__ records,
-                                                            const uint8_t *__restrict__ only,
-                                                            const uint32_t *__restrict__ only_any) {
+// (the body: chunk bx of nbx of plane c of the frame; k3_ar_generic below and the wide chain's tail kernel, k3w.hip.h, call it)
+__device__ __forceinline__ void k3_ar_generic_body(const FrameTable ft, const Geom &g, uint8_t *__restrict__ records,
+                                                   const uint8_t *__restrict__ only, const uint32_t *__restrict__ only_any,
+                                                   int bx, int nbx, int c, int frame) {
   __shared__ int tile[kMaxTile + kBlock * kBlock];  // d tile, then luma-sum tile
   __shared__ int red[4];
-  const int c = blockIdx.y;
-  const int frame = blockIdx.z;
   if (only_any && only_any[frame] == 0) return;
   const uint8_t *only_f = only ? only + ((size_t)frame * 3 + c) * g.nblocks : nullptr;
   const FramePlanes fp = ft.f[frame];
@@ -613,7 +611,7 @@ __global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FrameTable ft,
   const uint8_t *sp = fp.src[c], *dp = fp.den[c];
   const uint32_t sst = fp.src_stride[c], dst = fp.den_stride[c];
 
-  for (int blk = blockIdx.x; blk < g.nblocks; blk += gridDim.x) {
+  for (int blk = bx; blk < g.nblocks; blk += nbx) {
     if (!mask[blk]) continue;
     if (only_f && !only_f[blk]) continue;
     const int bx = blk % g.nbw, by = blk / g.nbw;
@@ -689,6 +687,12 @@ __global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FrameTable ft,
   for (int s = 0; s < 2; ++s)
     if (have[s] && acc64[s] != 0) atomicAdd(&ar[out_idx[s]], (unsigned long long)acc64[s]);
   if (threadIdx.x == 0 && nobs != 0) atomicAdd(&ar[nc * nc + nc], (unsigned long long)nobs);
+}
+__global__ __launch_bounds__(kK3Threads) void k3_ar_generic(const FrameTable ft, Geom g,
+                                                            uint8_t *__restrict__ records,
+                                                            const uint8_t *__restrict__ only,
+                                                            const uint32_t *__restrict__ only_any) {
+  k3_ar_generic_body(ft, g, records, only, only_any, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 }  // namespace g1s
