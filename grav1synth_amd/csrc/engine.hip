@@ -1002,24 +1002,27 @@ int g1s_diff::launch_front(int si) {
     }
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
-  kmark(sl, fstream, "k2_flat_select");
-  if (!dbg_skip("k2")) hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
+  const bool w_lists = fast_ok && use_mfma() && wide_ok(g);  // the wide chain: the unit lists come out of the select kernel
+  WUnitParams wup{};
+  if (w_lists) {
+    for (int k = 0; k < 2; ++k) {
+      wup.units[k] = reinterpret_cast<uint32_t *>(sl.d_wu + w_off_units[k]);
+      wup.ncell[k] = w_ncell[k];
+      wup.gx[k] = w_gx[k];
+    }
+    wup.count = reinterpret_cast<uint32_t *>(sl.d_wu + w_off_count);
+    wup.ub[0] = 4;
+    wup.ub[1] = w_ub_c;
+  }
+  kmark(sl, fstream, w_lists ? "k2w_select_units" : "k2_flat_select");
+  if (w_lists) hipLaunchKernelGGL(k2w_select_units, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, (const uint8_t *)sl.d_flags, wup);
+  else if (!dbg_skip("k2")) hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
   if (fast_ok && use_mfma()) {
     // the unit lists (chunks with a flat block) need the flat mask
     const MParams mp = make_mparams(sl);
-    if (wide_ok(g)) {
-      WUnitParams up;
-      for (int k = 0; k < 2; ++k) {
-        up.units[k] = reinterpret_cast<uint32_t *>(sl.d_wu + w_off_units[k]);
-        up.ncell[k] = w_ncell[k];
-        up.gx[k] = w_gx[k];
-      }
-      up.count = reinterpret_cast<uint32_t *>(sl.d_wu + w_off_count);
-      up.ub[0] = 4;
-      up.ub[1] = w_ub_c;
-      kmark(sl, fstream, "k3w_units");
-      hipLaunchKernelGGL(k3w_units, dim3(2, B), dim3(1024), 0, fstream, g, (const uint8_t *)sl.d_records, up);
+    if (w_lists) {
+      // (k2w_select_units has built them)
     } else {
       kmark(sl, fstream, "k3m_units");
       hipLaunchKernelGGL(k3m_units, dim3((m_nunits + 255) / 256, B), dim3(256), 0, fstream, g, (const uint8_t *)sl.d_records, mp);

@@ -112,9 +112,8 @@ struct WUnitParams {
   uint32_t *count;      // [batch][2]
   int ncell[2], gx[2], ub[2];  // cells a frame, cells a block row, blocks a unit
 };
-__global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restrict__ records, WUnitParams up) {
-  const int kind = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;
-  if (kind == 1 && g.nplanes != 3) return;
+// (the body: the list of plane kind `kind` of the frame, by one workgroup of 1024 threads)
+__device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *__restrict__ records, const WUnitParams &up, int kind, int frame) {
   const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
   const int UB = up.ub[kind], gx = up.gx[kind], ncell = up.ncell[kind];
   const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
@@ -182,6 +181,26 @@ __global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restr
     __syncthreads();
   }
   if (threadIdx.x == 0) up.count[2 * frame + kind] = s_base;
+}
+__global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restrict__ records, WUnitParams up) {
+  const int kind = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;
+  if (kind == 1 && g.nplanes != 3) return;
+  w_build_units(g, records, up, kind, frame);
+}
+// k2w_select_units: k2_flat_select (the frame's threshold score, its mask bytes) and, behind it, the frame's unit lists: one launch
+// instead of two in the finder's chain.  grid = (batch), block = 1024 (= kK2Threads).
+static_assert(kK2Threads == 1024, "k2w_select_units: the list builder's workgroup");
+__global__ __launch_bounds__(1024) void k2w_select_units(Geom g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, WUnitParams up) {
+  const int frame = blockIdx.x;
+  k2_flat_select_body(g, records, flags, frame);
+  // (the mask bytes were written by this workgroup: a workgroup-scope fence and a barrier make them visible to its own loads)
+  __threadfence_block();
+  __syncthreads();
+  w_build_units(g, records, up, 0, frame);
+  if (g.nplanes == 3) {
+    __syncthreads();
+    w_build_units(g, records, up, 1, frame);
+  }
 }
 
 // ---------------------------------------------------------------------------------

@@ -450,10 +450,9 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
 // ----------------------------------------------------------------------------
 constexpr int kK2Threads = 1024;
 constexpr int kK2PerThread = 8;  // scores kept in registers: up to 8192 blocks (a 4K frame has 8160)
-__global__ __launch_bounds__(kK2Threads) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
-                                                             const uint8_t *__restrict__ flags) {
+// (the body: k2_flat_select below and the wide chain's k2w_select_units, k3w.hip.h, which builds the unit lists behind it)
+__device__ __forceinline__ void k2_flat_select_body(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame) {
   __shared__ uint32_t s_hist[256], s_wsum[4], s_sel[2];
-  const int frame = blockIdx.x;
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint32_t *sc = reinterpret_cast<const uint32_t *>(rec + g.off_scores);
   const int nb = g.nblocks;
@@ -516,6 +515,10 @@ __global__ __launch_bounds__(kK2Threads) void k2_flat_select(Geom g, uint8_t *__
   uint8_t *mask = rec + g.off_mask;
   const uint8_t *fl = flags + (size_t)frame * nb;
   for (int i = tid; i < nb; i += kK2Threads) mask[i] = fl[i] | (sc[i] >= thr ? 1 : 0);
+}
+__global__ __launch_bounds__(kK2Threads) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
+                                                             const uint8_t *__restrict__ flags) {
+  k2_flat_select_body(g, records, flags, (int)blockIdx.x);
 }
 
 // ----------------------------------------------------------------------------

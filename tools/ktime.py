@@ -18,6 +18,15 @@ nd = int(os.environ.get("DISTINCT", "64"))  # (distinct frame pairs: 64 = none s
 pairs = [make_pair(spec, k, device="cuda") for k in range(nd)]
 torch.cuda.synchronize()
 g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=B)
+try:
+    # one untimed batch first: the first launch of a kernel in a process loads its code object (milliseconds, on whichever
+    # kernel it lands)
+    for k in range(B):
+        s, d = pairs[k % nd]
+        g.diff_frame(s, d, xd, yd, sync_torch=False)
+    g.sync()
+except Exception as e:
+    print("error (ignored):", str(e)[:100], file=sys.stderr)
 g.set_timing(True)
 try:
     for k in range(nb * B):
