@@ -1073,7 +1073,7 @@ bool g1s_diff::wide_ok(const Geom &g) const {
   if (!use_wide()) return false;
   static const bool off = getenv("G1S_W_OFF") != nullptr;  // debugging aid
   if (off) return false;
-  if (g.src_bps != g.den_bps || g.lag < 1) return false;
+  if (g.src_bps != g.den_bps || g.src_shift != g.den_shift || g.src_shift > 4 || g.lag < 1) return false;
   const int need = g.nplanes == 3 ? 0x3f : 0x09;
   if ((g.vec_mask & need) != need) return false;
   if ((g.W & 7) != 0 || (g.nplanes == 3 && ((g.W >> g.xdec) & 7) != 0)) return false;
@@ -1134,6 +1134,8 @@ int g1s_diff::launch_back(int si) {
     wq.frames = (int)B;
     static const int w_dbg = getenv("G1S_W_DBG") ? atoi(getenv("G1S_W_DBG")) : 0;  // timing experiments (a -DG1S_W_DBG_BUILD library)
     wq.dbg = w_dbg;
+    static const int w_pf = getenv("G1S_W_PREFETCH") ? atoi(getenv("G1S_W_PREFETCH")) : 0;  // tuning aid (measured: +2 % on both launches, profiles/r04_prefetch.txt: off)
+    wq.prefetch = w_pf;
     static const int w_rev = getenv("G1S_W_REV") ? atoi(getenv("G1S_W_REV")) : 0;  // tuning aid: bit 0 the luma launch, bit 1 the chroma launch walk the frames last to first
     int Gk[2] = {w_wgs_per_frame(w_ncell[0], (int)B, 0), w_wgs_per_frame(std::max(w_ncell[1], 1), (int)B, 1)};
     for (int k = 0; k < 2; ++k)

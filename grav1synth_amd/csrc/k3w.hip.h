@@ -60,6 +60,7 @@ struct WParams {
   int ncell, ncell_y;       // grid cells a frame of this launch's kind / of the luma kind
   int gx_y;                 // luma cells a block row
   int frames, wgs, wg_cap;
+  int prefetch;             // 1: touch a unit's lines an iteration before its words are requested
   int rev;                  // 1: the launch walks the batch's frames last to first (what the kernel before it touched last is read first)
   int dbg;                  // timing experiments (G1S_W_DBG, builds with -DG1S_W_DBG_BUILD only): 1 no global loads, 2 no residual arithmetic, 4 no statistics / L, 8 no copy writes, 16 no multiplies, 32 no barriers in the loop, 64 no statistics stores, 128 no L loads; wrong results
 };
@@ -208,16 +209,19 @@ __global__ __launch_bounds__(1024) void k2w_select_units(Geom g, uint8_t *__rest
 //   BPS 2: T[q] = samples (2 q, 2 q + 1);  BPS 1: T[0] = (0, 2), T[1] = (1, 3), T[2] = (4, 6), T[3] = (5, 7).
 // acc |= every T (some d outside int8 <=> (acc & 0xff00ff00) != 0); ssum += the narrowed source halves.
 // ---------------------------------------------------------------------------------
+// BPS 2: both inputs are narrowed by the same shift sh <= 4 (the engine sends other pairs of depths down the stream chain), so
+// the eight bits are masked where they lie and the difference is shifted once: km = 0xff << sh in both halves, bm = 128 << sh;
+// ssum then holds the source halves times 2^sh.
 template <int BPS>
-__device__ __forceinline__ void w_residual(const w_u4 &s, const w_u4 &v, int ssh, int dsh, uint32_t (&T)[4], uint32_t &acc, uint32_t &ssum) {
+__device__ __forceinline__ void w_residual(const w_u4 &s, const w_u4 &v, int sh, uint32_t km, uint32_t bm, uint32_t (&T)[4], uint32_t &acc, uint32_t &ssum) {
   constexpr uint32_t K = 0x00ff00ffu, B = 0x00800080u;
   if (BPS == 2) {
     const uint32_t ws[4] = {s.x, s.y, s.z, s.w}, wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint32_t a = (ws[q] >> ssh) & K, b = (wv[q] >> dsh) & K;
+      const uint32_t a = ws[q] & km, b = wv[q] & km;
       ssum += a;
-      T[q] = (a + B) - b;
+      T[q] = ((a - b) + bm) >> sh;
       acc |= T[q];
     }
   } else {
@@ -348,7 +352,8 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   const FramePlanes fp = wp.ft.f[frame];
   constexpr int sxc = CHR ? SX : 0, syc = CHR ? SY : 0;
   const int pw = g.W >> sxc, ph = g.H >> syc;
-  const int ssh = g.src_shift, dsh = g.den_shift;
+  const int ssh = g.src_shift;  // (== g.den_shift, <= 4: wide_ok)
+  const uint32_t r_km = (0xffu << ssh) * 0x00010001u, r_bm = (128u << ssh) * 0x00010001u;
 
   // ---- this lane's staging work: pair p (two tile rows), word w ----
   const int p = lane >> 4, w = lane & 15;
@@ -495,6 +500,39 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       }
     }
   };
+  // Touch the lines of a unit one iteration before its words are requested (one dword a line, into a register nobody reads):
+  // the request then finds them in the L2 instead of waiting out an HBM round trip with one unit's worth of loads in flight.
+  // Interior units only; the lanes of words 0 and 8 (the two 128-byte lines of a row).  Inline assembly: the compiler's wait
+  // counts do not know these loads -- they can only make a wait longer, and they are an iteration old when one comes.
+  // (the register the touches land in is this one for the whole kernel: a load in flight owns its destination, and the compiler
+  //  does not know these loads are in flight)
+  uint32_t pf_sink = 0;
+  auto prefetch = [&](uint32_t ex) __attribute__((always_inline)) {
+    if (G1S_W_DBGBIT(256) || !wp.prefetch) return;
+    if (!((ex >> 25) & 1u)) return;
+    const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
+    const int X0 = c * kWUnitW, Y0 = by * BH - 4;
+    const uint8_t *sb = psrc + ((ptrdiff_t)Y0 * (ptrdiff_t)sst + (ptrdiff_t)(X0 * BPS));
+    const uint8_t *vb = pden + ((ptrdiff_t)Y0 * (ptrdiff_t)dst_ + (ptrdiff_t)(X0 * BPS));
+    if ((w & 7) == 0) {
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i) {
+        const uint8_t *s0 = sb + (size_t)(8 * i) * sst, *s1 = s0 + sst, *v0 = vb + (size_t)(8 * i) * dst_, *v1 = v0 + dst_;
+        asm volatile("global_load_dword %0, %1, %3\n\tglobal_load_dword %0, %1, %4\n\tglobal_load_dword %0, %2, %5\n\tglobal_load_dword %0, %2, %6"
+                     : "+v"(pf_sink)
+                     : "v"(lo_s), "v"(lo_v), "s"(s0), "s"(s1), "s"(v0), "s"(v1)
+                     : "memory");
+      }
+      if (h_wave && h_lane) {
+        const uint8_t *s0 = sb - (ptrdiff_t)(4 + own_row0) * (ptrdiff_t)sst, *s1 = s0 + sst;
+        const uint8_t *v0 = vb - (ptrdiff_t)(4 + own_row0) * (ptrdiff_t)dst_, *v1 = v0 + dst_;
+        asm volatile("global_load_dword %0, %1, %3\n\tglobal_load_dword %0, %1, %4\n\tglobal_load_dword %0, %2, %5\n\tglobal_load_dword %0, %2, %6"
+                     : "+v"(pf_sink)
+                     : "v"(lo_s), "v"(lo_v), "s"(s0), "s"(s1), "s"(v0), "s"(v1)
+                     : "memory");
+      }
+    }
+  };
   // chroma launch: this thread's words of the unit's L tile (BH rows of 128 bytes, one 8-byte word a thread and 16 rows)
   w_u2 Lc[CHR ? (BH / 16) : 1];
   (void)Lc;
@@ -531,7 +569,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       uint32_t T[2][4], ssum = 0;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        w_residual<BPS>(rs[i][r], rv[i][r], ssh, dsh, T[r], racc, ssum);
+        w_residual<BPS>(rs[i][r], rv[i][r], ssh, r_km, r_bm, T[r], racc, ssum);
         w_pack<BPS>(T[r], Dn[i][r][0], Dn[i][r][1]);
         __builtin_amdgcn_sched_barrier(0);  // (row by row: the scheduler would otherwise keep both rows' temporaries alive)
       }
@@ -546,7 +584,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
         }
         unsigned long long pk;
         if (!CHR) {
-          const uint32_t ls = (ssum & 0xffffu) + (ssum >> 16);
+          const uint32_t ls = ((ssum & 0xffffu) + (ssum >> 16)) >> (BPS == 2 ? ssh : 0);
           pk = ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)ls << 19) | (unsigned long long)(uint32_t)(sd + 16 * 128);
         } else {
           pk = ((unsigned long long)(uint32_t)sd2 << 32) | (unsigned long long)(uint32_t)(sd + 16 * 128);
@@ -608,7 +646,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       uint32_t T[4], dummy = 0;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        w_residual<BPS>(hs[r], hv[r], ssh, dsh, T, hacc, dummy);
+        w_residual<BPS>(hs[r], hv[r], ssh, r_km, r_bm, T, hacc, dummy);
         w_pack<BPS>(T, Hn[r][0], Hn[r][1]);
       }
     }
@@ -766,6 +804,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     }
     if (!last) load_L(x1);  // (the next unit's L tile, an iteration ahead)
     if (!last && (k + 2 < nmine || ((x1 >> 23) & 1u))) request(x2);
+    if (k + 3 < nmine) prefetch(entry_x(k + 3));
     // (the stores BEHIND the loads: the compiler guards the loads' destination registers with a wait that would take the stores
     //  with it; the next wait for memory, form's in the next iteration, is a whole iteration away)
     if (k > 0) stats_out(k - 1, defer_prev);
@@ -788,6 +827,18 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     const bool mine_deferred = ((defer >> (CHR ? s_plane : 0)) & 1u) != 0;
     if (!mine_deferred && !G1S_W_DBGBIT(16)) {
       if ((ex >> 24) & 1u) {
+        w_multiply<NSTEP, 0>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, w_v4{0, 0, 0, 0}, 0u);
+      } else if ([&]() {
+                   // the windows of this wave's strip (64 columns: 64 / BW blocks), in SGPRs: every one of them the whole block
+                   // -> the plain products, without building a mask
+                   constexpr int DPS = (64 / BW + 1) / 2;  // dwords of window codes a strip
+                   constexpr uint32_t whole1 = (uint32_t)BW | ((uint32_t)BH << 6) | (1u << 15), whole2 = whole1 | (whole1 << 16);
+                   const uint32_t wsel[4] = {eb.x, eb.y, eb.z, eb.w};
+                   bool all = true;
+#pragma unroll
+                   for (int q = 0; q < DPS; ++q) all = all && wsel[m_strip * DPS + q] == whole2;
+                   return all;
+                 }()) {
         w_multiply<NSTEP, 0>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, w_v4{0, 0, 0, 0}, 0u);
       } else {
         // this lane's window: block m_blk of the unit
@@ -828,6 +879,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   }
   if (nmine > 0) stats_out(nmine - 1, defer_prev);
 
+  asm volatile("" ::"v"(pf_sink));  // (live to here)
   // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
   long long *s_S = reinterpret_cast<long long *>(w_smem);
   for (int k = tid; k < NPL * kMRec; k += kWThreads) s_S[k] = 0;
