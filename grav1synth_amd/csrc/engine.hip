@@ -26,7 +26,6 @@
 #include "fold.h"
 #include "kernels.hip.h"
 #include "k1f.hip.h"
-#include "k3q.hip.h"
 #include "k3m.hip.h"
 #include "k3f.hip.h"
 #include "k3s.hip.h"
@@ -44,14 +43,14 @@ constexpr uint32_t kDefaultBatch = 32;
 constexpr int kK3Chunks = 48;
 
 // The AR accumulation is an exact int8 SYRK on the matrix cores.  G1S_K3 selects the chain:
-//   stream (default)  k3s.hip.h: the accumulation kernel reads the source / denoised planes of the flat blocks' tiles itself and
-//                     takes the block statistics on the way (no pixel pass but the finder's moments of the luma source, no
-//                     intermediate planes); 16x16x64 MFMAs on operand pairs, two tile buffers, a fast path for units in a run;
-//   fused             k3f.hip.h: round 2's form of the same pass (32x32x32 MFMAs, one tile buffer, two barriers a unit);
-//   planes            the pixel pass K0 (k0.hip.h: one streaming pass -> int8 residual and L planes, block statistics,
-//                     the finder's moments) runs first, k3f stages K0's planes (a copy);
-//   dot4              round 1's chain -- K0, then the lag-structured v_dot4 kernels (k3q.hip.h).
-// All four are bit-exact against each other and the oracle (tests/test_gpu_parity.py::test_accumulation_modes_agree).
+//   wide (default)    k3w.hip.h: 128-sample units, residuals in 32-bit SWAR, windows as masks on the A operand at multiply time,
+//                     entries parked in LDS, ghost units instead of halo loads; the launches scatter the block statistics
+//                     themselves, k3w_tail = the partial-system reduction + the exact kernel.  Serves aligned planes of equal depth;
+//   stream            k3s.hip.h: round 3's form of the same pass (two-block units, two tile buffers); what `wide` falls back on for
+//                     unaligned planes, widths that are not a multiple of 8 samples and mixed depths.
+// Both are bit-exact against the oracle; tests/test_gpu_selfcheck.py compares them with each other.  (Rounds 1 and 2's chains --
+// the lag-structured v_dot4 kernels behind the pixel pass K0, K0's planes in front of the matrix-core kernel, the 32x32x32 form
+// of the fused pass -- were removed in round 4: git history)
 // timing experiments: G1S_DBG_SKIP=name[,name...] leaves kernels out (wrong results; never set in tests or bench lines)
 bool dbg_skip(const char *name) {
   static const std::string v = getenv("G1S_DBG_SKIP") ? std::string(",") + getenv("G1S_DBG_SKIP") + "," : std::string();
@@ -60,19 +59,12 @@ bool dbg_skip(const char *name) {
 int k3_mode() {
   static const int v = [] {
     const char *e = getenv("G1S_K3");
-    if (e && std::strcmp(e, "dot4") == 0) return 0;
-    if (e && std::strcmp(e, "planes") == 0) return 2;
-    if (e && std::strcmp(e, "fused") == 0) return 1;
     if (e && std::strcmp(e, "stream") == 0) return 3;
     return 4;
   }();
   return v;
 }
-bool use_mfma() { return k3_mode() != 0; }
-bool use_k0() { return k3_mode() == 0 || k3_mode() == 2; }
-bool use_planes() { return k3_mode() == 2; }
-bool use_stream() { return k3_mode() >= 3; }  // k3s.hip.h: the second-generation fused pass (also what `wide` falls back on)
-bool use_wide() { return k3_mode() == 4; }    // k3w.hip.h: wide units (the default; formats it does not serve run the stream chain)
+bool use_wide() { return k3_mode() == 4;}
 constexpr int kMTargetWgs = 1024;  // accumulation workgroups per launch: 4 per CU, one round
 // workgroups per frame for a launch of B frames: enough to fill the chip, and few enough units each for int32.
 // kind 0: the luma launch, 1: the chroma launch.  The luma launch likes workgroups of ~64 units of the list (4 096 - 6 144
@@ -351,32 +343,6 @@ void release_streams(StreamSet &ss) {
   ss = StreamSet{};
 }
 
-// Workgroups of k3_lag<K, mixed> that are resident at once on the current device.
-int lag_resident_blocks(int K, bool mixed) {
-  static std::mutex m;
-  static int cache[64][4][2];  // [device][K][mixed], 0 = unknown
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> lk(m);
-  int &c = cache[dev & 63][K][mixed ? 1 : 0];
-  if (c == 0) {
-    int per_cu = 0, cus = 0;
-    hipError_t e = hipSuccess;
-#define G1S_OCC(KK)                                                                                                   \
-  e = mixed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_lag<KK, true>, 64 * kLagWaves, 0)         \
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_lag<KK, false>, 64 * kLagWaves, 0)
-    if (K == 0) G1S_OCC(0);
-    else if (K == 1) G1S_OCC(1);
-    else if (K == 2) G1S_OCC(2);
-    else G1S_OCC(3);
-#undef G1S_OCC
-    if (e != hipSuccess || per_cu < 1) per_cu = 2;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    c = per_cu * cus;
-  }
-  return c;
-}
-
 }  // namespace
 
 struct g1s_diff {
@@ -398,8 +364,6 @@ struct g1s_diff {
   FlatConsts fc{};
   double *d_lut = nullptr;
   size_t defer_bytes = 0;
-  PlaneSet ps{};
-  uint32_t pg_cap = 0;
   uint32_t m_lpitch = 0, m_lframe = 0;  // MFMA path: L plane geometry
   int m_nunits = 0;          // MFMA path: chunks per frame
   size_t m_wg_cap = 0;       // ... workgroups (partial systems) the slots hold
@@ -495,7 +459,6 @@ struct g1s_diff {
   int launch_back(int si);   // accumulation kernels, records D2H, hand-over to the drainer
   int flush_pending();
   Geom batch_geom(const Slot &sl) const;
-  QParams make_qparams(const Slot &sl) const;
   int drain_front(int si);  // drainer thread
   int drain_back(int si);   // folder thread
   void drainer_main();
@@ -576,28 +539,14 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
     frame_bytes += ((pw * s->bytes_per_sample + 15) & ~size_t(15)) * ph;
     frame_bytes += ((pw * d->bytes_per_sample + 15) & ~size_t(15)) * ph;
   }
-  size_t partial_bytes = 0, k0_bytes = 0, pgl_bytes = 0;
+  const size_t partial_bytes = 0, k0_bytes = 0, pgl_bytes = 0;  // (buffers of the chains removed in round 4: the slot key keeps its fields)
   defer_bytes = 0;
-  if (use_k0()) {
-    const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
-    // [cls][bad][lists u32 x6 per frame][counts]   (the matrix-core path: [cls][bad] only)
-    defer_bytes = 2 * cls_bytes;
-    ps = make_planeset(g);
-    k0_bytes = (size_t)ps.frame_bytes * batch;
-  }
-  if (!use_mfma()) {  // the lag-structured path serves every lag (1 and 2 through lag-3 tiles and a scratch lag-3 system)
-    partial_bytes = sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart + kAr3);
-    defer_bytes += sizeof(uint32_t) * ((size_t)batch * 6 * g.nblocks + (size_t)batch * 8);
-    pg_cap = (uint32_t)g.nblocks * 256u;
-    pgl_bytes = sizeof(uint32_t) * ((size_t)batch * 2 * pg_cap + (size_t)batch * 2);
-  }
   m_nunits = ((g.nbw + kMUnitBlocks - 1) / kMUnitBlocks) * g.nbh;
   m_only_bytes = ((size_t)g.nblocks * 3 * batch + 15) & ~size_t(15);
   // [units][unit counts][any-deferred flags][deferred-block flags]
   // ... [per-unit statistics records]
-  const size_t mu_bytes = !use_mfma() ? 0
-                                      : sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch) + m_only_bytes +
-                                            sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
+  const size_t mu_bytes = sizeof(uint32_t) * ((size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch) + m_only_bytes +
+                          sizeof(int32_t) * (size_t)batch * m_nunits * kMStatInts;
   // one partial system per accumulation workgroup and plane: the most workgroups a launch of 1 .. batch frames asks for
   m_wg_cap = 0;
   for (uint32_t b = 1; b <= batch; ++b)
@@ -626,8 +575,8 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
   if (use_wide())
     for (uint32_t b = 1; b <= batch; ++b)
       m_wg_cap = std::max(m_wg_cap, (size_t)b * std::max(w_wgs_per_frame(w_ncell[0], (int)b, 0), w_wgs_per_frame(std::max(w_ncell[1], 1), (int)b, 1)));
-  const size_t mpart_bytes2 = !use_mfma() ? 0 : sizeof(long long) * 3 * kMRec * m_wg_cap;
-  const size_t lplane_bytes = (k3_mode() == 1 || k3_mode() >= 3) ? (size_t)std::max(m_lframe, use_wide() ? w_lframe : 0u) * batch : 0;
+  const size_t mpart_bytes2 = sizeof(long long) * 3 * kMRec * m_wg_cap;
+  const size_t lplane_bytes = (size_t)std::max(m_lframe, use_wide() ? w_lframe : 0u) * batch;
   slot_key = SlotKey{device, sizeof(FramePlanes) * batch, L.size * batch, (size_t)g.nblocks * batch,
                      partial_bytes, defer_bytes, frame_bytes * batch, k0_bytes, pgl_bytes, mu_bytes + w_bytes, mpart_bytes2, lplane_bytes,
                      g.W, g.H, g.xdec, g.ydec, g.nplanes};
@@ -651,13 +600,6 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
     HIP_TRY(hipHostMalloc((void **)&sl.h_records, slot_key.records, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&sl.d_flags, slot_key.flags));
     HIP_TRY(hipMalloc((void **)&sl.d_k1, sizeof(int32_t) * ((size_t)g.nblocks * batch * (kMomInts + 1) + batch)));
-    if (partial_bytes) HIP_TRY(hipMalloc((void **)&sl.d_partials, partial_bytes));
-    if (defer_bytes) HIP_TRY(hipMalloc((void **)&sl.d_defer, defer_bytes));
-    if (k0_bytes) {
-      HIP_TRY(hipMalloc((void **)&sl.d_k0, k0_bytes));
-      HIP_TRY(hipMemset(sl.d_k0, 0, k0_bytes));  // the padding of the planes stays zero for good
-    }
-    if (pgl_bytes) HIP_TRY(hipMalloc((void **)&sl.d_pgl, pgl_bytes));
     if (mu_bytes) HIP_TRY(hipMalloc((void **)&sl.d_mu, mu_bytes));
     if (mpart_bytes2) HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes2));
     if (w_bytes) HIP_TRY(hipMalloc((void **)&sl.d_wu, w_bytes));
@@ -852,7 +794,7 @@ int g1s_diff::launch_front(int si) {
   // the pixel pass of round 1's chain (K0) runs on the main stream; the fused pass has no K0: its only pixel pass before
   // the mask is the finder's luma-source moments kernel, which joins the finder chain on the side stream and runs next to
   // the accumulation of the batch before
-  hipStream_t pstream = use_k0() ? stream : fstream;
+  hipStream_t pstream = fstream;
   // the frame table: pinned host copy -> device, on the upload stream (idle: done long before the main
   // stream gets here); per-kernel timing / one-stream mode: in line
   FrameTable ft;
@@ -873,27 +815,10 @@ int g1s_diff::launch_front(int si) {
     ZeroJob z{};
     z.ptr[0] = reinterpret_cast<uint32_t *>(sl.d_records);
     z.ndw[0] = (uint32_t)(L.size * B / 4);
-    if (use_mfma()) {
-      z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords;  // unit counts (2 lists), any-deferred flags
-      z.ndw[1] = 3 * (uint32_t)batch;
-      z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch;  // deferred-block flags
-      z.ndw[3] = (uint32_t)(m_only_bytes / 4);
-      if (use_k0()) {
-        const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
-        z.ptr[2] = reinterpret_cast<uint32_t *>(sl.d_defer + cls_bytes);  // K0's bad flags
-        z.ndw[2] = (uint32_t)(cls_bytes / 4);
-      }
-    } else {
-      const size_t cls_bytes = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
-      z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_partials);
-      z.ndw[1] = (uint32_t)(sizeof(long long) * (size_t)batch * 3 * (kQPart + kPPart + ((int)lag == kQLag ? 0 : kAr3)) / 4);
-      z.ptr[2] = reinterpret_cast<uint32_t *>(sl.d_defer + cls_bytes);  // bad flags
-      z.ndw[2] = (uint32_t)(cls_bytes / 4);
-      z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes) + (size_t)batch * 6 * g.nblocks;  // list counts
-      z.ndw[3] = (uint32_t)batch * 8;
-      z.ptr[4] = sl.d_pgl + (size_t)batch * 2 * pg_cap;  // partial-group list counts
-      z.ndw[4] = (uint32_t)batch * 2;
-    }
+    z.ptr[1] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords;  // unit counts (2 lists), any-deferred flags
+    z.ndw[1] = 3 * (uint32_t)batch;
+    z.ptr[3] = reinterpret_cast<uint32_t *>(sl.d_mu) + (size_t)batch * m_nunits * kMUnitDwords + 3 * (size_t)batch;  // deferred-block flags
+    z.ndw[3] = (uint32_t)(m_only_bytes / 4);
     if (use_wide() && sl.d_wu) {
       z.ptr[6] = reinterpret_cast<uint32_t *>(sl.d_wu + w_off_lbad);  // luma units whose L left int8
       z.ndw[6] = (uint32_t)(w_lbad_bytes / 4);
@@ -913,8 +838,6 @@ int g1s_diff::launch_front(int si) {
   sl.nk = 0;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], pstream));
   // (the fused pass serves every format; round 1's chain has no structured path for 4:4:0)
-  const bool fast_ok = use_mfma() || !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
-  const size_t cls_bytes_q = ((size_t)g.nblocks * 2 * batch + 15) & ~size_t(15);
   {
     // flat-block features: integer moments + certified evaluation; the literal f64 kernel only for
     // the blocks the certificate leaves open (G1S_K1_LITERAL=1 / g1s_diff_set_flat_finder: for every block)
@@ -926,7 +849,7 @@ int g1s_diff::launch_front(int si) {
     CertifyLists cl;
     cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
     cl.count = cl.list + (size_t)g.nblocks * batch;
-    if (!use_k0()) {
+    {
       // the finder's moments of the luma source: the only pass over pixels that are not in a flat block's tile
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
       if (!force_literal) {
@@ -937,43 +860,6 @@ int g1s_diff::launch_front(int si) {
         else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, pstream, ft, g, mom);
       }
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
-    } else if (fast_ok) {
-      // K0: one pass over the source / denoised planes -> int8 residual and L planes, block statistics and
-      // the finder's moments of the luma source (it needs nothing from the finder: it runs before it)
-      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
-      const dim3 gr(8 * ((((g.nbw + 3) / 4) * g.nbh + 7) / 8), 1, B);
-      uint8_t *badp = sl.d_defer + cls_bytes_q;
-#define G1S_K0P(SB, DB, P) \
-  hipLaunchKernelGGL((k0_residual<SB, DB, P>), gr, dim3(256), 0, pstream, ft, g, ps, sl.d_k0, badp, sl.d_records, \
-                     force_literal ? (int32_t *)nullptr : mom)
-#define G1S_K0(P)                                                  \
-  do {                                                             \
-    if (g.src_bps == 1 && g.den_bps == 1) G1S_K0P(1, 1, P);        \
-    else if (g.src_bps == 1) G1S_K0P(1, 2, P);                     \
-    else if (g.den_bps == 1) G1S_K0P(2, 1, P);                     \
-    else G1S_K0P(2, 2, P);                                         \
-  } while (0)
-      // With a side stream and chroma planes the pass runs as two launches, luma half first: the finder chain
-      // needs only that one and starts next to the chroma half (bandwidth bound) instead of spending its
-      // whole length next to the VALU-bound lag kernels.
-      static const bool k0_split_env = getenv("G1S_K0_ONE") == nullptr;  // tuning aid
-      kmark(sl, pstream, "k0_residual");
-      if (pstream != fstream && g.nplanes == 3 && k0_split_env) {
-        G1S_K0(1);
-        HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
-        pix_recorded = true;
-        G1S_K0(2);
-      } else {
-        G1S_K0(0);
-      }
-#undef G1S_K0
-#undef G1S_K0P
-      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
-      if (use_planes() && pstream != fstream) HIP_TRY(hipEventRecord(ss.k0_done[si], pstream));
-    } else if (!force_literal) {
-      const dim3 mg((g.nblocks + 7) / 8, B);
-      if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
-      else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, pstream, ft, g, mom);
     }
     if (pstream != fstream) {  // the finder chain: on the side stream, behind the pixel pass (its luma half)
       if (!pix_recorded) HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
@@ -1002,7 +888,7 @@ int g1s_diff::launch_front(int si) {
     }
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
-  const bool w_lists = fast_ok && use_mfma() && wide_ok(g);  // the wide chain: the unit lists come out of the select kernel
+  const bool w_lists = wide_ok(g);  // the wide chain: the unit lists come out of the select kernel
   WUnitParams wup{};
   if (w_lists) {
     for (int k = 0; k < 2; ++k) {
@@ -1018,53 +904,16 @@ int g1s_diff::launch_front(int si) {
   if (w_lists) hipLaunchKernelGGL(k2w_select_units, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, (const uint8_t *)sl.d_flags, wup);
   else if (!dbg_skip("k2")) hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
-  if (fast_ok && use_mfma()) {
-    // the unit lists (chunks with a flat block) need the flat mask
+  if (!w_lists) {
+    // the unit lists (chunks with a flat block) need the flat mask (the wide chain: k2w_select_units has built them)
     const MParams mp = make_mparams(sl);
-    if (w_lists) {
-      // (k2w_select_units has built them)
-    } else {
-      kmark(sl, fstream, "k3m_units");
-      hipLaunchKernelGGL(k3m_units, dim3((m_nunits + 255) / 256, B), dim3(256), 0, fstream, g, (const uint8_t *)sl.d_records, mp);
-    }
-  } else if (fast_ok) {
-    // the window bit planes and the area lists need the flat mask: small kernels after K2
-    const QParams qp = make_qparams(sl);
-    const int kinds = g.nplanes == 3 ? 2 : 1;
-    const uint32_t wdw = std::max(ps.wpitch[0], kinds == 2 ? ps.wpitch[1] : 0u) / 4;
-    kmark(sl, fstream, "k3_windows + k3_classify");
-    // one workgroup per block row and dword column: the kernel runs off the critical path, next to the lag kernels,
-    // so the fewest instructions win (measured: split 1 / 2 / 4 = +1.0 / +0.7 / 0 %)
-    constexpr int kWinSplit = 1;
-    hipLaunchKernelGGL(k3_windows, dim3((wdw + 63) / 64, kWinSplit * g.nbh, B * kinds), dim3(64), 0, fstream, g, ps, sl.d_k0,
-                       (const uint8_t *)sl.d_records, kWinSplit);
-    hipLaunchKernelGGL(k3_classify, dim3((g.nblocks + kClsThreads - 1) / kClsThreads, 1, B), dim3(kClsThreads), 0, fstream, g,
-                       (const uint8_t *)sl.d_records, qp);
+    kmark(sl, fstream, "k3m_units");
+    hipLaunchKernelGGL(k3m_units, dim3((m_nunits + 255) / 256, B), dim3(256), 0, fstream, g, (const uint8_t *)sl.d_records, mp);
   }
   kmark(sl, fstream, nullptr);
   if (fstream != stream) HIP_TRY(hipEventRecord(ss.mask_done[si], fstream));
   HIP_TRY(hipGetLastError());
   return G1S_OK;
-}
-
-QParams g1s_diff::make_qparams(const Slot &sl) const {
-  QParams qp;
-  static const bool force_generic = getenv("G1S_MIXED_GENERIC") != nullptr;  // debugging aid
-  qp.mixed_fast = force_generic ? 0 : 1;
-  qp.lagacc = reinterpret_cast<long long *>(sl.d_partials);
-  qp.paracc = qp.lagacc + (size_t)batch * 3 * kQPart;
-  qp.ar3 = (int)lag == kQLag ? nullptr : qp.paracc + (size_t)batch * 3 * kPPart;
-  const size_t cls_bytes = ((size_t)geom.nblocks * 2 * batch + 15) & ~size_t(15);
-  qp.cls = sl.d_defer;
-  qp.bad = sl.d_defer + cls_bytes;
-  qp.lists = reinterpret_cast<uint32_t *>(sl.d_defer + 2 * cls_bytes);
-  qp.counts = qp.lists + (size_t)batch * 6 * geom.nblocks;
-  qp.pg_cap = pg_cap;
-  qp.pglist = sl.d_pgl;
-  qp.pgcount = sl.d_pgl + (size_t)batch * 2 * pg_cap;
-  qp.planes = sl.d_k0;
-  qp.ps = ps;
-  return qp;
 }
 
 // the wide chain serves: equal sample widths, every plane's rows 16-byte aligned, whole 8-sample words in every plane,
@@ -1084,7 +933,7 @@ bool g1s_diff::wide_ok(const Geom &g) const {
 MParams g1s_diff::make_mparams(const Slot &sl) const {
   MParams mp;
   // (the fused pass finds the residuals outside int8 itself; K0 flags them per block)
-  mp.bad = use_planes() ? sl.d_defer + (((size_t)geom.nblocks * 2 * batch + 15) & ~size_t(15)) : nullptr;
+  mp.bad = nullptr;  // (no pixel pass flags residuals outside int8: the accumulation launches find them themselves)
   mp.units = reinterpret_cast<uint32_t *>(sl.d_mu);
   mp.unit_count = mp.units + (size_t)batch * m_nunits * kMUnitDwords;
   mp.only_any = mp.unit_count + 2 * batch;
@@ -1101,21 +950,11 @@ int g1s_diff::launch_back(int si) {
   static const bool one_stream = getenv("G1S_ONE_STREAM") != nullptr;  // debugging aid
   hipStream_t stream = ss.compute;
   const bool side = !(one_stream || sl.timed || !ss.flat);
-  // (K0 + planes: the whole accumulation goes to the copy stream, next to the pixel pass of the batch after -- one streams
-  //  through HBM, the other lives in LDS and the matrix cores)
-  static const bool acc_aside_env = getenv("G1S_F_MAIN") == nullptr;  // tuning aid
-  const bool acc_aside = side && use_planes() && acc_aside_env;
-  if (acc_aside) {
-    HIP_TRY(hipStreamWaitEvent(ss.copy, ss.mask_done[si], 0));
-    HIP_TRY(hipStreamWaitEvent(ss.copy, ss.k0_done[si], 0));
-    stream = ss.copy;
-  } else if (side) {
-    HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));  // the mask, the window planes, the area lists
-  }
+  const bool acc_aside = false;
+  if (side) HIP_TRY(hipStreamWaitEvent(stream, ss.mask_done[si], 0));  // the mask, the unit lists
   FrameTable ft;
   ft.f = reinterpret_cast<const FramePlanes *>(sl.d_planes);  // (uploaded by the front half)
-  const bool fast_ok = use_mfma() || !(g.nplanes == 3 && g.xdec == 0 && g.ydec == 1);
-  if (use_mfma() && wide_ok(g)) {
+  if (wide_ok(g)) {
     // the wide chain (k3w.hip.h): luma launch (leaves L behind), chroma launch, the reducer, the exact kernel for deferred blocks
     const MParams mp = make_mparams(sl);
     const bool chroma = g.nplanes == 3;
@@ -1222,7 +1061,7 @@ int g1s_diff::launch_back(int si) {
     kmark(sl, stream, "k3w_tail");
     hipLaunchKernelGGL(k3w_tail, dim3(kMFinishParts + std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                        sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any, (const long long *)mp.partials, G_cap, Gk[0], Gk[1]);
-  } else if (use_mfma()) {
+  } else {
     // the fused pass: planes of the flat blocks' tiles -> residuals, block statistics, exact int8 SYRK on the matrix
     // cores, one partial system per workgroup; the reducer; then the exact int32 kernel for the few blocks next to a
     // residual outside int8
@@ -1239,16 +1078,7 @@ int g1s_diff::launch_back(int si) {
       if ((size_t)Gk * B > m_wg_cap) Gk = m_wgs_per_frame(m_nunits, 1 << 20);  // (G1S_F_WGS raised after the slots were sized: the fewest that hold the units)
     const int G_cap = std::max(G_kind[0], G_kind[1]);
     int G = G_kind[0];
-    // profiling aid: G1S_F_PHASES=1 prints, per batch, the cycles the accumulation waves spent in each phase
-    // (G1S_F_PHASES=1: the luma launch, 2: the chroma launch)
-    static const int phases = getenv("G1S_F_PHASES") ? atoi(getenv("G1S_F_PHASES")) : 0;
-    static long long *d_phase = nullptr;
     fq.phase_cycles = nullptr;
-    long long *phase_buf = nullptr;
-    if (phases) {
-      if (!d_phase) (void)hipMalloc((void **)&d_phase, sizeof(long long) * 8 * kFWaves * 4096);
-      if ((size_t)G * B <= 4096) phase_buf = d_phase;
-    }
     const int cbw = g.nplanes == 3 ? (kBlock >> g.xdec) : 0, cbh = g.nplanes == 3 ? (kBlock >> g.ydec) : 0;
     fq.lplane = sl.d_lplane;
     fq.lpitch = m_lpitch;
@@ -1262,44 +1092,26 @@ int g1s_diff::launch_back(int si) {
     static const int deal_env = getenv("G1S_F_DEAL") ? atoi(getenv("G1S_F_DEAL")) : 1;  // tuning aid
     fq.deal = deal_env;
     { const char *e = getenv("G1S_F_REUSE"); fq.reuse = e ? atoi(e) : 1; }  // test / tuning aid (0: every halo word is read)
-    fq.planes = sl.d_k0;
-    fq.ps = ps;
     static const int s_dbg = getenv("G1S_S_DBG") ? atoi(getenv("G1S_S_DBG")) : 0;  // timing experiments: parts of k3s_fused left out (wrong results)
     fq.dbg = s_dbg;
-    const bool planes = use_planes(), stream_mode = use_stream();
     dim3 gr((uint32_t)G * B);
     const int bpsm = g.src_bps == g.den_bps ? g.src_bps : 0;  // bytes per sample at compile time unless the depths are mixed
     // two launches: the luma plane (which leaves L behind), then the two chroma planes
-#define G1S_F(CW, CH, BP, PL)                                                                                        \
+    // (the stream chain is what the wide chain falls back on -- unaligned planes, odd widths, mixed or deep bit depths: ONE
+    //  instantiation per format and launch, sample widths at run time)
+#define G1S_FS(CW, CH, PL)                                                                                           \
   do {                                                                                                               \
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, BP, PL>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
-    (void)attr_rc;                                                                                                   \
-    static const hipError_t attr_rp = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3f_fused<CW, CH, 1, PL, 1>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
-    (void)attr_rp;                                                                                                   \
-    static const hipError_t attr_rs = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3s_fused<CW, CH, BP, PL>), \
+    static const hipError_t attr_rs = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3s_fused<CW, CH, 0, PL>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   \
     (void)attr_rs;                                                                                                   \
-    const size_t lds = std::min((size_t)(stream_mode ? s_lds_bytes(CW, CH, PL) : f_lds_bytes(CW, CH, PL)) + lds_pad, \
-                                (size_t)144 * 1024);                                                                 \
+    const size_t lds = std::min((size_t)s_lds_bytes(CW, CH, PL) + lds_pad, (size_t)144 * 1024);                      \
     char kn_[64];                                                                                                    \
-    if (stream_mode) snprintf(kn_, sizeof(kn_), "k3s_fused<%d, %d, %d, %d>", CW, CH, BP, PL);                        \
-    else snprintf(kn_, sizeof(kn_), "k3f_fused<%d, %d, %d, %d, %d>", CW, CH, planes ? 1 : BP, PL, planes ? 1 : 0);   \
+    snprintf(kn_, sizeof(kn_), "k3s_fused<%d, %d, %d, %d>", CW, CH, 0, PL);                                          \
     kmark(sl, stream, kn_);                                                                                          \
     G = G_kind[PL ? 1 : 0];                                                                                          \
     fq.wgs = G;                                                                                                      \
     gr = dim3((uint32_t)G * B);                                                                                      \
-    fq.phase_cycles = phases == PL + 1 ? phase_buf : nullptr;                                                        \
-    if (stream_mode) hipLaunchKernelGGL((k3s_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);       \
-    else if (planes) hipLaunchKernelGGL((k3f_fused<CW, CH, 1, PL, 1>), gr, dim3(kFThreads), lds, stream, g, fq);     \
-    else hipLaunchKernelGGL((k3f_fused<CW, CH, BP, PL>), gr, dim3(kFThreads), lds, stream, g, fq);                   \
-  } while (0)
-#define G1S_FS(CW, CH, PL)                 \
-  do {                                     \
-    if (bpsm == 2) G1S_F(CW, CH, 2, PL);   \
-    else if (bpsm == 1) G1S_F(CW, CH, 1, PL); \
-    else G1S_F(CW, CH, 0, PL);             \
+    hipLaunchKernelGGL((k3s_fused<CW, CH, 0, PL>), gr, dim3(kFThreads), lds, stream, g, fq);                         \
   } while (0)
     // (the chroma launch, the finisher and what follows go to the copy stream -- next to the luma launch of the batch after)
     static const bool chroma_aside = getenv("G1S_F_SERIAL") == nullptr;  // tuning aid
@@ -1313,43 +1125,16 @@ int g1s_diff::launch_back(int si) {
     }                                                                     \
     G1S_FS(CW, CH, 1);                                                    \
   } while (0)
-    // (G1S_F_SPLIT444=1, 4:4:4: one chroma plane a launch -- PL = 2, 3 -- three workgroups to a CU instead of the two that
-    //  two planes' 70 KB of tiles leave room for.  Measured at 8K: 3 015 + 2 553 us against 5 045 for the two-plane launch, which
-    //  shares the L tile and the loop between its planes: off by default, kept for the record and under test)
-    static const bool split444 = getenv("G1S_F_SPLIT444") ? atoi(getenv("G1S_F_SPLIT444")) != 0 : false;
     if (cbw == 0) G1S_FS(0, 0, 0);
     else if (cbw == 16 && cbh == 16) G1S_FP(16, 16);
     else if (cbw == 16) G1S_FP(16, 32);
-    else if (cbh == 32 && stream_mode && split444) {
-      G1S_FS(32, 32, 0);
-      if (side && chroma_aside && !acc_aside) {
-        HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
-        HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
-        stream = ss.copy;
-      }
-      G1S_FS(32, 32, 2);
-      G1S_FS(32, 32, 3);
-    } else if (cbh == 32) G1S_FP(32, 32);
+    else if (cbh == 32) G1S_FP(32, 32);
     else G1S_FP(32, 16);
 #undef G1S_FP
 #undef G1S_FS
-#undef G1S_F
     kmark(sl, stream, "k3m_finish");
     if (!dbg_skip("finish")) hipLaunchKernelGGL(k3m_finish, dim3(kMFinishParts * g.nplanes + kMFinishWgs, B), dim3(256), 0, stream, g, mp, G_kind[0], G_kind[1], G_cap,
-                       planes ? (const int32_t *)nullptr : (const int32_t *)fq.ustats, sl.d_records);
-    if (phase_buf) {
-      std::vector<long long> hc((size_t)G * B * kFWaves * 8);
-      (void)hipStreamSynchronize(stream);
-      (void)hipMemcpy(hc.data(), d_phase, hc.size() * sizeof(long long), hipMemcpyDeviceToHost);
-      double tot[kFWaves][8] = {};
-      for (size_t w = 0; w < (size_t)G * B; ++w)
-        for (int v = 0; v < kFWaves; ++v)
-          for (int k = 0; k < 8; ++k) tot[v][k] += (double)hc[(w * kFWaves + v) * 8 + k];
-      for (int v = 0; v < kFWaves; ++v)
-        fprintf(stderr, "k3f phases (%s launch), wave %d: copies %.0f  barrier 2 %.0f  multiply %.0f  wait for words %.0f  residuals %.0f  requests %.0f  stores %.0f  barrier 1 %.0f  (mean cycles per workgroup)\n",
-                phases == 1 ? "luma" : "chroma", v, tot[v][0] / (G * B), tot[v][1] / (G * B), tot[v][2] / (G * B), tot[v][4] / (G * B), tot[v][5] / (G * B), tot[v][6] / (G * B),
-                tot[v][7] / (G * B), tot[v][3] / (G * B));
-    }
+                       (const int32_t *)fq.ustats, sl.d_records);
     {
       // debugging aid (G1S_DBG_ONLY=1): how many flat blocks the accumulation launches left to the exact kernel
       static const bool count_only = getenv("G1S_DBG_ONLY") != nullptr;
@@ -1368,81 +1153,6 @@ int g1s_diff::launch_back(int si) {
     if (!dbg_skip("generic"))
       hipLaunchKernelGGL(k3_ar_generic, dim3(std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                          sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any);
-  } else if (fast_ok) {
-    // lag 3: classify block areas, 46-lag dot4 kernel on interior areas, chunk reducer,
-    // then the generic int32 kernel on mixed / deferred areas
-    const QParams qp = make_qparams(sl);
-    const uint32_t Bs = B;
-    kmark(sl, stream, "k3_lag + k3_partial_dense + k3q_reduce + k3q_generic");
-    const int ck = g.nplanes != 3 ? 0 : ((g.xdec == 1 && g.ydec == 1) ? 1 : (g.xdec == 1 ? 2 : 3));
-    // One round of workgroups: as many per frame as stay resident together (occupancy x CUs / batch,
-    // a multiple of 8 for the XCD-aware list slices), but never more than 128 areas each (int32 sums).
-    auto launch_lag = [&](int K, bool mixed, hipStream_t st) {
-      const int resident = lag_resident_blocks(K, mixed);
-      static const int lag_div = getenv("G1S_LAG_DIV") ? std::max(1, atoi(getenv("G1S_LAG_DIV"))) : 1;  // tuning aid
-      // (measured: the INT kernels are better off with half a round of longer-lived waves)
-      // (measured: the row-major INT kernels (chroma) are better off with half a round of longer-lived waves)
-      static const int lag_round = getenv("G1S_LAG_ROUND") ? std::max(1, atoi(getenv("G1S_LAG_ROUND"))) : 1;  // tuning aid
-      const int half = (!mixed && K != 0) ? 2 : 1;
-      int chunks = std::max(8, (resident * lag_round / (lag_div * half) / (int)Bs) & ~7);
-      // int32 sums: <= 128 areas per list slice; a workgroup walks 4 slices (chroma: 2, two waves to a slice)
-      const int slices_per_wg = K ? 2 : 4;
-      // (measured: the chroma MIX kernel wants twice the minimum: shorter slices, more waves in flight)
-      const int per_wg = 128 * slices_per_wg / ((K != 0 && mixed) ? 2 : 1);
-      chunks = std::max(chunks, ((g.nblocks + per_wg - 1) / per_wg + 7) & ~7);
-      const dim3 gr(chunks, 1, Bs);
-#define G1S_LAG(KK)                                                                                  \
-  if (mixed)                                                                                         \
-    hipLaunchKernelGGL((k3_lag<KK, true>), gr, dim3(64 * kLagWaves), 0, st, g, qp);              \
-  else                                                                                               \
-    hipLaunchKernelGGL((k3_lag<KK, false>), gr, dim3(64 * kLagWaves), 0, st, g, qp);
-      if (K == 0) { G1S_LAG(0) }
-      else if (K == 1) { G1S_LAG(1) }
-      else if (K == 2) { G1S_LAG(2) }
-      else { G1S_LAG(3) }
-#undef G1S_LAG
-    };
-    launch_lag(0, false, stream);
-    if (ck) launch_lag(ck, false, stream);
-    // The tail of the accumulation -- the partial-group kernel, the reducer, the generic kernel (G1S_TAIL=2:
-    // the MIX lag kernels as well) -- runs on the copy stream, i.e. next to the pixel pass of the batch after
-    // next: its gathers and LDS traffic mix well with K0's streaming, unlike the dot4-bound lag kernels.
-    static const int tail_env = getenv("G1S_TAIL") ? atoi(getenv("G1S_TAIL")) : 1;  // tuning aid
-    const int tail = side ? tail_env : 0;
-    auto to_tail = [&]() -> int {
-      HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
-      HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
-      stream = ss.copy;
-      return G1S_OK;
-    };
-    if (tail == 2) {
-      const int rc = to_tail();
-      if (rc) return rc;
-    }
-    if (qp.mixed_fast) {
-      launch_lag(0, true, stream);
-      if (ck) launch_lag(ck, true, stream);
-    }
-    if (tail == 1) {
-      const int rc = to_tail();
-      if (rc) return rc;
-    }
-    if (qp.mixed_fast) {
-      // <= pg_cap / (chunks * 256) = nblocks / chunks steps per lane; the int32 wave sums need < 520
-      static const int dense_env = getenv("G1S_DENSE_CHUNKS") ? atoi(getenv("G1S_DENSE_CHUNKS")) : 0;  // tuning aid
-      int chunks = std::max(std::max(8, std::min(16, g.nblocks / 512)), (g.nblocks + 511) / 512);
-      if (dense_env > 0) chunks = std::max(dense_env, (g.nblocks + 511) / 512);
-      hipLaunchKernelGGL(k3_partial_dense, dim3(chunks, Bs * g.nplanes), dim3(256), 0, stream, g, qp);
-    }
-    hipLaunchKernelGGL(k3q_reduce, dim3(g.nplanes, Bs), dim3(256), 0, stream, g, qp, sl.d_records);
-    const int chunks = std::min(64, g.nblocks);
-    hipLaunchKernelGGL(k3q_generic, dim3(chunks, g.nplanes, Bs), dim3(256), 0, stream, ft, g, qp, sl.d_records);
-    if (qp.ar3) hipLaunchKernelGGL(k3q_compact, dim3(g.nplanes, Bs), dim3(256), 0, stream, g, qp, sl.d_records);
-  } else {
-    const int chunks = std::min(kK3Chunks, g.nblocks);
-    kmark(sl, stream, "k3_ar_generic");
-    hipLaunchKernelGGL(k3_ar_generic, dim3(chunks, g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g, sl.d_records,
-                       (const uint8_t *)nullptr, (const uint32_t *)nullptr);
   }
   kmark(sl, stream, nullptr);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[3], stream));
@@ -1582,22 +1292,15 @@ int g1s_diff::drain_front(int si) {
   HIP_TRY(hipEventSynchronize(sl.done));
   if (sl.timed) {
     float ms = 0;
-    const bool k0_timed = use_mfma() || !(geom.nplanes == 3 && geom.xdec == 0 && geom.ydec == 1);
-    float ms_k0 = 0;  // round 1's chain: K0 (counted with the accumulation); fused pass: the finder's moments pass
-    if (k0_timed) HIP_TRY(hipEventElapsedTime(&ms_k0, sl.ev[5], sl.ev[4]));
+    float ms_mom = 0;  // the finder's moments pass
+    HIP_TRY(hipEventElapsedTime(&ms_mom, sl.ev[5], sl.ev[4]));
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]));
-    if (!use_k0()) {
-      stats.ms_flat_features += ms;
-      stats.ms_residual += ms_k0;
-      ms_k0 = 0;
-    } else {
-      stats.ms_flat_features += ms - ms_k0;  // (K0 sits between the finder's launches)
-    }
+    stats.ms_flat_features += ms;
+    stats.ms_residual += ms_mom;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
     stats.ms_flat_select += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]));
-    stats.ms_ar_accumulate += ms + ms_k0;
-    if (use_k0()) stats.ms_residual += ms_k0;
+    stats.ms_ar_accumulate += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
     stats.ms_total_gpu += ms;
     {

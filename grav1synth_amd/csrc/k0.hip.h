@@ -1,27 +1,7 @@
-// k0.hip.h -- K0: the one streaming pass over the source and denoised planes.
-//
-// Everything pixel-sized that the AR accumulation (K3, lag 3) needs is a function of
-//     d(q) = src8(q) - den8(q),   src8 = (v >> (bd - 8)) as u8   (av1-grain util.rs frame_into_u8)
-// so K0 reads the 8/16-bit planes ONCE (coalesced, vector loads) and leaves compact int8
-// planes behind for the many overlapping tile reads of K3:
-//     d8[c]   residual of component c, as int8 (a block with some |d| > 127 is flagged
-//             `bad` and its areas go to the exact int32 kernel instead);
-//     L8      chroma-resolution sum of the co-located luma residuals (the extra chroma
-//             regressor of add_block_observations before its division), int8, flagged likewise;
-//     w1[k]   one BIT per sample: it lies in the observation window of its (flat) block,
-//             per plane kind k (luma, chroma);
-// plus the per-block noise statistics (get_block_mean / get_noise_var: exact integer sums of src8,
-// d, d^2; the fold reads those of the flat blocks) straight into the frame record, and the fourteen
-// integer moments of every full 32x32 luma source block for the flat-block finder (k1f.hip.h).
-// K0 needs nothing from the flat-block finder, so it runs BEFORE it; the window bits, which need the
-// flat mask, are written by k3_windows afterwards.
-//
-// Plane layout (one frame): sample (x, y) of a d8 plane at byte
-//     (y + kPadY) * pitch + kPadX + x,     pitch = nbw * bw + 16,  rows = nbh * bh + 2 * kPadY
-// and its window bit at bit (kPadX + x) of bit row (y + kPadY), wpitch = pitch / 8 bytes per bit row,
-// so that the K3 tile of block area (bx, by), x in -8 .. bw+7, starts at the 16-byte aligned
-// byte bx * bw of its rows; the padding is zeroed once and never written.  L8 has no halo:
-// sample (x, y) at byte y * lpitch + x, lpitch = nbw * bw.
+// k0.hip.h -- shared helpers of the pixel kernels: packed 16-bit arithmetic, the block-window rule of
+// add_block_observations, the flat-block finder's row moments (k1f.hip.h), the per-batch zero fill.
+// (The streaming pixel pass K0 of rounds 1 and 2 -- int8 residual / L / window-bit planes in front of the accumulation -- and
+// its window kernel were removed in round 4; the name of the file stayed.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,46 +12,6 @@ namespace g1s {
 
 constexpr int kQLag = 3;
 constexpr int kPadX = 8, kPadY = 3;
-
-struct PlaneSet {
-  uint32_t pitch[2];   // d8 row pitch per kind (0 luma, 1 chroma)
-  uint32_t wpitch[2];  // w1 bit-row pitch in bytes (a multiple of 4)
-  uint32_t lpitch;     // L8 row pitch
-  uint32_t off_d[3];   // byte offsets inside one frame's plane set
-  uint32_t off_w[2];
-  uint32_t off_l;
-  uint32_t frame_bytes;
-};
-
-inline PlaneSet make_planeset(const Geom &g) {
-  PlaneSet ps{};
-  uint32_t off = 0;
-  auto take = [&](uint32_t bytes) {
-    const uint32_t o = off;
-    off += (bytes + 255u) & ~255u;
-    return o;
-  };
-  const int kinds = g.nplanes == 3 ? 2 : 1;
-  uint32_t plane_bytes[2] = {0, 0}, wplane_bytes[2] = {0, 0};
-  for (int k = 0; k < kinds; ++k) {
-    const int bw = kBlock >> (k ? g.xdec : 0), bh = kBlock >> (k ? g.ydec : 0);
-    ps.pitch[k] = (uint32_t)(g.nbw * bw + 16);
-    plane_bytes[k] = ps.pitch[k] * (uint32_t)(g.nbh * bh + 2 * kPadY) + 16;
-    ps.wpitch[k] = ((ps.pitch[k] >> 3) + 3u) & ~3u;
-    wplane_bytes[k] = ps.wpitch[k] * (uint32_t)(g.nbh * bh + 2 * kPadY) + 16;
-  }
-  ps.off_d[0] = take(plane_bytes[0]);
-  ps.off_w[0] = take(wplane_bytes[0]);
-  if (kinds == 2) {
-    ps.off_d[1] = take(plane_bytes[1]);
-    ps.off_d[2] = take(plane_bytes[1]);
-    ps.off_w[1] = take(wplane_bytes[1]);
-    ps.lpitch = (uint32_t)(g.nbw * (kBlock >> g.xdec));
-    ps.off_l = take(ps.lpitch * (uint32_t)(g.nbh * (kBlock >> g.ydec)) + 16);
-  }
-  ps.frame_bytes = off;
-  return ps;
-}
 
 // full-wave integer sum, all in the VALU (DPP): quad swaps, half-row / row mirrors, then
 // the row broadcasts; the total lands in lane 63 and is read back as a scalar.
@@ -344,249 +284,6 @@ __device__ __forceinline__ void half_sums_split14(const int (&v)[14], int (&x)[4
   for (int j = 0; j < 4; ++j) x[j] += __builtin_amdgcn_update_dpp(0, x[j], 0x128, 0xf, 0xf, false);  // row_ror:8
 #pragma unroll
   for (int j = 0; j < 4; ++j) x[j] += __shfl_xor(x[j], 16, 64);
-}
-
-// ---------------------------------------------------------------------------------
-// k0_residual<SBPS, DBPS>: grid = (8 * ceil(ceil(nbw / 4) * nbh / 8), 1, batch), block = 256.
-// A workgroup owns four horizontally adjacent blocks: every row it touches is at least one
-// full 128-byte line per plane, every lane moves 8 samples (16-byte loads of 16-bit input).
-//   luma:   512 items of 8 samples, two per thread: item -> (row = i / 16, segment = i % 16)
-//   chroma: (128 >> xdec) / 8 segments x (32 >> ydec) rows per component, one or more per thread
-// Block sums go through LDS atomics (block = segment / segments-per-block).  The 8-bit luma source
-// of the four blocks is also kept in LDS; 128 lanes (block, row) then take the flat-block finder's
-// moments from it.
-// ---------------------------------------------------------------------------------
-// PART: 0 = everything; 1 = the luma half (residual, L plane, statistics, finder moments); 2 = the chroma half.
-// The engine runs the halves as two launches so that the finder chain can start after the first.
-template <int SBPS, int DBPS, int PART = 0>
-__global__ __launch_bounds__(256) void k0_residual(const FrameTable ft, Geom g, PlaneSet ps,
-                                                   uint8_t *__restrict__ planes, uint8_t *__restrict__ bad,
-                                                   uint8_t *__restrict__ records, int32_t *__restrict__ mom) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_src[kBlock][4 * 8 + 1];  // [row][dword of the 128-px row], +1: banks
-  __shared__ int s_sum[3][4][3];  // [component][block][sum d, sum d^2, sum src8 (luma)]
-  __shared__ int s_bad[2][4];     // [kind][block]
-  // Workgroup b runs on XCD b % 8 (observed; speed only).  Regions are dealt so that an XCD owns a
-  // contiguous range of them: the int8 rows of horizontally adjacent regions share 128-byte lines
-  // (the planes are padded by 8 bytes), and the two partial writes of a line merge in one L2.
-  const int gx = (g.nbw + 3) / 4, nreg = gx * g.nbh, per = (nreg + 7) >> 3;
-  const int reg = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  if (reg >= nreg) return;
-  const int frame = g.frame0 + (int)blockIdx.z, by = reg / gx, bx0 = 4 * (reg - by * gx);
-  const int tid = threadIdx.x;
-  const FramePlanes fp = ft.f[frame];
-  uint8_t *fbase = planes + (size_t)frame * ps.frame_bytes;
-  uint8_t *rec = records + (size_t)frame * g.rec_size;
-  const bool chroma = g.nplanes == 3;
-  const int sx = g.xdec, sy = g.ydec;
-  if (tid < 36) (&s_sum[0][0][0])[tid] = 0;
-  if (tid < 8) (&s_bad[0][0])[tid] = 0;
-  __syncthreads();
-
-  // ------------------------------- luma -------------------------------
-  if constexpr (PART != 2) {
-    const int seg = tid & 15, b = seg >> 2;
-    const bool active = bx0 + b < g.nbw;
-    const int X0 = bx0 * kBlock + seg * 8;
-    int sd = 0, sd2 = 0, ls = 0;
-    uint32_t mx = 0, mn = 0, lmx = 0, lmn = 0;
-    // a lane takes the rows 2p and 2p + 1 of its segment (the two luma rows under a 4:2:0 chroma row)
-    uint32_t d[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int row = 2 * (tid >> 4) + k;
-      const int Y = by * kBlock + row;
-      uint32_t hs[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0};
-      if (active) {
-        load_narrow<SBPS, 8>(fp.src[0], fp.src_stride[0], g.src_shift, (g.vec_mask & 1) != 0, X0, Y, g.W, g.H, hs);
-        load_narrow<DBPS, 8>(fp.den[0], fp.den_stride[0], g.den_shift, (g.vec_mask & 8) != 0, X0, Y, g.W, g.H, hv);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        d[k][q] = pk_sub(hs[q], hv[q]);
-        mx = pk_max(mx, d[k][q]);
-        mn = pk_min(mn, d[k][q]);
-        sd = pk_dot(d[k][q], 0x00010001u, sd);
-        sd2 = pk_dot(d[k][q], d[k][q], sd2);
-      }
-      const uint32_t s_lo = pk_bytes(hs[0], hs[1]), s_hi = pk_bytes(hs[2], hs[3]);  // the 8 source pixels, packed
-      ls = (int)__builtin_amdgcn_sad_u8(s_lo, 0u, (uint32_t)ls);
-      ls = (int)__builtin_amdgcn_sad_u8(s_hi, 0u, (uint32_t)ls);
-      s_src[row][2 * seg] = s_lo;
-      s_src[row][2 * seg + 1] = s_hi;
-      if (active) {
-        const size_t o = (size_t)(Y + kPadY) * ps.pitch[0] + kPadX + X0;
-        *reinterpret_cast<uint2 *>(fbase + ps.off_d[0] + o) =
-            make_uint2(pk_bytes(d[k][0], d[k][1]), pk_bytes(d[k][2], d[k][3]));
-      }
-    }
-    if (chroma && active) {
-      // L = sum of the (1 << sx) x (1 << sy) luma residuals under a chroma sample
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (sy && k) break;
-        const int Y = by * kBlock + 2 * (tid >> 4) + k;
-        const int cy = Y >> sy;
-        uint32_t v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = sy ? pk_add(d[0][q], d[1][q]) : d[k][q];
-        if (sx) {
-          // horizontal pairs: lo + hi of every dword
-          const uint32_t p0 = ((uint32_t)pk_dot(v[0], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[1], 0x00010001u, 0) << 16);
-          const uint32_t p1 = ((uint32_t)pk_dot(v[2], 0x00010001u, 0) & 0xffffu) | ((uint32_t)pk_dot(v[3], 0x00010001u, 0) << 16);
-          lmx = pk_max(lmx, pk_max(p0, p1));
-          lmn = pk_min(lmn, pk_min(p0, p1));
-          *reinterpret_cast<uint32_t *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + (X0 >> 1)) = pk_bytes(p0, p1);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            lmx = pk_max(lmx, v[q]);
-            lmn = pk_min(lmn, v[q]);
-          }
-          *reinterpret_cast<uint2 *>(fbase + ps.off_l + (size_t)cy * ps.lpitch + X0) =
-              make_uint2(pk_bytes(v[0], v[1]), pk_bytes(v[2], v[3]));
-        }
-      }
-    }
-    if (active) {
-      atomicAdd(&s_sum[0][b][0], sd);
-      atomicAdd(&s_sum[0][b][1], sd2);
-      atomicAdd(&s_sum[0][b][2], ls);
-      if (range_bad(mx, mn)) s_bad[0][b] = 1;
-      if (range_bad(lmx, lmn)) s_bad[1][b] = 1;
-    }
-  }
-  // ------------------------------- chroma -------------------------------
-  if (PART != 1 && chroma) {
-    const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
-    const int segs = (4 * bw) >> 3, spb = bw >> 3;  // 8-sample segments per region row / per block
-    const int ipp = segs * bh;                       // items per component: 128, 256 or 512
-    for (int i = tid; i < 2 * ipp; i += 256) {
-      const int c = 1 + (i >= ipp ? 1 : 0);
-      const int it = i - (c - 1) * ipp;
-      const int row = it / segs, seg = it - row * segs;
-      const int b = seg / spb;
-      if (bx0 + b >= g.nbw) continue;
-      const uint8_t *sp = c == 1 ? fp.src[1] : fp.src[2];
-      const uint8_t *dp = c == 1 ? fp.den[1] : fp.den[2];
-      const uint32_t sst = c == 1 ? fp.src_stride[1] : fp.src_stride[2];
-      const uint32_t dst = c == 1 ? fp.den_stride[1] : fp.den_stride[2];
-      const bool vs = ((g.vec_mask >> c) & 1) != 0, vd = ((g.vec_mask >> (3 + c)) & 1) != 0;
-      const int X0 = bx0 * bw + seg * 8, Y = by * bh + row;
-      uint32_t hs[4], hv[4], d[4];
-      load_narrow<SBPS, 8>(sp, sst, g.src_shift, vs, X0, Y, pw, ph, hs);
-      load_narrow<DBPS, 8>(dp, dst, g.den_shift, vd, X0, Y, pw, ph, hv);
-      uint32_t mx = 0, mn = 0;
-      int sd = 0, sd2 = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        d[q] = pk_sub(hs[q], hv[q]);
-        mx = pk_max(mx, d[q]);
-        mn = pk_min(mn, d[q]);
-        sd = pk_dot(d[q], 0x00010001u, sd);
-        sd2 = pk_dot(d[q], d[q], sd2);
-      }
-      const size_t o = (size_t)(Y + kPadY) * ps.pitch[1] + kPadX + X0;
-      *reinterpret_cast<uint2 *>(fbase + (c == 1 ? ps.off_d[1] : ps.off_d[2]) + o) =
-          make_uint2(pk_bytes(d[0], d[1]), pk_bytes(d[2], d[3]));
-      atomicAdd(&s_sum[c][b][0], sd);
-      atomicAdd(&s_sum[c][b][1], sd2);
-      if (range_bad(mx, mn)) s_bad[1][b] = 1;
-    }
-  }
-  __syncthreads();
-  if (tid < 4 && bx0 + tid < g.nbw) {
-    const int blk = by * g.nbw + bx0 + tid;
-    if (PART != 2 && s_bad[0][tid]) bad[(size_t)frame * 2 * g.nblocks + blk] = 1;
-    if (chroma && s_bad[1][tid]) bad[((size_t)frame * 2 + 1) * g.nblocks + blk] = 1;  // (either half may raise it)
-    // noise statistics of every block (the fold reads those of the flat blocks)
-    if (PART != 2) {
-      reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = s_sum[0][tid][0];
-      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)s_sum[0][tid][1];
-      reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)s_sum[0][tid][2];
-    }
-    if (PART != 1 && chroma) {
-      reinterpret_cast<int32_t *>(rec + g.off_sum_d[1])[blk] = s_sum[1][tid][0];
-      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[1])[blk] = (uint32_t)s_sum[1][tid][1];
-      reinterpret_cast<int32_t *>(rec + g.off_sum_d[2])[blk] = s_sum[2][tid][0];
-      reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[2])[blk] = (uint32_t)s_sum[2][tid][1];
-    }
-  }
-  // ---- flat-block finder moments of the four luma source blocks (k1f.hip.h), from the LDS copy ----
-  if (PART != 2 && mom != nullptr && tid < 128) {
-    const int b = tid >> 5, yi = tid & 31;
-    uint32_t pk[8], pu[8], pd[8];
-    // the finder's block replicates the last row / column of the plane (extract_block): rows by index
-    // clamp, columns by byte fill
-    const int hv = min(kBlock, g.H - by * kBlock), wv = min(kBlock, g.W - (bx0 + b) * kBlock);
-    const int r0 = min(yi, hv - 1), r1 = min(max(yi - 1, 0), hv - 1), r2 = min(yi + 1, hv - 1);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      pk[k] = s_src[r0][8 * b + k];
-      pu[k] = s_src[r1][8 * b + k];
-      pd[k] = s_src[r2][8 * b + k];
-    }
-    if (wv > 0 && wv < kBlock) {
-      replicate_columns(pk, wv);
-      replicate_columns(pu, wv);
-      replicate_columns(pd, wv);
-    }
-    int32_t m[14];
-    row_moments(pk, pu, pd, yi, m);
-    half_sums_dpp<14>(m);
-    const int bxo = bx0 + b;
-    if (yi == kBlock - 1 && bxo < g.nbw) {
-      int32_t *out = mom + ((size_t)frame * g.nblocks + (size_t)by * g.nbw + bxo) * kMomInts;
-#pragma unroll
-      for (int i = 0; i < 14; ++i) out[i] = m[i];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// k3_windows: the window bit planes w1[kind] from the flat mask (after K2).  Lane = one aligned
-// dword column j of a block row by: bits 32 j .. 32 j + 31 = samples 32 j - 8 .. 32 j + 23, which
-// belong to up to three blocks; their windows are worked out once and written for 1 / split of
-// the block's rows.  Every dword of the sample rows is written (zeros where no window is); the
-// padding rows stay zero from the allocation.
-// grid = (ceil(dwords per bit row / 64), split * nbh, batch * kinds), block = 64; split = 1, 2 or 4 workgroups
-// per block row.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k3_windows(Geom g, PlaneSet ps, uint8_t *__restrict__ planes,
-                                                 const uint8_t *__restrict__ records, int kWinSplit) {
-  const int kinds = g.nplanes == 3 ? 2 : 1;
-  const int frame = g.frame0 + (int)blockIdx.z / kinds, kind = (int)blockIdx.z % kinds;
-  const int sx = kind ? g.xdec : 0, sy = kind ? g.ydec : 0;
-  const int bw = kBlock >> sx, bh = kBlock >> sy, pw = g.W >> sx, ph = g.H >> sy;
-  const int j = (int)blockIdx.x * 64 + (int)threadIdx.x;  // dword of the bit row
-  const int by = (int)blockIdx.y / kWinSplit, part = (int)blockIdx.y % kWinSplit;
-  const uint32_t wpitch = ps.wpitch[kind];
-  if (j * 4 >= (int)wpitch) return;
-  const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
-  const int x_first = 32 * j - kPadX;  // sample of bit 0
-  const int b_first = max(x_first, 0) / bw, b_last = min((x_first + 31) / bw, g.nbw - 1);
-  // bits of the window columns, and the window rows, of the (up to three) blocks under this dword
-  uint32_t colbits[3] = {0, 0, 0};
-  int ys[3] = {0, 0, 0}, ye[3] = {0, 0, 0};
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int bx = b_first + t;
-    if (bx > b_last) continue;
-    const Win w = block_window(mask, g.nbw, g.nbh, bx, by, bw, bh, pw, ph, g.lag);
-    if (!w.flat) continue;
-    const int lo = max(bx * bw + w.xs - x_first, 0), hi = min(bx * bw + w.xe - x_first, 32);
-    if (hi > lo) colbits[t] = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-    ys[t] = w.ys;
-    ye[t] = w.ye;
-  }
-  const int rows = bh / kWinSplit;
-  uint8_t *dst = planes + (size_t)frame * ps.frame_bytes + ps.off_w[kind] + 4 * (size_t)j;
-  for (int r = 0; r < rows; ++r) {
-    const int ly = part * rows + r;
-    uint32_t bits = 0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) bits |= (ly >= ys[t] && ly < ye[t]) ? colbits[t] : 0u;
-    *reinterpret_cast<uint32_t *>(dst + (size_t)(by * bh + ly + kPadY) * wpitch) = bits;
-  }
 }
 
 // ---------------------------------------------------------------------------------

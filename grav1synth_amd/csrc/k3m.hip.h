@@ -50,76 +50,6 @@ struct MParams {
   int nunits;             // chunks per frame = ceil(nbw / 4) * nbh
 };
 
-// tile geometry of a plane kind: block BW x BH, chunk of kMUnitBlocks blocks (pitch / 16 must be odd)
-__host__ __device__ constexpr int m_pitch(int BW) { return kMUnitBlocks * BW + 16; }
-__host__ __device__ constexpr int m_copy_stride(int BW, int BH) {
-  // >= rows * pitch, in 16-byte slots == 2 (mod 16)
-  int slots = ((BH + 3) * m_pitch(BW) + 15) / 16;
-  while ((slots & 15) != 2) ++slots;
-  return slots * 16;
-}
-__host__ __device__ constexpr int m_tile_bytes(int BW, int BH) { return kMCopies * m_copy_stride(BW, BH); }
-// LDS map of a workgroup: [luma tile][Cb tile][Cr tile][pad][L tile][zero block].  The pad puts the L tile on a
-// 16-byte slot (mod 16) that none of the rows read together with it (a in {0, 1}) uses, in the Cb and in the Cr tile.
-__host__ __device__ constexpr bool m_l_slot_free(int rel, int p) {
-  for (int a = 0; a < 2; ++a)
-    for (int cxp = 0; cxp < (a == 0 ? 4 : 7); ++cxp)
-      if (((2 * cxp + p * (3 - a) - rel) & 15) == 0) return false;
-  return true;
-}
-__host__ __device__ constexpr int m_l_pad(int CBW, int CBH) {
-  const int T = m_tile_bytes(CBW, CBH) / 16, p = m_pitch(CBW) / 16;
-  for (int pad = 0; pad < 16; ++pad)
-    if (m_l_slot_free(2 * T + pad, p) && m_l_slot_free(T + pad, p)) return 16 * pad;
-  return 0;
-}
-__host__ __device__ constexpr int m_lds_tiles(int CBW, int CBH) {
-  return m_tile_bytes(32, kBlock) + (CBW ? 2 * m_tile_bytes(CBW, CBH) + m_l_pad(CBW, CBH) + CBH * m_pitch(CBW) : 0);
-}
-// ... followed by a block of 16 zero bytes (the operand of rows outside a window)
-__host__ __device__ constexpr int m_lds_bytes(int CBW, int CBH) { return m_lds_tiles(CBW, CBH) + 16; }
-
-// ---- matrix row i (0..31) -> what it holds ------------------------------------------
-// order inside the two b128 lane groups
-__device__ __forceinline__ int m_group_order(int i, int &grp) {
-  if (i < 4) { grp = 0; return i; }
-  if (i < 12) { grp = 1; return i - 4; }
-  if (i < 16) { grp = 0; return 4 + (i - 12); }
-  if (i < 20) { grp = 1; return 8 + (i - 16); }
-  if (i < 28) { grp = 0; return 8 + (i - 20); }
-  grp = 1;
-  return 12 + (i - 28);
-}
-// special: 0 neighbour / the sample itself (a, cxp), 1 the luma regressor L, 2 spare
-__device__ __forceinline__ void m_entry(int i, int &a, int &cxp, int &special) {
-  int grp;
-  const int k = m_group_order(i, grp);
-  special = 0;
-  a = 0;
-  cxp = 3;
-  if (grp == 0) {
-    if (k < 4) { a = 0; cxp = k; }            // cx = -3 .. 0; k == 3: d(p) itself
-    else if (k < 11) { a = 1; cxp = k - 4; }
-    else if (k == 11) special = 1;
-    else special = 2;
-  } else {
-    if (k < 7) { a = 2; cxp = k; }
-    else if (k < 14) { a = 3; cxp = k - 7; }
-    else { special = 2; a = 2; cxp = 0; }  // (a spare row reads what another row of its group reads: a broadcast)
-  }
-}
-// index in the record's (nc+1)-vector: 0..n-1 neighbours, n = L (chroma), nc = the sample; -1 = not part of it
-__device__ __forceinline__ int m_rec_index(int i, int lag, int n, bool chroma) {
-  int a, cxp, sp;
-  m_entry(i, a, cxp, sp);
-  if (sp == 2) return -1;
-  if (sp == 1) return chroma ? n : -1;
-  const int cx = cxp - 3;
-  if (a == 0 && cx == 0) return n + (chroma ? 1 : 0);
-  if (a > lag || cx < -lag || cx > lag) return -1;
-  return (lag - a) * (2 * lag + 1) + (cx + lag);
-}
-
 // ---- per-block window of a unit, 16 bits: xe | ye << 6 | (ys != 0) << 13 | (xs != 0) << 14 | go << 15 ----
 struct MWin {
   int go, xs, xe, ys, ye;
@@ -267,73 +197,6 @@ __device__ __forceinline__ v4i32 m_lds16(const uint8_t *smem, int a) { return *r
 // rows [ys, ye) of a block as a bit mask (bit y = row y), ye <= 32
 __device__ __forceinline__ uint32_t m_rowmask(int ys, int ye) {
   return (uint32_t)(((1ull << ye) - 1ull) & ~((1ull << ys) - 1ull));
-}
-
-// The multiplies of a block run over ALL of the wave's rows, unrolled, on ONE code path (the register
-// allocator copies accumulators at every merge of two paths that both multiply): a row outside the window
-// rows (bit clear in `rm`, whose bit 0 is the wave's first row) reads the zero block at LDS offset `zoff`
-// instead of its tile row (3 of 32 rows when the block above is not flat).  One accumulator per plane:
-// dependent v_mfma_i32_32x32x32_i8 issue at the pipe rate (tools/mfma_chain_probe.hip).  All reads of a
-// block are issued before its first multiply.
-// R rows from a0 + j * P into one accumulator
-template <int R, int P>
-__device__ __forceinline__ void m_rows_one(v16i32 &acc, const uint8_t *smem, int a0, uint32_t rm, int zoff) {
-  constexpr int H = R > 4 ? 4 : R;  // rows per batch of reads
-#pragma unroll
-  for (int j0 = 0; j0 < R; j0 += H) {
-    v4i32 v[H];
-#pragma unroll
-    for (int j = 0; j < H; ++j) v[j] = m_lds16(smem, ((rm >> (j0 + j)) & 1u) ? a0 + (j0 + j) * P : zoff);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < H; ++j) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v[j], v[j], acc, 0, 0, 0);
-  }
-}
-// R rows of two planes: plane A from a0 into accA, plane B from b0 into accB (chroma blocks 32 wide)
-template <int R, int P>
-__device__ __forceinline__ void m_rows_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, uint32_t rm, int zoff) {
-  // (two rows a batch: 16 operand registers next to the two accumulators' 32; four rows a batch were 32, and the 32-wide
-  //  chroma launches spilled in their hot loops)
-  constexpr int H = R > 2 ? 2 : R;  // rows per batch of reads
-#pragma unroll
-  for (int j0 = 0; j0 < R; j0 += H) {
-    v4i32 va[H], vb[H];
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-      const bool ok = ((rm >> (j0 + j)) & 1u) != 0;
-      va[j] = m_lds16(smem, ok ? a0 + (j0 + j) * P : zoff);
-      vb[j] = m_lds16(smem, ok ? b0 + (j0 + j) * P : zoff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-      accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[j], va[j], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb[j], vb[j], accB, 0, 0, 0);
-    }
-  }
-}
-// S steps of two planes, blocks 16 wide: a step is two rows, one per lane half; rml = the row mask shifted so
-// that bit 2 j is this lane's row of step j
-template <int S, int P>
-__device__ __forceinline__ void m_steps_two(v16i32 &accA, v16i32 &accB, const uint8_t *smem, int a0, int b0, uint32_t rml, int zoff) {
-  constexpr int H = S > 2 ? 2 : S;  // steps per batch of reads (16 operand registers)
-  static_assert(S % H == 0, "steps per wave");
-#pragma unroll
-  for (int j0 = 0; j0 < S; j0 += H) {
-    v4i32 va[H], vb[H];
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-      const bool ok = ((rml >> (2 * (j0 + j))) & 1u) != 0;
-      va[j] = m_lds16(smem, ok ? a0 + 2 * (j0 + j) * P : zoff);
-      vb[j] = m_lds16(smem, ok ? b0 + 2 * (j0 + j) * P : zoff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-      accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[j], va[j], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(vb[j], vb[j], accB, 0, 0, 0);
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """python -m tests.k3_mode_digest -- one JSON line: for each case, the SHA-256 of what a frame's record means (flat mask,
 score bits, AR sums, statistics of the flat blocks) and of the final table.  G1S_K3 is read once per process, so
-tests/test_gpu_parity.py::test_accumulation_modes_agree runs this once per mode and compares the lines."""
+tests/test_gpu_selfcheck.py::test_wide_and_stream_chains_agree runs this once per chain and compares the lines."""
 import hashlib
 import json
 from fractions import Fraction

@@ -1,0 +1,97 @@
+"""GPU self-checks: the HIP path against ITSELF (another chain, another launch geometry, a tuning switch) -- not parity
+evidence (tests/test_gpu_parity.py holds every comparison with the oracle), but what keeps the fallback chain and the
+switches of DESIGN.md honest.  Everything here runs in its own interpreter: the switches are read once per process."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wide_and_stream_chains_agree():
+    """G1S_K3 = wide (default: k3w.hip.h) and stream (round 3's kernel, what the wide chain falls back on for unaligned
+    planes, odd widths and mixed depths) give the same records and tables, bit for bit -- small odd formats, 12-bit
+    residuals outside int8, the 4K workload; the wide chain also with the fewest and with many workgroups a frame."""
+    lines = {}
+    for mode, extra in (("wide", {}), ("stream", {"G1S_K3": "stream"}), ("wide-few", {"G1S_W_WGS": "8", "G1S_W_WGS_C": "8"}),
+                        ("wide-many", {"G1S_W_WGS": "16384", "G1S_W_WGS_C": "16384"}), ("stream-noreuse", {"G1S_K3": "stream", "G1S_F_REUSE": "0"})):
+        env = dict(os.environ, **extra)
+        p = subprocess.run([sys.executable, "-m", "tests.k3_mode_digest"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, f"{mode}: {p.stderr[-2000:]}"
+        lines[mode] = json.loads(p.stdout.strip().splitlines()[-1])
+    for mode in lines:
+        assert lines[mode] == lines["wide"], f"wide vs {mode}"
+
+
+_SWITCH_CODE = (
+    "import hashlib, sys\n"
+    "from fractions import Fraction\n"
+    "from grav1synth_amd.diff import DiffGenerator, format_tbl\n"
+    "from grav1synth_amd.synth import SynthSpec, make_pair\n"
+    "spec = SynthSpec(352, 208, 10)\n"
+    "h = hashlib.sha256()\n"
+    "g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=2, records_only=True)\n"
+    "for k in range(5):\n"
+    "    s, d = make_pair(spec, k, device='cuda'); g.diff_frame(s, d, 1, 1)\n"
+    "recs, n = g.take_records(spec.width, spec.height, 3, 5); g.close(); h.update(recs.tobytes())\n"
+    "g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=2)\n"
+    "for k in range(5):\n"
+    "    s, d = make_pair(spec, k, device='cuda'); g.diff_frame(s, d, 1, 1)\n"
+    "h.update(format_tbl(g.finish())); g.close(); print(h.hexdigest())\n"
+)
+
+
+def _run(code, extra):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout.strip().splitlines()[-1]
+
+
+def test_tuning_switches_do_not_change_results():
+    """The environment switches of DESIGN.md (stream layout, launch sizes and frame order of the wide launches, the prefetch
+    touches, finder modes, fold threads): records and table must equal the default run's."""
+    ref = _run(_SWITCH_CODE, {})
+    assert len(ref) == 64
+    for extra in ({"G1S_ONE_STREAM": "1"}, {"G1S_NO_DEFER": "1"}, {"G1S_K1_LITERAL": "1"}, {"G1S_K1_LITERAL": "2"}, {"G1S_FOLD_THREADS": "1"},
+                  {"G1S_W_REV": "3"}, {"G1S_W_PREFETCH": "1"}, {"G1S_W_WGS": "4096", "G1S_W_WGS_C": "8"}, {"G1S_W_OFF": "1"},
+                  {"G1S_F_SERIAL": "1"}):
+        assert _run(_SWITCH_CODE, extra) == ref, extra
+
+
+def test_per_plane_deferrals_agree_between_the_chains():
+    """4:4:4 frames whose Cb plane alone, and whose Cr plane alone, holds residuals outside int8: the chroma launch defers
+    a unit per PLANE; the records and the table must be the stream chain's (which is held to the oracle on the same
+    mechanism in tests/test_gpu_parity.py)."""
+    code = (
+        "import hashlib, numpy as np\n"
+        "from fractions import Fraction\n"
+        "from grav1synth_amd.diff import DiffGenerator, format_tbl\n"
+        "from grav1synth_amd.synth import SynthSpec, make_pair\n"
+        "h = hashlib.sha256()\n"
+        "for bd, w, hh in ((10, 352, 224), (8, 288, 160)):\n"
+        "    spec = SynthSpec(w, hh, bd, xdec=0, ydec=0, textured=False)\n"
+        "    pairs = []\n"
+        "    for k in range(4):\n"
+        "        s, d = make_pair(spec, k, device='cpu')\n"
+        "        s = [np.array(p) for p in s]; d = [np.array(p) for p in d]\n"
+        "        if k in (1, 3): d[1][40:44, 70:75] = 0 if bd == 8 else 3   # Cb far off: |d| > 127 after narrowing\n"
+        "        if k in (2, 3): d[2][100:103, 200:204] = (255 if bd == 8 else 1020)\n"
+        "        pairs.append((s, d))\n"
+        "    g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=2, records_only=True)\n"
+        "    for s, d in pairs: g.diff_frame(s, d, 0, 0)\n"
+        "    recs, n = g.take_records(w, hh, 3, 4); g.close(); h.update(recs.tobytes())\n"
+        "    g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=2)\n"
+        "    for s, d in pairs: g.diff_frame(s, d, 0, 0)\n"
+        "    h.update(format_tbl(g.finish())); g.close()\n"
+        "print(h.hexdigest())\n"
+    )
+    ref = _run(code, {})
+    assert len(ref) == 64
+    assert _run(code, {"G1S_K3": "stream"}) == ref
+    assert _run(code, {"G1S_K3": "stream", "G1S_F_REUSE": "0"}) == ref
