@@ -185,6 +185,7 @@ SYMBOLS = [
     ("g1s_filters_apply_bd", C.c_int, [C.c_void_p, C.POINTER(G1SFrame), C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(G1SFrame), C.c_char_p,
                                         C.c_size_t]),
     ("g1s_filters_has_resize", C.c_int, [C.c_void_p]),
+    ("g1s_fold_frames", C.c_uint64, [C.c_void_p]),
     ("g1s_resize_plan", C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_size_t]),
     ("g1s_resize_frame_to_host", C.c_int, [C.c_char_p, C.POINTER(G1SFrame), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),

@@ -63,12 +63,15 @@ def build_parser() -> argparse.ArgumentParser:
     d.add_argument("-y", "--overwrite", action="store_true", help="Overwrite the output file without prompting.")
     d.add_argument("-f", "--filters", default=None,
                    help='A semicolon-separated list of filters to apply to the source before running the diff, e.g. '
-                        '"crop:top=42,left=64".  crop: top, bottom, left, right.  resize (width, height, alg) parses like the '
-                        "reference's but is not supported here.")
+                        '"crop:top=42,left=64".  crop: top, bottom, left, right.  resize: width, height, alg (hermite, catmullrom, '
+                        "mitchell, lanczos, spline36) runs on the device; its arithmetic restates the video-resize crate, which "
+                        "is not in the reference tree: the resized planes are UNVERIFIED against grav1synth's (a warning is logged).")
     d.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: the current device)")
     d.add_argument("--gpus", type=int, default=1,
                    help="shard the frames over the first N devices of the node (one generator each, batches dealt round-robin, "
-                        "ordered merge on the host: the same table as one device)")
+                        "ordered merge on the host: the same table as one device).  From .y4m files the command is bound by "
+                        "reading them (about 25 GB/s, 560 4K 10-bit frames a second) long before a second device matters; "
+                        "does not combine with a resize filter or with --device")
     d.add_argument("--devices", default=None, help="the same with an explicit list of HIP ordinals, e.g. 0,2,3")
     e = sub.add_parser("estimate", help="Estimates the amount of noise in a source video, frame by frame (y4m input; the reference's "
                                         "`estimate`, feature \"unstable\").")
@@ -93,10 +96,18 @@ def diff_command(source: str, denoised: str, output: str, overwrite: bool = Fals
         return -1
     if filters is not None:
         try:
-            FilterChain(filters).close()
+            fc = FilterChain(filters)
         except FilterError as e:
             log.error("Invalid filter chain: %s", e)
             return -1
+        resizes = any(f.__class__.__name__ == "Resize" for f in fc.filters)
+        fc.close()
+        if resizes and devices is not None and len(devices) > 1:
+            log.error("A resize filter does not combine with --gpus / --devices (one chain, one device)")
+            return -1
+        if resizes:
+            log.warning("resize: the resampling arithmetic restates the video-resize crate (not in the reference tree): the "
+                        "resized source, and the table made from it, are UNVERIFIED against grav1synth's")
     if os.path.exists(output) and not overwrite and not confirm(f"File {output} exists. Overwrite?"):
         log.warning(NOT_OVERWRITING)
         return -1
@@ -127,6 +138,10 @@ def main(argv: Optional[List[str]] = None) -> int:
     if args.command == "diff":
         try:
             devices = None
+            if args.gpus < 1:
+                raise ValueError("--gpus: at least 1")
+            if (args.devices or args.gpus > 1) and args.device >= 0:
+                raise ValueError("--device does not combine with --gpus / --devices")
             if args.devices:
                 devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
             elif args.gpus > 1:

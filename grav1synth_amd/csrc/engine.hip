@@ -2035,6 +2035,7 @@ int g1s_shard_merge(g1s_fold_t *f, const void *msgs, size_t stride_bytes, uint32
 }
 void g1s_fold_free(g1s_fold_t *f) { delete f; }
 const char *g1s_fold_last_error(const g1s_fold_t *f) { return f ? f->err.c_str() : ""; }
+uint64_t g1s_fold_frames(const g1s_fold_t *f) { return f ? f->fold.frames() : 0; }
 
 long g1s_format_tbl(const g1s_segment_t *segs, size_t n, char *buf, size_t cap) {
   return format_tbl(segs, n, buf, cap);

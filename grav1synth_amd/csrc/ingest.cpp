@@ -611,7 +611,13 @@ int g1s_diff_y4m_files_sharded(const char *source_path, const char *denoised_pat
     }
     if (rc == G1S_OK) rc = round(0);
   }
-  for (int k = 0; k < 4 && rc == G1S_OK; ++k) rc = round(1);  // what is still in the generators' pipelines
+  // what is still in the generators' pipelines: flush rounds until every frame fed has been merged (a generator holds at most
+  // its slots' worth of batches: a handful of rounds; the bound only stops a protocol error from spinning)
+  for (int k = 0; k < 64 && rc == G1S_OK && g1s_fold_frames(fold) < frames; ++k) rc = round(1);
+  if (rc == G1S_OK && g1s_fold_frames(fold) != frames) {
+    set_err(err, errcap, "sharded diff: " + std::to_string(g1s_fold_frames(fold)) + " of " + std::to_string(frames) + " frames merged after the flush rounds");
+    rc = G1S_ERR_STATE;
+  }
   if (rc) goto done;
   rc = g1s_fold_finish(fold, segs.data(), segs.size(), &n);
   if (rc == G1S_ERR_CAPACITY) {

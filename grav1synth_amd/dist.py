@@ -119,9 +119,21 @@ class _RcclRounds:
         self.send_dev = [torch.zeros(msg_bytes, dtype=torch.uint8, device=device) for _ in range(self.RING)]
         self.gathered = [None] * self.RING  # event: the gather that read send_dev[i] has run
         self.round = 0
+        # gather-to-root or all-gather: decided ONCE, here, by every rank together (a one-byte probe, then a barrier) -- never
+        # under an `except` in the round loop, where an error on one rank would leave it issuing a different collective from
+        # its peers.  An exception in a later round is fatal.
         self.rooted = True
+        try:
+            probe = torch.zeros(1, dtype=torch.uint8, device=device)
+            parts = [torch.zeros(1, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(probe, gather_list=parts, dst=0)
+        except (RuntimeError, NotImplementedError):
+            self.rooted = False
+        flag = torch.tensor([1 if self.rooted else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # (every rank rooted, or none)
+        self.rooted = bool(int(flag.item()))
         self.recv_dev = None
-        if self.rank == 0:
+        if self.rank == 0 or not self.rooted:
             self.recv_dev = torch.zeros((self.world, msg_bytes), dtype=torch.uint8, device=device)
             self.recv_host = [torch.zeros((self.world, msg_bytes), dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
             self.free = queue.Queue()
@@ -148,14 +160,9 @@ class _RcclRounds:
         with torch.cuda.stream(self.coll_stream):
             self.coll_stream.wait_event(copied)
             if self.rooted:
-                try:
-                    parts = [self.recv_dev[r] for r in range(self.world)] if self.rank == 0 else None
-                    self.dist.gather(self.send_dev[i], gather_list=parts, dst=0)
-                except (RuntimeError, NotImplementedError):  # raised on every rank alike, before any traffic
-                    self.rooted = False
-            if not self.rooted:
-                if self.recv_dev is None:
-                    self.recv_dev = torch.zeros((self.world, self.send_dev[i].numel()), dtype=torch.uint8, device=self.dev)
+                parts = [self.recv_dev[r] for r in range(self.world)] if self.rank == 0 else None
+                self.dist.gather(self.send_dev[i], gather_list=parts, dst=0)
+            else:
                 self.dist.all_gather_into_tensor(self.recv_dev, self.send_dev[i])
             done = torch.cuda.Event()
             done.record(self.coll_stream)
@@ -173,6 +180,13 @@ class _RcclRounds:
 
     def release(self, k: int) -> None:
         self.free.put(k)
+
+    def close(self) -> None:
+        """frees the pinned rings (the cache below holds one transport per process group and message size)"""
+        self.send_host = self.send_dev = []
+        self.recv_dev = None
+        if self.rank == 0:
+            self.recv_host = []
 
 
 class StreamingShardedDiff:
@@ -284,6 +298,7 @@ class StreamingShardedDiff:
     def diff_prepared(self, prepared, sync_torch: bool = True) -> None:
         """Feeds ONE batch (this rank's next batch in the global order)."""
         self.generator.diff_prepared(prepared, sync_torch=sync_torch)
+        self._fed = getattr(self, "_fed", 0) + int(prepared.n)
         if self.dist is not None:
             # the states of an earlier batch (which one is a function of the call sequence only, so every
             # rank contributes the same batch index; nothing on the first calls)
@@ -303,11 +318,23 @@ class StreamingShardedDiff:
             self._exchange_one(flush=True)
         while self._group_n:  # (the last group goes out full: empty messages behind the last states)
             self._exchange_one(flush=True)
+        # every frame fed by any rank must have been merged: PIPELINE_BATCHES is what a generator's slots can hold, and a change
+        # there must fail here, loudly, not drop the video's last batches
+        total = None
+        if self._dev is not None and self.dist.get_world_size() > 1:
+            t = torch.tensor([getattr(self, "_fed", 0)], dtype=torch.int64, device=self._dev if self.dist.get_backend() == "nccl" else "cpu")
+            self.dist.all_reduce(t)
+            total = int(t.item())
+        elif self.dist.get_world_size() == 1:
+            total = getattr(self, "_fed", 0)
         if self._fold is None:
             return None
         self._stop_merger()
         if self._merge_err is not None:
             raise self._merge_err
+        merged = int(self.generator._L.g1s_fold_frames(self._fold._h))
+        if total is not None and merged != total:
+            raise RuntimeError(f"frame-shard job: {merged} of {total} frames merged after the flush rounds")
         segs = self._fold.finish()
         self._fold.close()
         self._fold = None

@@ -209,6 +209,9 @@ int g1s_shard_merge(g1s_fold_t *, const void *msgs, size_t stride_bytes, uint32_
 int g1s_fold_finish(g1s_fold_t *, g1s_segment_t *out, size_t cap, size_t *n_out);
 void g1s_fold_free(g1s_fold_t *);
 const char *g1s_fold_last_error(const g1s_fold_t *);
+/* Frames folded so far (pushed or merged in order): a driver of the round protocol checks it against the frames it fed
+ * before g1s_fold_finish -- a batch still inside a generator's pipeline is a frame missing here. */
+uint64_t g1s_fold_frames(const g1s_fold_t *);
 
 /* ---- `.tbl` text, byte for byte what src/main.rs:525-529,631-696 writes ---- */
 /* Returns the number of bytes written (no NUL), or G1S_ERR_CAPACITY. */
@@ -292,8 +295,8 @@ int g1s_filters_get(const g1s_filters_t *, size_t i, g1s_filter_desc_t *out);
 /* FilterChain::apply (src/filters.rs:112-116) on a frame descriptor.  crop is extent arithmetic: *out points into
  * *in's planes (host or device), same strides, smaller width / height -- no sample is touched, so it costs nothing on
  * the device.  Crop amounts must be multiples of the chroma subsampling and leave at least one sample
- * (G1S_ERR_INVALID otherwise).  A chain with a resize filter parses but is refused here: G1S_ERR_UNSUPPORTED, with
- * the filter named in err.  filters == NULL: *out = *in. */
+ * (G1S_ERR_INVALID otherwise).  A chain with a resize filter is served by g1s_filters_apply_bd below (this call, without a
+ * bit depth, takes 8-bit samples only and answers G1S_ERR_UNSUPPORTED for deeper ones).  filters == NULL: *out = *in. */
 int g1s_filters_apply(const g1s_filters_t *, const g1s_frame_t *in, g1s_frame_t *out, char *err, size_t errcap);
 /* FilterChain::apply(frame, source_bd) (src/filters.rs:112-116) with the resize filter served: crop as above; resize
  * (src/filters.rs:150-178: hermite / catmullrom / mitchell / lanczos / spline36) runs ON THE DEVICE `device` (-1: the
