@@ -87,7 +87,10 @@ def main() -> None:
 
     if world > 1:  # the host fold pools of the ranks share the node's cores
         lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        os.environ.setdefault("G1S_FOLD_THREADS", str(max(2, min(32, (os.cpu_count() or 8) // max(lws, 1)))))
+        from grav1synth_amd import _lib
+
+        # (usable = hardware threads cut to the cgroup CPU quota: the ranks of a node share it)
+        os.environ.setdefault("G1S_FOLD_THREADS", str(max(2, min(32, int(_lib.lib().g1s_usable_cpus()) // max(lws, 1)))))
     from grav1synth_amd.diff import DiffGenerator, format_tbl
     from grav1synth_amd.dist import ShardedDiff, StreamingShardedDiff
     from grav1synth_amd.synth import SynthSpec, make_pair
@@ -293,10 +296,7 @@ def main() -> None:
             "resident_frames_per_rank": F,
             "batch_frames": args.batch,
             "accumulation": {"wide": "exact int8 SYRK on the matrix cores (v_mfma_i32_16x16x64_i8 on operand pairs), 128-sample units, residuals in 32-bit SWAR fused into the consumer, windows as masks on the A operand, one tile buffer -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01",
-                             "stream": "exact int8 SYRK on the matrix cores (v_mfma_i32_16x16x64_i8 on operand pairs, one LDS operand read per 64 samples), residual fused into the consumer, two tile buffers -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01",
-                             "fused": "exact int8 SYRK on the matrix cores (v_mfma_i32_32x32x32_i8), residual fused into the consumer -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01",
-                             "planes": "pixel pass K0 -> int8 planes -> exact int8 SYRK on the matrix cores",
-                             "dot4": "round 1: pixel pass K0 -> int8 planes -> lag-structured v_dot4 kernels"}[os.environ.get("G1S_K3", "wide")],
+                             "stream": "exact int8 SYRK on the matrix cores (v_mfma_i32_16x16x64_i8 on operand pairs, one LDS operand read per 64 samples), residual fused into the consumer, two tile buffers -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01"}[os.environ.get("G1S_K3", "wide")],
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
             "rccl_ranks": (dist.get_world_size() if (world > 1 and not share) else (1 if world == 1 else 0)),
@@ -372,6 +372,9 @@ def main() -> None:
             nproc = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        from grav1synth_amd import _lib as _l
+
+        nproc = max(1, min(nproc, int(_l.lib().g1s_usable_cpus())))  # (a cgroup CPU quota below the hardware threads: what runs at once)
         # all cores: every thread a strip, sized so that the leg stays near 20 s even if the threads scale no better than 8x
         strip = H if nproc <= 8 else max(32, min(H, (int(H * 8 * 20.0 / (one_s * nproc)) // 32) * 32))
         t0 = time.perf_counter()

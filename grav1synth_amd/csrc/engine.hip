@@ -179,10 +179,34 @@ class Pool {
   bool stop_ = false;
 };
 
+// The cores this process may really use: the hardware threads, cut to the cgroup's CPU quota where there is one (a 1-GPU box
+// of the pool this was measured on shows 256 hardware threads and `cpu.max` = 16 cores: 32 pool threads there do 80 k frames/s
+// of the per-frame half where 16 do 95 k -- the quota's throttling stops every thread of the group, the launching one included;
+// profiles/r04_host_budget_8ranks.txt).
+unsigned usable_cpus() {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (!hw) hw = 1;
+  long long quota = -1, period = 100000;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    char q[32] = {0};
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+    fclose(f1);
+    if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(f2, "%lld", &period) != 1) period = 100000;
+      fclose(f2);
+    }
+  }
+  if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+  return hw;
+}
+
 // One pool per process (creating 30 threads per generator would dominate short jobs).
 Pool *shared_pool() {
   static Pool *p = [] {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = usable_cpus();
     if (const char *e = getenv("G1S_FOLD_THREADS")) hw = (unsigned)atoi(e);
     if (hw > 32) hw = 32;
     return hw > 1 ? new Pool(hw - 1) : nullptr;  // the calling thread participates
@@ -195,7 +219,7 @@ std::mutex g_pool_mutex;  // parallel_for is not re-entrant: one fold batch at a
 // and a merge that waits for it falls behind the eight GPUs it serves.
 Pool *merge_pool() {
   static Pool *p = [] {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = usable_cpus();
     if (const char *e = getenv("G1S_FOLD_THREADS")) hw = (unsigned)atoi(e);
     unsigned n = std::min(8u, hw / 2);  // (8: 1.5 - 1.6 us a frame, steady; 16 reaches 1.0 but swings to 2 - 8 on a busy host: profiles/r03_fold_budget.txt)
     if (const char *e = getenv("G1S_MERGE_POOL")) n = (unsigned)atoi(e);  // (measurement: the pool's size itself)
@@ -1059,7 +1083,7 @@ int g1s_diff::launch_back(int si) {
     // (the record's block statistics and AR sums: k3_ar_generic adds to / overwrites what the launches and the reduction wrote,
     //  and the exact kernel reads the frame number relative to the launch: frame0 is 0 here)
     kmark(sl, stream, "k3w_tail");
-    hipLaunchKernelGGL(k3w_tail, dim3(kMFinishParts + std::min(kK3Chunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
+    hipLaunchKernelGGL(k3w_tail, dim3(kWTailParts + std::min(kWTailChunks, g.nblocks), g.nplanes, B), dim3(kK3Threads), 0, stream, ft, g,
                        sl.d_records, (const uint8_t *)mp.only, (const uint32_t *)mp.only_any, (const long long *)mp.partials, G_cap, Gk[0], Gk[1]);
   } else {
     // the fused pass: planes of the flat blocks' tiles -> residuals, block statistics, exact int8 SYRK on the matrix
@@ -1842,6 +1866,31 @@ int g1s_latest_from_record(const void *record, size_t size_bytes, uint32_t ar_co
   latest_to_blob(fl, ar_coeff_lag, (uint8_t *)blob);
   return G1S_OK;
 }
+
+// The per-frame half of a batch of records on the process' per-frame pool (G1S_FOLD_THREADS; the calling thread takes part):
+// what a generator's drainer does with a batch, as a call of its own -- a host that runs the half next to a foreign transport,
+// and tools/host_budget_8ranks.py, which replays eight ranks' worth of it.
+int g1s_latest_from_records(const void *records, size_t stride_bytes, size_t n, uint32_t ar_coeff_lag, void *blobs, size_t blob_stride_bytes) {
+  if ((!records || !blobs) && n) return G1S_ERR_INVALID;
+  if (ar_coeff_lag < 1 || ar_coeff_lag > 3) return G1S_ERR_INVALID;
+  const size_t bs = latest_blob_size(ar_coeff_lag);
+  if (blob_stride_bytes < bs) return G1S_ERR_CAPACITY;
+  auto one = [&](int i) {
+    static thread_local FrameLatest fl;  // (kept per thread: its vectors are sized once, not once a frame)
+    compute_latest((const uint8_t *)records + (size_t)i * stride_bytes, stride_bytes, ar_coeff_lag, fl);
+    latest_to_blob(fl, ar_coeff_lag, (uint8_t *)blobs + (size_t)i * blob_stride_bytes);
+  };
+  Pool *p = shared_pool();
+  if (p && n > 1) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    p->parallel_for((int)n, one);
+  } else {
+    for (size_t i = 0; i < n; ++i) one((int)i);
+  }
+  return G1S_OK;
+}
+
+unsigned g1s_usable_cpus(void) { return usable_cpus(); }
 
 struct g1s_fold {
   NoiseFold fold;

@@ -925,36 +925,42 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
 }
 
 // ---------------------------------------------------------------------------------
-// k3w_tail: the launch behind the accumulation launches.  x < kMFinishParts: a third of the G partial systems of plane y of the
-// frame, summed into its record; x >= kMFinishParts: the exact kernel (k3_ar_generic's body) on the blocks the launches deferred
-// -- on most frames none: it returns at once.  grid = (kMFinishParts + chunks, nplanes, batch), block = kK3Threads (256).
+// k3w_tail: the launch behind the accumulation launches.  x < kWTailParts: the G partial systems of plane y of the frame, summed
+// into its record -- four threads an entry, each with its share of the workgroups' systems in flight at once (the kernel is as
+// long as its longest chain of dependent loads); x >= kWTailParts: the exact kernel (k3_ar_generic's body) on the blocks the
+// launches deferred -- on most frames none: it returns at once.  grid = (kWTailParts + chunks, nplanes, batch), block = 256.
 // ---------------------------------------------------------------------------------
-static_assert(kK3Threads == 256, "k3w_tail: one entry per thread");
+constexpr int kWTailParts = 11, kWTailChunks = 16;
+static_assert(kK3Threads == 256 && kWTailParts * 64 >= 26 * 26 + 26, "k3w_tail: four threads per entry");
 __global__ __launch_bounds__(kK3Threads) void k3w_tail(const FrameTable ft, Geom g, uint8_t *__restrict__ records, const uint8_t *__restrict__ only,
                                                        const uint32_t *__restrict__ only_any, const long long *__restrict__ partials, int wg_cap, int G_luma,
                                                        int G_chroma) {
   const int c = blockIdx.y, frame = g.frame0 + (int)blockIdx.z;
-  if ((int)blockIdx.x < kMFinishParts) {
-    const int nc = g.n + (c > 0), k = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (k >= nc * nc + nc) return;
-    long long *ar = reinterpret_cast<long long *>(records + (size_t)frame * g.rec_size + g.off_ar[c]);
+  if ((int)blockIdx.x < kWTailParts) {
+    const int nc = g.n + (c > 0), k = ((int)blockIdx.x * 256 + (int)threadIdx.x) >> 2, q = (int)threadIdx.x & 3;
+    const bool live = k < nc * nc + nc;
     const int G = c == 0 ? G_luma : G_chroma;
-    const long long *p = partials + (size_t)frame * wg_cap * 3 * kMRec + (size_t)c * kMRec + k;
+    const long long *p = partials + (size_t)frame * wg_cap * 3 * kMRec + (size_t)c * kMRec + (live ? k : 0);
     long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int w = 0;
-    for (; w + 4 <= G; w += 4) {  // (independent loads in flight)
+    int w = q;
+    for (; w + 12 < G; w += 16) {  // (independent loads in flight)
       s0 += p[(size_t)(w + 0) * 3 * kMRec];
-      s1 += p[(size_t)(w + 1) * 3 * kMRec];
-      s2 += p[(size_t)(w + 2) * 3 * kMRec];
-      s3 += p[(size_t)(w + 3) * 3 * kMRec];
+      s1 += p[(size_t)(w + 4) * 3 * kMRec];
+      s2 += p[(size_t)(w + 8) * 3 * kMRec];
+      s3 += p[(size_t)(w + 12) * 3 * kMRec];
     }
-    for (; w < G; ++w) s0 += p[(size_t)w * 3 * kMRec];
+    for (; w < G; w += 4) s0 += p[(size_t)w * 3 * kMRec];
+    long long tot = (s0 + s1) + (s2 + s3);
+    tot += __shfl_xor(tot, 1, 64);
+    tot += __shfl_xor(tot, 2, 64);
     // (an atomic: the exact kernel's workgroups of this launch add to the same entries)
-    const long long tot = (s0 + s1) + (s2 + s3);
-    if (tot != 0) atomicAdd(reinterpret_cast<unsigned long long *>(ar) + k, (unsigned long long)tot);
+    if (live && q == 0 && tot != 0) {
+      long long *ar = reinterpret_cast<long long *>(records + (size_t)frame * g.rec_size + g.off_ar[c]);
+      atomicAdd(reinterpret_cast<unsigned long long *>(ar) + k, (unsigned long long)tot);
+    }
     return;
   }
-  k3_ar_generic_body(ft, g, records, only, only_any, (int)blockIdx.x - kMFinishParts, (int)gridDim.x - kMFinishParts, c, (int)blockIdx.z);
+  k3_ar_generic_body(ft, g, records, only, only_any, (int)blockIdx.x - kWTailParts, (int)gridDim.x - kWTailParts, c, (int)blockIdx.z);
 }
 
 }  // namespace g1s

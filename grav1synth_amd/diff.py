@@ -482,10 +482,9 @@ def latest_from_records(records: np.ndarray, ar_coeff_lag: int = 3) -> np.ndarra
     records = np.ascontiguousarray(records, dtype=np.uint8)
     bs = int(L.g1s_latest_size(ar_coeff_lag))
     out = np.zeros((records.shape[0], bs), dtype=np.uint8)
-    for i in range(records.shape[0]):
-        rc = L.g1s_latest_from_record(records[i].ctypes.data, records.shape[1], ar_coeff_lag, out[i].ctypes.data, bs)
-        if rc != 0:
-            raise G1SError(rc, "g1s_latest_from_record failed")
+    rc = L.g1s_latest_from_records(records.ctypes.data, records.shape[1], records.shape[0], ar_coeff_lag, out.ctypes.data, bs)
+    if rc != 0:
+        raise G1SError(rc, "g1s_latest_from_records failed")
     return out
 
 

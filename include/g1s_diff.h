@@ -191,6 +191,12 @@ size_t g1s_latest_size(uint32_t ar_coeff_lag);
  * it surfaces when the blob is pushed. */
 int g1s_latest_from_record(const void *record, size_t size_bytes, uint32_t ar_coeff_lag, void *blob,
                            size_t cap_bytes);
+/* The same for n records a stride apart, on the process' per-frame pool (G1S_FOLD_THREADS threads, the caller included). */
+int g1s_latest_from_records(const void *records, size_t stride_bytes, size_t n, uint32_t ar_coeff_lag, void *blobs,
+                            size_t blob_stride_bytes);
+/* The cores this process may use: hardware threads cut to the cgroup CPU quota (the default size of the per-frame pool;
+ * a launcher of several local ranks divides it among them: bench.py). */
+unsigned g1s_usable_cpus(void);
 
 typedef struct g1s_fold g1s_fold_t;
 /* The sequential part of DiffGenerator (noise-model update, segmentation,
