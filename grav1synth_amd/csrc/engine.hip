@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1943,19 +1944,18 @@ int g1s_fold_push_many(g1s_fold_t *f, const void *records, size_t stride_bytes, 
   }
   return G1S_OK;
 }
-int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, size_t n) {
-  if (!f || (!blobs && n)) return G1S_ERR_INVALID;
+// Runs of latest-state blobs, merged in the order given.  The frames of ALL runs are taken in windows of kChunk frames (the
+// solves of a window run on the merge pool, fold.cpp: push_latest_many): a round of a frame-shard job -- eight messages of
+// one batch each -- is merged as two windows of 256, not eight of 64 (the pool's hand-over per window is what a small
+// window pays: 3.8 -> 5.5 us a frame single-threaded at 64, profiles/r04_host_budget_8ranks.txt).
+struct BlobRun {
+  const uint8_t *base;
+  size_t stride, n;
+};
+static int fold_push_runs(g1s_fold_t *f, const BlobRun *runs, size_t nruns) {
   if (f->finished) return G1S_ERR_STATE;
   Pool *mp = merge_pool();
   constexpr size_t kChunk = 256;  // frames parsed and merged per pass (bounds the staging memory)
-  if (n > kChunk) {
-    for (size_t o = 0; o < n; o += kChunk) {
-      const int rc = g1s_fold_push_latest(f, (const uint8_t *)blobs + o * stride_bytes, stride_bytes, std::min(kChunk, n - o));
-      if (rc) return rc;
-    }
-    return G1S_OK;
-  }
-  const uint8_t *base = (const uint8_t *)blobs;
   const NoiseFold::ParallelFor pfor = [&](int m, const std::function<void(int)> &fn) {
     if (mp && m > 1) {
       std::lock_guard<std::mutex> lk(g_merge_pool_mutex);
@@ -1972,42 +1972,62 @@ int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, 
       if (on && frames) fprintf(stderr, "ordered merge, us per frame: blob headers %.2f, whole call %.2f (%zu frames)\n", s * 1e6 / frames, all * 1e6 / frames, frames);
     }
   } pp;
-  const auto t_p0 = std::chrono::steady_clock::now();
-  // The blobs are read where they lie (fold.h, FrameView); only a caller's unaligned buffer is copied first.
-  const bool in_place = !((reinterpret_cast<uintptr_t>(base) | stride_bytes) & 7);
-  if (f->views.size() < n) f->views.resize(n);
-  if (!in_place && f->latest.size() < n) f->latest.resize(n);
-  size_t good = n;
-  int bad_rc = G1S_OK;
-  for (size_t i = 0; i < n; ++i) {
-    int rc = G1S_OK;
-    if (in_place) rc = view_of_blob(base + i * stride_bytes, stride_bytes, f->lag, f->views[i]);
-    else {
-      rc = latest_from_blob(base + i * stride_bytes, stride_bytes, f->lag, f->latest[i]);
-      if (!rc) view_of(f->latest[i], f->views[i]);
+  if (f->views.size() < kChunk) f->views.resize(kChunk);
+  size_t run = 0, at = 0;  // the next frame to take: frame `at` of run `run`
+  for (;;) {
+    while (run < nruns && at == runs[run].n) {
+      ++run;
+      at = 0;
+    }
+    if (run == nruns) return G1S_OK;
+    const auto t_p0 = std::chrono::steady_clock::now();
+    size_t good = 0;
+    int bad_rc = G1S_OK;
+    while (good < kChunk && run < nruns) {
+      if (at == runs[run].n) {
+        ++run;
+        at = 0;
+        continue;
+      }
+      const BlobRun &R = runs[run];
+      const uint8_t *b = R.base + at * R.stride;
+      // The blobs are read where they lie (fold.h, FrameView); only a caller's unaligned buffer is copied first.
+      int rc;
+      if (!((reinterpret_cast<uintptr_t>(R.base) | R.stride) & 7)) {
+        rc = view_of_blob(b, R.stride, f->lag, f->views[good]);
+      } else {
+        if (f->latest.size() < kChunk) f->latest.resize(kChunk);
+        rc = latest_from_blob(b, R.stride, f->lag, f->latest[good]);
+        if (!rc) view_of(f->latest[good], f->views[good]);
+      }
+      if (rc) {
+        bad_rc = rc;
+        break;
+      }
+      ++good;
+      ++at;
+    }
+    const auto t_p1 = std::chrono::steady_clock::now();
+    const int rc = f->fold.push_latest_many(f->views.data(), good, pfor);  // (the frames before a bad blob still count)
+    if (pp.on) {
+      pp.s += std::chrono::duration<double>(t_p1 - t_p0).count();
+      pp.all += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count();
+      pp.frames += good;
     }
     if (rc) {
-      good = i;
-      bad_rc = rc;
-      break;
+      f->err = f->fold.error();
+      return rc;
+    }
+    if (bad_rc) {
+      f->err = "bad latest blob";
+      return bad_rc;
     }
   }
-  const auto t_p1 = std::chrono::steady_clock::now();
-  const int rc = f->fold.push_latest_many(f->views.data(), good, pfor);  // (the frames before a bad blob still count)
-  if (pp.on) {
-    pp.s += std::chrono::duration<double>(t_p1 - t_p0).count();
-    pp.all += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count();
-    pp.frames += good;
-  }
-  if (rc) {
-    f->err = f->fold.error();
-    return rc;
-  }
-  if (good < n) {
-    f->err = "bad latest blob";
-    return bad_rc;
-  }
-  return G1S_OK;
+}
+int g1s_fold_push_latest(g1s_fold_t *f, const void *blobs, size_t stride_bytes, size_t n) {
+  if (!f || (!blobs && n)) return G1S_ERR_INVALID;
+  const BlobRun r{(const uint8_t *)blobs, stride_bytes, n};
+  return fold_push_runs(f, &r, 1);
 }
 int g1s_fold_finish(g1s_fold_t *f, g1s_segment_t *out, size_t cap, size_t *n_out) {
   if (!f) return G1S_ERR_INVALID;
@@ -2046,12 +2066,35 @@ int g1s_shard_merge(g1s_fold_t *f, const void *msgs, size_t stride_bytes, uint32
     }
   }
   const size_t bs = latest_blob_size(f->lag);
+  // The batches of this round that are next in the global order -- straight from the messages, or from `early` once their
+  // predecessors have come -- are collected as runs and merged in one go (fold_push_runs: windows across messages).
+  std::vector<BlobRun> runs;
+  uint64_t next = f->next_batch;  // the global batch the next run must be
+  size_t from_early = 0;          // how many of `early`'s first entries are in `runs`
+  auto drain_early = [&] {
+    auto it = f->early.begin();
+    std::advance(it, from_early);
+    while (it != f->early.end() && it->first == next) {
+      runs.push_back(BlobRun{it->second.data(), bs, it->second.size() / bs});
+      ++it;
+      ++from_early;
+      ++next;
+    }
+  };
+  auto flush = [&]() -> int {
+    const int rc = runs.empty() ? G1S_OK : fold_push_runs(f, runs.data(), runs.size());
+    runs.clear();
+    f->next_batch = next;
+    for (; from_early; --from_early) f->early.erase(f->early.begin());
+    return rc;
+  };
   for (uint32_t r = 0; r < world; ++r) {
     const uint8_t *m = (const uint8_t *)msgs + (size_t)r * stride_bytes;
     ShardHeader h;
     std::memcpy(&h, m, sizeof(h));
     if (!h.count) continue;
     if (h.local_batch == kShardNoIndex) {
+      if (const int rc = flush()) return rc;
       if (!f->early.empty()) {
         f->err = "frame-shard merge: a message without a batch index while indexed batches are waiting";
         return G1S_ERR_STATE;
@@ -2061,26 +2104,20 @@ int g1s_shard_merge(g1s_fold_t *f, const void *msgs, size_t stride_bytes, uint32
       continue;
     }
     const uint64_t j = (uint64_t)h.local_batch * world + r;
-    if (j < f->next_batch || f->early.count(j)) {
+    if (j < next || f->early.count(j)) {
+      flush();
       f->err = "frame-shard merge: batch " + std::to_string(j) + " arrived twice (rank " + std::to_string(r) + ")";
       return G1S_ERR_STATE;
     }
-    if (j == f->next_batch) {
-      const int rc = g1s_fold_push_latest(f, m + sizeof(h), bs, h.count);
-      if (rc) return rc;
-      ++f->next_batch;
+    if (j == next) {
+      runs.push_back(BlobRun{m + sizeof(h), bs, h.count});
+      ++next;
     } else {
       f->early.emplace(j, std::vector<uint8_t>(m + sizeof(h), m + sizeof(h) + (size_t)h.count * bs));
     }
-    while (!f->early.empty() && f->early.begin()->first == f->next_batch) {
-      const std::vector<uint8_t> &v = f->early.begin()->second;
-      const int rc = g1s_fold_push_latest(f, v.data(), bs, v.size() / bs);
-      if (rc) return rc;
-      f->early.erase(f->early.begin());
-      ++f->next_batch;
-    }
+    drain_early();
   }
-  return G1S_OK;
+  return flush();
 }
 void g1s_fold_free(g1s_fold_t *f) { delete f; }
 const char *g1s_fold_last_error(const g1s_fold_t *f) { return f ? f->err.c_str() : ""; }

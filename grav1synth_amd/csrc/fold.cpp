@@ -123,7 +123,7 @@ void StrengthSolver::add(const StrengthSolver &o) {
   num_equations += o.num_equations;
   total += o.total;
 }
-void StrengthSolver::add(const double *oA, const double *ob, int o_num_equations, double o_total) {
+void StrengthSolver::add(const double *oA, const double *ob, int64_t o_num_equations, double o_total) {
   eq.add(oA, ob);
   num_equations += o_num_equations;
   total += o_total;
@@ -153,6 +153,62 @@ void StrengthSolver::add_measurement(double block_mean, double noise_std) {
   eq.b[i1] += a * noise_std;
   total += noise_std;
   num_equations++;
+}
+// m measurements in order: bin[sel[k]] = bin_index(block mean) (in [0, kNumBins - 1]: truncation is the floor), noise_std[k].
+// Every element of the system receives the additions add_measurement would make, in the same order; the six elements of
+// the bin pair in hand stay in registers while successive blocks fall into the same pair (flat blocks next to each other
+// mostly do: through memory every such addition waits for the store before it, ~10 cycles a block instead of an add's 4).
+void StrengthSolver::add_measurements(const double *bin, const uint32_t *sel, const double *noise_std, size_t m) {
+  const int n = kNumBins;
+  double *A = eq.A.data(), *b = eq.b.data();
+  int cur = -1;  // the pair (cur, cur + 1) is in registers
+  double a00 = 0, a10 = 0, a01 = 0, a11 = 0, b0 = 0, b1 = 0, tot = total;
+  auto put = [&] {
+    if (cur < 0) return;
+    A[cur * n + cur] = a00;
+    A[(cur + 1) * n + cur] = a10;
+    A[cur * n + cur + 1] = a01;
+    A[(cur + 1) * n + cur + 1] = a11;
+    b[cur] = b0;
+    b[cur + 1] = b1;
+    cur = -1;
+  };
+  for (size_t k = 0; k < m; ++k) {
+    const double bn = bin[sel[k]], sd = noise_std[k];
+    const int i0 = (int)bn;
+    const double a = bn - i0;
+    if (i0 >= n - 1) {  // the last bin is its own neighbour: all six additions as the reference makes them
+      put();
+      const int i1 = n - 1;
+      A[i0 * n + i0] += (1.0 - a) * (1.0 - a);
+      A[i1 * n + i0] += a * (1.0 - a);
+      A[i1 * n + i1] += a * a;
+      A[i0 * n + i1] += a * (1.0 - a);
+      b[i0] += (1.0 - a) * sd;
+      b[i1] += a * sd;
+    } else {
+      if (i0 != cur) {
+        put();
+        cur = i0;
+        a00 = A[cur * n + cur];
+        a10 = A[(cur + 1) * n + cur];
+        a01 = A[cur * n + cur + 1];
+        a11 = A[(cur + 1) * n + cur + 1];
+        b0 = b[cur];
+        b1 = b[cur + 1];
+      }
+      a00 += (1.0 - a) * (1.0 - a);
+      a10 += a * (1.0 - a);
+      a11 += a * a;
+      a01 += a * (1.0 - a);
+      b0 += (1.0 - a) * sd;
+      b1 += a * sd;
+    }
+    tot += sd;
+  }
+  put();
+  total = tot;
+  num_equations += (int64_t)m;
 }
 void StrengthSolver::apply_regularisation_to_b() {
   const double mean = total / num_equations;
@@ -277,7 +333,7 @@ static PlaneView view_of_plane(const PlaneState &s) {
   v.n = s.ar.n;
   v.num_observations = s.num_observations;
   v.ar_gain = s.ar_gain;
-  v.num_equations = s.strength.num_equations;
+  v.num_equations = (int)s.strength.num_equations;  // (a view is of one frame)
   v.total = s.strength.total;
   return v;
 }
@@ -349,7 +405,63 @@ static void set_error(std::string &dst, const char *fmt, ...) {
   dst = buf;
 }
 
+// compute_latest's elementwise passes (see there).
+// A division by a power of two is the multiplication by its reciprocal, bit for bit (the same real number, rounded once):
+// block areas and sample counts are powers of two except in a cut last row or column, so the passes multiply by `rcp`
+// (1 / count where count is a power of two, else 0) and the few other blocks are divided one by one afterwards.
+static inline double pow2_rcp(int count) { return (count & (count - 1)) == 0 ? 1.0 / count : 0.0; }
+// mean[k] comes in as the block's luma sum and leaves as its mean; bin[k] = StrengthSolver::bin_index(mean[k]).
+G1S_HOST_CLONES static void flat_means(size_t m, double *__restrict mean, const double *__restrict area, const double *__restrict rcp,
+                                       double *__restrict bin) {
+  for (size_t k = 0; k < m; ++k) bin[k] = mean[k] * rcp[k];
+  for (size_t k = 0; k < m; ++k)
+    if (rcp[k] == 0.0) bin[k] = mean[k] / area[k];  // (not a power of two)
+  for (size_t k = 0; k < m; ++k) {
+    const double bm = bin[k];
+    mean[k] = bm;
+    const double val = bm < 0.0 ? 0.0 : (bm > 255.0 ? 255.0 : bm);
+    bin[k] = (kNumBins - 1) * val / 255.0;
+  }
+}
+// noise_var = sum_d2 / count - (sum_d / count)^2
+G1S_HOST_CLONES static void noise_variances(size_t m, const double *__restrict sd, const double *__restrict sd2, const double *__restrict cnt,
+                                            const double *__restrict rcp, double *__restrict nv) {
+  for (size_t k = 0; k < m; ++k) {
+    const double noise_mean = sd[k] * rcp[k];
+    nv[k] = sd2[k] * rcp[k] - noise_mean * noise_mean;
+  }
+  for (size_t k = 0; k < m; ++k)
+    if (rcp[k] == 0.0) {
+      const double noise_mean = sd[k] / cnt[k];
+      nv[k] = sd2[k] / cnt[k] - noise_mean * noise_mean;
+    }
+}
+// uncorr_std / noise_gain, uncorr_std = sqrt(max(noise_var / 16, noise_var - (corr * luma_strength)^2))
+G1S_HOST_CLONES static void uncorrelated_stds(size_t m, const double *__restrict nv, const double *__restrict ls, double corr, double noise_gain,
+                                              double *__restrict out) {
+  for (size_t k = 0; k < m; ++k) {
+    const double cl = corr * ls[k];
+    const double t0 = nv[k] / 16, t1 = nv[k] - cl * cl;
+    out[k] = std::sqrt(t0 > t1 ? t0 : t1) / noise_gain;
+  }
+}
+
+#ifdef G1S_LATEST_PROFILE  // (a measurement build of tools/: where the per-frame half's time goes)
+double g_latest_stage_s[8];
+#define STAGE(i)                                                                                                   \
+  do {                                                                                                             \
+    const double t_now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); \
+    g_latest_stage_s[i] += t_now - t_stage;                                                                        \
+    t_stage = t_now;                                                                                               \
+  } while (0)
+#else
+#define STAGE(i) ((void)0)
+#endif
+
 int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &out) {
+#ifdef G1S_LATEST_PROFILE
+  double t_stage = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+#endif
   out.status = G1S_OK;
   out.err.clear();
   auto fail = [&](int code, const char *fmt, int arg = 0) {
@@ -382,6 +494,36 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
   int num_flat = 0;
   for (int i = 0; i < nbw * nbh; ++i) num_flat += mask[i] != 0;
   if (num_flat <= 1) return fail(G1S_ERR_NOT_ENOUGH_FLAT, "Not enough flat blocks to update noise estimate");
+  // the flat blocks in raster order, their luma means and the means' bin positions (every plane's measurements use them)
+  {
+    const size_t nf = (size_t)num_flat;
+    out.scratch_idx.resize(nf);
+    out.scratch_pos.resize(nf);
+    out.scratch_mean.resize(nf);
+    out.scratch_std.resize(2 * nf);  // (here: the luma blocks' areas and their reciprocals)
+    out.scratch_bin.resize(nf);
+    uint32_t *idx = out.scratch_idx.data(), *pos = out.scratch_pos.data();
+    double *sum = out.scratch_mean.data(), *area = out.scratch_std.data(), *rcp = area + nf;
+    const double rcp_full = pow2_rcp(kBlock * kBlock);
+    size_t k = 0;
+    for (int by = 0; by < nbh; ++by) {
+      const int lh = std::min(hh - by * kBlock, kBlock);
+      const uint8_t *mrow = mask + (size_t)by * nbw;
+      for (int bx = 0; bx < nbw; ++bx) {
+        if (!mrow[bx]) continue;
+        const int bi = by * nbw + bx;
+        const int lw = std::min(w - bx * kBlock, kBlock);
+        idx[k] = (uint32_t)bi;
+        pos[k] = (uint32_t)by << 16 | (uint32_t)bx;
+        sum[k] = (double)luma_sum[bi];
+        area[k] = (double)(lw * lh);
+        rcp[k] = (lw == kBlock && lh == kBlock) ? rcp_full : pow2_rcp(lw * lh);
+        ++k;
+      }
+    }
+    flat_means(nf, sum, area, rcp, out.scratch_bin.data());
+  }
+  STAGE(0);
 
   for (int c = 0; c < (int)h.nplanes; ++c) {
     const bool is_chroma = c != 0;
@@ -408,12 +550,14 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
       }
       lat.num_observations = Sb[nc];
     }
+    STAGE(1);
     if (!ar_solve(lat, is_chroma)) {
       if (is_chroma)
         chroma_fallback(lat);
       else
         return fail(G1S_ERR_SOLVE, "Solving latest noise equation system failed %d!", c);
     }
+    STAGE(2);
     // ---- noise strength vs. intensity measurements, block raster order ----
     {
       const int32_t *sum_d = reinterpret_cast<const int32_t *>(rec + L.off_sum_d[c]);
@@ -422,39 +566,68 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
       const double luma_gain = out.st[0].ar_gain;
       const double noise_gain = lat.ar_gain;
       const double corr = is_chroma ? lat.ar.x[n] : 0;
-      // Two passes over the flat blocks, raster order both times.  First the measurements themselves -- independent
-      // from block to block (six divisions and a square root each: the core overlaps them across iterations) --
-      // then their accumulation into the equation system, whose f64 sums must run in the reference's order.
+      // Three passes over the plane's flat blocks, raster order every time.  The measurements are independent from block to
+      // block and nearly all divisions and square roots (the divider was 150 of this function's 158 us a 4K frame): they run
+      // as elementwise loops over compact arrays, which the compiler turns into packed divides -- IEEE division and square
+      // root round the same packed or scalar, -ffp-contract=off keeps every product and difference its own operation.  The
+      // block mean and its bin position are the luma block's for every plane: worked out once per frame (flat_means).  Then
+      // the accumulation into the equation system, whose f64 sums must run in the reference's order.
       // Every operation and its operands are those of the single loop this replaces: same bits.
-      std::vector<double> &mx = out.scratch_mean, &my = out.scratch_std;
-      mx.clear();
-      my.clear();
-      for (int by = 0; by < nbh; ++by) {
-        const int sh = std::min((hh >> sy) - by * bh, bh);
-        const int lh = std::min(hh - by * kBlock, kBlock);
-        for (int bx = 0; bx < nbw; ++bx) {
-          const int bi = by * nbw + bx;
-          if (!mask[bi]) continue;
-          const int sw = std::min((w >> sx) - bx * bw, bw);
-          if (sw * sh > kBlock) {
-            const int lw = std::min(w - bx * kBlock, kBlock);
-            const double block_mean = (double)luma_sum[bi] / (lw * lh);
-            double noise_mean = (double)sum_d[bi];
-            const double noise_sq = (double)sum_d2[bi];
-            noise_mean /= (sw * sh);
-            const double noise_var = noise_sq / (sw * sh) - noise_mean * noise_mean;
-            const double luma_strength = is_chroma ? luma_gain * out.st[0].strength.value_at(block_mean) : 0;
-            const double cl = corr * luma_strength;
-            const double t0 = noise_var / 16, t1 = noise_var - cl * cl;
-            const double uncorr_std = std::sqrt(t0 > t1 ? t0 : t1);
-            mx.push_back(block_mean);
-            my.push_back(uncorr_std / noise_gain);
-          }
+      std::vector<double> &sc = out.scratch_plane;
+      const size_t cap = out.scratch_idx.size();
+      sc.resize(7 * cap);
+      double *p_sd = sc.data(), *p_sd2 = p_sd + cap, *p_cnt = p_sd2 + cap, *p_rcp = p_cnt + cap, *p_ls = p_rcp + cap, *p_nv = p_ls + cap,
+             *p_std = p_nv + cap;
+      out.scratch_sel.resize(cap);
+      uint32_t *sel = out.scratch_sel.data();  // position in the frame's flat list of the blocks this plane measures
+      const uint32_t *idx = out.scratch_idx.data(), *pos = out.scratch_pos.data();
+      const int pw = w >> sx, ph = hh >> sy;
+      const int full_bx = pw / bw, full_by = ph / bh;  // blocks left of / above these are whole
+      const double cnt_full = (double)(bw * bh), rcp_full = pow2_rcp(bw * bh);
+      const bool full_counts = bw * bh > kBlock;
+      size_t m = 0;
+      for (size_t k = 0; k < cap; ++k) {
+        const int bi = (int)idx[k];
+        const int by = (int)(pos[k] >> 16), bx = (int)(pos[k] & 0xffffu);
+        if (bx < full_bx && by < full_by) {
+          if (!full_counts) continue;
+          p_cnt[m] = cnt_full;
+          p_rcp[m] = rcp_full;
+        } else {
+          const int sh = std::min(ph - by * bh, bh);
+          const int sw = std::min(pw - bx * bw, bw);
+          if (!(sw * sh > kBlock)) continue;
+          p_cnt[m] = (double)(sw * sh);
+          p_rcp[m] = pow2_rcp(sw * sh);
         }
+        p_sd[m] = (double)sum_d[bi];
+        p_sd2[m] = (double)sum_d2[bi];
+        sel[m] = (uint32_t)k;
+        ++m;
       }
-      for (size_t k = 0; k < mx.size(); ++k) lat.strength.add_measurement(mx[k], my[k]);
+      STAGE(3);
+      noise_variances(m, p_sd, p_sd2, p_cnt, p_rcp, p_nv);
+      STAGE(7);
+      const double *bins = out.scratch_bin.data();
+      if (is_chroma) {
+        const double *lx = out.st[0].strength.eq.x.data();
+        for (size_t k = 0; k < m; ++k) {  // luma_gain * luma strength.value_at(block_mean)
+          const double bin = bins[sel[k]];
+          const int i0 = (int)bin;  // (bin >= 0: the floor)
+          const int i1 = std::min(kNumBins - 1, i0 + 1);
+          const double a = bin - i0;
+          p_ls[k] = luma_gain * ((1.0 - a) * lx[i0] + a * lx[i1]);
+        }
+      } else {
+        for (size_t k = 0; k < m; ++k) p_ls[k] = 0;
+      }
+      uncorrelated_stds(m, p_nv, p_ls, corr, noise_gain, p_std);
+      STAGE(4);
+      lat.strength.add_measurements(bins, sel, p_std, m);
+      STAGE(5);
     }
     if (!lat.strength.solve()) return fail(G1S_ERR_SOLVE, "Solving latest noise strength failed!");
+    STAGE(6);
   }
   return G1S_OK;
 }
@@ -499,7 +672,7 @@ void latest_to_blob(const FrameLatest &fl, uint32_t lag, uint8_t *blob) {
     LatestPlaneHead ph{};
     ph.num_observations = s.num_observations;
     ph.ar_gain = s.ar_gain;
-    ph.num_equations = s.strength.num_equations;
+    ph.num_equations = (int32_t)s.strength.num_equations;
     ph.total = s.strength.total;
     std::memcpy(p, &ph, sizeof(ph));
     double *d = reinterpret_cast<double *>(p + sizeof(ph));

@@ -41,15 +41,16 @@ void chroma_fallback(PlaneState &s);
 
 struct StrengthSolver {
   LinearSystem eq;
-  int num_equations = 0;
+  int64_t num_equations = 0;  // (the reference's is a usize: a combined state passes 2^31 block measurements after ~420 k 4K frames)
   double total = 0.0;
   StrengthSolver();
   void clear();
   void add(const StrengthSolver &o);
-  void add(const double *oA, const double *ob, int o_num_equations, double o_total);
+  void add(const double *oA, const double *ob, int64_t o_num_equations, double o_total);
   static double bin_index(double value);
   double value_at(double x) const;
   void add_measurement(double block_mean, double noise_std);
+  void add_measurements(const double *bin, const uint32_t *sel, const double *noise_std, size_t m);  // (in order; fold.cpp)
   bool solve();
   // The two halves of solve(): the reference's solve() both perturbs b
   // (b += mean/8192, never undone) and computes x.  When x is not needed yet
@@ -76,7 +77,9 @@ struct FrameLatest {
   uint32_t nplanes = 0;
   int status = 0;  // G1S_OK or error code
   std::string err;
-  std::vector<double> scratch_mean, scratch_std;  // compute_latest: a plane's block measurements before they are accumulated
+  // compute_latest: the frame's flat blocks (raster order), their luma means and bin positions; a plane's measurement arrays
+  std::vector<double> scratch_mean, scratch_std, scratch_bin, scratch_plane;
+  std::vector<uint32_t> scratch_idx, scratch_pos, scratch_sel;
 };
 // Thread-safe: record -> latest state (AR solve, measurements, strength solve).
 int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &out);

@@ -126,7 +126,7 @@ static void eq_copy(eqsys *dst, const eqsys *src) {
 typedef struct {
   eqsys eqns;
   int num_bins;
-  int num_equations;
+  long long num_equations; /* (usize in the reference) */
   double total;
 } strength_solver;
 

@@ -60,6 +60,7 @@ CASES = [
     (SynthSpec(256, 160, 8, xdec=0, ydec=0), 2, True, 2),
     (SynthSpec(256, 160, 8), 2, False, 2),
     (SynthSpec(256, 160, 12), 1, True, 2),
+    (SynthSpec(216, 152, 10), 3, True, 2),  # cut last row and column: block sample counts that are no powers of two (768, 576, 192, 144)
 ]
 
 

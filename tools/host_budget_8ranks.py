@@ -61,21 +61,44 @@ def rank_main(rank, rec_path, seconds, threads, out_q, start_evt, rate):
     L = _lib.lib()
     R = np.load(rec_path)
     src = np.concatenate([R] * (BATCH // len(R)))  # one batch of records (what the kernels of a batch leave)
-    ring = np.empty_like(src)                      # the pinned ring buffer a D2H copy lands in
+    ring = [np.empty_like(src) for _ in range(2)]  # the pinned ring a D2H copy lands in: one batch lands while one is read
     bs = int(L.g1s_latest_size(LAG))
     blobs = np.zeros((BATCH, bs), dtype=np.uint8)
     latest_from_records(src[:2], LAG)              # (pool made -- G1S_FOLD_THREADS threads, native -- code warm)
+    import threading
+
+    landed = [threading.Semaphore(0), threading.Semaphore(0)]
+    free = [threading.Semaphore(1), threading.Semaphore(1)]
+    stop = threading.Event()
+
+    def lander():  # the copy landing: 18 MB written per batch (a DMA in the real job: here a core's memcpy, GIL released)
+        k = 0
+        while not stop.is_set():
+            free[k & 1].acquire()
+            np.copyto(ring[k & 1], src)
+            landed[k & 1].release()
+            k += 1
+
+    th = threading.Thread(target=lander, daemon=True)
     start_evt.wait()
+    th.start()
     t0 = time.perf_counter()
     c0 = time.process_time()
     frames = 0
+    k = 0
     while time.perf_counter() - t0 < seconds:
-        np.copyto(ring, src)                       # the copy landing: 18 MB written per batch
+        landed[k & 1].acquire()
+        r = ring[k & 1]
         # the per-frame half of the batch on this rank's pool: what the generator's drainer does (Pool::parallel_for)
-        rc = L.g1s_latest_from_records(ring.ctypes.data, ring.shape[1], BATCH, LAG, blobs.ctypes.data, bs)
+        rc = L.g1s_latest_from_records(r.ctypes.data, r.shape[1], BATCH, LAG, blobs.ctypes.data, bs)
         assert rc == 0
+        free[k & 1].release()
+        k += 1
         frames += BATCH
         pace(t0, frames, rate)
+    stop.set()
+    free[0].release()
+    free[1].release()
     wall = time.perf_counter() - t0
     out_q.put({"rank": rank, "frames": frames, "wall_s": wall, "cpu_s": time.process_time() - c0})
 
@@ -118,6 +141,8 @@ def merge_main(rec_path, seconds, threads, out_q, start_evt, rate):
 
 def d2h_main(rec_bytes, seconds, out_q, start_evt):
     try:
+        if os.environ.get("NO_D2H"):
+            raise RuntimeError("switched off (NO_D2H)")
         import torch
 
         if not torch.cuda.is_available():
@@ -157,7 +182,7 @@ def main():
     from grav1synth_amd import _lib
 
     ncpu = int(_lib.lib().g1s_usable_cpus())
-    per_rank = int(os.environ.get("HALF_THREADS", "0")) or max(2, min(32, ncpu // local))  # (bench.py: G1S_FOLD_THREADS of a local rank)
+    per_rank = int(os.environ.get("HALF_THREADS", "0")) or max(2, min(32, ncpu // max(1, local)))  # (bench.py: G1S_FOLD_THREADS of a local rank)
     merge_threads = int(os.environ.get("G1S_MERGE_THREADS", "8"))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -176,13 +201,13 @@ def main():
     ranks = sorted((r for r in res if isinstance(r["rank"], int)), key=lambda r: r["rank"])
     merge = next(r for r in res if r["rank"] == "merge")
     d2h = next(r for r in res if r["rank"] == "d2h")
-    rank_fps = [r["frames"] / r["wall_s"] for r in ranks]
+    rank_fps = [r["frames"] / r["wall_s"] for r in ranks] or [float("inf")]  # (local_ranks 0: the merge alone)
     out = {
         "host": {"hw_threads": os.cpu_count(), "usable_cores_cgroup": ncpu, "ranks_replayed_here": local, "paced": paced, "ranks": RANKS, "per_rank_pool_threads": per_rank, "merge_pool_threads": merge_threads, "window_s": seconds},
         "record_bytes": int(R.shape[1]),
-        "per_frame_half": {"frames_per_s_per_rank": [round(x) for x in rank_fps], "min": round(min(rank_fps)), "sum": round(sum(rank_fps)),
+        "per_frame_half": {"frames_per_s_per_rank": [round(x) for x in rank_fps] if ranks else [], "min": round(min(rank_fps)) if ranks else None, "sum": round(sum(rank_fps)) if ranks else 0,
                            "cpu_us_per_frame": round(1e6 * sum(r["cpu_s"] for r in ranks) / max(1, sum(r["frames"] for r in ranks)), 1),
-                           "host_memory_GBps_read_plus_written": round(2 * sum(rank_fps) * R.shape[1] / 1e9, 1)},
+                           "host_memory_GBps_read_plus_written": round(2 * sum(rank_fps) * R.shape[1] / 1e9, 1) if ranks else 0},
         "ordered_merge": {"frames_per_s": round(merge["frames"] / merge["wall_s"]), "cpu_us_per_frame": round(1e6 * merge["cpu_s"] / max(1, merge["frames"]), 2),
                           "rounds": merge["rounds"]},
         "d2h_next_to_it": {"GBps": round(d2h["bytes"] / d2h["wall_s"] / 1e9, 1) if d2h["wall_s"] else None, "note": d2h.get("note")},

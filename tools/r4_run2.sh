@@ -7,3 +7,5 @@ PACE=0 python tools/host_budget_8ranks.py 12 1 > gpurun_out/r04_host_rank0_flat.
 python bench.py > gpurun_out/r04f_bench.json 2>gpurun_out/r04f_bench.err
 G1S_LATEST=device python bench.py > gpurun_out/r04f_bench_devlatest.json 2>gpurun_out/r04f_bench_devlatest.err
 tail -c 600 gpurun_out/r04f_bench.json; echo; tail -c 600 gpurun_out/r04f_bench_devlatest.json
+echo; WL=1080p8 BATCH=128 DISTINCT=128 python tools/ktime.py 3 2>/dev/null | tail -1 | tee gpurun_out/r04f_1080p8.txt
+WL=8k10_444 BATCH=16 DISTINCT=16 python tools/ktime.py 3 2>/dev/null | tail -1 | tee gpurun_out/r04f_8k444.txt
