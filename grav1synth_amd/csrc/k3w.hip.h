@@ -114,8 +114,8 @@ struct WUnitParams {
   int ncell[2], gx[2], ub[2];  // cells a frame, cells a block row, blocks a unit
 };
 // (the body: the list of plane kind `kind` of the frame, by one workgroup of 1024 threads)
-__device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *__restrict__ records, const WUnitParams &up, int kind, int frame) {
-  const uint8_t *mask = records + (size_t)frame * g.rec_size + g.off_mask;
+// (`mask`: the frame's mask bytes -- in the record, or a copy in LDS: a cell asks for ~25 of them, one dependent load each)
+__device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *mask, const WUnitParams &up, int kind, int frame) {
   const int UB = up.ub[kind], gx = up.gx[kind], ncell = up.ncell[kind];
   const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
   const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
@@ -186,7 +186,7 @@ __device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *__re
 __global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restrict__ records, WUnitParams up) {
   const int kind = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;
   if (kind == 1 && g.nplanes != 3) return;
-  w_build_units(g, records, up, kind, frame);
+  w_build_units(g, records + (size_t)frame * g.rec_size + g.off_mask, up, kind, frame);
 }
 // k2w_select_units: k2_flat_select (the frame's threshold score, its mask bytes) and, behind it, the frame's unit lists: one launch
 // instead of two in the finder's chain.  grid = (batch), block = 1024 (= kK2Threads).
@@ -197,10 +197,25 @@ __global__ __launch_bounds__(1024) void k2w_select_units(Geom g, uint8_t *__rest
   // (the mask bytes were written by this workgroup: a workgroup-scope fence and a barrier make them visible to its own loads)
   __threadfence_block();
   __syncthreads();
-  w_build_units(g, records, up, 0, frame);
-  if (g.nplanes == 3) {
+  // the mask bytes into LDS (up to an 8K frame's 32 400), the list builder reads them there
+  constexpr int kMaskLds = 32768;
+  __shared__ uint8_t s_mask[kMaskLds];
+  const uint8_t *gmask = records + (size_t)frame * g.rec_size + g.off_mask;
+  const bool in_lds = g.nblocks <= kMaskLds;
+  if (in_lds) {
+    for (int i = (int)threadIdx.x; i < g.nblocks; i += 1024) s_mask[i] = gmask[i];
     __syncthreads();
-    w_build_units(g, records, up, 1, frame);
+    w_build_units(g, s_mask, up, 0, frame);
+    if (g.nplanes == 3) {
+      __syncthreads();
+      w_build_units(g, s_mask, up, 1, frame);
+    }
+  } else {
+    w_build_units(g, gmask, up, 0, frame);
+    if (g.nplanes == 3) {
+      __syncthreads();
+      w_build_units(g, gmask, up, 1, frame);
+    }
   }
 }
 
@@ -926,35 +941,34 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
 
 // ---------------------------------------------------------------------------------
 // k3w_tail: the launch behind the accumulation launches.  x < kWTailParts: the G partial systems of plane y of the frame, summed
-// into its record -- four threads an entry, each with its share of the workgroups' systems in flight at once (the kernel is as
-// long as its longest chain of dependent loads); x >= kWTailParts: the exact kernel (k3_ar_generic's body) on the blocks the
-// launches deferred -- on most frames none: it returns at once.  grid = (kWTailParts + chunks, nplanes, batch), block = 256.
+// into its record -- a thread an entry, eight of the workgroups' systems in flight at once (the kernel is as long as its longest
+// chain of dependent loads); x >= kWTailParts: the exact kernel (k3_ar_generic's body) on the blocks the launches deferred --
+// on most frames none: it returns at once.  The grid is kept SMALL: at (11 + 16) x 3 workgroups a frame the launch was as
+// long as the dispatch of its 5 000 - 10 000 workgroups (48 us at 4K, 62 at 1080p with 128-frame batches), whatever they did.
+// grid = (kWTailParts + chunks, nplanes, batch), block = 256.
 // ---------------------------------------------------------------------------------
-constexpr int kWTailParts = 11, kWTailChunks = 16;
-static_assert(kK3Threads == 256 && kWTailParts * 64 >= 26 * 26 + 26, "k3w_tail: four threads per entry");
+constexpr int kWTailParts = 3, kWTailChunks = 4;
+static_assert(kK3Threads == 256 && kWTailParts * 256 >= 26 * 26 + 26, "k3w_tail: a thread per entry");
 __global__ __launch_bounds__(kK3Threads) void k3w_tail(const FrameTable ft, Geom g, uint8_t *__restrict__ records, const uint8_t *__restrict__ only,
                                                        const uint32_t *__restrict__ only_any, const long long *__restrict__ partials, int wg_cap, int G_luma,
                                                        int G_chroma) {
   const int c = blockIdx.y, frame = g.frame0 + (int)blockIdx.z;
   if ((int)blockIdx.x < kWTailParts) {
-    const int nc = g.n + (c > 0), k = ((int)blockIdx.x * 256 + (int)threadIdx.x) >> 2, q = (int)threadIdx.x & 3;
-    const bool live = k < nc * nc + nc;
+    const int nc = g.n + (c > 0), k = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (k >= nc * nc + nc) return;
     const int G = c == 0 ? G_luma : G_chroma;
-    const long long *p = partials + (size_t)frame * wg_cap * 3 * kMRec + (size_t)c * kMRec + (live ? k : 0);
-    long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int w = q;
-    for (; w + 12 < G; w += 16) {  // (independent loads in flight)
-      s0 += p[(size_t)(w + 0) * 3 * kMRec];
-      s1 += p[(size_t)(w + 4) * 3 * kMRec];
-      s2 += p[(size_t)(w + 8) * 3 * kMRec];
-      s3 += p[(size_t)(w + 12) * 3 * kMRec];
+    const long long *p = partials + (size_t)frame * wg_cap * 3 * kMRec + (size_t)c * kMRec + k;
+    constexpr size_t kStep = (size_t)3 * kMRec;
+    long long s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int w = 0;
+    for (; w + 8 <= G; w += 8) {  // (independent loads in flight)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(w + u) * kStep];
     }
-    for (; w < G; w += 4) s0 += p[(size_t)w * 3 * kMRec];
-    long long tot = (s0 + s1) + (s2 + s3);
-    tot += __shfl_xor(tot, 1, 64);
-    tot += __shfl_xor(tot, 2, 64);
+    for (; w < G; ++w) s[0] += p[(size_t)w * kStep];
+    const long long tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     // (an atomic: the exact kernel's workgroups of this launch add to the same entries)
-    if (live && q == 0 && tot != 0) {
+    if (tot != 0) {
       long long *ar = reinterpret_cast<long long *>(records + (size_t)frame * g.rec_size + g.off_ar[c]);
       atomicAdd(reinterpret_cast<unsigned long long *>(ar) + k, (unsigned long long)tot);
     }

@@ -359,21 +359,39 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
   __shared__ double lut[256];
   __shared__ double s_v[kBlock * kBlock];  // pixel / 255, later the residual
   __shared__ double s_t[5 * kFbInner];     // [3][1024] fit products, then [5][900] gradient terms
+  __shared__ uint32_t s_pre[kMaxBatch + 1];  // exclusive prefix of the frames' list lengths: the launch's sequence of blocks
   const int lane = threadIdx.x;
   const int W = (int)gridDim.x, w = (int)blockIdx.x;
+  // (the wave sums the counts 64 frames at a time; a loop over the frames with a scalar load of each count in turn was most
+  //  of the launch: 64 dependent round trips before the first block was touched)
+  {
+    uint32_t carry = 0;
+    if (lane == 0) s_pre[0] = 0;
+    for (int base = 0; base < nframes; base += 64) {
+      const uint32_t c = base + lane < nframes ? count[base + lane] : 0u;
+      uint32_t incl = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (base + lane < nframes) s_pre[base + lane + 1] = carry + incl;
+      carry += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+  }
+  __syncthreads();
+  const int total = (int)s_pre[nframes];
   bool have_lut = false;
-  int pos0 = 0;  // position of the frame's first listed block in the launch's sequence
-  for (int frame = 0; frame < nframes; ++frame) {
-  const int n = (int)count[frame];
-  const int it0 = ((w - pos0) % W + W) % W;
-  pos0 += n;
-  if (it0 >= n) continue;
+  int frame = 0;
+  for (int p = w; p < total; p += W) {
+  while ((int)s_pre[frame + 1] <= p) ++frame;  // (p grows: the search goes on from the last frame)
   if (!have_lut) {
     for (int i = lane; i < 256; i += 64) lut[i] = lut_g[i];
     have_lut = true;
   }
   const FramePlanes fp = ft.f[frame];
-  for (int it = it0; it < n; it += W) {
+  {
+    const int it = p - (int)s_pre[frame];
     const int blk = (int)list[(size_t)frame * g.nblocks + it];
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int ox = bx * kBlock, oy = by * kBlock;
@@ -382,8 +400,8 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
 #pragma unroll 4
     for (int i = lane; i < kBlock * kBlock; i += 64) {
       const int yi = i >> 5, xi = i & 31;
-      const int p = load_px<BPS>(fp.src[0], fp.src_stride[0], g.src_shift, min(ox + xi, g.W - 1), min(oy + yi, g.H - 1));
-      const double v = lut[p];
+      const int px = load_px<BPS>(fp.src[0], fp.src_stride[0], g.src_shift, min(ox + xi, g.W - 1), min(oy + yi, g.H - 1));
+      const double v = lut[px];
       const double yd = (double)(yi - 16) * 0.0625, xd = (double)(xi - 16) * 0.0625;
       s_v[i] = v;
       s_t[i] = v * yd;
@@ -449,18 +467,19 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
 // grid = (batch), block = kK2Threads.
 // ----------------------------------------------------------------------------
 constexpr int kK2Threads = 1024;
-constexpr int kK2PerThread = 8;  // scores kept in registers: up to 8192 blocks (a 4K frame has 8160)
+constexpr int kK2PerThread = 8;  // scores kept in registers: up to 8192 blocks (a 4K frame has 8160); 32 for up to 32768 (8K: 32400)
 // (the body: k2_flat_select below and the wide chain's k2w_select_units, k3w.hip.h, which builds the unit lists behind it)
-__device__ __forceinline__ void k2_flat_select_body(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame) {
+template <int PER>
+__device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame) {
   __shared__ uint32_t s_hist[256], s_wsum[4], s_sel[2];
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint32_t *sc = reinterpret_cast<const uint32_t *>(rec + g.off_scores);
   const int nb = g.nblocks;
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool in_regs = nb <= kK2Threads * kK2PerThread;
-  uint32_t v[kK2PerThread];
+  const bool in_regs = nb <= kK2Threads * PER;
+  uint32_t v[PER];
 #pragma unroll
-  for (int k = 0; k < kK2PerThread; ++k) {
+  for (int k = 0; k < PER; ++k) {
     const int i = tid + k * kK2Threads;
     v[k] = i < nb ? sc[i] : 0xffffffffu;  // the filler sorts last
   }
@@ -476,7 +495,7 @@ __device__ __forceinline__ void k2_flat_select_body(const Geom &g, uint8_t *__re
     __syncthreads();
     if (in_regs) {
 #pragma unroll
-      for (int k = 0; k < kK2PerThread; ++k)
+      for (int k = 0; k < PER; ++k)
         if ((v[k] & himask) == thr) atomicAdd(&s_hist[(v[k] >> shift) & 0xffu], 1u);
     } else {
       for (int i = tid; i < nb; i += kK2Threads) {
@@ -515,6 +534,10 @@ __device__ __forceinline__ void k2_flat_select_body(const Geom &g, uint8_t *__re
   uint8_t *mask = rec + g.off_mask;
   const uint8_t *fl = flags + (size_t)frame * nb;
   for (int i = tid; i < nb; i += kK2Threads) mask[i] = fl[i] | (sc[i] >= thr ? 1 : 0);
+}
+__device__ __forceinline__ void k2_flat_select_body(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame) {
+  if (g.nblocks <= kK2Threads * kK2PerThread) k2_flat_select_sized<kK2PerThread>(g, records, flags, frame);
+  else k2_flat_select_sized<32>(g, records, flags, frame);  // (8K: 32 400 scores, still in registers; larger frames re-read them)
 }
 __global__ __launch_bounds__(kK2Threads) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
                                                              const uint8_t *__restrict__ flags) {
