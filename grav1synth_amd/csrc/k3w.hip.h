@@ -9,8 +9,10 @@
 //    every staging lane holds a word of its own (k3s: 48 of 64), the per-unit costs (entry, branches, barriers, halo
 //    exchange) are paid once per 4 096 samples instead of once per 2 048, and a row of a 10-bit unit is two whole 128-byte
 //    lines (a chroma row of k3s's units was half a line).
-//  * The unit entries are read with SCALAR loads straight into SGPRs (constant address space): no parking in LDS, no
-//    control words, no v_readfirstlane.
+//  * The unit entries (8 dwords) of a workgroup's slice are parked in LDS once and read back a unit at a time
+//    (ds_read + v_readfirstlane into SGPRs).  Scalar loads straight from the list were tried first and cost more than
+//    half of the luma launch: an s_load in the unit loop is a 2 - 3 us round trip that nothing hides
+//    (profiles/r04b_elim.txt).
 //  * Observation windows are applied when the tile is MULTIPLIED, as a byte mask on the A operand only
 //    (S = sum_p m(p) v(p) v(p)^T = (M V) V^T): a k-group's 16 samples sit in fixed columns, so the column window of a block
 //    is one 16-byte lane constant per unit and a row outside the window rows zeroes it for that step.  The staging code
@@ -24,7 +26,7 @@
 //    from the registers of the unit before / after it in the workgroup's run (a DPP row rotation); the list is in raster
 //    order (k3w_units compacts it deterministically), a neighbour that exists is therefore adjacent in the list, and the
 //    one in front of / behind the workgroup's slice is formed as a GHOST (loads and residuals only).
-//  * ONE tile buffer (two barriers a unit): 32 KB a luma workgroup, four to a CU.
+//  * ONE tile buffer (two barriers a unit): 36 KB a luma workgroup, four to a CU.
 //
 // Exactness: int8 x int8 -> int32 products, int32 accumulators (a workgroup's slice is bounded so that they cannot
 // overflow), int64 partial systems: every sum is the reference's own sum of integers, in another order.
