@@ -380,10 +380,13 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   const uint32_t sst = CHR ? (s_plane ? fp.src_stride[2] : fp.src_stride[1]) : fp.src_stride[0];
   const uint32_t dst_ = CHR ? (s_plane ? fp.den_stride[2] : fp.den_stride[1]) : fp.den_stride[0];
   // own iteration i: tile rows t = 4 + own_row0 + 8 i + 2 p + r
-  const int own_row0 = CHR ? (wave & 1) * (BH / 2) : 8 * wave;
+  // (measured and dropped: the halo wave rotating with the workgroup -- pseudo-randomly, so that the four workgroups of a CU
+  //  would not all load the same SIMD with it: luma 399 - 429 -> 430 - 441 us, tools/r4_rot.sh)
+  const int swave = wave;
+  const int own_row0 = CHR ? (swave & 1) * (BH / 2) : 8 * swave;
   // the halo rows (tile rows 0 .. 3) of a plane: one more iteration on the plane's last wave, lanes p & 1 -> rows 2 (p & 1) + r
   // (the upper half of the wave repeats the lower half: same loads, same stores)
-  const bool h_wave = CHR ? (wave & 1) == 1 : wave == kWWaves - 1;
+  const bool h_wave = CHR ? (swave & 1) == 1 : swave == kWWaves - 1;
   // constants of the lane: ONE load offset per input (tile row 4 + own_row0 + 2 p, word w, from the unit's origin = tile row 0,
   // word 0); the second row of the pair, the further own iterations and the halo iteration move the SCALAR base instead.
   // Halo iteration: pair p -> tile rows 2 p + r; only p < 2 (rows 0 .. 3) is wanted: the upper half of the wave sits out.
