@@ -1711,6 +1711,8 @@ const char *g1s_diff_last_error(const g1s_diff_t *g) { return g ? g->err.c_str()
 // (internal, ingest.cpp: the frame-pair loop prefixes errors with the index of the pair)
 uint32_t g1s_diff_source_bit_depth_(const g1s_diff_t *g) { return g ? g->src_bd : 0; }
 int32_t g1s_diff_device_(const g1s_diff_t *g) { return g ? g->device : -1; }
+// frames the generator can hold at once (its slots x the launch group); 0 until the first frame has set the geometry
+uint32_t g1s_diff_frames_in_flight_max_(const g1s_diff_t *g) { return g && g->shape.width ? (uint32_t)kSlots * g->batch : 0; }
 void g1s_diff_set_error_text_(g1s_diff_t *g, const char *msg) {
   if (g && msg) g->err = msg;
 }

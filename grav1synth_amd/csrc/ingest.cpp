@@ -344,6 +344,7 @@ void g1s_y4m_close(g1s_y4m_t *y) {
 extern "C" void g1s_diff_set_error_text_(g1s_diff_t *, const char *);
 extern "C" uint32_t g1s_diff_source_bit_depth_(const g1s_diff_t *);
 extern "C" int32_t g1s_diff_device_(const g1s_diff_t *);
+extern "C" uint32_t g1s_diff_frames_in_flight_max_(const g1s_diff_t *);
 
 int g1s_diff_run_filtered(g1s_diff_t *g, g1s_next_frame_fn source, void *source_user, g1s_next_frame_fn denoised,
                           void *denoised_user, const g1s_filters_t *filters, uint64_t *frames_out, int *unequal_out) {
@@ -352,7 +353,10 @@ int g1s_diff_run_filtered(g1s_diff_t *g, g1s_next_frame_fn source, void *source_
   int unequal = 0;
   int rc = G1S_OK;
   const bool resizes = filters && g1s_filters_has_resize(filters);
-  constexpr uint64_t kResizeRing = 512;  // resized frames that may be inside the generator at once (4 batches of <= 128)
+  // resized frames that may be inside the generator at once: its slots x its launch group, and one more group so that a slot is
+  // rarely waited for (4K: 5 x 64 frames = 8 GB of device memory, 8K 4:4:4: 5 x 16 = 16 GB; a fixed 512 was 12.7 / 100 GB).
+  // Frame 0 goes to slot 0 before the generator has chosen its group: any ring agrees on that.
+  uint64_t kResizeRing = 512;
   auto note = [&](const std::string &what) {
     g1s_diff_set_error_text_(g, ("frame " + std::to_string(frames) + ": " + what).c_str());
   };
@@ -379,6 +383,10 @@ int g1s_diff_run_filtered(g1s_diff_t *g, g1s_next_frame_fn source, void *source_
       // place, so a slot is taken again only when the frame that was there has been released
       uint32_t slot = 0;
       if (resizes) {
+        if (frames == 1) {
+          const uint32_t inside = g1s_diff_frames_in_flight_max_(g);
+          if (inside) kResizeRing = std::min<uint64_t>(512, inside + inside / 4);
+        }
         slot = (uint32_t)(frames % kResizeRing);
         if (frames >= kResizeRing && g1s_diff_frames_released(g) + kResizeRing <= frames) {
           rc = g1s_diff_sync(g);

@@ -230,6 +230,9 @@ int ResizeState::run(const g1s_frame_t &in, uint32_t bit_depth, uint32_t out_w, 
     in_need = std::max(in_need, align(pw[c] * bps) * ph[c]);
   }
   if (total != im->out_bytes) {  // a new geometry: the ring starts over
+    // (every slot's frame is gone with it: a caller that still has frames of the old geometry inside a generator must
+    //  g1s_diff_sync first -- the device is drained here so that at least no running kernel reads freed memory)
+    if (!im->ring.empty()) (void)hipDeviceSynchronize();
     for (uint8_t *p : im->ring) (void)hipFree(p);
     im->ring.clear();
     im->out_bytes = total;
@@ -244,13 +247,23 @@ int ResizeState::run(const g1s_frame_t &in, uint32_t bit_depth, uint32_t out_w, 
   }
   if (tmp_need > im->tmp_cap) {
     (void)hipFree(im->d_tmp);
-    if (hipMalloc((void **)&im->d_tmp, tmp_need) != hipSuccess) return G1S_ERR_HIP;
+    im->d_tmp = nullptr;
+    im->tmp_cap = 0;
+    if (hipMalloc((void **)&im->d_tmp, tmp_need) != hipSuccess) {
+      err = "resize: out of device memory (intermediate plane)";
+      return G1S_ERR_HIP;
+    }
     im->tmp_cap = tmp_need;
   }
   const bool host_in = in.on_device != 1;  // (0: pageable host, 2: pinned host)
   if (host_in && in_need > im->in_cap) {
     (void)hipFree(im->d_in);
-    if (hipMalloc((void **)&im->d_in, in_need) != hipSuccess) return G1S_ERR_HIP;
+    im->d_in = nullptr;
+    im->in_cap = 0;
+    if (hipMalloc((void **)&im->d_in, in_need) != hipSuccess) {
+      err = "resize: out of device memory (input staging)";
+      return G1S_ERR_HIP;
+    }
     im->in_cap = in_need;
   }
   out = in;
@@ -268,8 +281,10 @@ int ResizeState::run(const g1s_frame_t &in, uint32_t bit_depth, uint32_t out_w, 
     size_t sstride = in.stride_bytes[c];
     if (host_in) {  // (the filter works on the device: stage the host plane)
       sstride = align(pw[c] * bps);
-      if (hipMemcpy2DAsync(im->d_in, sstride, in.data[c], in.stride_bytes[c], pw[c] * bps, ph[c], hipMemcpyHostToDevice, im->stream) != hipSuccess)
+      if (hipMemcpy2DAsync(im->d_in, sstride, in.data[c], in.stride_bytes[c], pw[c] * bps, ph[c], hipMemcpyHostToDevice, im->stream) != hipSuccess) {
+        err = "resize: staging a host plane failed (hipMemcpy2DAsync)";
         return G1S_ERR_HIP;
+      }
       src = im->d_in;
     }
     uint8_t *dst = im->ring[slot] + off_out[c];
@@ -285,7 +300,10 @@ int ResizeState::run(const g1s_frame_t &in, uint32_t bit_depth, uint32_t out_w, 
       hipLaunchKernelGGL(k_resize_v<uint16_t>, gv, bh, 0, im->stream, (const uint16_t *)im->d_tmp, stride_out[c], (uint16_t *)dst, stride_out[c],
                          (int)ow[c], (int)oh[c], vp->host.taps, vp->d_idx, vp->d_coef, maxv);
     }
-    if (host_in && hipStreamSynchronize(im->stream) != hipSuccess) return G1S_ERR_HIP;  // (d_in is reused by the next plane)
+    if (host_in && hipStreamSynchronize(im->stream) != hipSuccess) {  // (d_in is reused by the next plane)
+      err = "resize: a plane's kernels failed";
+      return G1S_ERR_HIP;
+    }
     out.data[c] = dst;
     out.stride_bytes[c] = stride_out[c];
   }

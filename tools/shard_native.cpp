@@ -7,7 +7,7 @@
 //   shard_native [N devices, default all] [frames, default 40] [batch_frames, default 4] [W H, default 352 224]
 //
 // It feeds a deterministic synthetic 10-bit 4:2:0 video (flat field + noise on the source side, a scene change halfway so
-// that the table has two segments), batch j to device j % N, runs rounds + 4 flush rounds, merges on device 0's host, and
+// that the table has two segments), batch j to device j % N, runs rounds + flush rounds until every frame is merged, merges on device 0's host, and
 // compares the table, byte for byte, with the one a single generator gives for the same frames.  Exit code 0 = identical.
 // Build: hipcc --offload-arch=gfx950 -O2 -I include tools/shard_native.cpp -L grav1synth_amd -lg1s_diff -lrccl -o tools/shard_native
 #include <hip/hip_runtime.h>
@@ -160,7 +160,11 @@ int main(int argc, char **argv) {
   g1s_fold_t *fold = g1s_fold_new(fps_num, fps_den, 3);
 
   const size_t nbatches = ((size_t)frames + B - 1) / B, rounds = (nbatches + N - 1) / N;
-  for (size_t k = 0; k < rounds + 4; ++k) {  // + 4 flush rounds: what is still in the generators' pipelines
+  // (flush rounds behind the feeding rounds until every frame fed has been merged -- what is still in the generators'
+  //  pipelines: usually 4 rounds; a count that does not arrive is an error, not a shorter table)
+  size_t flush_rounds = 0;
+  for (size_t k = 0; k < rounds || (g1s_fold_frames(fold) < (uint64_t)frames && flush_rounds < 64); ++k) {
+    if (k >= rounds) ++flush_rounds;
     for (int r = 0; r < N; ++r) {
       CHECK_HIP(hipSetDevice(r));
       const size_t j = k * N + r;
@@ -195,6 +199,10 @@ int main(int argc, char **argv) {
       return 2;
     }
   }
+  if (g1s_fold_frames(fold) != (uint64_t)frames) {
+    fprintf(stderr, "merged %llu of %d frames after %zu flush rounds\n", (unsigned long long)g1s_fold_frames(fold), frames, flush_rounds);
+    return 2;
+  }
   std::vector<g1s_segment_t> segs(64);
   size_t n = 0;
   if (g1s_fold_finish(fold, segs.data(), segs.size(), &n)) {
@@ -209,8 +217,8 @@ int main(int argc, char **argv) {
   }
   g1s_fold_free(fold);
   const bool same = got == want;
-  printf("shard_native: %d device(s), %d frames in batches of %u, %zu rounds + 4: %zu segment(s), table %s the single generator's (%zu bytes)\n",
-         N, frames, B, rounds, n, same ? "IDENTICAL to" : "DIFFERS from", got.size());
+  printf("shard_native: %d device(s), %d frames in batches of %u, %zu rounds + %zu flush rounds: %zu segment(s), table %s the single generator's (%zu bytes)\n",
+         N, frames, B, rounds, flush_rounds, n, same ? "IDENTICAL to" : "DIFFERS from", got.size());
   if (!same) fprintf(stderr, "--- sharded\n%s--- single\n%s", got.c_str(), want.c_str());
   return same ? 0 : 1;
 }
