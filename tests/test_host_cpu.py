@@ -177,6 +177,19 @@ def test_batched_merge_equals_frame_by_frame_merge_across_segment_cuts():
         tables.append(format_tbl(fold.finish()))
         fold.close()
     assert all(t == tbl for t in tables)
+    # the batch call (g1s_latest_from_records: the process pool) gives the bytes of the one-record call, whatever the strides
+    L = _lib.lib()
+    bs = int(L.g1s_latest_size(3))
+    wide_recs = np.zeros((len(recs), recs.shape[1] + 64), np.uint8)
+    wide_recs[:, :recs.shape[1]] = recs
+    wide_blobs = np.zeros((len(recs), bs + 24), np.uint8)
+    assert L.g1s_latest_from_records(wide_recs.ctypes.data, wide_recs.shape[1], len(recs), 3, wide_blobs.ctypes.data, wide_blobs.shape[1]) == 0
+    one = np.zeros(bs, np.uint8)
+    for k in range(len(recs)):
+        assert L.g1s_latest_from_record(recs[k].ctypes.data, recs.shape[1], 3, one.ctypes.data, bs) == 0
+        assert np.array_equal(one, wide_blobs[k, :bs]) and np.array_equal(one, blobs[k])
+    assert L.g1s_latest_from_records(wide_recs.ctypes.data, wide_recs.shape[1], 2, 3, wide_blobs.ctypes.data, bs - 8) != 0  # blobs too small
+    assert 1 <= int(L.g1s_usable_cpus()) <= (os.cpu_count() or 1)
 
 
 def test_native_tbl_reader_round_trips_and_matches_the_python_reader():
