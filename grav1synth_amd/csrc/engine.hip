@@ -926,7 +926,7 @@ int g1s_diff::launch_front(int si) {
     wup.ub[1] = w_ub_c;
   }
   kmark(sl, fstream, w_lists ? "k2w_select_units" : "k2_flat_select");
-  if (w_lists) hipLaunchKernelGGL(k2w_select_units, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, (const uint8_t *)sl.d_flags, wup);
+  if (w_lists) hipLaunchKernelGGL(k2w_select_units, dim3(B, g.nplanes == 3 ? 2 : 1), dim3(kK2Threads), 0, fstream, g, sl.d_records, (const uint8_t *)sl.d_flags, wup);
   else if (!dbg_skip("k2")) hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
   if (!w_lists) {
@@ -1041,7 +1041,10 @@ int g1s_diff::launch_back(int si) {
       G1S_WB(0, -1, -1);
     } else {
       G1S_WK(0);
-      static const bool chroma_aside = getenv("G1S_F_SERIAL") == nullptr;  // tuning aid
+      // The chroma launch stays on the main stream behind the luma launch.  Round 3's chain moved it (and what follows) to the
+      // copy stream, next to the luma launch of the batch after; with this chain both launches fill every register of the
+      // chip and only stretch each other: serial is +2 - 5 % on the 4K job, +10 % at 8K 4:4:4 (profiles/r04_streams.txt).
+      static const bool chroma_aside = getenv("G1S_W_ASIDE") != nullptr;  // tuning aid: round 3's placement
       if (side && chroma_aside) {  // the chroma launch and what follows: next to the luma launch of the batch after
         HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
         HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
@@ -1241,8 +1244,12 @@ int g1s_diff::launch_back(int si) {
   }
   // profiling aid (G1S_D2H_SYNC=1, with G1S_ONE_STREAM=1): the records copy has ended before the next batch's first kernel
   // starts -- under rocprofv3 the copy is a blit kernel that otherwise shares the chip with k1_moments and doubles its time
+  // A timed batch (g1s_diff_set_timing: every kernel between two events, "alone on the chip") waits for it too: the copy of
+  // batch N next to the kernels of batch N + 1 costs the luma launch 4 % at 8K, and on some boxes of the pool the event pair of
+  // the batch's last kernel read 280 - 500 us instead of 45 - 75 with it in flight (profiles/r04_rot.txt vs r04_hwq.txt).
   static const bool d2h_sync = getenv("G1S_D2H_SYNC") != nullptr;
   if (d2h_sync) HIP_TRY(hipStreamSynchronize(ss.copy));
+  else if (sl.timed) HIP_TRY(hipEventSynchronize(sl.done));  // (the copy's end, whichever stream carried it)
   stats.launches_flat_features++;
   stats.launches_flat_select++;
   stats.launches_ar_accumulate++;

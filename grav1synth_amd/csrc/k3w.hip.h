@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restr
   w_build_units(g, records + (size_t)frame * g.rec_size + g.off_mask, up, kind, frame);
 }
 // k2w_select_units: k2_flat_select (the frame's threshold score, its mask bytes) and, behind it, the frame's unit lists: one launch
-// instead of two in the finder's chain.  grid = (batch), block = 1024 (= kK2Threads).
+// instead of two in the finder's chain.  grid = (batch, kinds of planes: 1 or 2), block = 1024 (= kK2Threads).
 static_assert(kK2Threads == 1024, "k2w_select_units: the list builder's workgroup");
 __global__ __launch_bounds__(1024) void k2w_select_units(Geom g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, WUnitParams up) {
   const int frame = blockIdx.x;
@@ -204,20 +204,16 @@ __global__ __launch_bounds__(1024) void k2w_select_units(Geom g, uint8_t *__rest
   __shared__ uint8_t s_mask[kMaskLds];
   const uint8_t *gmask = records + (size_t)frame * g.rec_size + g.off_mask;
   const bool in_lds = g.nblocks <= kMaskLds;
+  // (grid.y = the list's kind: the two workgroups of a frame both find the threshold and write the same mask bytes, then each
+  //  builds one list -- the lists were a third of this kernel's time one behind the other, and a frame's workgroup is alone on
+  //  its CU either way)
+  const int kind = (int)blockIdx.y;
   if (in_lds) {
     for (int i = (int)threadIdx.x; i < g.nblocks; i += 1024) s_mask[i] = gmask[i];
     __syncthreads();
-    w_build_units(g, s_mask, up, 0, frame);
-    if (g.nplanes == 3) {
-      __syncthreads();
-      w_build_units(g, s_mask, up, 1, frame);
-    }
+    w_build_units(g, s_mask, up, kind, frame);
   } else {
-    w_build_units(g, gmask, up, 0, frame);
-    if (g.nplanes == 3) {
-      __syncthreads();
-      w_build_units(g, gmask, up, 1, frame);
-    }
+    w_build_units(g, gmask, up, kind, frame);
   }
 }
 
