@@ -30,6 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The HIP runtime gives a process 4 hardware queues by default; the generator's four streams and torch's own then share them
+# and kernels of different streams wait for each other (the same build: 544 - 593 k Mpx/s from run to run; with 8 queues
+# 590 - 595 k: profiles/r04_streams.txt).  Read by the runtime when it starts: set before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -322,7 +322,8 @@ std::vector<CachedSlot> g_slot_cache;
 struct StreamSet {
   int device = -1;
   hipStream_t compute = nullptr, copy = nullptr, flat = nullptr, flat2 = nullptr, upload = nullptr;
-  hipStream_t latest = nullptr;  // k4_latest and the blobs' D2H (the copy stream carries the accumulation's tail kernels)
+  hipStream_t latest = nullptr;  // k4_latest and the blobs' D2H (made when a generator first runs the half on the device)
+  int prio_side = 0;
   hipEvent_t kernels_done[kSlots] = {};
   hipEvent_t mask_done[kSlots] = {};
   hipEvent_t pix_done[kSlots] = {};
@@ -343,16 +344,27 @@ bool acquire_streams(int device, StreamSet &out) {
   }
   out = StreamSet{};
   out.device = device;
-  // the side stream (finder chain, window planes, area lists: small latency-bound kernels) outranks the
-  // main stream's big kernels, next to which it runs
+  // the side stream (the finder chain: small latency-bound kernels) outranks the main stream's big kernels, next to which it
+  // runs.  What matters more than the order of the two: that the streams do not share a hardware queue.  The runtime gives a
+  // process 4 by default (GPU_MAX_HW_QUEUES); the 4 - 6 streams here plus the host application's own then share, by creation
+  // order, and kernels of different streams wait for each other: the same build read 544 - 593 k Mpx/s from run to run, 590 -
+  // 595 k with GPU_MAX_HW_QUEUES=8, and 393 - 406 k with every stream in one priority class on 4 queues
+  // (profiles/r04_streams.txt).  bench.py and the command set the variable before the runtime starts; the streams only some
+  // jobs use (the second side stream, the device half's) are made when they are first needed.
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = more urgent
+  if (const char *e = getenv("G1S_PRIO")) {  // tuning aid: 1 = the main stream outranks the side stream, 2 = no priorities
+    const int m = atoi(e);
+    if (m == 1) std::swap(prio_lo, prio_hi);
+    else if (m == 2) prio_lo = prio_hi = (prio_lo + prio_hi) / 2;
+  }
+  static const bool want_flat2 = getenv("G1S_SIDE2") && atoi(getenv("G1S_SIDE2")) != 0;
+  out.prio_side = prio_hi;
   bool ok = hipStreamCreateWithPriority(&out.compute, hipStreamNonBlocking, prio_lo) == hipSuccess &&
             hipStreamCreateWithFlags(&out.copy, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithPriority(&out.flat, hipStreamNonBlocking, prio_hi) == hipSuccess &&
-            hipStreamCreateWithPriority(&out.flat2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
-            hipStreamCreateWithFlags(&out.upload, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&out.latest, hipStreamNonBlocking) == hipSuccess;
+            (!want_flat2 || hipStreamCreateWithPriority(&out.flat2, hipStreamNonBlocking, prio_hi) == hipSuccess) &&
+            hipStreamCreateWithFlags(&out.upload, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < kSlots && ok; ++i)
     ok = hipEventCreateWithFlags(&out.kernels_done[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&out.mask_done[i], hipEventDisableTiming) == hipSuccess &&
@@ -1231,6 +1243,7 @@ int g1s_diff::launch_back(int si) {
       HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
       HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
     } else {
+      if (!ss.latest) HIP_TRY(hipStreamCreateWithFlags(&ss.latest, hipStreamNonBlocking));
       HIP_TRY(hipStreamWaitEvent(ss.latest, ss.kernels_done[si], 0));
       HIP_TRY(launch_latest(job, B, ss.latest));
     }
