@@ -397,11 +397,17 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
     const int ox = bx * kBlock, oy = by * kBlock;
     __syncthreads();
     // ---- block(1x1024) and its products with the columns of A ----
-#pragma unroll 4
-    for (int i = lane; i < kBlock * kBlock; i += 64) {
-      const int yi = i >> 5, xi = i & 31;
-      const int px = load_px<BPS>(fp.src[0], fp.src_stride[0], g.src_shift, min(ox + xi, g.W - 1), min(oy + yi, g.H - 1));
-      const double v = lut[px];
+    // (the lane's 16 pixels are requested at once: four at a time was four dependent round trips to memory)
+    int pxs[kBlock * kBlock / 64];
+#pragma unroll
+    for (int k = 0; k < kBlock * kBlock / 64; ++k) {
+      const int i = lane + 64 * k, yi = i >> 5, xi = i & 31;
+      pxs[k] = load_px<BPS>(fp.src[0], fp.src_stride[0], g.src_shift, min(ox + xi, g.W - 1), min(oy + yi, g.H - 1));
+    }
+#pragma unroll
+    for (int k = 0; k < kBlock * kBlock / 64; ++k) {
+      const int i = lane + 64 * k, yi = i >> 5, xi = i & 31;
+      const double v = lut[pxs[k]];
       const double yd = (double)(yi - 16) * 0.0625, xd = (double)(xi - 16) * 0.0625;
       s_v[i] = v;
       s_t[i] = v * yd;
