@@ -210,6 +210,39 @@ void StrengthSolver::add_measurements(const double *bin, const uint32_t *sel, co
   total = tot;
   num_equations += (int64_t)m;
 }
+// The same measurements' b side only, with the matrix copied from a system that has accumulated EXACTLY this sequence of bin
+// positions (another plane of the frame: the entries of A depend on the bin positions alone, so they are the same sums of the
+// same terms in the same order); b and total get this plane's noise_std as in add_measurements.
+void StrengthSolver::add_measurements_like(const StrengthSolver &same_bins, const double *bin, const uint32_t *sel, const double *noise_std, size_t m) {
+  const int n = kNumBins;
+  eq.A = same_bins.eq.A;
+  double *b = eq.b.data();
+  int cur = -1;
+  double b0 = 0, b1 = 0, tot = total;
+  for (size_t k = 0; k < m; ++k) {
+    const double bn = bin[sel[k]], sd = noise_std[k];
+    const int i0 = (int)bn;
+    const double a = bn - i0;
+    if (i0 >= n - 1) {
+      if (cur >= 0) b[cur] = b0, b[cur + 1] = b1, cur = -1;
+      b[i0] += (1.0 - a) * sd;
+      b[n - 1] += a * sd;
+    } else {
+      if (i0 != cur) {
+        if (cur >= 0) b[cur] = b0, b[cur + 1] = b1;
+        cur = i0;
+        b0 = b[cur];
+        b1 = b[cur + 1];
+      }
+      b0 += (1.0 - a) * sd;
+      b1 += a * sd;
+    }
+    tot += sd;
+  }
+  if (cur >= 0) b[cur] = b0, b[cur + 1] = b1;
+  total = tot;
+  num_equations += (int64_t)m;
+}
 void StrengthSolver::apply_regularisation_to_b() {
   const double mean = total / num_equations;
   for (int i = 0; i < kNumBins; ++i) eq.b[i] += mean / 8192.;
@@ -578,38 +611,51 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
       sc.resize(7 * cap);
       double *p_sd = sc.data(), *p_sd2 = p_sd + cap, *p_cnt = p_sd2 + cap, *p_rcp = p_cnt + cap, *p_ls = p_rcp + cap, *p_nv = p_ls + cap,
              *p_std = p_nv + cap;
-      out.scratch_sel.resize(cap);
-      uint32_t *sel = out.scratch_sel.data();  // position in the frame's flat list of the blocks this plane measures
+      // the blocks a plane measures, their counts: luma's list in scratch_sel0, the chroma planes' (one list: the two planes
+      // have one geometry) in scratch_sel; plane 2 takes plane 1's
+      std::vector<uint32_t> &selv = c == 0 ? out.scratch_sel0 : out.scratch_sel;
+      selv.resize(cap);
+      uint32_t *sel = selv.data();  // position in the frame's flat list of the blocks this plane measures
       const uint32_t *idx = out.scratch_idx.data(), *pos = out.scratch_pos.data();
       const int pw = w >> sx, ph = hh >> sy;
       const int full_bx = pw / bw, full_by = ph / bh;  // blocks left of / above these are whole
       const double cnt_full = (double)(bw * bh), rcp_full = pow2_rcp(bw * bh);
       const bool full_counts = bw * bh > kBlock;
       size_t m = 0;
-      for (size_t k = 0; k < cap; ++k) {
-        const int bi = (int)idx[k];
-        const int by = (int)(pos[k] >> 16), bx = (int)(pos[k] & 0xffffu);
-        if (bx < full_bx && by < full_by) {
-          if (!full_counts) continue;
-          p_cnt[m] = cnt_full;
-          p_rcp[m] = rcp_full;
-        } else {
-          const int sh = std::min(ph - by * bh, bh);
-          const int sw = std::min(pw - bx * bw, bw);
-          if (!(sw * sh > kBlock)) continue;
-          p_cnt[m] = (double)(sw * sh);
-          p_rcp[m] = pow2_rcp(sw * sh);
+      if (c == 2) {
+        m = out.scratch_m[1];
+        for (size_t k = 0; k < m; ++k) {
+          const int bi = (int)idx[sel[k]];
+          p_sd[k] = (double)sum_d[bi];
+          p_sd2[k] = (double)sum_d2[bi];
         }
-        p_sd[m] = (double)sum_d[bi];
-        p_sd2[m] = (double)sum_d2[bi];
-        sel[m] = (uint32_t)k;
-        ++m;
+      } else {
+        for (size_t k = 0; k < cap; ++k) {
+          const int bi = (int)idx[k];
+          const int by = (int)(pos[k] >> 16), bx = (int)(pos[k] & 0xffffu);
+          if (bx < full_bx && by < full_by) {
+            if (!full_counts) continue;
+            p_cnt[m] = cnt_full;
+            p_rcp[m] = rcp_full;
+          } else {
+            const int sh = std::min(ph - by * bh, bh);
+            const int sw = std::min(pw - bx * bw, bw);
+            if (!(sw * sh > kBlock)) continue;
+            p_cnt[m] = (double)(sw * sh);
+            p_rcp[m] = pow2_rcp(sw * sh);
+          }
+          p_sd[m] = (double)sum_d[bi];
+          p_sd2[m] = (double)sum_d2[bi];
+          sel[m] = (uint32_t)k;
+          ++m;
+        }
+        out.scratch_m[c] = m;
       }
       STAGE(3);
       noise_variances(m, p_sd, p_sd2, p_cnt, p_rcp, p_nv);
       STAGE(7);
       const double *bins = out.scratch_bin.data();
-      if (is_chroma) {
+      if (c == 1) {
         const double *lx = out.st[0].strength.eq.x.data();
         for (size_t k = 0; k < m; ++k) {  // luma_gain * luma strength.value_at(block_mean)
           const double bin = bins[sel[k]];
@@ -618,12 +664,18 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
           const double a = bin - i0;
           p_ls[k] = luma_gain * ((1.0 - a) * lx[i0] + a * lx[i1]);
         }
-      } else {
+      } else if (c == 0) {
         for (size_t k = 0; k < m; ++k) p_ls[k] = 0;
-      }
+      }  // (c == 2: plane 1's values -- the same blocks, the same luma strength)
       uncorrelated_stds(m, p_nv, p_ls, corr, noise_gain, p_std);
       STAGE(4);
-      lat.strength.add_measurements(bins, sel, p_std, m);
+      // the matrix side of the accumulation depends on the bin positions alone: a plane that measures the very blocks an
+      // earlier plane measured (Cr after Cb always; Cb after luma unless a cut last row or column is too small at chroma
+      // resolution) copies that plane's matrix (solve() leaves A as it was) and accumulates its b side only
+      const int like = c == 2 ? 1
+                       : (c == 1 && m == out.scratch_m[0] && std::memcmp(sel, out.scratch_sel0.data(), m * sizeof(uint32_t)) == 0) ? 0 : -1;
+      if (like >= 0) lat.strength.add_measurements_like(out.st[like].strength, bins, sel, p_std, m);
+      else lat.strength.add_measurements(bins, sel, p_std, m);
       STAGE(5);
     }
     if (!lat.strength.solve()) return fail(G1S_ERR_SOLVE, "Solving latest noise strength failed!");

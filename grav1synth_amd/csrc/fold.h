@@ -51,6 +51,7 @@ struct StrengthSolver {
   double value_at(double x) const;
   void add_measurement(double block_mean, double noise_std);
   void add_measurements(const double *bin, const uint32_t *sel, const double *noise_std, size_t m);  // (in order; fold.cpp)
+  void add_measurements_like(const StrengthSolver &same_bins, const double *bin, const uint32_t *sel, const double *noise_std, size_t m);
   bool solve();
   // The two halves of solve(): the reference's solve() both perturbs b
   // (b += mean/8192, never undone) and computes x.  When x is not needed yet
@@ -79,7 +80,8 @@ struct FrameLatest {
   std::string err;
   // compute_latest: the frame's flat blocks (raster order), their luma means and bin positions; a plane's measurement arrays
   std::vector<double> scratch_mean, scratch_std, scratch_bin, scratch_plane;
-  std::vector<uint32_t> scratch_idx, scratch_pos, scratch_sel;
+  std::vector<uint32_t> scratch_idx, scratch_pos, scratch_sel, scratch_sel0;
+  size_t scratch_m[3] = {0, 0, 0};
 };
 // Thread-safe: record -> latest state (AR solve, measurements, strength solve).
 int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &out);
