@@ -831,6 +831,8 @@ int g1s_diff::launch_front(int si) {
   // the pixel pass of round 1's chain (K0) runs on the main stream; the fused pass has no K0: its only pixel pass before
   // the mask is the finder's luma-source moments kernel, which joins the finder chain on the side stream and runs next to
   // the accumulation of the batch before
+  // (measured and dropped: k1_moments on the main stream in front of the accumulation of the batch before, the rest of the
+  //  finder chain beside that accumulation: -3 to -10 % at 4K, +11 % at 1080p, -4 % at 8K; profiles/r04_streams.txt)
   hipStream_t pstream = fstream;
   // the frame table: pinned host copy -> device, on the upload stream (idle: done long before the main
   // stream gets here); per-kernel timing / one-stream mode: in line
