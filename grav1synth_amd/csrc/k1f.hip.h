@@ -100,6 +100,14 @@ __device__ __forceinline__ dd dd_div_d(dd a, double b) {
   return two_sum(q1, q2);
 }
 
+// a / c for the constants of the evaluation, as a multiplication by the double-double reciprocal (hi + lo = 1 / c to 2^-108;
+// the product to ~2^-103): the two f64 divisions of dd_div_d were a third of k1_certify's instructions
+constexpr dd kRcp4080{0.00024509803921568627, 3.4014185803466805e-21};
+constexpr dd kRcp255{0.00392156862745098, 5.442269728554689e-20};
+constexpr dd kRcp260100{3.844675124951942e-06, -4.216472044548166e-22};
+constexpr dd kRcp8160{0.00012254901960784314, 1.7007092901733403e-21};
+constexpr dd kRcp65025{1.5378700499807768e-05, -1.6865888178192663e-21};
+
 // ---- a value the way the reference computes it, known up to a bound ----
 // v: this kernel's f64 evaluation; e: bound on |reference's rounded evaluation - v|.
 struct VE {
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(256) void k1_certify(Geom g, FlatConsts fc, const i
     const double IPP = m[kM_IPP], DXX = m[kM_DXX], DYY = m[kM_DYY], DXY = m[kM_DXY], DX = m[kM_DX], DY = m[kM_DY];
     const double N = 900.0;
     // ---- plane fit: t = (sum v yd, sum v xd, sum v), c = M t ----
-    const dd t0 = dd_div_d(dd_from(SY), 4080.0), t1 = dd_div_d(dd_from(SX), 4080.0), t2 = dd_div_d(dd_from(S0), 255.0);
+    const dd t0 = dd_mul(dd_from(SY), kRcp4080), t1 = dd_mul(dd_from(SX), kRcp4080), t2 = dd_mul(dd_from(S0), kRcp255);
     // reference: 1024 products v*yd (v itself rounded) summed sequentially
     const double Et0 = 1030.0 * kU * SAY / 4080.0, Et1 = 1030.0 * kU * SAX / 4080.0, Et2 = 1026.0 * kU * S0 / 255.0;
     dd c[3];
@@ -178,22 +186,22 @@ __global__ __launch_bounds__(256) void k1_certify(Geom g, FlatConsts fc, const i
     const dd c0 = c[0], c1 = c[1], c2 = c[2];
     const dd c00 = dd_mul(c0, c0), c11 = dd_mul(c1, c1), c01 = dd_mul(c0, c1);
     // sum gx^2 = DXX/510^2 - c1 DX/4080 + N c1^2/256
-    const dd sGxx = dd_add(dd_add(dd_div_d(dd_from(DXX), 260100.0), dd_neg(dd_div_d(dd_mul_d(c1, DX), 4080.0))),
+    const dd sGxx = dd_add(dd_add(dd_mul(dd_from(DXX), kRcp260100), dd_neg(dd_mul(dd_mul_d(c1, DX), kRcp4080))),
                            dd_mul_d(c11, N / 256.0));
-    const dd sGyy = dd_add(dd_add(dd_div_d(dd_from(DYY), 260100.0), dd_neg(dd_div_d(dd_mul_d(c0, DY), 4080.0))),
+    const dd sGyy = dd_add(dd_add(dd_mul(dd_from(DYY), kRcp260100), dd_neg(dd_mul(dd_mul_d(c0, DY), kRcp4080))),
                            dd_mul_d(c00, N / 256.0));
     // sum gx gy = DXY/510^2 - c0 DX/8160 - c1 DY/8160 + N c0 c1/256
-    const dd sGxy = dd_add(dd_add(dd_div_d(dd_from(DXY), 260100.0), dd_neg(dd_div_d(dd_mul_d(c0, DX), 8160.0))),
-                           dd_add(dd_neg(dd_div_d(dd_mul_d(c1, DY), 8160.0)), dd_mul_d(c01, N / 256.0)));
+    const dd sGxy = dd_add(dd_add(dd_mul(dd_from(DXY), kRcp260100), dd_neg(dd_mul(dd_mul_d(c0, DX), kRcp8160))),
+                           dd_add(dd_neg(dd_mul(dd_mul_d(c1, DY), kRcp8160)), dd_mul_d(c01, N / 256.0)));
     // sum r = I0/255 - c0 sumY/16 - c1 sumX/16 - N c2,  sumX = sumY = -450 over the interior
-    const dd sR = dd_add(dd_add(dd_div_d(dd_from(I0), 255.0), dd_mul_d(dd_add(c0, c1), 450.0 / 16.0)), dd_neg(dd_mul_d(c2, N)));
+    const dd sR = dd_add(dd_add(dd_mul(dd_from(I0), kRcp255), dd_mul_d(dd_add(c0, c1), 450.0 / 16.0)), dd_neg(dd_mul_d(c2, N)));
     // sum r^2 = IPP/255^2 - 2 [c0 IY/4080 + c1 IX/4080 + c2 I0/255] + sum fit^2
-    const dd cross = dd_add(dd_add(dd_div_d(dd_mul_d(c0, IY), 4080.0), dd_div_d(dd_mul_d(c1, IX), 4080.0)),
-                            dd_div_d(dd_mul_d(c2, I0), 255.0));
+    const dd cross = dd_add(dd_add(dd_mul(dd_mul_d(c0, IY), kRcp4080), dd_mul(dd_mul_d(c1, IX), kRcp4080)),
+                            dd_mul(dd_mul_d(c2, I0), kRcp255));
     // sum fit^2 = (c0^2 + c1^2) 67650/256 + N c2^2 + 2 c0 c1 225/256 + 2 (c0 + c1) c2 (-450)/16
     const dd fit2 = dd_add(dd_add(dd_mul_d(dd_add(c00, c11), 67650.0 / 256.0), dd_mul_d(dd_mul(c2, c2), N)),
                            dd_add(dd_mul_d(c01, 450.0 / 256.0), dd_neg(dd_mul_d(dd_mul(dd_add(c0, c1), c2), 900.0 / 16.0))));
-    const dd sR2 = dd_add(dd_add(dd_div_d(dd_from(IPP), 65025.0), dd_neg(dd_mul_d(cross, 2.0))), fit2);
+    const dd sR2 = dd_add(dd_add(dd_mul(dd_from(IPP), kRcp65025), dd_neg(dd_mul_d(cross, 2.0))), fit2);
     const double gxx = fmax(sGxx.hi, 0.0), gyy = fmax(sGyy.hi, 0.0), r2 = fmax(sR2.hi, 0.0);
     // ---- how far the reference's rounded sequential sums can be from these ----
     const double kSafety = 4.0;
