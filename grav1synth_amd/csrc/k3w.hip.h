@@ -195,22 +195,20 @@ __global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restr
 static_assert(kK2Threads == 1024, "k2w_select_units: the list builder's workgroup");
 __global__ __launch_bounds__(1024) void k2w_select_units(Geom g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, WUnitParams up) {
   const int frame = blockIdx.x;
-  k2_flat_select_body(g, records, flags, frame);
-  // (the mask bytes were written by this workgroup: a workgroup-scope fence and a barrier make them visible to its own loads)
-  __threadfence_block();
-  __syncthreads();
-  // the mask bytes into LDS (up to an 8K frame's 32 400), the list builder reads them there
+  // the mask bytes also go into LDS (up to an 8K frame's 32 400): the list builder reads them there
   constexpr int kMaskLds = 32768;
   __shared__ uint8_t s_mask[kMaskLds];
-  const uint8_t *gmask = records + (size_t)frame * g.rec_size + g.off_mask;
   const bool in_lds = g.nblocks <= kMaskLds;
+  k2_flat_select_body(g, records, flags, frame, in_lds ? s_mask : nullptr);
+  // (larger frames: the bytes were written by this workgroup -- a workgroup-scope fence and a barrier make them visible to its own loads)
+  __threadfence_block();
+  __syncthreads();
+  const uint8_t *gmask = records + (size_t)frame * g.rec_size + g.off_mask;
   // (grid.y = the list's kind: the two workgroups of a frame both find the threshold and write the same mask bytes, then each
   //  builds one list -- the lists were a third of this kernel's time one behind the other, and a frame's workgroup is alone on
   //  its CU either way)
   const int kind = (int)blockIdx.y;
   if (in_lds) {
-    for (int i = (int)threadIdx.x; i < g.nblocks; i += 1024) s_mask[i] = gmask[i];
-    __syncthreads();
     w_build_units(g, s_mask, up, kind, frame);
   } else {
     w_build_units(g, gmask, up, kind, frame);

@@ -476,7 +476,8 @@ constexpr int kK2Threads = 1024;
 constexpr int kK2PerThread = 8;  // scores kept in registers: up to 8192 blocks (a 4K frame has 8160); 32 for up to 32768 (8K: 32400)
 // (the body: k2_flat_select below and the wide chain's k2w_select_units, k3w.hip.h, which builds the unit lists behind it)
 template <int PER>
-__device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame) {
+__device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame,
+                                                     uint8_t *lds_mask) {
   __shared__ uint32_t s_hist[256], s_wsum[4], s_sel[2];
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint32_t *sc = reinterpret_cast<const uint32_t *>(rec + g.off_scores);
@@ -539,11 +540,35 @@ __device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__r
   // thr = bit pattern of the threshold score
   uint8_t *mask = rec + g.off_mask;
   const uint8_t *fl = flags + (size_t)frame * nb;
-  for (int i = tid; i < nb; i += kK2Threads) mask[i] = fl[i] | (sc[i] >= thr ? 1 : 0);
+  // (the scores from the registers where they are; the bytes also into `lds_mask` when the caller builds the lists from them)
+  if (in_regs) {
+    uint8_t f[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * kK2Threads;
+      f[k] = i < nb ? fl[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * kK2Threads;
+      if (i < nb) {
+        const uint8_t mb = f[k] | (v[k] >= thr ? 1 : 0);
+        mask[i] = mb;
+        if (lds_mask) lds_mask[i] = mb;
+      }
+    }
+  } else {
+    for (int i = tid; i < nb; i += kK2Threads) {
+      const uint8_t mb = fl[i] | (sc[i] >= thr ? 1 : 0);
+      mask[i] = mb;
+      if (lds_mask) lds_mask[i] = mb;
+    }
+  }
 }
-__device__ __forceinline__ void k2_flat_select_body(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame) {
-  if (g.nblocks <= kK2Threads * kK2PerThread) k2_flat_select_sized<kK2PerThread>(g, records, flags, frame);
-  else k2_flat_select_sized<32>(g, records, flags, frame);  // (8K: 32 400 scores, still in registers; larger frames re-read them)
+__device__ __forceinline__ void k2_flat_select_body(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame,
+                                                    uint8_t *lds_mask = nullptr) {
+  if (g.nblocks <= kK2Threads * kK2PerThread) k2_flat_select_sized<kK2PerThread>(g, records, flags, frame, lds_mask);
+  else k2_flat_select_sized<32>(g, records, flags, frame, lds_mask);  // (8K: 32 400 scores, still in registers; larger frames re-read them)
 }
 __global__ __launch_bounds__(kK2Threads) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
                                                              const uint8_t *__restrict__ flags) {
