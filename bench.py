@@ -98,10 +98,10 @@ def main() -> None:
         # (usable = hardware threads cut to the cgroup CPU quota: the ranks of a node share it)
         share = int(_lib.lib().g1s_usable_cpus()) // max(lws, 1)
         os.environ.setdefault("G1S_FOLD_THREADS", str(max(2, min(32, share))))
-        # A rank's per-frame half wants ~6.5 cores at 4K (profiles/r04_host_budget_8ranks.txt).  A job whose CPU quota gives a
-        # rank less than that is bound by the host at (share / 7) of a GPU: the half on the device (k4_latest, 0.66 x of a
-        # GPU's host-half rate) is the faster job from there down.
-        if share < 6:
+        # A rank's per-frame half wants ~5.5 cores at 4K (72 us of a core per frame next to the merge and the copies:
+        # profiles/r04_host_budget_8ranks.txt).  A job whose CPU quota gives a rank less is bound by the host at (share / 5.5) of
+        # a GPU; the half on the device (k4_latest) runs a GPU at 0.62 x of its host-half rate: the faster job below ~3.4 cores.
+        if share < 4:
             os.environ.setdefault("G1S_LATEST", "device")
     from grav1synth_amd.diff import DiffGenerator, format_tbl
     from grav1synth_amd.dist import ShardedDiff, StreamingShardedDiff
