@@ -94,7 +94,16 @@ def gather_msgs(msg: np.ndarray, dist, device: Optional[torch.device] = None) ->
     return host
 
 
-_RCCL_ROUNDS = {}
+_RCCL_ROUNDS = {}  # (group identity, device, message bytes) -> _RcclRounds; a transport keeps its group alive (self.dist), so an
+#                     id() in a key cannot be handed to another group while the entry stands
+
+
+def release_transports() -> None:
+    """frees the pinned rings and streams of every cached RCCL transport (a process that is done with its process groups)"""
+    for t in _RCCL_ROUNDS.values():
+        t.close()
+    _RCCL_ROUNDS.clear()
+
 
 
 class _RcclRounds:
