@@ -59,7 +59,7 @@ def main() -> None:
                     help="a step feeds the resident frames this many times over: one job of frames x cycles frame pairs "
                          "(default: a step of about half a second, so that the timed region of --steps 20 is 10 s)")
     ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch group (<= 256; default: the engine's own choice, "
-                    "about 530 Mpixels a group: 64 at 4K, 128 at 1080p, 16 at 8K)")
+                    "about 530 Mpixels a group: 64 at 4K, 128 at 1080p, 32 at 8K)")
     ap.add_argument("--workload", default="4k10", choices=sorted(WORKLOADS))
     ap.add_argument("--flat", action="store_true", help="all-flat stress variant (no textured region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,7 +116,7 @@ def main() -> None:
     # ---- synthetic frame pairs, resident in HBM before any timed region ----
     # N > 1: the video is dealt to the ranks batch by batch (global batch j -> rank j % N)
     if args.batch <= 0:  # the engine's own choice (engine.hip: set_geometry_alloc), said out loud so that the line can report it
-        args.batch = int(min(128, max(16, (530000000 + W * H // 2) // (W * H))))
+        args.batch = int(min(128, max(32, (530000000 + W * H // 2) // (W * H))))
     B = max(1, args.batch)  # (frames per launch, the same at any N; what the line reports as config.batch_frames)
     frames = []
     for k in range(F):

@@ -539,9 +539,10 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
   if (batch_auto) {
     // about 530 Mpixels a launch group (64 4K frames; measured: 32 -> 64 frames a launch +12 % on the 4K job, no gain
     // beyond): the per-launch costs of the small kernels are the same for small frames, so they get more frames per
-    // launch (1080p: 128, +6 % over 64; 8K: 16, +6.5 % over 64 -- profiles/r04_other_workloads.txt)
+    // launch (1080p: 128, +6 % over 64 and +13 % over 256; 8K: 32 -- 16 is 5 % slower, 64 the same; 4K: 64 -- 96 and 128 are
+    // 5 - 7 % slower: profiles/r04_other_workloads.txt, tools/r4_batch.sh)
     const uint64_t px = (uint64_t)s->width * s->height;
-    batch = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(16, (530000000ull + px / 2) / std::max<uint64_t>(px, 1)));
+    batch = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(32, (530000000ull + px / 2) / std::max<uint64_t>(px, 1)));
   }
   const uint32_t np = luma_only ? 1u : (uint32_t)s->nplanes;
   L = make_layout(s->width, s->height, np, lag);

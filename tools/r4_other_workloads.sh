@@ -13,7 +13,7 @@ echo "bench.py --workload W --steps 5 --warmup 2 --no-cpu-baseline: value, whole
 for w in 1080p8_lag2_luma 1080p8 8k10_444; do echo "== $w"; one --workload $w; done
 echo "== 1080p8 --batch 64 (the default is the engine's choice: 128)"; one --workload 1080p8 --batch 64
 echo "== 1080p8_lag2_luma --batch 64"; one --workload 1080p8_lag2_luma --batch 64
-echo "== 8k10_444 --batch 64 (default: 16)"; one --workload 8k10_444 --batch 64
+echo "== 8k10_444 --batch 64 (default: 32)"; one --workload 8k10_444 --batch 64
 echo "== 4k10 --flat"; one --flat
 echo "== 4k10 G1S_K3=stream (round 3's chain, the fallback)"; G1S_K3=stream one
 echo "== 4k10 --batch 32"; one --batch 32
