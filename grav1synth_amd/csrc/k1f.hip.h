@@ -131,8 +131,11 @@ __device__ __forceinline__ VE ve_mul_c(double c, VE a) {  // exact constant
   return VE{v, fabs(c) * a.e + 2.0 * kU * fabs(v)};
 }
 __device__ __forceinline__ VE ve_div_c(VE a, double c) {
-  const double v = a.v / c;
-  return VE{v, a.e / fabs(c) + 2.0 * kU * fabs(v)};
+  // (a multiplication by the rounded reciprocal: within 1.5 ulp of the quotient the reference rounds once -- 4 u instead of 2 u
+  //  in the bound, a dozen instructions less than the division)
+  const double rc = 1.0 / c;  // (c is a constant of the evaluation: folded)
+  const double v = a.v * rc;
+  return VE{v, a.e * fabs(rc) * (1.0 + 4.0 * kU) + 4.0 * kU * fabs(v)};
 }
 __device__ __forceinline__ VE ve_add_c(VE a, double c) {
   const double v = a.v + c;
