@@ -258,7 +258,14 @@ __global__ __launch_bounds__(256) void k1_certify(Geom g, FlatConsts fc, const i
     auto clamp_sw = [](double x) { return x < -25.0 ? -25.0 : (x > 100.0 ? 100.0 : x); };
     auto sigmoid = [](double x) { return 1.0 / (1.0 + exp(-x)); };
     const double sv = sigmoid(clamp_sw(sw.v));
-    const double s_lo = sigmoid(clamp_sw(sw.v - sw.e)), s_hi = sigmoid(clamp_sw(sw.v + sw.e));
+    // The images of the interval's ends without evaluating them (two exponentials, two divisions): x -> sigmoid(clamp(x)) has
+    // slope s (1 - s) <= 1 / 4 and |second derivative| <= 1 / (6 sqrt 3) < 0.1, so over [sw.v - e, sw.v + e] it stays within
+    // e (s (1 - s) + 0.1 e) of sv; the few ulps of sv's own evaluation are inside the 16 u factors below.
+    // (the interval as far as the clamp lets it through: a block far outside [-25, 100] has none left)
+    const double x_c = clamp_sw(sw.v);
+    const double e_c = fmax(clamp_sw(sw.v + sw.e) - x_c, x_c - clamp_sw(sw.v - sw.e)) * (1.0 + 4.0 * kU);
+    const double s_dev = e_c * (sv * (1.0 - sv) + 0.1 * e_c + 8.0 * kU) * (1.0 + 8.0 * kU);
+    const double s_lo = sv - s_dev, s_hi = sv + s_dev;
     const float f_lo = (float)(s_lo * (1.0 - 16.0 * kU)), f_hi = (float)(s_hi * (1.0 + 16.0 * kU));
     const bool score_ok = ratio_ok && (f_lo == f_hi) && isfinite(sw.e);
     if (flat >= 0 && va_gt >= 0 && (va_gt == 0 || score_ok)) {
