@@ -49,6 +49,47 @@ WORKLOADS = {
 }
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: re-run this command line as N ranks under torch.distributed.run
+    (what the driver's own N > 1 command is), one rank per GPU, and pass the children's output through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def bind_to_gpu_numa_node(dev_index: int):
+    """Pin this rank (its launch threads, the fold pools made later, its pinned rings' first touch) to the CPUs of the NUMA
+    node its GPU hangs off: torch.distributed.run binds nothing.  Returns the node, or None when the host does not say."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,9 +111,13 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: start the N ranks the way the driver would (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1), hand the one JSON line of rank 0 through, leave with its exit code
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the diff path has no CPU fallback)")
     # one rank per GPU; G1S_BENCH_SHARE_GPU=1 lets several ranks share a device (single-GPU smoke test of
@@ -81,6 +126,7 @@ def main() -> None:
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    numa = bind_to_gpu_numa_node(dev_index) if world > 1 and not share else None
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
@@ -315,6 +361,7 @@ def main() -> None:
             "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
             "rccl_ranks": (dist.get_world_size() if (world > 1 and not share) else (1 if world == 1 else 0)),
             "backend": (dist.get_backend() if world > 1 else "none (one process)"),
+            "numa_node_rank0": numa,  # (N > 1: the NUMA node rank 0 bound itself to -- its GPU's; None: the host does not say)
             "exchange_ms_per_round": (exchange_s * 1e3 / exchange_rounds) if exchange_rounds else None,  # (N > 1: pack + gather + hand-over, on the feeding thread of this rank)
             "per_frame_fold_half": ("device (k4_latest)" if os.environ.get("G1S_LATEST") == "device" else "host pool"),
             "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if world > 1 else "single GPU",

@@ -10,10 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# One hardware queue per stream (the HIP runtime's default is 4 per process, shared by creation order: kernels of different
-# streams then wait for each other -- profiles/r04_streams.txt).  The runtime reads it when it starts, so this only helps a
-# process that imports the package before its first GPU call; a host application sets it itself.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES=8 -- a hardware queue per stream, INTEGRATION.md section 3 -- is the PROCESS' choice: the entry points
+#  set it (bench.py, the command in cli.py, tests/conftest.py), importing this package changes nobody's environment; the
+#  engine says so once on stderr when a generator's streams are made with fewer queues than they want)
 LIB_PATH = os.environ.get("G1S_LIB") or os.path.join(_HERE, "libg1s_diff.so")  # (G1S_LIB: an instrumented build, tools/ only)
 
 G1S_OK = 0

@@ -85,7 +85,7 @@ def build_parser() -> argparse.ArgumentParser:
 def diff_command(source: str, denoised: str, output: str, overwrite: bool = False, filters: Optional[str] = None,
                  device: int = -1, confirm=_confirm, devices: Optional[List[int]] = None) -> int:
     """Returns the number of frame pairs diffed, or -1 when the command refused to run (a logged line, exit 0)."""
-    from .filters import FilterChain, FilterError
+    from .filters import FilterChain, FilterError, Resize
     from .ingest import diff_y4m_files
 
     if _same_path(source, output) or _same_path(denoised, output):
@@ -100,11 +100,13 @@ def diff_command(source: str, denoised: str, output: str, overwrite: bool = Fals
         except FilterError as e:
             log.error("Invalid filter chain: %s", e)
             return -1
-        resizes = any(f.__class__.__name__ == "Resize" for f in fc.filters)
+        resizes = any(isinstance(f, Resize) for f in fc.filters)
         fc.close()
         if resizes and devices is not None and len(devices) > 1:
             log.error("A resize filter does not combine with --gpus / --devices (one chain, one device)")
             return -1
+        if resizes and devices is not None:  # (`--devices 2`: one device -- the plain command on it, not the sharded one)
+            device, devices = devices[0], None
         if resizes:
             log.warning("resize: the resampling arithmetic restates the video-resize crate (not in the reference tree): the "
                         "resized source, and the table made from it, are UNVERIFIED against grav1synth's")
@@ -133,6 +135,8 @@ def estimate_command(source: str, output: str, overwrite: bool = False, device: 
 
 
 def main(argv: Optional[List[str]] = None) -> int:
+    # a hardware queue per stream of the generator (the HIP runtime reads this when it starts: before the first GPU call)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     args = build_parser().parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(levelname)s %(message)s", stream=sys.stderr)
     if args.command == "diff":

@@ -351,6 +351,13 @@ bool acquire_streams(int device, StreamSet &out) {
   // 595 k with GPU_MAX_HW_QUEUES=8, and 393 - 406 k with every stream in one priority class on 4 queues
   // (profiles/r04_streams.txt).  bench.py and the command set the variable before the runtime starts; the streams only some
   // jobs use (the second side stream, the device half's) are made when they are first needed.
+  {
+    static std::atomic<bool> said{false};
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    if ((!q || atoi(q) < 8) && !said.exchange(true))
+      fprintf(stderr, "g1s: GPU_MAX_HW_QUEUES is %s: the generator's streams will share hardware queues (slower, not wrong); set "
+                      "GPU_MAX_HW_QUEUES=8 before the process' first HIP call\n", q ? q : "unset");
+  }
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = more urgent
   if (const char *e = getenv("G1S_PRIO")) {  // tuning aid: 1 = the main stream outranks the side stream, 2 = no priorities
@@ -1017,8 +1024,15 @@ int g1s_diff::launch_back(int si) {
     wq.prefetch = w_pf;
     static const int w_rev = getenv("G1S_W_REV") ? atoi(getenv("G1S_W_REV")) : 0;  // tuning aid: bit 0 the luma launch, bit 1 the chroma launch walk the frames last to first
     int Gk[2] = {w_wgs_per_frame(w_ncell[0], (int)B, 0), w_wgs_per_frame(std::max(w_ncell[1], 1), (int)B, 1)};
-    for (int k = 0; k < 2; ++k)
-      if ((size_t)Gk[k] * B > m_wg_cap) Gk[k] = (int)(m_wg_cap / B) & ~7;  // (the environment changed after the slots were sized)
+    for (int k = 0; k < 2; ++k) {
+      if ((size_t)Gk[k] * B <= m_wg_cap) continue;
+      // the environment (G1S_W_WGS / G1S_W_WGS_C) changed after the slots were sized: what the slots hold -- but never fewer
+      // workgroups than the int32 accumulators and the parked entries of a workgroup allow
+      Gk[k] = (int)(m_wg_cap / B) & ~7;
+      const int ncell_k = k == 0 ? w_ncell[0] : std::max(w_ncell[1], 1), cap_k = k == 1 ? kWMaxUnitsC : kWMaxUnits;
+      if (Gk[k] <= 0 || Gk[k] < (ncell_k + cap_k - 1) / cap_k)
+        return fail(G1S_ERR_STATE, "the wide launches' workgroup count was raised (G1S_W_WGS / G1S_W_WGS_C) after this generator's buffers were sized");
+    }
     const int G_cap = std::max(Gk[0], Gk[1]);
     wq.wg_cap = G_cap;
     auto set_kind = [&](int k) {

@@ -622,7 +622,9 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
       const double cnt_full = (double)(bw * bh), rcp_full = pow2_rcp(bw * bh);
       const bool full_counts = bw * bh > kBlock;
       size_t m = 0;
-      if (c == 2) {
+      // (G1S_FOLD_NO_SHARE=1, a test aid: every plane builds its own list and its own matrix -- what the sharing must equal)
+      static const bool no_share = getenv("G1S_FOLD_NO_SHARE") != nullptr;
+      if (c == 2 && !no_share) {
         m = out.scratch_m[1];
         for (size_t k = 0; k < m; ++k) {
           const int bi = (int)idx[sel[k]];
@@ -666,13 +668,14 @@ int compute_latest(const uint8_t *rec, size_t size, uint32_t lag, FrameLatest &o
         }
       } else if (c == 0) {
         for (size_t k = 0; k < m; ++k) p_ls[k] = 0;
-      }  // (c == 2: plane 1's values -- the same blocks, the same luma strength)
+      }  // (c == 2: plane 1's values -- the same blocks, the same luma strength; nothing between the planes writes p_ls)
       uncorrelated_stds(m, p_nv, p_ls, corr, noise_gain, p_std);
       STAGE(4);
       // the matrix side of the accumulation depends on the bin positions alone: a plane that measures the very blocks an
       // earlier plane measured (Cr after Cb always; Cb after luma unless a cut last row or column is too small at chroma
       // resolution) copies that plane's matrix (solve() leaves A as it was) and accumulates its b side only
-      const int like = c == 2 ? 1
+      const int like = no_share ? -1
+                       : c == 2 ? 1
                        : (c == 1 && m == out.scratch_m[0] && std::memcmp(sel, out.scratch_sel0.data(), m * sizeof(uint32_t)) == 0) ? 0 : -1;
       if (like >= 0) lat.strength.add_measurements_like(out.st[like].strength, bins, sel, p_std, m);
       else lat.strength.add_measurements(bins, sel, p_std, m);

@@ -142,6 +142,8 @@ class _RcclRounds:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # (every rank rooted, or none)
         self.rooted = bool(int(flag.item()))
         self.recv_dev = None
+        self.recv_host = []
+        self.closed = False
         if self.rank == 0 or not self.rooted:
             self.recv_dev = torch.zeros((self.world, msg_bytes), dtype=torch.uint8, device=device)
             self.recv_host = [torch.zeros((self.world, msg_bytes), dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
@@ -151,6 +153,8 @@ class _RcclRounds:
 
     def pack_buffer(self) -> np.ndarray:
         """where this round's message is packed (the round RING rounds ago has left it)"""
+        if self.closed:
+            raise RuntimeError("this RCCL transport was released (release_transports): make a new StreamingShardedDiff")
         i = self.round % self.RING
         if self.gathered[i] is not None:
             self.gathered[i].synchronize()
@@ -159,6 +163,8 @@ class _RcclRounds:
     def exchange(self):
         """the packed message -> rank 0.  Returns (ring index, event) on rank 0 -- the rows are in recv_host[index] once the
         event has passed; release(index) hands the buffer back -- and None elsewhere."""
+        if self.closed:
+            raise RuntimeError("this RCCL transport was released (release_transports): make a new StreamingShardedDiff")
         i = self.round % self.RING
         self.round += 1
         with torch.cuda.stream(self.copy_stream):
@@ -192,10 +198,15 @@ class _RcclRounds:
 
     def close(self) -> None:
         """frees the pinned rings (the cache below holds one transport per process group and message size)"""
-        self.send_host = self.send_dev = []
+        if self.closed:
+            return
+        self.closed = True  # (a generator that still holds this transport gets an error, not an IndexError, from its next round)
+        for st in (self.copy_stream, self.coll_stream):
+            st.synchronize()
+        self.send_host, self.send_dev, self.recv_host = [], [], []
+        self.gathered = [None] * self.RING
         self.recv_dev = None
-        if self.rank == 0:
-            self.recv_host = []
+        self.copy_stream = self.coll_stream = None  # (torch frees a stream when its last reference goes)
 
 
 class StreamingShardedDiff:
@@ -329,12 +340,13 @@ class StreamingShardedDiff:
             self._exchange_one(flush=True)
         # every frame fed by any rank must have been merged: PIPELINE_BATCHES is what a generator's slots can hold, and a change
         # there must fail here, loudly, not drop the video's last batches
-        total = None
-        if self._dev is not None and self.dist.get_world_size() > 1:
-            t = torch.tensor([getattr(self, "_fed", 0)], dtype=torch.int64, device=self._dev if self.dist.get_backend() == "nccl" else "cpu")
+        if self.dist.get_world_size() > 1:
+            # (a CPU tensor unless the backend only moves device memory: a gloo job without a GPU is checked too)
+            on_dev = self._dev is not None and self.dist.get_backend() == "nccl"
+            t = torch.tensor([getattr(self, "_fed", 0)], dtype=torch.int64, device=self._dev if on_dev else "cpu")
             self.dist.all_reduce(t)
             total = int(t.item())
-        elif self.dist.get_world_size() == 1:
+        else:
             total = getattr(self, "_fed", 0)
         if self._fold is None:
             return None

@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (an entry point: a hardware queue per stream, before the runtime starts)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -95,3 +95,20 @@ def test_per_plane_deferrals_agree_between_the_chains():
     assert len(ref) == 64
     assert _run(code, {"G1S_K3": "stream"}) == ref
     assert _run(code, {"G1S_K3": "stream", "G1S_F_REUSE": "0"}) == ref
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver's SCALE tier would start it): bench.py spawns
+    its two ranks under torch.distributed.run, rank 0 prints ONE JSON line.  Two ranks on this one GPU (gloo: RCCL refuses two
+    ranks on a device)."""
+    env = dict(os.environ, G1S_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cycles", "2",
+                        "--frames", "64", "--no-all-flat", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["value"] > 0
+    assert out["config"]["backend"] == "gloo" and out["scaling"] == "weak"

@@ -61,6 +61,12 @@ CASES = [
     (SynthSpec(256, 160, 8), 2, False, 2),
     (SynthSpec(256, 160, 12), 1, True, 2),
     (SynthSpec(216, 152, 10), 3, True, 2),  # cut last row and column: block sample counts that are no powers of two (768, 576, 192, 144)
+    # a cut last column / row that luma measures and chroma does not (<= 32 samples at chroma resolution): Cb's list of measured
+    # blocks differs from luma's, so Cb builds its own strength matrix instead of copying luma's (fold.cpp compute_latest, like = -1)
+    (SynthSpec(228, 152, 10), 3, True, 2),
+    (SynthSpec(216, 132, 8), 3, True, 2),
+    (SynthSpec(226, 160, 10, xdec=1, ydec=0), 3, True, 2),
+    (SynthSpec(228, 132, 8, textured=False), 2, True, 2),
 ]
 
 
@@ -225,3 +231,53 @@ def test_native_tbl_reader_round_trips_and_matches_the_python_reader():
     second = t.segment_for(segs[0].end_time)
     assert second.start_time == segs[1].start_time and second.random_seed == (segs[1].random_seed + 10956) & 0xffff
     assert GrainTable(segs[:1]).segment_for(segs[0].end_time) is None
+
+
+_SHARE_CODE = r"""
+import hashlib, sys
+import numpy as np
+from fractions import Fraction
+from grav1synth_amd.diff import latest_from_records
+from grav1synth_amd.synth import SynthSpec
+from tests.helpers import oracle_run, record_from_oracle
+h = hashlib.sha256()
+for spec, cut in ((SynthSpec(228, 152, 10), "col"), (SynthSpec(216, 132, 8), "row"), (SynthSpec(226, 160, 10, xdec=1, ydec=0), "col"),
+                  (SynthSpec(216, 152, 10), "none")):
+    recs = []
+    oracle_run(spec, range(2), 3, True, collect=lambda o, k: recs.append(record_from_oracle(o, spec, 3, 3)))
+    for r in recs:
+        nbw, nbh = r.nbw, r.nbh
+        m = r.views(0)["mask"].reshape(nbh, nbw)
+        # the cut last column / row: flagged flat, with statistics of its own (4 luma columns or rows: 128 luma samples,
+        # 32 -- or 16 -- chroma samples: luma measures the block, the chroma planes do not)
+        idx = [] if cut == "none" else [by * nbw + nbw - 1 for by in range(nbh - 1)] if cut == "col" else [(nbh - 1) * nbw + bx for bx in range(nbw - 1)]
+        for c in range(3):
+            v = r.views(c)
+            for j, b in enumerate(idx):
+                if c == 0:
+                    v["mask"][b] = 1
+                    v["luma_sum"][b] = 128 * (90 + 7 * j)
+                v["sum_d"][b] = 5 - 3 * j + c
+                v["sum_d2"][b] = 400 + 37 * j + 11 * c
+        assert cut == "none" or m[:, -1].any() or m[-1, :].any()
+    blobs = latest_from_records(np.stack([r.buf for r in recs]), 3)
+    h.update(blobs.tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_planes_sharing_the_strength_matrix_equals_every_plane_on_its_own():
+    """compute_latest's plane sharing (fold.cpp: Cb copies luma's strength matrix when it measures the very blocks luma measures,
+    Cr Cb's list and matrix) against every plane building its own (G1S_FOLD_NO_SHARE=1), blob for blob -- on records whose cut
+    last column / row luma measures and chroma does not (<= 32 chroma samples: Cb's list differs from luma's, the branch no
+    synthetic frame reaches: the finder never marks such a block flat on this content, so the mask is set by hand)."""
+    import subprocess
+    import sys
+
+    outs = []
+    for extra in ({}, {"G1S_FOLD_NO_SHARE": "1"}):
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra)
+        p = subprocess.run([sys.executable, "-c", _SHARE_CODE], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(p.stdout.strip().splitlines()[-1])
+    assert len(outs[0]) == 64 and outs[0] == outs[1]
