@@ -236,11 +236,12 @@ def main() -> None:
         one_step(False)
     barrier()
     t0 = time.perf_counter()
-    step_ms = []
+    step_ms, step_fold_ms = [], []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        one_step(False)
+        st_ = one_step(False)
         step_ms.append((time.perf_counter() - ts) * 1e3)
+        step_fold_ms.append(st_.ms_host_fold)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -345,6 +346,7 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "step_ms": [round(x, 3) for x in step_ms],
+        "step_host_fold_ms": [round(x, 3) for x in step_fold_ms],  # (the ordered merge's wall time inside each step: a thread of its own)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -1020,8 +1020,6 @@ int g1s_diff::launch_back(int si) {
     wq.frames = (int)B;
     static const int w_dbg = getenv("G1S_W_DBG") ? atoi(getenv("G1S_W_DBG")) : 0;  // timing experiments (a -DG1S_W_DBG_BUILD library)
     wq.dbg = w_dbg;
-    static const int w_pf = getenv("G1S_W_PREFETCH") ? atoi(getenv("G1S_W_PREFETCH")) : 0;  // tuning aid (measured: +2 % on both launches, profiles/r04_prefetch.txt: off)
-    wq.prefetch = w_pf;
     static const int w_rev = getenv("G1S_W_REV") ? atoi(getenv("G1S_W_REV")) : 0;  // tuning aid: bit 0 the luma launch, bit 1 the chroma launch walk the frames last to first
     int Gk[2] = {w_wgs_per_frame(w_ncell[0], (int)B, 0), w_wgs_per_frame(std::max(w_ncell[1], 1), (int)B, 1)};
     for (int k = 0; k < 2; ++k) {

@@ -62,7 +62,6 @@ struct WParams {
   int ncell, ncell_y;       // grid cells a frame of this launch's kind / of the luma kind
   int gx_y;                 // luma cells a block row
   int frames, wgs, wg_cap;
-  int prefetch;             // 1: touch a unit's lines an iteration before its words are requested
   int rev;                  // 1: the launch walks the batch's frames last to first (what the kernel before it touched last is read first)
   int dbg;                  // timing experiments (G1S_W_DBG, builds with -DG1S_W_DBG_BUILD only): 1 no global loads, 2 no residual arithmetic, 4 no statistics / L, 8 no copy writes, 16 no multiplies, 32 no barriers in the loop, 64 no statistics stores, 128 no L loads; wrong results
 };
@@ -337,8 +336,14 @@ struct WShape {
   static constexpr int LBW = LOUT ? (32 >> SX) : 32, LBH = LOUT ? (32 >> SY) : 32;
 };
 
+#ifndef G1S_W_OCC_C
+#define G1S_W_OCC_C 4  // workgroups a CU the 4:2:0 / 4:4:0 chroma launch is compiled for (a variant build's switch)
+#endif
+#ifndef G1S_W_OCC_L
+#define G1S_W_OCC_L 4
+#endif
 template <int KIND, int BPS, int SX, int SY>
-__global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w_pass(Geom g, WParams wp) {
+__global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) : G1S_W_OCC_L) void k3w_pass(Geom g, WParams wp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t w_smem[];
   using SH = WShape<KIND, SX, SY>;
   constexpr bool CHR = SH::CHR, LOUT = SH::LOUT;
@@ -352,6 +357,8 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   constexpr int MAXU = CHR ? kWMaxUnitsC : kWMaxUnits;
   __shared__ uint4 s_ent[2 * (MAXU + 4)];
 
+  // (blockIdx -> frame = blockIdx % frames: every frame of the batch live at once, on one XCD when the batch is a multiple of 8.
+  //  Measured and dropped, profiles/r05_ab_knobs.txt: whole frames dealt to the XCDs one after the other)
   const int fi = (int)blockIdx.x % wp.frames;
   const int G = wp.wgs, frame = g.frame0 + (wp.rev ? wp.frames - 1 - fi : fi), wg = (int)blockIdx.x / wp.frames;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -378,15 +385,17 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   //  would not all load the same SIMD with it: luma 399 - 429 -> 430 - 441 us, tools/r4_rot.sh)
   const int swave = wave;
   const int own_row0 = CHR ? (swave & 1) * (BH / 2) : 8 * swave;
-  // the halo rows (tile rows 0 .. 3) of a plane: one more iteration on the plane's last wave, lanes p & 1 -> rows 2 (p & 1) + r
-  // (the upper half of the wave repeats the lower half: same loads, same stores)
+  // the halo rows (tile rows 0 .. 3) of a plane: one more QUARTER iteration on the plane's last wave -- its 64 lanes are the
+  // 4 rows x 16 words, ONE row a lane (lane = row p, word w: the same rows of 16 lanes, so the neighbour exchange is the own
+  // rows').  (Round 4 gave the lower 32 lanes two rows each: a whole iteration's instructions on the wave every other wave
+  // of the workgroup then waits for at the barrier.)
   const bool h_wave = CHR ? (swave & 1) == 1 : swave == kWWaves - 1;
   // constants of the lane: ONE load offset per input (tile row 4 + own_row0 + 2 p, word w, from the unit's origin = tile row 0,
-  // word 0); the second row of the pair, the further own iterations and the halo iteration move the SCALAR base instead.
-  // Halo iteration: pair p -> tile rows 2 p + r; only p < 2 (rows 0 .. 3) is wanted: the upper half of the wave sits out.
+  // word 0); the second row of the pair and the further own iterations move the SCALAR base instead; the halo row has an
+  // offset of its own (tile row p, word w).
   const uint32_t lo_s = (uint32_t)(4 + own_row0 + 2 * p) * sst + (uint32_t)(8 * w * BPS);
   const uint32_t lo_v = (uint32_t)(4 + own_row0 + 2 * p) * dst_ + (uint32_t)(8 * w * BPS);
-  const bool h_lane = lane < 32;
+  const uint32_t lo_hs = (uint32_t)p * sst + (uint32_t)(8 * w * BPS), lo_hv = (uint32_t)p * dst_ + (uint32_t)(8 * w * BPS);
 
   // the L plane of the frame; this thread's word(s) of a unit's L tile (chroma launch) / this lane's L bytes (luma launch)
   uint8_t *lframe = wp.lplane + (size_t)frame * wp.lframe_bytes;
@@ -445,9 +454,9 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
 
   // ---- pipeline registers ----
   w_u4 rs[NOWN][2], rv[NOWN][2];                      // raw words in flight: own iterations
-  w_u4 hs[2] = {}, hv[2] = {};                        // ... halo iteration (the lanes that sit it out keep zeros)
+  w_u4 hs = {}, hv = {};                              // ... the halo row
   uint32_t Dc[NOWN][2][2] = {}, Dn[NOWN][2][2] = {}, Dl[NOWN][2] = {};   // residual words: unit k, unit k + 1; last dwords of unit k - 1
-  uint32_t Hc[2][2] = {}, Hn[2][2] = {}, Hl[2] = {};
+  uint32_t Hc[2] = {}, Hn[2] = {}, Hl = 0;
 
   auto entry_x = [&](int j) -> uint32_t { return __builtin_amdgcn_readfirstlane(s_ent[2 * (j + 1)].x); };
 
@@ -470,7 +479,6 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     // (scalar origin + the lane's constant offset)
     const uint8_t *sb = psrc + ((ptrdiff_t)Y0 * (ptrdiff_t)sst + (ptrdiff_t)(X0 * BPS));
     const uint8_t *vb = pden + ((ptrdiff_t)Y0 * (ptrdiff_t)dst_ + (ptrdiff_t)(X0 * BPS));
-    const uint8_t *hsb = sb - (ptrdiff_t)(4 + own_row0) * (ptrdiff_t)sst, *hvb = vb - (ptrdiff_t)(4 + own_row0) * (ptrdiff_t)dst_;
     if ((ex >> 25) & 1u) {  // every row and word of the tile inside the plane
 #pragma unroll
       for (int i = 0; i < NOWN; ++i)
@@ -479,12 +487,9 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
           rs[i][r] = load8(sb + (size_t)(8 * i + r) * sst, lo_s);
           rv[i][r] = load8(vb + (size_t)(8 * i + r) * dst_, lo_v);
         }
-      if (h_wave && h_lane) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          hs[r] = load8(hsb + (size_t)r * sst, lo_s);
-          hv[r] = load8(hvb + (size_t)r * dst_, lo_v);
-        }
+      if (h_wave) {
+        hs = load8(sb, lo_hs);
+        hv = load8(vb, lo_hv);
       }
     } else {
       const bool xok = X0 + 8 * w + 8 <= pw;
@@ -501,49 +506,12 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
           }
         }
       if (h_wave) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int t = 2 * p + r;
-          hs[r] = w_u4{0u, 0u, 0u, 0u};
-          hv[r] = w_u4{0u, 0u, 0u, 0u};
-          if (h_lane && xok && Y0 + t >= 0 && Y0 + t < ph) {
-            hs[r] = load8(hsb + (size_t)r * sst, lo_s);
-            hv[r] = load8(hvb + (size_t)r * dst_, lo_v);
-          }
+        hs = w_u4{0u, 0u, 0u, 0u};
+        hv = w_u4{0u, 0u, 0u, 0u};
+        if (xok && Y0 + p >= 0 && Y0 + p < ph) {
+          hs = load8(sb, lo_hs);
+          hv = load8(vb, lo_hv);
         }
-      }
-    }
-  };
-  // Touch the lines of a unit one iteration before its words are requested (one dword a line, into a register nobody reads):
-  // the request then finds them in the L2 instead of waiting out an HBM round trip with one unit's worth of loads in flight.
-  // Interior units only; the lanes of words 0 and 8 (the two 128-byte lines of a row).  Inline assembly: the compiler's wait
-  // counts do not know these loads -- they can only make a wait longer, and they are an iteration old when one comes.
-  // (the register the touches land in is this one for the whole kernel: a load in flight owns its destination, and the compiler
-  //  does not know these loads are in flight)
-  uint32_t pf_sink = 0;
-  auto prefetch = [&](uint32_t ex) __attribute__((always_inline)) {
-    if (G1S_W_DBGBIT(256) || !wp.prefetch) return;
-    if (!((ex >> 25) & 1u)) return;
-    const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
-    const int X0 = c * kWUnitW, Y0 = by * BH - 4;
-    const uint8_t *sb = psrc + ((ptrdiff_t)Y0 * (ptrdiff_t)sst + (ptrdiff_t)(X0 * BPS));
-    const uint8_t *vb = pden + ((ptrdiff_t)Y0 * (ptrdiff_t)dst_ + (ptrdiff_t)(X0 * BPS));
-    if ((w & 7) == 0) {
-#pragma unroll
-      for (int i = 0; i < NOWN; ++i) {
-        const uint8_t *s0 = sb + (size_t)(8 * i) * sst, *s1 = s0 + sst, *v0 = vb + (size_t)(8 * i) * dst_, *v1 = v0 + dst_;
-        asm volatile("global_load_dword %0, %1, %3\n\tglobal_load_dword %0, %1, %4\n\tglobal_load_dword %0, %2, %5\n\tglobal_load_dword %0, %2, %6"
-                     : "+v"(pf_sink)
-                     : "v"(lo_s), "v"(lo_v), "s"(s0), "s"(s1), "s"(v0), "s"(v1)
-                     : "memory");
-      }
-      if (h_wave && h_lane) {
-        const uint8_t *s0 = sb - (ptrdiff_t)(4 + own_row0) * (ptrdiff_t)sst, *s1 = s0 + sst;
-        const uint8_t *v0 = vb - (ptrdiff_t)(4 + own_row0) * (ptrdiff_t)dst_, *v1 = v0 + dst_;
-        asm volatile("global_load_dword %0, %1, %3\n\tglobal_load_dword %0, %1, %4\n\tglobal_load_dword %0, %2, %5\n\tglobal_load_dword %0, %2, %6"
-                     : "+v"(pf_sink)
-                     : "v"(lo_s), "v"(lo_v), "s"(s0), "s"(s1), "s"(v0), "s"(v1)
-                     : "memory");
       }
     }
   };
@@ -574,8 +542,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       for (int i = 0; i < NOWN; ++i)
 #pragma unroll
         for (int r = 0; r < 2; ++r) Dn[i][r][0] = rs[i][r].x ^ rv[i][r].x, Dn[i][r][1] = rs[i][r].y ^ rv[i][r].y;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) Hn[r][0] = hs[r].x ^ hv[r].x, Hn[r][1] = hs[r].y ^ hv[r].y;
+      Hn[0] = hs.x ^ hv.x, Hn[1] = hs.y ^ hv.y;
       return;
     }
 #pragma unroll
@@ -658,11 +625,8 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     uint32_t hacc = 0;
     if (h_wave) {
       uint32_t T[4], dummy = 0;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        w_residual<BPS>(hs[r], hv[r], ssh, r_km, r_bm, T, hacc, dummy);
-        w_pack<BPS>(T, Hn[r][0], Hn[r][1]);
-      }
+      w_residual<BPS>(hs, hv, ssh, r_km, r_bm, T, hacc, dummy);
+      w_pack<BPS>(T, Hn[0], Hn[1]);
     }
     // ---- residuals (or L) outside int8: rare; one wave-uniform test on the usual way ----
     const uint32_t out = (racc | hacc | lacc) & 0xff00ff00u;
@@ -699,13 +663,10 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
         neighbours(Dl[i][r], Dc[i][r][0], Dc[i][r][1], Dn[i][r][0], mL, mR, prev1, next0);
         w_write_copies<CS>(base + (4 + own_row0 + 8 * i + r) * kWUnitW, prev1, Dc[i][r][0], Dc[i][r][1], next0);
       }
-    if (h_wave) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        uint32_t prev1, next0;
-        neighbours(Hl[r], Hc[r][0], Hc[r][1], Hn[r][0], mL, mR, prev1, next0);
-        if (h_lane) w_write_copies<CS>(base + r * kWUnitW, prev1, Hc[r][0], Hc[r][1], next0);
-      }
+    if (h_wave) {  // (tile row p, word w)
+      uint32_t prev1, next0;
+      neighbours(Hl, Hc[0], Hc[1], Hn[0], mL, mR, prev1, next0);
+      w_write_copies<CS>(base - p * kWUnitW, prev1, Hc[0], Hc[1], next0);
     }
   };
   // unit k <- unit k + 1
@@ -718,12 +679,9 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
         Dc[i][r][0] = Dn[i][r][0];
         Dc[i][r][1] = Dn[i][r][1];
       }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      Hl[r] = Hc[r][1];
-      Hc[r][0] = Hn[r][0];
-      Hc[r][1] = Hn[r][1];
-    }
+    Hl = Hc[1];
+    Hc[0] = Hn[0];
+    Hc[1] = Hn[1];
   };
 
   // the block statistics of unit j (sequence position) -> the frame's record (flat blocks); its deferred blocks -> the exact
@@ -805,7 +763,7 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
       for (int i = 0; i < NOWN; ++i)
 #pragma unroll
         for (int r = 0; r < 2; ++r) Dn[i][r][0] = Dn[i][r][1] = 0u;
-      Hn[0][0] = Hn[0][1] = Hn[1][0] = Hn[1][1] = 0u;
+      Hn[0] = Hn[1] = 0u;
     }
     // (every wait for memory is behind us: what follows only issues -- the L tile of this unit into the buffer, the stores of the
     //  unit before, the loads of the units ahead -- and nothing in the rest of the iteration waits for a load or a store)
@@ -818,7 +776,6 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
     }
     if (!last) load_L(x1);  // (the next unit's L tile, an iteration ahead)
     if (!last && (k + 2 < nmine || ((x1 >> 23) & 1u))) request(x2);
-    if (k + 3 < nmine) prefetch(entry_x(k + 3));
     // (the stores BEHIND the loads: the compiler guards the loads' destination registers with a wait that would take the stores
     //  with it; the next wait for memory, form's in the next iteration, is a whole iteration away)
     if (k > 0) stats_out(k - 1, defer_prev);
@@ -893,7 +850,6 @@ __global__ __launch_bounds__(kWThreads, (KIND == 1 && SY == 0) ? 2 : 4) void k3w
   }
   if (nmine > 0) stats_out(nmine - 1, defer_prev);
 
-  asm volatile("" ::"v"(pf_sink));  // (live to here)
   // ---- the workgroup's partial systems: waves add into LDS (int64), one plain store per entry ----
   long long *s_S = reinterpret_cast<long long *>(w_smem);
   for (int k = tid; k < NPL * kMRec; k += kWThreads) s_S[k] = 0;

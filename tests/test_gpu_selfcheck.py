@@ -59,7 +59,7 @@ def test_tuning_switches_do_not_change_results():
     ref = _run(_SWITCH_CODE, {})
     assert len(ref) == 64
     for extra in ({"G1S_ONE_STREAM": "1"}, {"G1S_NO_DEFER": "1"}, {"G1S_K1_LITERAL": "1"}, {"G1S_K1_LITERAL": "2"}, {"G1S_FOLD_THREADS": "1"},
-                  {"G1S_W_REV": "3"}, {"G1S_W_PREFETCH": "1"}, {"G1S_W_WGS": "4096", "G1S_W_WGS_C": "8"}, {"G1S_W_OFF": "1"},
+                  {"G1S_W_REV": "3"}, {"G1S_W_WGS": "4096", "G1S_W_WGS_C": "8"}, {"G1S_W_OFF": "1"},
                   {"G1S_F_SERIAL": "1"}, {"G1S_W_ASIDE": "1"}, {"G1S_SIDE2": "1"}):
         assert _run(_SWITCH_CODE, extra) == ref, extra
 
