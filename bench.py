@@ -146,8 +146,9 @@ def main() -> None:
         os.environ.setdefault("G1S_FOLD_THREADS", str(max(2, min(32, share))))
         # A rank's per-frame half wants ~5.5 cores at 4K (72 us of a core per frame next to the merge and the copies:
         # profiles/r04_host_budget_8ranks.txt).  A job whose CPU quota gives a rank less is bound by the host at (share / 5.5) of
-        # a GPU; the half on the device (k4_latest) runs a GPU at 0.62 x of its host-half rate: the faster job below ~3.4 cores.
-        if share < 4:
+        # a GPU; the half on the device (k4_latest, rebuilt in round 5: profiles/r05_device_latest.txt) runs a GPU at 0.90 - 0.95 x
+        # of its host-half rate and leaves the host the launches, 27 KB a frame and the merge: the faster job below ~5 cores.
+        if share < 5:
             os.environ.setdefault("G1S_LATEST", "device")
     from grav1synth_amd.diff import DiffGenerator, format_tbl
     from grav1synth_amd.dist import ShardedDiff, StreamingShardedDiff

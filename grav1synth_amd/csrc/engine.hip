@@ -231,7 +231,7 @@ Pool *merge_pool() {
 std::mutex g_merge_pool_mutex;
 
 constexpr bool kDeviceLatestDefault = false;
-constexpr int kSlots = 4;  // batches in flight: pixel pass + finder, accumulation, D2H + fold, being filled
+constexpr int kSlots = 6;  // batches in flight: being filled, pixel pass + finder, accumulation, (the per-frame half on the device,) D2H, fold
 
 struct Slot {
   FramePlanes *h_planes = nullptr;  // pinned
@@ -261,6 +261,7 @@ struct Slot {
   // per-kernel timing (g1s_diff_set_timing): an event before each launch, the name of the kernel it precedes
   std::vector<hipEvent_t> kev;
   std::vector<std::string> kname;
+  std::vector<hipStream_t> kstream;
   size_t nk = 0;
 };
 
@@ -322,7 +323,11 @@ std::vector<CachedSlot> g_slot_cache;
 struct StreamSet {
   int device = -1;
   hipStream_t compute = nullptr, copy = nullptr, flat = nullptr, flat2 = nullptr, upload = nullptr;
-  hipStream_t latest = nullptr;  // k4_latest and the blobs' D2H (made when a generator first runs the half on the device)
+  // k4_latest of the even / odd slots (made when a generator first runs the half on the device): the kernel is a few serial
+  // chains per frame and twice as long next to the accumulation launches as alone -- on ONE stream, with the blobs' copy behind
+  // it, a batch's half would only start when the half of the batch before had been copied out (period >= 1 040 us at 4K)
+  hipStream_t latest = nullptr, latest2 = nullptr;
+  hipEvent_t latest_done[kSlots] = {};
   int prio_side = 0;
   hipEvent_t kernels_done[kSlots] = {};
   hipEvent_t mask_done[kSlots] = {};
@@ -471,16 +476,33 @@ struct g1s_diff {
   std::mutex ktimes_mutex;
   // timed batches run on one stream: an event before each launch (and one after the last), named after the kernel
   int kmark(Slot &sl, hipStream_t st, const char *name) {
-    if (!sl.timed) return G1S_OK;
+    if (!sl.timed && !trace) return G1S_OK;
     if (sl.nk == sl.kev.size()) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return fail(G1S_ERR_HIP, "hipEventCreate failed");
       sl.kev.push_back(e);
       sl.kname.emplace_back();
+      sl.kstream.push_back(nullptr);
     }
     if (hipEventRecord(sl.kev[sl.nk], st) != hipSuccess) return fail(G1S_ERR_HIP, "hipEventRecord failed");
+    sl.kstream[sl.nk] = st;
     sl.kname[sl.nk++] = name ? name : "";
     return G1S_OK;
+  }
+  // G1S_TRACE=file (a measurement aid): the PIPELINED job's own timeline -- an event in front of every launch on the stream it
+  // is launched on (its end = the next event of that stream), the host's time at every submit; written at finish
+  bool trace = false;
+  hipEvent_t trace_base = nullptr;
+  std::chrono::steady_clock::time_point trace_host0;
+  std::vector<std::string> trace_lines;
+  std::mutex trace_mutex;
+  double trace_now() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - trace_host0).count(); }
+  void trace_host(const char *what, int si) {
+    if (!trace) return;
+    char b[96];
+    snprintf(b, sizeof(b), "H %12.1f %s slot %d", trace_now(), what, si);
+    std::lock_guard<std::mutex> lk(trace_mutex);
+    trace_lines.emplace_back(b);
   }
 
   int fail(int code, const std::string &msg) {
@@ -797,13 +819,16 @@ int g1s_diff::submit(int si) {
     std::lock_guard<std::mutex> lk(dm);
     slot_busy[si] = true;  // until the drainer has folded it
   }
+  trace_host("submit", si);
   int rc = launch_front(si);
   if (rc) return rc;
+  trace_host("front queued", si);
   const int prev = pending;
   pending = si;
   if (prev >= 0) {
     rc = launch_back(prev);
     if (rc) return rc;
+    trace_host("back queued", prev);
   }
   if (one_stream || no_defer || timing || !ss.flat) {
     rc = flush_pending();
@@ -815,6 +840,7 @@ int g1s_diff::submit(int si) {
     cur = (si + 1) % kSlots;
     cv_free.wait(lk, [&] { return !slot_busy[cur]; });
   }
+  trace_host("next slot free", cur);
   return G1S_OK;
 }
 
@@ -856,7 +882,11 @@ int g1s_diff::launch_front(int si) {
     }
     sl.async_in = false;
   }
+  sl.timed = timing;
+  sl.nk = 0;
+  if (!sl.timed) kmark(sl, up, "table H2D");  // (trace mode only: the timed batches' table of kernels stays what it was)
   HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, up));
+  if (!sl.timed) kmark(sl, up, "k_zero");
   {
     // all per-batch zero fills in one launch: records, lag / masked accumulators, bad flags + list counters
     ZeroJob z{};
@@ -876,13 +906,12 @@ int g1s_diff::launch_front(int si) {
     //  with earlier batches)
     hipLaunchKernelGGL(k_zero, dim3(256), dim3(256), 0, up, z);
   }
+  if (!sl.timed) kmark(sl, up, nullptr);
   if (up != stream) {
     HIP_TRY(hipEventRecord(ss.table_done[si], up));
     HIP_TRY(hipStreamWaitEvent(stream, ss.table_done[si], 0));
     if (pstream != stream) HIP_TRY(hipStreamWaitEvent(pstream, ss.table_done[si], 0));
   }
-  sl.timed = timing;
-  sl.nk = 0;
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[0], pstream));
   // (the fused pass serves every format; round 1's chain has no structured path for 4:4:0)
   {
@@ -1258,13 +1287,34 @@ int g1s_diff::launch_back(int si) {
       HIP_TRY(hipEventRecord(ss.kernels_done[si], stream));
       HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
     } else {
-      if (!ss.latest) HIP_TRY(hipStreamCreateWithFlags(&ss.latest, hipStreamNonBlocking));
-      HIP_TRY(hipStreamWaitEvent(ss.latest, ss.kernels_done[si], 0));
-      HIP_TRY(launch_latest(job, B, ss.latest));
+      if (!ss.latest) {
+        // the main stream's priority class (the least urgent: the kernel fills in; measured 4 % better than the runtime's default
+        // class, profiles/r05_device_latest.txt).  G1S_LATEST_PRIO (tuning aid): 0 the runtime's default class, 1 the main
+        // stream's, 2 the side stream's
+        static const int lp = getenv("G1S_LATEST_PRIO") ? atoi(getenv("G1S_LATEST_PRIO")) : 1;
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+        for (hipStream_t *st : {&ss.latest, &ss.latest2}) {
+          if (lp == 0) HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+          else HIP_TRY(hipStreamCreateWithPriority(st, hipStreamNonBlocking, lp == 1 ? plo : phi));
+        }
+        for (int i = 0; i < kSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&ss.latest_done[i], hipEventDisableTiming));
+      }
+      static const bool one_latest = getenv("G1S_LATEST_ONE_STREAM") != nullptr;  // (tuning aid: round 4's placement)
+      hipStream_t lst = (si & 1) && !one_latest ? ss.latest2 : ss.latest;
+      HIP_TRY(hipStreamWaitEvent(lst, ss.kernels_done[si], 0));
+      kmark(sl, lst, latest_kernel_name());  // (trace mode)
+      HIP_TRY(launch_latest(job, B, lst));
+      kmark(sl, lst, nullptr);
+      // the blobs' copy: on the copy stream, behind the kernel
+      HIP_TRY(hipEventRecord(ss.latest_done[si], lst));
+      HIP_TRY(hipStreamWaitEvent(ss.copy, ss.latest_done[si], 0));
     }
-    hipStream_t ls = sl.timed ? ss.copy : ss.latest;
+    hipStream_t ls = ss.copy;
+    if (!sl.timed) kmark(sl, ls, "blobs D2H");
     HIP_TRY(hipMemcpyAsync(sl.h_latest, sl.d_latest, blob * B, hipMemcpyDeviceToHost, ls));
     HIP_TRY(hipMemcpyAsync(sl.h_records + L.size * (B - 1), sl.d_records + L.size * (B - 1), L.size, hipMemcpyDeviceToHost, ls));
+    if (!sl.timed) kmark(sl, ls, nullptr);
     HIP_TRY(hipEventRecord(sl.done, ls));
   } else {
     HIP_TRY(hipMemcpyAsync(sl.h_records, sl.d_records, L.size * B, hipMemcpyDeviceToHost, ss.copy));
@@ -1350,6 +1400,17 @@ int g1s_diff::drain_front(int si) {
   std::vector<uint32_t> &nflat_v = nflat_s[si];
   std::vector<uint8_t> &latest_stage = stage_s[si];
   HIP_TRY(hipEventSynchronize(sl.done));
+  if (trace && !sl.timed && trace_base) {
+    std::lock_guard<std::mutex> lk(trace_mutex);
+    for (size_t i = 0; i < sl.nk; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, trace_base, sl.kev[i]) != hipSuccess) continue;
+      char b[160];
+      snprintf(b, sizeof(b), "G %12.1f slot %d stream %p %s", ms * 1e3, si, (void *)sl.kstream[i], sl.kname[i].empty() ? "-" : sl.kname[i].c_str());
+      trace_lines.emplace_back(b);
+    }
+    trace_lines.emplace_back(std::string("H ") + std::to_string(trace_now()) + " drained slot " + std::to_string(si));
+  }
   if (sl.timed) {
     float ms = 0;
     float ms_mom = 0;  // the finder's moments pass
@@ -1519,6 +1580,13 @@ int g1s_diff::drain_all() {
 }
 
 void g1s_diff::release() {
+  if (trace && !trace_lines.empty()) {
+    if (FILE *f = fopen(getenv("G1S_TRACE"), "a")) {
+      for (const auto &l : trace_lines) fprintf(f, "%s\n", l.c_str());
+      fclose(f);
+    }
+    trace_lines.clear();
+  }
   if (drainer.joinable()) {
     {
       std::lock_guard<std::mutex> lk(dm);
@@ -1538,6 +1606,7 @@ void g1s_diff::release() {
   if (ss.compute) (void)hipStreamSynchronize(ss.compute);
   if (ss.copy) (void)hipStreamSynchronize(ss.copy);
   if (ss.latest) (void)hipStreamSynchronize(ss.latest);
+  if (ss.latest2) (void)hipStreamSynchronize(ss.latest2);
   if (ss.flat) (void)hipStreamSynchronize(ss.flat);
   if (ss.flat2) (void)hipStreamSynchronize(ss.flat2);
   if (ss.upload) (void)hipStreamSynchronize(ss.upload);
@@ -1668,6 +1737,11 @@ g1s_diff_t *g1s_diff_new(int64_t fps_num, int64_t fps_den, uint32_t source_bit_d
   }
   if (!records_only && !latest_only) g->fold = new NoiseFold(fps_num, fps_den, lag);
   g->pool = shared_pool();
+  if (getenv("G1S_TRACE")) {
+    g->trace = hipEventCreate(&g->trace_base) == hipSuccess && hipEventRecord(g->trace_base, g->ss.compute) == hipSuccess &&
+               hipEventSynchronize(g->trace_base) == hipSuccess;
+    g->trace_host0 = std::chrono::steady_clock::now();
+  }
   g->drainer = std::thread([g] { g->drainer_main(); });
   g->folder = std::thread([g] { g->folder_main(); });
   return g;

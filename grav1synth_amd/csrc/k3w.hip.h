@@ -395,7 +395,10 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
   // offset of its own (tile row p, word w).
   const uint32_t lo_s = (uint32_t)(4 + own_row0 + 2 * p) * sst + (uint32_t)(8 * w * BPS);
   const uint32_t lo_v = (uint32_t)(4 + own_row0 + 2 * p) * dst_ + (uint32_t)(8 * w * BPS);
-  const uint32_t lo_hs = (uint32_t)p * sst + (uint32_t)(8 * w * BPS), lo_hv = (uint32_t)p * dst_ + (uint32_t)(8 * w * BPS);
+  // (tile row 0 is never read by a multiply: its lanes ask for row 1's words again -- the same lines as the lanes of row 1, no
+  //  bytes of their own from memory: 1 / 36 of the luma launch's tile bytes, 1 / 20 of the 4:2:0 chroma launch's)
+  const int ph_ = p > 0 ? p : 1;
+  const uint32_t lo_hs = (uint32_t)ph_ * sst + (uint32_t)(8 * w * BPS), lo_hv = (uint32_t)ph_ * dst_ + (uint32_t)(8 * w * BPS);
 
   // the L plane of the frame; this thread's word(s) of a unit's L tile (chroma launch) / this lane's L bytes (luma launch)
   uint8_t *lframe = wp.lplane + (size_t)frame * wp.lframe_bytes;
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
       if (h_wave) {
         hs = w_u4{0u, 0u, 0u, 0u};
         hv = w_u4{0u, 0u, 0u, 0u};
-        if (xok && Y0 + p >= 0 && Y0 + p < ph) {
+        if (xok && Y0 + ph_ >= 0 && Y0 + ph_ < ph) {
           hs = load8(sb, lo_hs);
           hv = load8(vb, lo_hv);
         }
