@@ -237,6 +237,7 @@ def main() -> None:
         one_step(False)
     barrier()
     t0 = time.perf_counter()
+    cpu0 = sum(os.times()[:2])  # (this process' user + system seconds, every thread: the host cores a rank keeps busy)
     step_ms, step_fold_ms = [], []
     for _ in range(args.steps):
         ts = time.perf_counter()
@@ -245,6 +246,7 @@ def main() -> None:
         step_fold_ms.append(st_.ms_host_fold)
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cores_busy = (sum(os.times()[:2]) - cpu0) / max(elapsed, 1e-9)
     if world > 1:
         t = torch.tensor([elapsed], device=torch.device("cpu") if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,6 +350,7 @@ def main() -> None:
         "ms_per_step": elapsed / args.steps * 1e3,
         "step_ms": [round(x, 3) for x in step_ms],
         "step_host_fold_ms": [round(x, 3) for x in step_fold_ms],  # (the ordered merge's wall time inside each step: a thread of its own)
+        "host_cores_busy": round(host_cores_busy, 2),  # (rank 0's process over the timed steps: CPU seconds / wall seconds)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

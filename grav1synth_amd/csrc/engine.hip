@@ -327,6 +327,7 @@ struct StreamSet {
   // chains per frame and twice as long next to the accumulation launches as alone -- on ONE stream, with the blobs' copy behind
   // it, a batch's half would only start when the half of the batch before had been copied out (period >= 1 040 us at 4K)
   hipStream_t latest = nullptr, latest2 = nullptr;
+  hipStream_t mom = nullptr;  // (G1S_MOM_STREAM: a tuning aid)
   hipEvent_t latest_done[kSlots] = {};
   int prio_side = 0;
   hipEvent_t kernels_done[kSlots] = {};
@@ -523,6 +524,7 @@ struct g1s_diff {
   int submit(int si);        // front half now; back half now or with the next batch's front half
   int launch_front(int si);  // zero, pixel pass, flat-block finder, window planes, area lists
   int launch_back(int si);   // accumulation kernels, records D2H, hand-over to the drainer
+  static bool wide_gen(const Geom &g);  // the wide chain's general residual form (mixed sample sizes / shifts)
   int flush_pending();
   Geom batch_geom(const Slot &sl) const;
   int drain_front(int si);  // drainer thread
@@ -868,6 +870,18 @@ int g1s_diff::launch_front(int si) {
   // (measured and dropped: k1_moments on the main stream in front of the accumulation of the batch before, the rest of the
   //  finder chain beside that accumulation: -3 to -10 % at 4K, +11 % at 1080p, -4 % at 8K; profiles/r04_streams.txt)
   hipStream_t pstream = fstream;
+  // G1S_MOM_STREAM=1|2 (tuning aid): k1_moments on a stream of its own in the main stream's priority class (1) / the default
+  // class (2), the latency-bound rest of the finder chain alone on the high-priority side stream
+  static const int mom_mode = getenv("G1S_MOM_STREAM") ? atoi(getenv("G1S_MOM_STREAM")) : 0;
+  if (mom_mode && fstream != stream) {
+    if (!ss.mom) {
+      int plo = 0, phi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+      if (mom_mode == 1) HIP_TRY(hipStreamCreateWithPriority(&ss.mom, hipStreamNonBlocking, plo));
+      else HIP_TRY(hipStreamCreateWithFlags(&ss.mom, hipStreamNonBlocking));
+    }
+    pstream = ss.mom;
+  }
   // the frame table: pinned host copy -> device, on the upload stream (idle: done long before the main
   // stream gets here); per-kernel timing / one-stream mode: in line
   FrameTable ft;
@@ -998,13 +1012,19 @@ bool g1s_diff::wide_ok(const Geom &g) const {
   if (!use_wide()) return false;
   static const bool off = getenv("G1S_W_OFF") != nullptr;  // debugging aid
   if (off) return false;
-  if (g.src_bps != g.den_bps || g.src_shift != g.den_shift || g.src_shift > 4 || g.lag < 1) return false;
+  if (g.lag < 1) return false;
+  // inputs of one sample size and one narrowing shift <= 4: the residual in place (w_residual); any other pair of depths: the
+  // general form (w_residual_gen), built for 4:2:0 and for frames without chroma planes (the other subsamplings of such a pair
+  // run the stream chain)
+  if (wide_gen(g) && !(g.nplanes != 3 || (g.xdec == 1 && g.ydec == 1))) return false;
   const int need = g.nplanes == 3 ? 0x3f : 0x09;
   if ((g.vec_mask & need) != need) return false;
   if ((g.W & 7) != 0 || (g.nplanes == 3 && ((g.W >> g.xdec) & 7) != 0)) return false;
   if (g.nbw > 1023 * 4 || g.nbh > 4095) return false;
   return true;
 }
+
+bool g1s_diff::wide_gen(const Geom &g) { return g.src_bps != g.den_bps || g.src_shift != g.den_shift || g.src_shift > 4; }
 
 MParams g1s_diff::make_mparams(const Slot &sl) const {
   MParams mp;
@@ -1068,23 +1088,32 @@ int g1s_diff::launch_back(int si) {
       wq.ncell = w_ncell[k];
       wq.wgs = Gk[k];
     };
-#define G1S_W(KIND, BP, SX, SY)                                                                                        \
+#define G1S_WG(KIND, BP, SX, SY, BD, GEN)                                                                              \
   do {                                                                                                                 \
     constexpr int lds_ = w_lds_bytes(KIND, WShape<KIND, SX, SY>::BH);                                                  \
-    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3w_pass<KIND, BP, SX, SY>),   \
+    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k3w_pass<KIND, BP, SX, SY, BD, GEN>), \
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_);             \
     (void)attr_;                                                                                                       \
     char kn_[64];                                                                                                      \
-    snprintf(kn_, sizeof(kn_), "k3w_pass<%d, %d, %d, %d>", KIND, BP, SX, SY);                                          \
+    if (GEN) snprintf(kn_, sizeof(kn_), "k3w_pass<%d, %d, %d, %d, %d, true>", KIND, BP, SX, SY, BD);                   \
+    else snprintf(kn_, sizeof(kn_), "k3w_pass<%d, %d, %d, %d>", KIND, BP, SX, SY);                                     \
     kmark(sl, stream, kn_);                                                                                            \
     set_kind(KIND);                                                                                                    \
     wq.rev = (w_rev >> KIND) & 1;                                                                                      \
-    hipLaunchKernelGGL((k3w_pass<KIND, BP, SX, SY>), dim3((uint32_t)Gk[KIND] * B), dim3(kWThreads), lds_, stream, g, wq); \
+    hipLaunchKernelGGL((k3w_pass<KIND, BP, SX, SY, BD, GEN>), dim3((uint32_t)Gk[KIND] * B), dim3(kWThreads), lds_, stream, g, wq); \
   } while (0)
+#define G1S_W(KIND, BP, SX, SY) G1S_WG(KIND, BP, SX, SY, BP, false)
 #define G1S_WB(KIND, SX, SY)                   \
   do {                                         \
     if (g.src_bps == 2) G1S_W(KIND, 2, SX, SY); \
     else G1S_W(KIND, 1, SX, SY);               \
+  } while (0)
+  // (the general form: wide_ok lets it through for 4:2:0 and for frames without chroma planes)
+#define G1S_WGEN(KIND, SX, SY)                                              \
+  do {                                                                      \
+    if (g.src_bps == 2 && g.den_bps == 2) G1S_WG(KIND, 2, SX, SY, 2, true); \
+    else if (g.src_bps == 2) G1S_WG(KIND, 2, SX, SY, 1, true);              \
+    else G1S_WG(KIND, 1, SX, SY, 2, true); /* (two 8-bit inputs are never general) */ \
   } while (0)
 #define G1S_WK(KIND)                                 \
   do {                                               \
@@ -1093,10 +1122,13 @@ int g1s_diff::launch_back(int si) {
     else if (g.ydec == 1) G1S_WB(KIND, 0, 1);        \
     else G1S_WB(KIND, 0, 0);                         \
   } while (0)
+    const bool gen = wide_gen(g);
     if (!chroma) {
-      G1S_WB(0, -1, -1);
+      if (gen) G1S_WGEN(0, -1, -1);
+      else G1S_WB(0, -1, -1);
     } else {
-      G1S_WK(0);
+      if (gen) G1S_WGEN(0, 1, 1);
+      else G1S_WK(0);
       // The chroma launch stays on the main stream behind the luma launch.  Round 3's chain moved it (and what follows) to the
       // copy stream, next to the luma launch of the batch after; with this chain both launches fill every register of the
       // chip and only stretch each other: serial is +2 - 5 % on the 4K job, +10 % at 8K 4:4:4 (profiles/r04_streams.txt).
@@ -1106,8 +1138,11 @@ int g1s_diff::launch_back(int si) {
         HIP_TRY(hipStreamWaitEvent(ss.copy, ss.kernels_done[si], 0));
         stream = ss.copy;
       }
-      G1S_WK(1);
+      if (gen) G1S_WGEN(1, 1, 1);
+      else G1S_WK(1);
     }
+#undef G1S_WGEN
+#undef G1S_WG
 #undef G1S_WK
 #undef G1S_WB
 #undef G1S_W
@@ -1609,6 +1644,7 @@ void g1s_diff::release() {
   if (ss.latest2) (void)hipStreamSynchronize(ss.latest2);
   if (ss.flat) (void)hipStreamSynchronize(ss.flat);
   if (ss.flat2) (void)hipStreamSynchronize(ss.flat2);
+  if (ss.mom) (void)hipStreamSynchronize(ss.mom);
   if (ss.upload) (void)hipStreamSynchronize(ss.upload);
   release_streams(ss);
   for (Slot &sl : slots) {

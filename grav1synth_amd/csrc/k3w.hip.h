@@ -248,6 +248,36 @@ __device__ __forceinline__ void w_residual(const w_u4 &s, const w_u4 &v, int sh,
     }
   }
 }
+// The general form (GEN: the inputs differ in sample size or in narrowing shift): each input narrowed on its own into 16-bit
+// halves in the BPS 2 order -- 16-bit samples shifted and masked, bytes spread by one v_perm per two samples -- then the same
+// difference; ssum holds the narrowed source halves themselves.
+template <int BS, int BD>
+__device__ __forceinline__ void w_residual_gen(const w_u4 &s, const w_u4 &v, int sh_s, int sh_d, uint32_t (&T)[4], uint32_t &acc, uint32_t &ssum) {
+  constexpr uint32_t K = 0x00ff00ffu, B = 0x00800080u;
+  uint32_t a[4], b[4];
+  if (BS == 2) {
+    const uint32_t ws[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = (ws[q] >> sh_s) & K;
+  } else {
+    a[0] = __builtin_amdgcn_perm(0u, s.x, 0x0c010c00u), a[1] = __builtin_amdgcn_perm(0u, s.x, 0x0c030c02u);
+    a[2] = __builtin_amdgcn_perm(0u, s.y, 0x0c010c00u), a[3] = __builtin_amdgcn_perm(0u, s.y, 0x0c030c02u);
+  }
+  if (BD == 2) {
+    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = (wv[q] >> sh_d) & K;
+  } else {
+    b[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u), b[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
+    b[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u), b[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ssum += a[q];
+    T[q] = (a[q] + B) - b[q];
+    acc |= T[q];
+  }
+}
 // T -> the word's 8 residual bytes (two's complement)
 template <int BPS>
 __device__ __forceinline__ void w_pack(const uint32_t (&T)[4], uint32_t &d0, uint32_t &d1) {
@@ -342,8 +372,11 @@ struct WShape {
 #ifndef G1S_W_OCC_L
 #define G1S_W_OCC_L 4
 #endif
-template <int KIND, int BPS, int SX, int SY>
+// BPD, GEN: the denoised planes' sample size, and the general residual form (inputs of different sample sizes or narrowing
+// shifts: w_residual_gen); the layouts behind the residual words are the BPS 2 ones then
+template <int KIND, int BPS, int SX, int SY, int BPD = BPS, bool GEN = false>
 __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) : G1S_W_OCC_L) void k3w_pass(Geom g, WParams wp) {
+  constexpr int LAY = GEN ? 2 : BPS;  // the order of the samples in the residual words T
   extern __shared__ __attribute__((aligned(16))) uint8_t w_smem[];
   using SH = WShape<KIND, SX, SY>;
   constexpr bool CHR = SH::CHR, LOUT = SH::LOUT;
@@ -394,11 +427,11 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
   // word 0); the second row of the pair and the further own iterations move the SCALAR base instead; the halo row has an
   // offset of its own (tile row p, word w).
   const uint32_t lo_s = (uint32_t)(4 + own_row0 + 2 * p) * sst + (uint32_t)(8 * w * BPS);
-  const uint32_t lo_v = (uint32_t)(4 + own_row0 + 2 * p) * dst_ + (uint32_t)(8 * w * BPS);
+  const uint32_t lo_v = (uint32_t)(4 + own_row0 + 2 * p) * dst_ + (uint32_t)(8 * w * BPD);
   // (tile row 0 is never read by a multiply: its lanes ask for row 1's words again -- the same lines as the lanes of row 1, no
   //  bytes of their own from memory: 1 / 36 of the luma launch's tile bytes, 1 / 20 of the 4:2:0 chroma launch's)
   const int ph_ = p > 0 ? p : 1;
-  const uint32_t lo_hs = (uint32_t)ph_ * sst + (uint32_t)(8 * w * BPS), lo_hv = (uint32_t)ph_ * dst_ + (uint32_t)(8 * w * BPS);
+  const uint32_t lo_hs = (uint32_t)ph_ * sst + (uint32_t)(8 * w * BPS), lo_hv = (uint32_t)ph_ * dst_ + (uint32_t)(8 * w * BPD);
 
   // the L plane of the frame; this thread's word(s) of a unit's L tile (chroma launch) / this lane's L bytes (luma launch)
   uint8_t *lframe = wp.lplane + (size_t)frame * wp.lframe_bytes;
@@ -464,10 +497,10 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
   auto entry_x = [&](int j) -> uint32_t { return __builtin_amdgcn_readfirstlane(s_ent[2 * (j + 1)].x); };
 
   // the raw words of the unit with entry word ex, into rs / rv (and hs / hv)
-  auto load8 = [&](const uint8_t *base, uint32_t off) __attribute__((always_inline)) -> w_u4 {
+  auto load8 = [&](const uint8_t *base, uint32_t off, bool wide) __attribute__((always_inline)) -> w_u4 {
     w_u4 r = {0u, 0u, 0u, 0u};
     asm volatile("" : "+v"(off));  // (opaque: scalar base + 32-bit lane offset, not a 64-bit lane address)
-    if (BPS == 2) {
+    if (wide) {
       r = *(gptr_u4)(as_global(base) + off);
     } else {
       const u32x2 a = *(gptr_u2)(as_global(base) + off);
@@ -481,18 +514,18 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
     const int X0 = c * kWUnitW, Y0 = by * BH - 4;
     // (scalar origin + the lane's constant offset)
     const uint8_t *sb = psrc + ((ptrdiff_t)Y0 * (ptrdiff_t)sst + (ptrdiff_t)(X0 * BPS));
-    const uint8_t *vb = pden + ((ptrdiff_t)Y0 * (ptrdiff_t)dst_ + (ptrdiff_t)(X0 * BPS));
+    const uint8_t *vb = pden + ((ptrdiff_t)Y0 * (ptrdiff_t)dst_ + (ptrdiff_t)(X0 * BPD));
     if ((ex >> 25) & 1u) {  // every row and word of the tile inside the plane
 #pragma unroll
       for (int i = 0; i < NOWN; ++i)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          rs[i][r] = load8(sb + (size_t)(8 * i + r) * sst, lo_s);
-          rv[i][r] = load8(vb + (size_t)(8 * i + r) * dst_, lo_v);
+          rs[i][r] = load8(sb + (size_t)(8 * i + r) * sst, lo_s, BPS == 2);
+          rv[i][r] = load8(vb + (size_t)(8 * i + r) * dst_, lo_v, BPD == 2);
         }
       if (h_wave) {
-        hs = load8(sb, lo_hs);
-        hv = load8(vb, lo_hv);
+        hs = load8(sb, lo_hs, BPS == 2);
+        hv = load8(vb, lo_hv, BPD == 2);
       }
     } else {
       const bool xok = X0 + 8 * w + 8 <= pw;
@@ -504,16 +537,16 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
           rs[i][r] = w_u4{0u, 0u, 0u, 0u};
           rv[i][r] = w_u4{0u, 0u, 0u, 0u};
           if (xok && Y0 + t < ph) {
-            rs[i][r] = load8(sb + (size_t)(8 * i + r) * sst, lo_s);
-            rv[i][r] = load8(vb + (size_t)(8 * i + r) * dst_, lo_v);
+            rs[i][r] = load8(sb + (size_t)(8 * i + r) * sst, lo_s, BPS == 2);
+            rv[i][r] = load8(vb + (size_t)(8 * i + r) * dst_, lo_v, BPD == 2);
           }
         }
       if (h_wave) {
         hs = w_u4{0u, 0u, 0u, 0u};
         hv = w_u4{0u, 0u, 0u, 0u};
         if (xok && Y0 + ph_ >= 0 && Y0 + ph_ < ph) {
-          hs = load8(sb, lo_hs);
-          hv = load8(vb, lo_hv);
+          hs = load8(sb, lo_hs, BPS == 2);
+          hv = load8(vb, lo_hv, BPD == 2);
         }
       }
     }
@@ -553,8 +586,9 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
       uint32_t T[2][4], ssum = 0;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        w_residual<BPS>(rs[i][r], rv[i][r], ssh, r_km, r_bm, T[r], racc, ssum);
-        w_pack<BPS>(T[r], Dn[i][r][0], Dn[i][r][1]);
+        if constexpr (GEN) w_residual_gen<BPS, BPD>(rs[i][r], rv[i][r], ssh, g.den_shift, T[r], racc, ssum);
+        else w_residual<BPS>(rs[i][r], rv[i][r], ssh, r_km, r_bm, T[r], racc, ssum);
+        w_pack<LAY>(T[r], Dn[i][r][0], Dn[i][r][1]);
         __builtin_amdgcn_sched_barrier(0);  // (row by row: the scheduler would otherwise keep both rows' temporaries alive)
       }
       if (real && !G1S_W_DBGBIT(4)) {
@@ -568,7 +602,7 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
         }
         unsigned long long pk;
         if (!CHR) {
-          const uint32_t ls = ((ssum & 0xffffu) + (ssum >> 16)) >> (BPS == 2 ? ssh : 0);
+          const uint32_t ls = ((ssum & 0xffffu) + (ssum >> 16)) >> (BPS == 2 && !GEN ? ssh : 0);
           pk = ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)ls << 19) | (unsigned long long)(uint32_t)(sd + 16 * 128);
         } else {
           pk = ((unsigned long long)(uint32_t)sd2 << 32) | (unsigned long long)(uint32_t)(sd + 16 * 128);
@@ -593,7 +627,7 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
               constexpr uint32_t bias1 = SY ? 256u : 128u;
               if (SX) {
                 uint32_t x01, x23;
-                if (BPS == 2) {
+                if (LAY == 2) {
                   uint32_t h[4];
 #pragma unroll
                   for (int q = 0; q < 4; ++q) h[q] = V[q] + (V[q] >> 16);
@@ -616,7 +650,7 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
                   y[q] = V[q] + add;
                   lacc |= y[q] ^ 0x02000200u;
                 }
-                constexpr uint32_t sel = BPS == 2 ? 0x06040200u : 0x06020400u;
+                constexpr uint32_t sel = LAY == 2 ? 0x06040200u : 0x06020400u;
                 *reinterpret_cast<uint2 *>(lp + (size_t)r * wp.lpitch) =
                     make_uint2(__builtin_amdgcn_perm(y[1], y[0], sel) ^ 0x80808080u, __builtin_amdgcn_perm(y[3], y[2], sel) ^ 0x80808080u);
               }
@@ -628,8 +662,9 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
     uint32_t hacc = 0;
     if (h_wave) {
       uint32_t T[4], dummy = 0;
-      w_residual<BPS>(hs, hv, ssh, r_km, r_bm, T, hacc, dummy);
-      w_pack<BPS>(T, Hn[0], Hn[1]);
+      if constexpr (GEN) w_residual_gen<BPS, BPD>(hs, hv, ssh, g.den_shift, T, hacc, dummy);
+      else w_residual<BPS>(hs, hv, ssh, r_km, r_bm, T, hacc, dummy);
+      w_pack<LAY>(T, Hn[0], Hn[1]);
     }
     // ---- residuals (or L) outside int8: rare; one wave-uniform test on the usual way ----
     const uint32_t out = (racc | hacc | lacc) & 0xff00ff00u;

@@ -543,6 +543,44 @@ def test_mixed_bit_depths():
         assert format_tbl(g.finish()) == ofmt(o.finish())
 
 
+@pytest.mark.parametrize("sb,db,chroma,size", [(10, 8, True, (352, 208)), (8, 10, True, (352, 208)), (10, 12, True, (320, 200)), (12, 10, False, (384, 192)),
+                                              (10, 8, False, (320, 192)), (16, 10, True, (320, 192))])
+def test_mixed_depths_records_match_oracle(sb, db, chroma, size):
+    """Source and denoised frames of different depths (4:2:0 and luma-only: the wide chain's general residual form -- each input
+    narrowed on its own, engine.hip wide_gen): every frame's mask, score bits, integer sums and block statistics, and the table,
+    against the oracle; block rows cut at the bottom (200 = 6.25 blocks)."""
+    from tests.oracle_binding import OracleDiff, format_tbl as ofmt
+
+    w, h = size
+    ss, sd = SynthSpec(w, h, sb), SynthSpec(w, h, db)
+    o = OracleDiff(24, 1, sb, db, 3, chroma)
+    g = DiffGenerator(Fraction(24, 1), sb, db, luma_only=not chroma, batch_frames=1)
+    nplanes = 3 if chroma else 1
+    for k in range(3):
+        src, den = np_pair(ss, k)[0], np_pair(sd, k)[1]
+        if k == 2:  # (a few residuals outside int8: the deferred path of the general form)
+            den = [p.copy() for p in den]
+            den[0][40:43, 100:104] = 0
+        o.diff_frame(src, den, 1, 1)
+        g.diff_frame(Frame([torch.from_numpy(p).cuda() for p in src], 1, 1), Frame([torch.from_numpy(p).cuda() for p in den], 1, 1))
+        g.sync()
+        r = g.last_record()
+        assert np.array_equal(o.flat_mask(), r.flat_mask()), f"frame {k}: flat mask"
+        assert np.array_equal(o.scores().view(np.uint32), r.scores().view(np.uint32)), f"frame {k}: score bits"
+        flat = o.flat_mask().ravel() != 0
+        for c in range(nplanes):
+            S, Sb, nobs = o.ar_sums(c)
+            S2, Sb2, nobs2 = r.ar_sums(c)
+            assert nobs == nobs2 and np.array_equal(S, S2) and np.array_equal(Sb, Sb2), f"frame {k} plane {c}: AR sums"
+            ls, sdd, sd2 = o.block_stats(c)
+            ls2, sdd2, sd22 = r.block_stats(c)
+            meas = flat & ((sd2 != 0) | (sdd != 0) | ((ls != 0) if c == 0 else False))
+            if c == 0:
+                assert np.array_equal(ls[meas], ls2[meas]), f"frame {k}: luma block sums"
+            assert np.array_equal(sdd[meas], sdd2[meas]) and np.array_equal(sd2[meas], sd22[meas]), f"frame {k} plane {c}: block noise sums"
+    assert format_tbl(g.finish()) == ofmt(o.finish())
+
+
 def test_errors_match_reference_behaviour():
     from grav1synth_amd._lib import G1SError
 

@@ -64,6 +64,32 @@ def test_tuning_switches_do_not_change_results():
         assert _run(_SWITCH_CODE, extra) == ref, extra
 
 
+def test_mixed_depths_agree_between_the_chains():
+    """A 10-bit source against an 8-bit denoised video (and the other way round, and 10 against 12 bits): the wide chain's general
+    residual form and the stream chain give the same records and tables (the oracle comparison:
+    tests/test_gpu_parity.py::test_mixed_depths_records_match_oracle)."""
+    code = (
+        "import hashlib\n"
+        "from fractions import Fraction\n"
+        "from grav1synth_amd.diff import DiffGenerator, format_tbl\n"
+        "from grav1synth_amd.synth import SynthSpec, make_pair\n"
+        "h = hashlib.sha256()\n"
+        "for sb, db, lo in ((10, 8, False), (8, 10, False), (10, 12, False), (10, 8, True)):\n"
+        "    ss, sd = SynthSpec(416, 232, sb), SynthSpec(416, 232, db)\n"
+        "    pairs = [(make_pair(ss, k, device='cuda')[0], make_pair(sd, k, device='cuda')[1]) for k in range(5)]\n"
+        "    g = DiffGenerator(Fraction(24, 1), sb, db, luma_only=lo, batch_frames=2, records_only=True)\n"
+        "    for s, d in pairs: g.diff_frame(s, d, 1, 1)\n"
+        "    recs, n = g.take_records(416, 232, 1 if lo else 3, 5); g.close(); h.update(recs.tobytes())\n"
+        "    g = DiffGenerator(Fraction(24, 1), sb, db, luma_only=lo, batch_frames=2)\n"
+        "    for s, d in pairs: g.diff_frame(s, d, 1, 1)\n"
+        "    h.update(format_tbl(g.finish())); g.close()\n"
+        "print(h.hexdigest())\n"
+    )
+    ref = _run(code, {})
+    assert len(ref) == 64
+    assert _run(code, {"G1S_K3": "stream"}) == ref
+
+
 def test_per_plane_deferrals_agree_between_the_chains():
     """4:4:4 frames whose Cb plane alone, and whose Cr plane alone, holds residuals outside int8: the chroma launch defers
     a unit per PLANE; the records and the table must be the stream chain's (which is held to the oracle on the same

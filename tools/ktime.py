@@ -15,9 +15,14 @@ wl = os.environ.get("WL", "4k10")
 W, H, bd, xd, yd = {"4k10": (3840, 2160, 10, 1, 1), "1080p8": (1920, 1080, 8, 1, 1), "8k10_444": (7680, 4320, 10, 0, 0)}[wl]
 spec = SynthSpec(W, H, bd, xdec=xd, ydec=yd, textured=not flat)
 nd = int(os.environ.get("DISTINCT", "64"))  # (distinct frame pairs: 64 = none shared inside a launch, what a video gives the caches)
-pairs = [make_pair(spec, k, device="cuda") for k in range(nd)]
+dbd = int(os.environ.get("DEN_BD", str(bd)))  # (a denoised video of another depth: the wide chain's general residual form)
+if dbd == bd:
+    pairs = [make_pair(spec, k, device="cuda") for k in range(nd)]
+else:
+    dspec = SynthSpec(W, H, dbd, xdec=xd, ydec=yd, textured=not flat)
+    pairs = [(make_pair(spec, k, device="cuda")[0], make_pair(dspec, k, device="cuda")[1]) for k in range(nd)]
 torch.cuda.synchronize()
-g = DiffGenerator(Fraction(24, 1), bd, bd, batch_frames=B)
+g = DiffGenerator(Fraction(24, 1), bd, dbd, batch_frames=B)
 try:
     # one untimed batch first: the first launch of a kernel in a process loads its code object (milliseconds, on whichever
     # kernel it lands)
