@@ -942,7 +942,7 @@ int g1s_diff::launch_front(int si) {
     {
       // the finder's moments of the luma source: the only pass over pixels that are not in a flat block's tile
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
-      if (!force_literal) {
+      {  // (also when every block is evaluated literally: the record's luma_sum comes from the moments)
         const dim3 mg((g.nblocks + 7) / 8, B);
         kmark(sl, pstream, g.src_bps == 1 ? "k1_moments<1>" : "k1_moments<2>");
         if (dbg_skip("moments")) {

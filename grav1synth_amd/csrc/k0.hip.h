@@ -163,7 +163,9 @@ constexpr int kMomInts = 16;  // ints per block in the moments buffer
 enum {
   kM_S0 = 0, kM_SXU, kM_SYU, kM_SAX, kM_SAY,        // full block: sum p, sum p xi, sum p yi, sum p |xi-16|, sum p |yi-16|
   kM_I0, kM_IXU, kM_IYU, kM_IPP,                    // interior (1..30)^2: sum p, sum p xi, sum p yi, sum p^2
-  kM_DXX, kM_DYY, kM_DXY, kM_DX, kM_DY              // interior central differences
+  kM_DXX, kM_DYY, kM_DXY, kM_DX, kM_DY,             // interior central differences
+  kM_CLIP                                           // sum p over the block's pixels INSIDE the plane (no replication): get_block_mean's sum, the
+                                                    // record's luma_sum (k1_certify writes it; the accumulation launches no longer form it)
 };
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 __device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
@@ -258,25 +260,23 @@ __device__ __forceinline__ void half_sums_dpp(int (&v)[N]) {
   for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x142, 0xa, 0xf, false);
 }
 
-// The same sums for 14 values, with the values SPLIT between the lanes in the first two stages -- a lane pair, then a quad,
-// keeps half of the values each and hands the other half over: half the additions (49 instructions instead of 70; the
-// reduction was a quarter of k1_moments).  On return every lane holds, with c = lane & 3, in x[j], j < 3, its 32-lane half's
-// total of v[4 j + c] and in x[3] the total of v[12 + (c & 1)].
-__device__ __forceinline__ void half_sums_split14(const int (&v)[14], int (&x)[4]) {
+// The same sums for 16 values, with the values SPLIT between the lanes in the first two stages -- a lane pair, then a quad,
+// keeps half of the values each and hands the other half over: half the additions (the reduction was a quarter of
+// k1_moments).  On return every lane holds, with c = lane & 3, in x[j], j < 4, its 32-lane half's total of v[4 j + c].
+__device__ __forceinline__ void half_sums_split16(const int (&v)[16], int (&x)[4]) {
   const int lane = (int)(threadIdx.x & 63);
   const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-  int w[7];
+  int w[8];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
     w[i] = keep + __builtin_amdgcn_update_dpp(0, send, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]: the lane next door
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < 4; ++j) {
     const int keep = b1 ? w[2 * j + 1] : w[2 * j], send = b1 ? w[2 * j] : w[2 * j + 1];
     x[j] = keep + __builtin_amdgcn_update_dpp(0, send, 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
   }
-  x[3] = w[6] + __builtin_amdgcn_update_dpp(0, w[6], 0x4E, 0xf, 0xf, false);
   // the other lanes of the same class: four lanes apart inside a row of 16 (rotations), then the other row of the half
 #pragma unroll
   for (int j = 0; j < 4; ++j) x[j] += __builtin_amdgcn_update_dpp(0, x[j], 0x124, 0xf, 0xf, false);  // row_ror:4

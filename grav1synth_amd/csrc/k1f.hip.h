@@ -54,15 +54,35 @@ __global__ __launch_bounds__(256) void k1_moments(const FrameTable ft, Geom g, i
   }
   int32_t s[14];
   row_moments(pk, pu, pd, yi, s);
-  // sum over the 32 rows of the block: the last four lanes of the block hold the fourteen totals between them
+  // the block's pixels inside the plane (get_block_mean's sum): the row's sum, but for the blocks on the plane's right and
+  // bottom edges, whose replicated pixels do not count
+  int32_t clip = s[kM_S0];
+  if (!(fast && oy + kBlock <= g.H)) {
+    clip = 0;
+    if (oy + yi < g.H) {
+      const int nvalid = min(g.W - ox, kBlock);
+      uint32_t c = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int nv = min(max(nvalid - 4 * k, 0), 4);
+        c = sad4(pk[k] & (nv == 4 ? 0xffffffffu : ((1u << (8 * nv)) - 1u)), c);
+      }
+      clip = (int32_t)c;
+    }
+  }
+  // sum over the 32 rows of the block: the last four lanes of the block hold the sixteen totals between them
+  int v16[16];
+#pragma unroll
+  for (int k = 0; k < 14; ++k) v16[k] = s[k];
+  v16[kM_CLIP] = live ? clip : 0;
+  v16[15] = 0;
   int x[4];
-  half_sums_split14(s, x);
+  half_sums_split16(v16, x);
   if (live && yi >= kBlock - 4) {
     int32_t *out = mom + ((size_t)frame * g.nblocks + blk) * kMomInts;
     const int c = yi & 3;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) out[4 * j + c] = x[j];
-    if (c < 2) out[12 + c] = x[3];
+    for (int j = 0; j < 4; ++j) out[4 * j + c] = x[j];
   }
 }
 
@@ -275,8 +295,11 @@ __global__ __launch_bounds__(256) void k1_certify(Geom g, FlatConsts fc, const i
     }
   }
   if (blk < g.nblocks) {
+    uint8_t *rec = records + (size_t)frame * g.rec_size;
+    // the record's luma_sum (get_block_mean as an exact sum) comes from the finder's moments: the accumulation launches do
+    // not form it (4 additions a row word of the luma launch)
+    reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)mom[((size_t)frame * g.nblocks + blk) * kMomInts + kM_CLIP];
     if (certain) {
-      uint8_t *rec = records + (size_t)frame * g.rec_size;
       reinterpret_cast<float *>(rec + g.off_scores)[blk] = score_out;
       flags[(size_t)frame * g.nblocks + blk] = flag_out;
     }

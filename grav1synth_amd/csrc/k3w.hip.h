@@ -217,20 +217,19 @@ __global__ __launch_bounds__(1024) void k2w_select_units(Geom g, uint8_t *__rest
 // ---------------------------------------------------------------------------------
 // residual arithmetic of one row word (8 samples): raw source / denoised words -> T[4], 16-bit halves holding d + 128
 //   BPS 2: T[q] = samples (2 q, 2 q + 1);  BPS 1: T[0] = (0, 2), T[1] = (1, 3), T[2] = (4, 6), T[3] = (5, 7).
-// acc |= every T (some d outside int8 <=> (acc & 0xff00ff00) != 0); ssum += the narrowed source halves.
+// acc |= every T (some d outside int8 <=> (acc & 0xff00ff00) != 0).  (The sum of the narrowed source samples -- the record's
+// luma_sum -- is no longer formed here: k1_certify writes it from the finder's moments.)
 // ---------------------------------------------------------------------------------
 // BPS 2: both inputs are narrowed by the same shift sh <= 4 (the engine sends other pairs of depths down the stream chain), so
-// the eight bits are masked where they lie and the difference is shifted once: km = 0xff << sh in both halves, bm = 128 << sh;
-// ssum then holds the source halves times 2^sh.
+// the eight bits are masked where they lie and the difference is shifted once: km = 0xff << sh in both halves, bm = 128 << sh.
 template <int BPS>
-__device__ __forceinline__ void w_residual(const w_u4 &s, const w_u4 &v, int sh, uint32_t km, uint32_t bm, uint32_t (&T)[4], uint32_t &acc, uint32_t &ssum) {
+__device__ __forceinline__ void w_residual(const w_u4 &s, const w_u4 &v, int sh, uint32_t km, uint32_t bm, uint32_t (&T)[4], uint32_t &acc) {
   constexpr uint32_t K = 0x00ff00ffu, B = 0x00800080u;
   if (BPS == 2) {
     const uint32_t ws[4] = {s.x, s.y, s.z, s.w}, wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t a = ws[q] & km, b = wv[q] & km;
-      ssum += a;
       T[q] = ((a - b) + bm) >> sh;
       acc |= T[q];
     }
@@ -239,8 +238,6 @@ __device__ __forceinline__ void w_residual(const w_u4 &s, const w_u4 &v, int sh,
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const uint32_t a0 = ws[q] & K, b0 = wv[q] & K, a1 = (ws[q] >> 8) & K, b1 = (wv[q] >> 8) & K;
-      ssum += a0;
-      ssum += a1;
       T[2 * q] = (a0 + B) - b0;
       T[2 * q + 1] = (a1 + B) - b1;
       acc |= T[2 * q];
@@ -250,9 +247,9 @@ __device__ __forceinline__ void w_residual(const w_u4 &s, const w_u4 &v, int sh,
 }
 // The general form (GEN: the inputs differ in sample size or in narrowing shift): each input narrowed on its own into 16-bit
 // halves in the BPS 2 order -- 16-bit samples shifted and masked, bytes spread by one v_perm per two samples -- then the same
-// difference; ssum holds the narrowed source halves themselves.
+// difference.
 template <int BS, int BD>
-__device__ __forceinline__ void w_residual_gen(const w_u4 &s, const w_u4 &v, int sh_s, int sh_d, uint32_t (&T)[4], uint32_t &acc, uint32_t &ssum) {
+__device__ __forceinline__ void w_residual_gen(const w_u4 &s, const w_u4 &v, int sh_s, int sh_d, uint32_t (&T)[4], uint32_t &acc) {
   constexpr uint32_t K = 0x00ff00ffu, B = 0x00800080u;
   uint32_t a[4], b[4];
   if (BS == 2) {
@@ -273,7 +270,6 @@ __device__ __forceinline__ void w_residual_gen(const w_u4 &s, const w_u4 &v, int
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    ssum += a[q];
     T[q] = (a[q] + B) - b[q];
     acc |= T[q];
   }
@@ -583,11 +579,11 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
     }
 #pragma unroll
     for (int i = 0; i < NOWN; ++i) {
-      uint32_t T[2][4], ssum = 0;
+      uint32_t T[2][4];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        if constexpr (GEN) w_residual_gen<BPS, BPD>(rs[i][r], rv[i][r], ssh, g.den_shift, T[r], racc, ssum);
-        else w_residual<BPS>(rs[i][r], rv[i][r], ssh, r_km, r_bm, T[r], racc, ssum);
+        if constexpr (GEN) w_residual_gen<BPS, BPD>(rs[i][r], rv[i][r], ssh, g.den_shift, T[r], racc);
+        else w_residual<BPS>(rs[i][r], rv[i][r], ssh, r_km, r_bm, T[r], racc);
         w_pack<LAY>(T[r], Dn[i][r][0], Dn[i][r][1]);
         __builtin_amdgcn_sched_barrier(0);  // (row by row: the scheduler would otherwise keep both rows' temporaries alive)
       }
@@ -600,13 +596,7 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
           sd2 = __builtin_amdgcn_sdot4((int)Dn[i][r][0], (int)Dn[i][r][0], sd2, false);
           sd2 = __builtin_amdgcn_sdot4((int)Dn[i][r][1], (int)Dn[i][r][1], sd2, false);
         }
-        unsigned long long pk;
-        if (!CHR) {
-          const uint32_t ls = ((ssum & 0xffffu) + (ssum >> 16)) >> (BPS == 2 && !GEN ? ssh : 0);
-          pk = ((unsigned long long)(uint32_t)sd2 << 37) | ((unsigned long long)ls << 19) | (unsigned long long)(uint32_t)(sd + 16 * 128);
-        } else {
-          pk = ((unsigned long long)(uint32_t)sd2 << 32) | (unsigned long long)(uint32_t)(sd + 16 * 128);
-        }
+        const unsigned long long pk = ((unsigned long long)(uint32_t)sd2 << 32) | (unsigned long long)(uint32_t)(sd + 16 * 128);
         atomicAdd(&s_sum[slot][s_plane][w / SH::WPB], pk);
         if constexpr (LOUT) {
           // ---- the chroma regressor L of this lane's samples -> the L plane ----
@@ -661,9 +651,9 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
     }
     uint32_t hacc = 0;
     if (h_wave) {
-      uint32_t T[4], dummy = 0;
-      if constexpr (GEN) w_residual_gen<BPS, BPD>(hs, hv, ssh, g.den_shift, T, hacc, dummy);
-      else w_residual<BPS>(hs, hv, ssh, r_km, r_bm, T, hacc, dummy);
+      uint32_t T[4];
+      if constexpr (GEN) w_residual_gen<BPS, BPD>(hs, hv, ssh, g.den_shift, T, hacc);
+      else w_residual<BPS>(hs, hv, ssh, r_km, r_bm, T, hacc);
       w_pack<LAY>(T, Hn[0], Hn[1]);
     }
     // ---- residuals (or L) outside int8: rare; one wave-uniform test on the usual way ----
@@ -682,28 +672,31 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
   // the copies of unit k (Dc / Hc; left halo dwords Dl / Hl, right halo dwords in Dn / Hn) -> the tile buffer.
   // The dword left of word w is word w - 1's second dword (row_shr:1; lane 0 of the row keeps what the first move put there: the
   // unit before's last dword, rotated in from lane 15), the dword right of it word w + 1's first (row_shl:1; lane 15 likewise).
-  auto neighbours = [&](uint32_t dl, uint32_t d0, uint32_t d1, uint32_t dn0, uint32_t mL, uint32_t mR, uint32_t &prev1, uint32_t &next0)
+  // (What lane 0 / lane 15 get when the unit has NO neighbour on that side -- words of some other unit, or zeros -- is never
+  //  multiplied into a sum: a block without a flat neighbour keeps `lag` columns from that edge out of its window, the window
+  //  masks the A operand, and a sample inside the window reads at most `lag` columns to its side: words of its own unit.  The
+  //  plain products need every block's whole window, i.e. real neighbours.  Round 4 zeroed them: two v_and a row.)
+  auto neighbours = [&](uint32_t dl, uint32_t d0, uint32_t d1, uint32_t dn0, uint32_t &prev1, uint32_t &next0)
                         __attribute__((always_inline)) {
-    const int hl = __builtin_amdgcn_mov_dpp((int)(dl & mL), 0x121, 0xf, 0xf, true);   // row_ror:1:  lane 0 <- lane 15
-    const int hr = __builtin_amdgcn_mov_dpp((int)(dn0 & mR), 0x12f, 0xf, 0xf, true);  // row_ror:15: lane 15 <- lane 0
+    const int hl = __builtin_amdgcn_mov_dpp((int)dl, 0x121, 0xf, 0xf, true);   // row_ror:1:  lane 0 <- lane 15
+    const int hr = __builtin_amdgcn_mov_dpp((int)dn0, 0x12f, 0xf, 0xf, true);  // row_ror:15: lane 15 <- lane 0
     prev1 = (uint32_t)__builtin_amdgcn_update_dpp(hl, (int)d1, 0x111, 0xf, 0xf, false);  // row_shr:1
     next0 = (uint32_t)__builtin_amdgcn_update_dpp(hr, (int)d0, 0x101, 0xf, 0xf, false);  // row_shl:1
   };
   auto write_copies = [&](uint32_t ex) __attribute__((always_inline)) {
     if (G1S_W_DBGBIT(8)) return;
-    const uint32_t mL = ((ex >> 22) & 1u) ? ~0u : 0u, mR = ((ex >> 23) & 1u) ? ~0u : 0u;
     uint8_t *base = w_smem + (CHR && s_plane ? SH::OFF_P1 : 0) + 2 * p * kWUnitW + 8 * w;
 #pragma unroll
     for (int i = 0; i < NOWN; ++i)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         uint32_t prev1, next0;
-        neighbours(Dl[i][r], Dc[i][r][0], Dc[i][r][1], Dn[i][r][0], mL, mR, prev1, next0);
+        neighbours(Dl[i][r], Dc[i][r][0], Dc[i][r][1], Dn[i][r][0], prev1, next0);
         w_write_copies<CS>(base + (4 + own_row0 + 8 * i + r) * kWUnitW, prev1, Dc[i][r][0], Dc[i][r][1], next0);
       }
     if (h_wave) {  // (tile row p, word w)
       uint32_t prev1, next0;
-      neighbours(Hl, Hc[0], Hc[1], Hn[0], mL, mR, prev1, next0);
+      neighbours(Hl, Hc[0], Hc[1], Hn[0], prev1, next0);
       w_write_copies<CS>(base - p * kWUnitW, prev1, Hc[0], Hc[1], next0);
     }
   };
@@ -740,9 +733,8 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
         const int blk = by * g.nbw + c * UB + b, plane = CHR ? 1 + pl : 0;
         const int samples = BW * BH;
         if (!CHR) {
-          reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = (int)(pk & 0x7ffffu) - samples * 128;
-          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)(pk >> 37);
-          reinterpret_cast<uint32_t *>(rec + g.off_luma_sum)[blk] = (uint32_t)((pk >> 19) & 0x3ffffu);
+          reinterpret_cast<int32_t *>(rec + g.off_sum_d[0])[blk] = (int)(uint32_t)(pk & 0xffffffffu) - samples * 128;
+          reinterpret_cast<uint32_t *>(rec + g.off_sum_d2[0])[blk] = (uint32_t)(pk >> 32);
         } else {
           // (arithmetic, not an indexed read of the kernel arguments: that is a global load and a wait in the loop)
           const uint32_t od = g.off_sum_d[1] + (uint32_t)pl * (g.off_sum_d[2] - g.off_sum_d[1]), od2 = g.off_sum_d2[1] + (uint32_t)pl * (g.off_sum_d2[2] - g.off_sum_d2[1]);
