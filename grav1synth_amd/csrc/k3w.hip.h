@@ -493,11 +493,16 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
   auto entry_x = [&](int j) -> uint32_t { return __builtin_amdgcn_readfirstlane(s_ent[2 * (j + 1)].x); };
 
   // the raw words of the unit with entry word ex, into rs / rv (and hs / hv)
+  // (16-bit planes are read with the non-temporal hint: a launch walks gigabytes it touches once, and read that way the lines the
+  //  finder's moments kernel left in the caches -- the luma source of the batch's last frames -- survive until this launch asks
+  //  for them.  4K 10-bit: luma launch 391 -> 377 us, chroma 220 -> 212 with its L tiles read the same way; all-flat 578 -> 560,
+  //  324 -> 305.  A 1080p 8-bit batch is about the size of the Infinity Cache: plain loads there (178 vs 184 us).
+  //  profiles/r05e_nontemporal.txt)
   auto load8 = [&](const uint8_t *base, uint32_t off, bool wide) __attribute__((always_inline)) -> w_u4 {
     w_u4 r = {0u, 0u, 0u, 0u};
     asm volatile("" : "+v"(off));  // (opaque: scalar base + 32-bit lane offset, not a 64-bit lane address)
     if (wide) {
-      r = *(gptr_u4)(as_global(base) + off);
+      r = __builtin_nontemporal_load((gptr_u4)(as_global(base) + off));
     } else {
       const u32x2 a = *(gptr_u2)(as_global(base) + off);
       r.x = a.x, r.y = a.y;
@@ -559,7 +564,8 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
       for (int q = 0; q < BH / 16; ++q) {
         uint32_t o = l_off[q];
         asm volatile("" : "+v"(o));
-        Lc[q] = *(gptr_u2)(as_global(lb) + o);
+        if (BPS == 2) Lc[q] = __builtin_nontemporal_load((gptr_u2)(as_global(lb) + o));
+        else Lc[q] = *(gptr_u2)(as_global(lb) + o);
       }
     }
   };
