@@ -121,10 +121,10 @@ __device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *mask
   const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
   const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
   uint32_t *out = up.units[kind] + (size_t)frame * ncell * kWEntry;
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_base;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
+  // (one barrier a chunk of 1024 cells: the waves' counts go into one of two rows by the chunk's parity, every thread adds the
+  //  sixteen up for itself and keeps the running total in a register)
+  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][16];
+  uint32_t base_count = 0;
   auto at = [&](int x, int y) { return (x >= 0 && x < g.nbw && y >= 0 && y < g.nbh) ? (int)mask[y * g.nbw + x] : 0; };
   auto cell_bits = [&](int c, int by) {
     uint32_t b = 0;
@@ -162,27 +162,24 @@ __device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *mask
       }
     }
     // ordered compaction: ballot inside the wave, prefix over the 16 waves
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, par = (base >> 10) & 1;
     const unsigned long long vote = __ballot(bits != 0);
-    if (lane == 0) s_wave[wv] = (uint32_t)__popcll(vote);
+    if (lane == 0) s_wave[par][wv] = (uint32_t)__popcll(vote);
     __syncthreads();
-    uint32_t before = s_base;
-    for (int k = 0; k < wv; ++k) before += s_wave[k];
+    // (lane k < 16 takes wave k's count; a DPP scan; the totals in front of this wave and of all sixteen read back as scalars)
+    const uint32_t mine = lane < 16 ? s_wave[par][lane] : 0u;
+    const uint32_t incl = wave_scan_incl(mine);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+    const uint32_t before = base_count + (wv > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (wv - 1) & 15) : 0u);
     if (bits) {
       const uint32_t pos = before + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
       uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)pos * kWEntry);
       dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
       dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t t = s_base;
-      for (int k = 0; k < 16; ++k) t += s_wave[k];
-      s_base = t;
-    }
-    __syncthreads();
+    base_count += total;
   }
-  if (threadIdx.x == 0) up.count[2 * frame + kind] = s_base;
+  if (threadIdx.x == 0) up.count[2 * frame + kind] = base_count;
 }
 __global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restrict__ records, WUnitParams up) {
   const int kind = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;

@@ -475,21 +475,51 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
 constexpr int kK2Threads = 1024;
 constexpr int kK2PerThread = 8;  // scores kept in registers: up to 8192 blocks (a 4K frame has 8160); 32 for up to 32768 (8K: 32400)
 // (the body: k2_flat_select below and the wide chain's k2w_select_units, k3w.hip.h, which builds the unit lists behind it)
+// inclusive prefix sums over the 64 lanes of a wave, all in the VALU (DPP: the steps inside a row of 16, then the row totals)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
+  return (uint32_t)x;
+}
+
 template <int PER>
 __device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame,
                                                      uint8_t *lds_mask) {
-  __shared__ uint32_t s_hist[256], s_wsum[4], s_sel[2];
+  // Three histograms in rotation and ONE barrier a pass: a pass counts into its own, which was zeroed a pass earlier; behind the
+  // barrier EVERY wave finds the bin that holds the rank for itself (a lane takes 4 bins, a DPP scan over the wave: no
+  // cross-wave step, no second and third barrier).  (Round 4: one histogram, four barriers a pass -- 16 waves meeting 17 times
+  // were a third of the kernel.)
+  __shared__ __attribute__((aligned(16))) uint32_t s_hist[3][256];
   uint8_t *rec = records + (size_t)frame * g.rec_size;
   const uint32_t *sc = reinterpret_cast<const uint32_t *>(rec + g.off_scores);
   const int nb = g.nblocks;
   const int tid = threadIdx.x, lane = tid & 63;
   const bool in_regs = nb <= kK2Threads * PER;
+  const uint8_t *fl = flags + (size_t)frame * nb;
   uint32_t v[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int i = tid + k * kK2Threads;
     v[k] = i < nb ? sc[i] : 0xffffffffu;  // the filler sorts last
   }
+  // (the finder's flag bytes are asked for now: they are needed when the threshold is known, a round trip to memory later)
+  // (8 a thread; the 32 of an 8K frame would not fit the registers next to the scores: those are read when needed)
+  constexpr bool kEarlyFlags = PER <= 8;
+  uint8_t f[PER];
+  if (kEarlyFlags && in_regs) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * kK2Threads;
+      f[k] = i < nb ? fl[i] : 0;
+    }
+  }
+  if (tid < 256) s_hist[0][tid] = 0;
+  __syncthreads();
   // The k-th smallest pattern, a byte at a time from the top (radix select: 4 passes of histogram + scan; bit by bit it was
   // 32 rounds of count + barrier, 33 us a launch whatever the frame).  `rank` = 0-based rank among the patterns that share
   // the bytes decided so far.
@@ -498,8 +528,8 @@ __device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__r
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     const uint32_t himask = pass ? ~0u << (shift + 8) : 0u;  // the bytes decided so far
-    if (tid < 256) s_hist[tid] = 0;
-    __syncthreads();
+    uint32_t *hist = s_hist[pass % 3];
+    if (tid < 256) s_hist[(pass + 1) % 3][tid] = 0;  // (the next pass's: its last readers are two barriers behind)
     // Scores cluster: the top byte of a score in [0, 1] takes two or three values, and many blocks share one score (0, or a
     // saturated sigmoid; the fillers of a small frame).  64 lanes adding to one LDS word are served one after the other, so in
     // the first pass the wave counts each distinct byte with a ballot and adds once (23 instead of 28 us a 4K launch); in the
@@ -514,7 +544,7 @@ __device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__r
           const int first = __ffsll((long long)todo) - 1;
           const uint32_t dv = (uint32_t)__shfl((int)d, first, 64);
           const unsigned long long same = __ballot(d == dv) & todo;
-          if (lane == first) atomicAdd(&s_hist[dv], (uint32_t)__popcll(same));
+          if (lane == first) atomicAdd(&hist[dv], (uint32_t)__popcll(same));
           todo &= ~same;
         }
       }
@@ -530,58 +560,54 @@ __device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__r
           const int first = __ffsll((long long)todo) - 1;
           const uint32_t dv = (uint32_t)__shfl((int)d, first, 64);
           const unsigned long long same = __ballot(in && d == dv) & todo;
-          if (lane == first) atomicAdd(&s_hist[dv], (uint32_t)__popcll(same));
+          if (lane == first) atomicAdd(&hist[dv], (uint32_t)__popcll(same));
           todo &= ~same;
         }
-        if ((todo >> lane) & 1ull) atomicAdd(&s_hist[d], 1u);
+        if ((todo >> lane) & 1ull) atomicAdd(&hist[d], 1u);
       }
     } else if (in_regs) {
 #pragma unroll
       for (int k = 0; k < PER; ++k)
-        if ((v[k] & himask) == thr) atomicAdd(&s_hist[(v[k] >> shift) & 0xffu], 1u);
+        if ((v[k] & himask) == thr) atomicAdd(&hist[(v[k] >> shift) & 0xffu], 1u);
     } else {
       for (int i = tid; i < nb; i += kK2Threads) {
         const uint32_t x = sc[i];
-        if ((x & himask) == thr) atomicAdd(&s_hist[(x >> shift) & 0xffu], 1u);
+        if ((x & himask) == thr) atomicAdd(&hist[(x >> shift) & 0xffu], 1u);
       }
     }
     __syncthreads();
-    // exclusive prefix of the 256 bins (threads 0 .. 255: four waves), the bin that holds the rank
-    uint32_t c = 0, incl = 0;
-    if (tid < 256) {
-      c = s_hist[tid];
-      incl = c;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += t;
+    // the bin that holds the rank: every wave for itself (lane = bins 4 lane .. 4 lane + 3)
+    {
+      const uint4 c = *reinterpret_cast<const uint4 *>(&hist[4 * lane]);
+      const uint32_t tot = (c.x + c.y) + (c.z + c.w);
+      const uint32_t incl = wave_scan_incl(tot), excl = incl - tot;
+      const bool mine = tot != 0 && excl <= rank && rank < incl;
+      // (exactly one lane: the histogram holds more than `rank` entries)
+      uint32_t bin = 4u * (uint32_t)lane, ex = excl;
+      if (rank >= ex + c.x) {
+        ex += c.x, ++bin;
+        if (rank >= ex + c.y) {
+          ex += c.y, ++bin;
+          if (rank >= ex + c.z) ex += c.z, ++bin;
+        }
       }
-      if (lane == 63) s_wsum[tid >> 6] = incl;
+      const unsigned long long who = __ballot(mine);
+      const int src = __ffsll((long long)who) - 1;
+      thr |= (uint32_t)__builtin_amdgcn_readlane((int)bin, src) << shift;
+      rank -= (uint32_t)__builtin_amdgcn_readlane((int)ex, src);
     }
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t base = 0;
-      for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
-      const uint32_t excl = base + incl - c;
-      if (c != 0 && excl <= rank && rank < excl + c) {
-        s_sel[0] = (uint32_t)tid;
-        s_sel[1] = excl;
-      }
-    }
-    __syncthreads();
-    thr |= s_sel[0] << shift;
-    rank -= s_sel[1];
   }
   // thr = bit pattern of the threshold score
   uint8_t *mask = rec + g.off_mask;
-  const uint8_t *fl = flags + (size_t)frame * nb;
+
   // (the scores from the registers where they are; the bytes also into `lds_mask` when the caller builds the lists from them)
   if (in_regs) {
-    uint8_t f[PER];
+    if (!kEarlyFlags) {
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = tid + k * kK2Threads;
-      f[k] = i < nb ? fl[i] : 0;
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * kK2Threads;
+        f[k] = i < nb ? fl[i] : 0;
+      }
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
