@@ -24,7 +24,7 @@
 //    one v_perm per four samples and flipped to two's complement with one v_xor.
 //  * No halo words are ever loaded: the left / right halo dwords of a unit are the neighbouring unit's own dwords, taken
 //    from the registers of the unit before / after it in the workgroup's run (a DPP row rotation); the list is in raster
-//    order (k3w_units compacts it deterministically), a neighbour that exists is therefore adjacent in the list, and the
+//    order (k2w_select_units compacts it deterministically), a neighbour that exists is therefore adjacent in the list, and the
 //    one in front of / behind the workgroup's slice is formed as a GHOST (loads and residuals only).
 //  * ONE tile buffer (two barriers a unit): 36 KB a luma workgroup, four to a CU.
 //
@@ -50,7 +50,7 @@ constexpr int kWMaxUnitsC = 32;    // ... chroma launch: what fits beside four w
 //        [4 .. 7] = the windows of the unit's blocks, 16 bits each (m_unpack's format)
 struct WParams {
   FrameTable ft;
-  const uint32_t *units;    // [batch][ncell][kWEntry]  this launch's list (k3w_units), raster order
+  const uint32_t *units;    // [batch][ncell][kWEntry]  this launch's list (k2w_select_units), raster order
   const uint32_t *count;    // [batch]
   uint8_t *records;         // [batch] x g.rec_size: the workgroups scatter the block statistics themselves
   long long *partials;      // [batch][wg_cap][3][kMRec]  one partial system per workgroup and plane (k3w_tail sums them)
@@ -107,7 +107,7 @@ typedef uint32_t w_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t w_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
 
 // ---------------------------------------------------------------------------------
-// k3w_units: the raster-ordered unit list of a frame and plane kind.  grid = (2 kinds, batch), block = 1024.
+// the raster-ordered unit list of a frame and plane kind (built by k2w_select_units behind the frame's threshold)
 // ---------------------------------------------------------------------------------
 struct WUnitParams {
   uint32_t *units[2];   // [batch][ncell[k]][kWEntry]
@@ -115,12 +115,22 @@ struct WUnitParams {
   int ncell[2], gx[2], ub[2];  // cells a frame, cells a block row, blocks a unit
 };
 // (the body: the list of plane kind `kind` of the frame, by one workgroup of 1024 threads)
-// (`mask`: the frame's mask bytes -- in the record, or a copy in LDS: a cell asks for ~25 of them, one dependent load each)
-__device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *mask, const WUnitParams &up, int kind, int frame) {
+// BITS: `maskp` is the mask as a bitmap in LDS (k2_flat_select_sized: bit 32 + i = block i is flat, zeros around it): a cell's own
+// blocks, its neighbour cells and the blocks above come out of two windows of it.  Otherwise (frames of more than 32 768 blocks)
+// `maskp` is the frame's mask bytes in the record: a cell asks for ~25 of them, one dependent load each.
+__device__ __forceinline__ uint32_t w_bits_at(const uint32_t *bm, int p, int n) {  // n <= 24 bits from block p on (p >= -32)
+  const int q = p + 32;
+  const uint32_t lo = bm[q >> 5], hi = bm[(q >> 5) + 1];
+  return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (q & 31)) & ((1u << n) - 1u);
+}
+template <bool BITS>
+__device__ __forceinline__ void w_build_units(const Geom &g, const void *maskp, const WUnitParams &up, int kind, int frame) {
   const int UB = up.ub[kind], gx = up.gx[kind], ncell = up.ncell[kind];
   const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
   const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
   uint32_t *out = up.units[kind] + (size_t)frame * ncell * kWEntry;
+  const uint8_t *mask = reinterpret_cast<const uint8_t *>(maskp);
+  const uint32_t *bm = reinterpret_cast<const uint32_t *>(maskp);
   // (one barrier a chunk of 1024 cells: the waves' counts go into one of two rows by the chunk's parity, every thread adds the
   //  sixteen up for itself and keeps the running total in a register)
   __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][16];
@@ -132,19 +142,32 @@ __device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *mask
     for (int k = 0; k < UB; ++k) b |= at(c * UB + k, by) ? 1u << k : 0u;
     return b;
   };
+  const uint32_t all = (1u << UB) - 1u;
   for (int base = 0; base < ncell; base += 1024) {
     const int idx = base + (int)threadIdx.x;
     uint32_t bits = 0, e[kWEntry] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (idx < ncell) {
       const int by = idx / gx, c = idx - by * gx;
-      bits = cell_bits(c, by);
+      // cur: the flat bits of the blocks c UB - UB .. c UB + 2 UB - 1 of block row by (left cell | this cell | right cell), upb: of the
+      // blocks above this cell's; blocks outside the row read as not flat
+      uint32_t cur = 0, upb = 0;
+      if (BITS) {
+        const int b0 = c * UB - UB;  // first block of the window
+        const int lo = max(-b0, 0), hi = min(max(g.nbw - b0, 0), 3 * UB);
+        cur = w_bits_at(bm, by * g.nbw + b0, 3 * UB) & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        if (by > 0) upb = w_bits_at(bm, (by - 1) * g.nbw + c * UB, UB) & ((1u << min(max(g.nbw - c * UB, 0), UB)) - 1u);
+        bits = (cur >> UB) & all;
+      } else {
+        bits = cell_bits(c, by);
+      }
       if (bits) {
-        const bool aL = cell_bits(c - 1, by) != 0, aR = cell_bits(c + 1, by) != 0;
-        bool plain = bits == (1u << UB) - 1u, top = false;
+        const bool aL = BITS ? (cur & all) != 0 : cell_bits(c - 1, by) != 0, aR = BITS ? ((cur >> (2 * UB)) & all) != 0 : cell_bits(c + 1, by) != 0;
+        bool plain = bits == all, top = false;
         for (int k = 0; k < UB; ++k) {
           if (!((bits >> k) & 1u)) continue;
           const int bx = c * UB + k;
-          const int left = at(bx - 1, by), right = at(bx + 1, by), upm = at(bx, by - 1);
+          const int left = BITS ? (int)((cur >> (UB + k - 1)) & 1u) : at(bx - 1, by), right = BITS ? (int)((cur >> (UB + k + 1)) & 1u) : at(bx + 1, by),
+                    upm = BITS ? (int)((upb >> k) & 1u) : at(bx, by - 1);
           const int ys = upm ? 0 : g.lag, xs = left ? 0 : g.lag;
           const int ye = min(ph - by * bh, bh), xe = min(pw - bx * bw - g.lag, right ? bw : (bw - g.lag));
           const bool go = xe > xs && ye > ys;
@@ -181,34 +204,25 @@ __device__ __forceinline__ void w_build_units(const Geom &g, const uint8_t *mask
   }
   if (threadIdx.x == 0) up.count[2 * frame + kind] = base_count;
 }
-__global__ __launch_bounds__(1024) void k3w_units(Geom g, const uint8_t *__restrict__ records, WUnitParams up) {
-  const int kind = blockIdx.x, frame = g.frame0 + (int)blockIdx.y;
-  if (kind == 1 && g.nplanes != 3) return;
-  w_build_units(g, records + (size_t)frame * g.rec_size + g.off_mask, up, kind, frame);
-}
 // k2w_select_units: k2_flat_select (the frame's threshold score, its mask bytes) and, behind it, the frame's unit lists: one launch
 // instead of two in the finder's chain.  grid = (batch, kinds of planes: 1 or 2), block = 1024 (= kK2Threads).
 static_assert(kK2Threads == 1024, "k2w_select_units: the list builder's workgroup");
 __global__ __launch_bounds__(1024) void k2w_select_units(Geom g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, WUnitParams up) {
   const int frame = blockIdx.x;
-  // the mask bytes also go into LDS (up to an 8K frame's 32 400): the list builder reads them there
-  constexpr int kMaskLds = 32768;
-  __shared__ uint8_t s_mask[kMaskLds];
-  const bool in_lds = g.nblocks <= kMaskLds;
-  k2_flat_select_body(g, records, flags, frame, in_lds ? s_mask : nullptr);
+  // the mask also goes into LDS as a bitmap (up to an 8K frame's 32 400 blocks: what the select keeps in registers): the list
+  // builder reads it there
+  __shared__ uint32_t s_bits[kK2BitWords];
+  const bool in_lds = g.nblocks <= kK2Threads * 32;
+  k2_flat_select_body(g, records, flags, frame, in_lds ? s_bits : nullptr);
   // (larger frames: the bytes were written by this workgroup -- a workgroup-scope fence and a barrier make them visible to its own loads)
   __threadfence_block();
   __syncthreads();
-  const uint8_t *gmask = records + (size_t)frame * g.rec_size + g.off_mask;
   // (grid.y = the list's kind: the two workgroups of a frame both find the threshold and write the same mask bytes, then each
   //  builds one list -- the lists were a third of this kernel's time one behind the other, and a frame's workgroup is alone on
   //  its CU either way)
   const int kind = (int)blockIdx.y;
-  if (in_lds) {
-    w_build_units(g, s_mask, up, kind, frame);
-  } else {
-    w_build_units(g, gmask, up, kind, frame);
-  }
+  if (in_lds) w_build_units<true>(g, s_bits, up, kind, frame);
+  else w_build_units<false>(g, records + (size_t)frame * g.rec_size + g.off_mask, up, kind, frame);
 }
 
 // ---------------------------------------------------------------------------------

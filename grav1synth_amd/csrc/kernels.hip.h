@@ -108,10 +108,9 @@ __device__ __forceinline__ void load_row32(const uint8_t *base, uint32_t stride,
         for (int h = 0; h < 2; ++h) {
           // `(v >> shift) as u8` of four samples: two packed 16-bit shifts and one byte permute (the low byte of each half);
           // written as shifts, masks and ors this was 12 instructions a dword -- 40 % of k1_moments, which is VALU bound
-          typedef unsigned short u16x2_ __attribute__((ext_vector_type(2)));
-          const u16x2_ sh = {(unsigned short)shift, (unsigned short)shift};
-          const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_, w[2 * h]) >> sh);
-          const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_, w[2 * h + 1]) >> sh);
+          // (a plain 32-bit shift: the bits that cross from the upper sample into the lower one's half land above its low byte,
+          //  which is all the permute takes -- v_lshrrev_b32 issues in 2.6 cycles, the packed 16-bit shift in 4.6)
+          const uint32_t lo = w[2 * h] >> shift, hi = w[2 * h + 1] >> shift;
           pk[2 * q + h] = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
         }
       }
@@ -156,13 +155,9 @@ __device__ __forceinline__ void narrow_row(const RowRaw<BPS> &r, int shift, uint
   } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint32_t w[4] = {r.v[q].x, r.v[q].y, r.v[q].z, r.v[q].w};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        typedef unsigned short u16x2_ __attribute__((ext_vector_type(2)));
-        const u16x2_ sh = {(unsigned short)shift, (unsigned short)shift};
-        const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_, w[2 * h]) >> sh);
-        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_, w[2 * h + 1]) >> sh);
+        const uint32_t lo = r.v[q][2 * h] >> shift, hi = r.v[q][2 * h + 1] >> shift;  // (plain shifts: see load_row32)
         pk[2 * q + h] = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
       }
     }
@@ -489,7 +484,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 
 template <int PER>
 __device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame,
-                                                     uint8_t *lds_mask) {
+                                                     uint32_t *lds_bits) {
   // Three histograms in rotation and ONE barrier a pass: a pass counts into its own, which was zeroed a pass earlier; behind the
   // barrier EVERY wave finds the bin that holds the rank for itself (a lane takes 4 bins, a DPP scan over the wave: no
   // cross-wave step, no second and third barrier).  (Round 4: one histogram, four barriers a pass -- 16 waves meeting 17 times
@@ -600,7 +595,9 @@ __device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__r
   // thr = bit pattern of the threshold score
   uint8_t *mask = rec + g.off_mask;
 
-  // (the scores from the registers where they are; the bytes also into `lds_mask` when the caller builds the lists from them)
+  // (the scores from the registers where they are.  `lds_bits`, when the caller builds the unit lists: the mask as a bitmap in
+  //  raster order, bit 32 + i = block i is flat, a zero word in front and zeros behind -- a wave's 64 lanes hold 64 consecutive
+  //  blocks, so a ballot is two words of it)
   if (in_regs) {
     if (!kEarlyFlags) {
 #pragma unroll
@@ -609,27 +606,31 @@ __device__ __forceinline__ void k2_flat_select_sized(const Geom &g, uint8_t *__r
         f[k] = i < nb ? fl[i] : 0;
       }
     }
+    if (lds_bits && tid < 3) lds_bits[tid == 0 ? 0 : kK2Threads * PER / 32 + tid] = 0u;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid + k * kK2Threads;
-      if (i < nb) {
-        const uint8_t mb = f[k] | (v[k] >= thr ? 1 : 0);
-        mask[i] = mb;
-        if (lds_mask) lds_mask[i] = mb;
+      const uint8_t mb = i < nb ? (uint8_t)(f[k] | (v[k] >= thr ? 1 : 0)) : (uint8_t)0;
+      if (i < nb) mask[i] = mb;
+      if (lds_bits) {
+        const unsigned long long bal = __ballot(mb != 0);
+        if (lane == 0) {
+          uint32_t *w = lds_bits + 1 + ((k * kK2Threads + (tid & ~63)) >> 5);
+          w[0] = (uint32_t)bal;
+          w[1] = (uint32_t)(bal >> 32);
+        }
       }
     }
   } else {
-    for (int i = tid; i < nb; i += kK2Threads) {
-      const uint8_t mb = fl[i] | (sc[i] >= thr ? 1 : 0);
-      mask[i] = mb;
-      if (lds_mask) lds_mask[i] = mb;
-    }
+    for (int i = tid; i < nb; i += kK2Threads) mask[i] = fl[i] | (sc[i] >= thr ? 1 : 0);
   }
 }
+// (the bitmap's size in words: the blocks the registers hold, a word in front, two behind)
+constexpr int kK2BitWords = kK2Threads * 32 / 32 + 3;
 __device__ __forceinline__ void k2_flat_select_body(const Geom &g, uint8_t *__restrict__ records, const uint8_t *__restrict__ flags, int frame,
-                                                    uint8_t *lds_mask = nullptr) {
-  if (g.nblocks <= kK2Threads * kK2PerThread) k2_flat_select_sized<kK2PerThread>(g, records, flags, frame, lds_mask);
-  else k2_flat_select_sized<32>(g, records, flags, frame, lds_mask);  // (8K: 32 400 scores, still in registers; larger frames re-read them)
+                                                    uint32_t *lds_bits = nullptr) {
+  if (g.nblocks <= kK2Threads * kK2PerThread) k2_flat_select_sized<kK2PerThread>(g, records, flags, frame, lds_bits);
+  else k2_flat_select_sized<32>(g, records, flags, frame, lds_bits);  // (8K: 32 400 scores, still in registers; larger frames re-read them)
 }
 __global__ __launch_bounds__(kK2Threads) void k2_flat_select(Geom g, uint8_t *__restrict__ records,
                                                              const uint8_t *__restrict__ flags) {
