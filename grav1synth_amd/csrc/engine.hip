@@ -939,6 +939,7 @@ int g1s_diff::launch_front(int si) {
     CertifyLists cl;
     cl.list = reinterpret_cast<uint32_t *>(sl.d_k1) + (size_t)g.nblocks * batch * kMomInts;
     cl.count = cl.list + (size_t)g.nblocks * batch;
+    cl.global = literal_mode == 0 ? 1 : 0;  // (the default chain: one sequence for the launch; "every block literally": per-frame lists)
     {
       // the finder's moments of the luma source: the only pass over pixels that are not in a flat block's tile
       if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
@@ -969,12 +970,16 @@ int g1s_diff::launch_front(int si) {
                            (const uint32_t *)cl.list, (const uint32_t *)cl.count);
     } else if (!dbg_skip("flatblock")) {  // the few blocks the certificate leaves open (mode 2, a test aid: every block): one wave per block
       dim3 grid(kFbGrid);
-      if (g.src_bps == 1)
-        hipLaunchKernelGGL(k1_flat_block<1>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
-                           (const uint32_t *)cl.list, (const uint32_t *)cl.count, (int)B);
-      else
-        hipLaunchKernelGGL(k1_flat_block<2>, grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags,
-                           (const uint32_t *)cl.list, (const uint32_t *)cl.count, (int)B);
+#define G1S_FB(BP, GL) hipLaunchKernelGGL((k1_flat_block<BP, GL>), grid, dim3(64), 0, fstream, ft, g, fc, d_lut, sl.d_records, sl.d_flags, \
+                                          (const uint32_t *)cl.list, (const uint32_t *)cl.count, (int)B)
+      if (cl.global) {
+        if (g.src_bps == 1) G1S_FB(1, true);
+        else G1S_FB(2, true);
+      } else {
+        if (g.src_bps == 1) G1S_FB(1, false);
+        else G1S_FB(2, false);
+      }
+#undef G1S_FB
     }
   }
   if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));

@@ -166,8 +166,9 @@ __device__ __forceinline__ int ve_lt(VE a, double K) { return a.v + a.e < K ? 1 
 __device__ __forceinline__ int ve_gt(VE a, double K) { return a.v - a.e > K ? 1 : (a.v + a.e <= K ? 0 : -1); }
 
 struct CertifyLists {
-  uint32_t *list;   // [batch][nblocks] blocks left to the literal kernel
-  uint32_t *count;  // [batch]
+  uint32_t *list;   // [batch][nblocks] blocks left to the literal kernel -- or, `global`, one sequence of frame * nblocks + block
+  uint32_t *count;  // [batch] -- global: count[0] the sequence's length
+  int global;
 };
 
 // ---------------------------------------------------------------------------------
@@ -310,9 +311,13 @@ __global__ __launch_bounds__(256) void k1_certify(Geom g, FlatConsts fc, const i
   if (bal != 0) {
     const int lane = threadIdx.x & 63;
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&cl.count[frame], (uint32_t)__popcll(bal));
+    if (lane == 0) base = atomicAdd(&cl.count[cl.global ? 0 : frame], (uint32_t)__popcll(bal));
     base = __shfl(base, 0, 64);
-    if (todo) cl.list[(size_t)frame * g.nblocks + base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)blk;
+    const uint32_t at = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (todo) {
+      if (cl.global) cl.list[at] = (uint32_t)frame * (uint32_t)g.nblocks + (uint32_t)blk;
+      else cl.list[(size_t)frame * g.nblocks + at] = (uint32_t)blk;
+    }
   }
 }
 

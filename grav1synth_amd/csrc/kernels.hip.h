@@ -346,7 +346,11 @@ __global__ __launch_bounds__(64) void k1_flat_features(const FrameTable ft, Geom
 // ----------------------------------------------------------------------------
 constexpr int kFbGrid = 768;
 constexpr int kFbInner = (kBlock - 2) * (kBlock - 2);
-template <int BPS>
+// GLOBAL: `list` is ONE sequence for the whole launch -- entry = frame * nblocks + block, count[0] its length (k1_certify's default
+// mode appends to it with one atomic a wave): item p of workgroup w is entry w + p W, no per-frame counts to sum and search first
+// (that prologue -- 64 counts from memory, their prefix, a walk over it -- was 5 of the kernel's 25 us).  Otherwise (the test aid
+// "every block"): per-frame lists [batch][nblocks] + count[batch].
+template <int BPS, bool GLOBAL>
 __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g, FlatConsts fc,
                                                     const double *__restrict__ lut_g, uint8_t *__restrict__ records,
                                                     uint8_t *__restrict__ flags, const uint32_t *__restrict__ list,
@@ -354,12 +358,18 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
   __shared__ double lut[256];
   __shared__ double s_v[kBlock * kBlock];  // pixel / 255, later the residual
   __shared__ double s_t[5 * kFbInner];     // [3][1024] fit products, then [5][900] gradient terms
-  __shared__ uint32_t s_pre[kMaxBatch + 1];  // exclusive prefix of the frames' list lengths: the launch's sequence of blocks
+  __shared__ uint32_t s_pre[GLOBAL ? 1 : kMaxBatch + 1];  // exclusive prefix of the frames' list lengths: the launch's sequence of blocks
   const int lane = threadIdx.x;
   const int W = (int)gridDim.x, w = (int)blockIdx.x;
-  // (the wave sums the counts 64 frames at a time; a loop over the frames with a scalar load of each count in turn was most
-  //  of the launch: 64 dependent round trips before the first block was touched)
-  {
+  int total;
+  if (GLOBAL) {
+    total = (int)count[0];
+    if (w >= total) return;
+    // (the table is asked for while the entry is on its way)
+    for (int i = lane; i < 256; i += 64) lut[i] = lut_g[i];
+  } else {
+    // (the wave sums the counts 64 frames at a time; a loop over the frames with a scalar load of each count in turn was most
+    //  of the launch: 64 dependent round trips before the first block was touched)
     uint32_t carry = 0;
     if (lane == 0) s_pre[0] = 0;
     for (int base = 0; base < nframes; base += 64) {
@@ -373,21 +383,27 @@ __global__ __launch_bounds__(64) void k1_flat_block(const FrameTable ft, Geom g,
       if (base + lane < nframes) s_pre[base + lane + 1] = carry + incl;
       carry += (uint32_t)__shfl((int)incl, 63, 64);
     }
+    __syncthreads();
+    total = (int)s_pre[nframes];
   }
-  __syncthreads();
-  const int total = (int)s_pre[nframes];
-  bool have_lut = false;
+  bool have_lut = GLOBAL;
   int frame = 0;
   for (int p = w; p < total; p += W) {
-  while ((int)s_pre[frame + 1] <= p) ++frame;  // (p grows: the search goes on from the last frame)
+  int blk;
+  if (GLOBAL) {
+    const uint32_t e = list[p];
+    frame = (int)(e / (uint32_t)g.nblocks);
+    blk = (int)(e - (uint32_t)frame * (uint32_t)g.nblocks);
+  } else {
+    while ((int)s_pre[frame + 1] <= p) ++frame;  // (p grows: the search goes on from the last frame)
+    blk = (int)list[(size_t)frame * g.nblocks + (p - (int)s_pre[frame])];
+  }
   if (!have_lut) {
     for (int i = lane; i < 256; i += 64) lut[i] = lut_g[i];
     have_lut = true;
   }
   const FramePlanes fp = ft.f[frame];
   {
-    const int it = p - (int)s_pre[frame];
-    const int blk = (int)list[(size_t)frame * g.nblocks + it];
     const int bx = blk % g.nbw, by = blk / g.nbw;
     const int ox = bx * kBlock, oy = by * kBlock;
     __syncthreads();

@@ -64,12 +64,26 @@ __global__ __launch_bounds__(256) void rate(int *out, int a0, int b0) {
       OPA(37, "v_subrev_u32 %0, %1, %0");
       OPA(38, "v_lshrrev_b64 %0, 3, %0");  // placeholder, replaced below
       OPA(39, "v_mul_lo_u32 %0, %1, %0");
+      OPA(40, "v_dot4c_i32_i8 %0, %1, %2");
+      OPA(41, "v_dot4_u32_u8 %0, %1, %2, %0");
+      OPA(42, "v_dot2c_i32_i16 %0, %1, %2");
+      OPA(43, "v_dot8c_i32_i4 %0, %1, %2");
+      OPA(44, "v_mac_f32 %0, %1, %2");
+      OPA(45, "v_fmac_f32 %0, %1, %2");
     }
     a += it;
   }
   int s = 0;
   for (int i = 0; i < NACC; ++i) s += acc[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void f64_chain(double *out, double x) {
+  double s = (double)threadIdx.x;
+  for (int i = 0; i < (1 << 17) / 16; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("v_add_f64 %0, %0, %1" : "+v"(s) : "v"(x));
+  }
+  out[threadIdx.x] = s;
 }
 template <int OP>
 void run_rate(const char *name) {
@@ -251,6 +265,28 @@ int main(int argc, char **argv) {
     run_rate<36>("v_sad_u8");
     run_rate<37>("v_subrev_u32");
     run_rate<39>("v_mul_lo_u32");
+    run_rate<40>("v_dot4c_i32_i8 (VOP2)");
+    run_rate<41>("v_dot4_u32_u8 (VOP3P)");
+    run_rate<42>("v_dot2c_i32_i16 (VOP2)");
+    run_rate<43>("v_dot8c_i32_i4 (VOP2)");
+    run_rate<45>("v_fmac_f32 (VOP2)");
+    {
+      // a chain of dependent v_add_f64 on one wave (k1_flat_block's sequential sums): ns an addition
+      double *dd;
+      CK(hipMalloc(&dd, 64 * 8));
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(f64_chain, dim3(1), dim3(64), 0, 0, dd, 1.0 + rep);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("F  dependent v_add_f64 chain: %d additions in %.1f us = %.2f ns an addition\n", 1 << 17, ms * 1e3, ms * 1e6 / (1 << 17));
+      }
+    }
   }
   int *d_in, *d_out;
   CK(hipMalloc(&d_in, 4096));
