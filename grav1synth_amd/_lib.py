@@ -157,6 +157,7 @@ SYMBOLS = [
     ("g1s_latest_from_record", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]),
     ("g1s_latest_from_records", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]),
     ("g1s_usable_cpus", C.c_uint, []),
+    ("g1s_shard_flush_rounds", C.c_uint, []),
     ("g1s_fold_push_latest", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("g1s_fold_push_many", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("g1s_fold_finish", C.c_int, [C.c_void_p, C.POINTER(G1SSegment), C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -673,7 +673,9 @@ int g1s_diff::set_geometry_alloc(const g1s_frame_t *s, const g1s_frame_t *d) {
     if (mpart_bytes2) HIP_TRY(hipMalloc((void **)&sl.d_mpart, mpart_bytes2));
     if (w_bytes) HIP_TRY(hipMalloc((void **)&sl.d_wu, w_bytes));
     if (lplane_bytes) HIP_TRY(hipMalloc((void **)&sl.d_lplane, lplane_bytes));
-    HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    // (blocking: the drainer SLEEPS until a batch's records have landed instead of spinning on the event -- a core a rank, which an
+    //  8-rank node inside a 16-core quota does not have; five more batches are in flight, the wake-up costs the job nothing)
+    HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync));
     for (auto &e : sl.ev) HIP_TRY(hipEventCreate(&e));
   }
   geometry_set = true;
@@ -1985,7 +1987,7 @@ int g1s_shard_pack(g1s_diff_t *g, int flush, void *msg, size_t cap_bytes) {
   // flush = 0: whatever is ready goes out, nothing is waited for -- the root orders by the batch index in the message, so the
   // ranks need not send the same batch in the same round (they did, and waited for it, when the root merged by arrival: the
   // feeding thread then ran at most two batches ahead of the drain, 3.5 % of a rank's throughput).  A rank is never more than
-  // the generator's four slots behind with its messages: a round sends nothing only when every unsent batch is still in a slot.
+  // the generator's slots (g1s_shard_flush_rounds) behind with its messages: a round sends nothing only when every unsent batch is still in a slot.
   if (flush) {
     const int rc = g1s_diff_sync(g);
     if (rc) return rc;
@@ -2008,6 +2010,8 @@ int g1s_shard_pack(g1s_diff_t *g, int flush, void *msg, size_t cap_bytes) {
   g->latest_out_frames -= n;
   return G1S_OK;
 }
+
+unsigned g1s_shard_flush_rounds(void) { return (unsigned)kSlots; }
 
 size_t g1s_latest_size(uint32_t ar_coeff_lag) { return ar_coeff_lag >= 1 && ar_coeff_lag <= 3 ? latest_blob_size(ar_coeff_lag) : 0; }
 

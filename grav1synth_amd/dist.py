@@ -252,8 +252,8 @@ class StreamingShardedDiff:
         self._group_buf, self._group_n = None, 0
         self.exchange_s = 0.0  # seconds the feeding thread spent in the rounds' exchange (bench.py prints it)
 
-    # batches that can still be inside a generator when the last frame has been queued: being filled,
-    # pixel pass queued, accumulation queued, draining (csrc/engine.hip, kSlots)
+    # batches that can still be inside a generator when the last frame has been queued (csrc/engine.hip, kSlots: the library says
+    # how many -- g1s_shard_flush_rounds; the constant is what a build without that entry point had)
     PIPELINE_BATCHES = 4
 
     # Rounds per gather: every rank packs one message a round (the library's protocol, unchanged), the transport moves
@@ -334,7 +334,7 @@ class StreamingShardedDiff:
     def finish(self) -> Optional[List[GrainTableSegment]]:
         if self.dist is None:
             return self.generator.finish()
-        for _ in range(self.PIPELINE_BATCHES):
+        for _ in range(int(self.generator._L.g1s_shard_flush_rounds())):
             self._exchange_one(flush=True)
         while self._group_n:  # (the last group goes out full: empty messages behind the last states)
             self._exchange_one(flush=True)

@@ -166,7 +166,7 @@ int g1s_diff_take_latest(g1s_diff_t *, int sync, void *buf, size_t cap_bytes, si
  * (3) takes part in ONE gather of the fixed-size messages to rank 0 -- ncclAllGather / ncclSend+Recv on RCCL, MPI_Gather,
  * torch.distributed.gather: whatever the host application owns; this library links no communication library --
  * and rank 0 hands the N gathered messages, rank order, to g1s_shard_merge.  After the last feeding round every rank runs
- * 4 more rounds with flush = 1 (the batches still in the generator's pipeline).  Rank 0's fold then finishes the table:
+ * g1s_shard_flush_rounds() more rounds with flush = 1 (the batches still in the generator's pipeline).  Rank 0's fold then finishes the table:
  * identical, byte for byte, to one generator fed the whole video (the states are exact; only their merge is ordered).
  * Message = 24-byte header + batch_frames latest states (g1s_latest_size() each, ~27 KB): N x 0.9 MB a round at 4K.
  * The header says WHICH of the sending rank's batches the message carries; the root merges by that index (global batch =
@@ -176,8 +176,11 @@ int g1s_diff_take_latest(g1s_diff_t *, int sync, void *buf, size_t cap_bytes, si
 size_t g1s_shard_msg_size(uint32_t ar_coeff_lag, uint32_t batch_frames);
 /* This rank's message of the round: the latest states of ONE batch -- the oldest one not sent yet among those the generator
  * has finished (flush = 0: never waits; the message is empty when every unsent batch is still in the pipeline, which holds
- * at most four) or among all (flush = 1: drains the generator first) -- or an empty message.  records_only = 2 generators. */
+ * at most g1s_shard_flush_rounds()) or among all (flush = 1: drains the generator first) -- or an empty message.  records_only = 2 generators. */
 int g1s_shard_pack(g1s_diff_t *, int flush, void *msg, size_t cap_bytes);
+/* How many batches a generator can still hold unsent when its last frame has been fed (its slots): the flush rounds every rank
+ * runs behind its last feeding round. */
+unsigned g1s_shard_flush_rounds(void);
 /* A message from latest states made elsewhere (g1s_latest_from_record): n <= batch_frames.  Without a batch index: the
  * root merges such messages as they come (rounds in order, ranks in order) -- the caller keeps its ranks in lock step. */
 int g1s_shard_msg_from_latest(const void *blobs, size_t n, uint32_t ar_coeff_lag, uint32_t batch_frames, void *msg, size_t cap_bytes);

@@ -130,7 +130,10 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ, G1S_BENCH_SHARE_GPU="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cycles", "2",
+    # (24 batches a rank and step: the feeding thread runs as far ahead of the device as the generator's slots let it, so the flush
+    #  rounds behind the last feed have every slot to empty -- with --cycles 2 a rank fed two batches and four rounds were enough
+    #  for a generator of six slots)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cycles", "24",
                         "--frames", "64", "--no-all-flat", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
