@@ -91,7 +91,17 @@ int w_wgs_per_frame(int ncell, int B, int kind) {
   const char *e = getenv(kind ? "G1S_W_WGS_C" : "G1S_W_WGS");  // tuning / test aid
   int target = std::max(kMTargetWgs, (kind ? 16 : 32) * B);
   if (e) target = std::max(8, atoi(e));
-  return (std::max(gmin, (target + B - 1) / std::max(B, 1)) + 7) & ~7;
+  int G = (std::max(gmin, (target + B - 1) / std::max(B, 1)) + 7) & ~7;
+  // (luma launch of a small frame: slices of at least 64 cells -- a slice pays two ghost units, its entries' parking and a partial
+  //  system whatever its length -- as long as a launch still has a workgroup for every slot of the chip.  1080p, 128 frames a
+  //  launch: 32 -> 8 workgroups a frame, luma launch 178 -> 168 us, k3w_tail 15 -> 11; 4K (32 a frame) and 8K are where they were.
+  //  profiles/r05n_wgs_small_frames.txt)
+  if (!e && kind == 0) {
+    const int by_cells = ((ncell + 63) / 64 + 7) & ~7, by_slots = ((kMTargetWgs + B - 1) / std::max(B, 1) + 7) & ~7;
+    G = std::max(gmin, std::min(G, std::max(by_cells, by_slots)));
+    G = (G + 7) & ~7;
+  }
+  return G;
 }
 
 #define HIP_TRY(expr)                                                                      \
