@@ -185,7 +185,7 @@ def main() -> None:
     window_samples = None  # per plane, of the last frame of the timed-kernels step
     exchange_s, exchange_rounds = 0.0, 0  # N > 1: the feeding thread's time in the rounds' exchange
 
-    def one_step(timing: bool, cycles: int = 0, prep=None):
+    def one_step(timing, cycles: int = 0, prep=None):  # timing: False | True (an event a kernel) | 2 (one pair a batch)
         """one job: the resident frames `cycles` times over through a fresh generator, up to the finished table"""
         nonlocal stats_total, last_tbl, window_samples, kernel_times, exchange_s, exchange_rounds
         cycles = cycles or args.cycles
@@ -214,7 +214,7 @@ def main() -> None:
             exchange_s += sd.exchange_s
             exchange_rounds += cycles * len(prepared_batches) + sd.PIPELINE_BATCHES
         st = sd.generator.stats()
-        if timing:
+        if timing is True:
             kernel_times = sd.generator.kernel_times()
         if segs is not None:
             last_tbl = format_tbl(segs)
@@ -271,7 +271,13 @@ def main() -> None:
     # bpp bytes per luma pixel of a frame pair = every source and denoised sample once
     alg_bytes_per_launch = bpp * W * H * frames_per_launch
     # the whole pass over one batch: every kernel from the finder's first to the accumulation's last, alone on the chip
-    batch_ms = (sum(v[0] for v in kt.values()) if kt else st.ms_total_gpu) / n_batches
+    batch_ms_events = (sum(v[0] for v in kt.values()) if kt else st.ms_total_gpu) / n_batches
+    # ... and the same batches with ONE pair of events, around the chain (first kernel's start -> last kernel's end; nothing between
+    # two launches but their own dependency): what a batch takes alone on the chip.  The per-kernel events above each put a
+    # barrier packet and a signal between two launches -- 5 - 7 us a kernel that rocprofv3's kernel trace does not see
+    # (profiles/r05_kernel_stats_one_stream.txt); this figure is the one that agrees with the profiler's sum.
+    stc = one_step(2, TC)
+    batch_ms = (stc.ms_chain / stc.chain_batches) if stc.chain_batches else batch_ms_events
     achieved = alg_bytes_per_launch / (batch_ms * 1e-3) / 1e9 if batch_ms > 0 else 0.0
     bps = 1 if bd == 8 else 2
     cpx = (W >> xdec) * (H >> ydec) if chroma else 0
@@ -332,8 +338,13 @@ def main() -> None:
         fkt = {k: v for k, v in kernel_times.items() if v[1] > 0}
         kernel_times = keep_kt
         fb = max(fst.launches_ar_accumulate, 1)
-        batch_ms_all_flat = sum(v[0] for v in fkt.values()) / fb
-        frac_all_flat = (bpp * W * H * (nfl * 8 / fb)) / (batch_ms_all_flat * 1e-3) / 1e9 / HBM_PEAK_GBS
+        fstc = one_step(2, 8, fl_prep)  # (one pair of events a batch, as above)
+        if fstc.chain_batches:  # (8 passes over nfl frames in chain_batches timed batches: the job's untimed first pass is not among them)
+            batch_ms_all_flat = fstc.ms_chain / fstc.chain_batches
+            frac_all_flat = (bpp * W * H * (nfl * 8 / fstc.chain_batches)) / (batch_ms_all_flat * 1e-3) / 1e9 / HBM_PEAK_GBS
+        else:  # (fb counts the untimed first pass' batches too: time and frames are both per fb)
+            batch_ms_all_flat = sum(v[0] for v in fkt.values()) / fb
+            frac_all_flat = (bpp * W * H * (nfl * 8 / fb)) / (batch_ms_all_flat * 1e-3) / 1e9 / HBM_PEAK_GBS
         flat_fraction_all_flat = (fst.flat_blocks / fst.blocks) if fst.blocks else None
         del fl_frames, fl_prep
         torch.cuda.empty_cache()
@@ -378,8 +389,9 @@ def main() -> None:
             # the kernel with the most time in a batch, by the name rocprofv3 prints; its family; and what `achieved` covers
             "kernel": dom,
             "family": "k3_ar_accumulate" if dom.startswith(("k3", "k0")) else "k1_flat_features" if dom.startswith("k1") else "k2_flat_select",
-            "scope": "all kernels of one batch (the pass needs every one of them to have read a frame pair once): "
-                     "algorithmic bytes of the batch / sum of their HIP-event durations, one stream",
+            "scope": "all kernels of one batch (the pass needs every one of them to have read a frame pair once): algorithmic bytes "
+                     "of the batch / HIP-event time from its first kernel's start to its last kernel's end, one stream, alone on the "
+                     "chip (frac_kernel_events: / the sum of per-kernel event pairs, each of which adds a barrier packet between two launches)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -391,12 +403,14 @@ def main() -> None:
             "avg_launch_ms_all_flat": batch_ms_all_flat,
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "avg_launch_ms": batch_ms,
+            "avg_launch_ms_kernel_events": batch_ms_events,
+            "frac_kernel_events": (alg_bytes_per_launch / (batch_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS) if batch_ms_events > 0 else None,
             "alg_bytes_per_launch": alg_bytes_per_launch,
             "frames_per_launch": frames_per_launch,
             "dominant_kernel": {
                 "name": dom,
                 "avg_launch_ms": dom_avg_ms,
-                "share_of_batch": dom_avg_ms / batch_ms if batch_ms > 0 else None,
+                "share_of_batch": dom_avg_ms / batch_ms_events if batch_ms_events > 0 else None,
                 # the bytes this one kernel exists to read (its planes), against its own duration
                 "alg_bytes_per_launch": ob * frames_per_launch if ob else None,
                 "achieved": (ob * frames_per_launch / (dom_avg_ms * 1e-3) / 1e9) if ob and dom_avg_ms > 0 else None,

@@ -101,6 +101,8 @@ class G1SStats(C.Structure):
         ("ms_host_fold", C.c_double),
         ("ms_residual", C.c_double),
         ("literal_blocks", C.c_uint64),
+        ("ms_chain", C.c_double),
+        ("chain_batches", C.c_uint64),
     ]
 
 

@@ -267,6 +267,7 @@ struct Slot {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: finder start, k2 start, k3 start, k3 end, k0 end, k0 start
   uint32_t count = 0;
   bool timed = false;
+  bool chain = false;  // a timed batch with ONE pair of events, around the batch's whole chain of kernels (g1s_diff_set_timing(g, 2))
   bool async_in = false;  // the batch holds frames whose H2D copies were queued on the upload stream
   // per-kernel timing (g1s_diff_set_timing): an event before each launch, the name of the kernel it precedes
   std::vector<hipEvent_t> kev;
@@ -481,13 +482,14 @@ struct g1s_diff {
   bool finished = false;
   std::vector<g1s_segment_t> final_segs;  // what finish() returned (kept: a too-small buffer can be retried)
   bool timing = false;
+  bool timing_chain = false;  // timed batches carry one pair of events (first kernel's start, last kernel's end) instead of one a kernel
   int flat_literal = 0;  // flat-block finder: literal f64 evaluation of every block (1: lane per block, 2: wave per block)
   g1s_stats_t stats{};
   std::map<std::string, std::pair<double, uint64_t>> ktimes;  // timed batches: kernel name -> (ms, launches)
   std::mutex ktimes_mutex;
   // timed batches run on one stream: an event before each launch (and one after the last), named after the kernel
   int kmark(Slot &sl, hipStream_t st, const char *name) {
-    if (!sl.timed && !trace) return G1S_OK;
+    if ((!sl.timed || sl.chain) && !trace) return G1S_OK;
     if (sl.nk == sl.kev.size()) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return fail(G1S_ERR_HIP, "hipEventCreate failed");
@@ -909,6 +911,7 @@ int g1s_diff::launch_front(int si) {
     sl.async_in = false;
   }
   sl.timed = timing;
+  sl.chain = timing && timing_chain;
   sl.nk = 0;
   if (!sl.timed) kmark(sl, up, "table H2D");  // (trace mode only: the timed batches' table of kernels stays what it was)
   HIP_TRY(hipMemcpyAsync(sl.d_planes, sl.h_planes, sizeof(FramePlanes) * B, hipMemcpyHostToDevice, up));
@@ -954,7 +957,7 @@ int g1s_diff::launch_front(int si) {
     cl.global = literal_mode == 0 ? 1 : 0;  // (the default chain: one sequence for the launch; "every block literally": per-frame lists)
     {
       // the finder's moments of the luma source: the only pass over pixels that are not in a flat block's tile
-      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
+      if (sl.timed && !sl.chain) HIP_TRY(hipEventRecord(sl.ev[5], pstream));
       {  // (also when every block is evaluated literally: the record's luma_sum comes from the moments)
         const dim3 mg((g.nblocks + 7) / 8, B);
         kmark(sl, pstream, g.src_bps == 1 ? "k1_moments<1>" : "k1_moments<2>");
@@ -962,7 +965,7 @@ int g1s_diff::launch_front(int si) {
         } else if (g.src_bps == 1) hipLaunchKernelGGL(k1_moments<1>, mg, dim3(256), 0, pstream, ft, g, mom);
         else hipLaunchKernelGGL(k1_moments<2>, mg, dim3(256), 0, pstream, ft, g, mom);
       }
-      if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
+      if (sl.timed && !sl.chain) HIP_TRY(hipEventRecord(sl.ev[4], pstream));
     }
     if (pstream != fstream) {  // the finder chain: on the side stream, behind the pixel pass (its luma half)
       if (!pix_recorded) HIP_TRY(hipEventRecord(ss.pix_done[si], pstream));
@@ -994,7 +997,7 @@ int g1s_diff::launch_front(int si) {
 #undef G1S_FB
     }
   }
-  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
+  if (sl.timed && !sl.chain) HIP_TRY(hipEventRecord(sl.ev[1], fstream));
   const bool w_lists = wide_ok(g);  // the wide chain: the unit lists come out of the select kernel
   WUnitParams wup{};
   if (w_lists) {
@@ -1010,7 +1013,7 @@ int g1s_diff::launch_front(int si) {
   kmark(sl, fstream, w_lists ? "k2w_select_units" : "k2_flat_select");
   if (w_lists) hipLaunchKernelGGL(k2w_select_units, dim3(B, g.nplanes == 3 ? 2 : 1), dim3(kK2Threads), 0, fstream, g, sl.d_records, (const uint8_t *)sl.d_flags, wup);
   else if (!dbg_skip("k2")) hipLaunchKernelGGL(k2_flat_select, dim3(B), dim3(kK2Threads), 0, fstream, g, sl.d_records, sl.d_flags);
-  if (sl.timed) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
+  if (sl.timed && !sl.chain) HIP_TRY(hipEventRecord(sl.ev[2], fstream));
   if (!w_lists) {
     // the unit lists (chunks with a flat block) need the flat mask (the wide chain: k2w_select_units has built them)
     const MParams mp = make_mparams(sl);
@@ -1463,7 +1466,14 @@ int g1s_diff::drain_front(int si) {
     }
     trace_lines.emplace_back(std::string("H ") + std::to_string(trace_now()) + " drained slot " + std::to_string(si));
   }
-  if (sl.timed) {
+  if (sl.timed && sl.chain) {
+    // (one pair of events around the batch's chain: what the chain takes alone on the chip with nothing between its kernels
+    //  but their own dependencies -- the per-kernel events below each put a barrier packet and a signal between two launches)
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[3]));
+    stats.ms_chain += ms;
+    stats.chain_batches += 1;
+  } else if (sl.timed) {
     float ms = 0;
     float ms_mom = 0;  // the finder's moments pass
     HIP_TRY(hipEventElapsedTime(&ms_mom, sl.ev[5], sl.ev[4]));
@@ -2367,6 +2377,7 @@ int g1s_diff_set_flat_finder(g1s_diff_t *g, int mode) {
 int g1s_diff_set_timing(g1s_diff_t *g, int enable) {
   if (!g) return G1S_ERR_INVALID;
   g->timing = enable != 0;
+  g->timing_chain = enable == 2;
   return G1S_OK;
 }
 

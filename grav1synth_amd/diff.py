@@ -291,7 +291,9 @@ class DiffGenerator:
         return buf[: bs * n.value].reshape(n.value, bs)
 
     # -- measurement / parity hooks ------------------------------------------------------
-    def set_timing(self, enable: bool) -> None:
+    def set_timing(self, enable) -> None:
+        """False / True: an event in front of every kernel of a batch (kernel_times); 2: one pair of events around the batch's
+        whole chain of kernels (stats().ms_chain / chain_batches)."""
         self._L.g1s_diff_set_timing(self._h, int(enable))
 
     def kernel_times(self) -> dict:

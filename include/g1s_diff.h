@@ -244,9 +244,13 @@ typedef struct {
   double ms_host_fold;        /* wall time spent in the ordered host fold */
   double ms_residual;         /* part of ms_ar_accumulate: the K0 residual pass over the input planes */
   uint64_t literal_blocks;    /* timed batches only: blocks the certified flat-block fast path left to the literal f64 kernel */
+  double ms_chain;            /* set_timing(2): HIP-event time from the first kernel's start to the last kernel's end, summed over batches */
+  uint64_t chain_batches;     /* ... the batches in that sum */
 } g1s_stats_t;
 int g1s_diff_get_stats(const g1s_diff_t *, g1s_stats_t *out);
-/* Enable per-kernel HIP-event timing (off by default: events serialise batches). */
+/* Enable HIP-event timing of the batches (off by default: events serialise batches; a timed batch runs on one stream, alone on
+ * the chip).  1: an event in front of every kernel (g1s_diff_kernel_times, the ms_* family sums); 2: ONE pair of events around the
+ * batch's whole chain of kernels (ms_chain / chain_batches) -- no barrier packet between two of its launches. */
 int g1s_diff_set_timing(g1s_diff_t *, int enable);
 /* Timed batches: one line per kernel, "name\tmilliseconds\tlaunches\n" (HIP events around each launch, on the
  * stream the kernel runs on; the names are the ones rocprofv3 --kernel-trace prints).  Returns the number of bytes

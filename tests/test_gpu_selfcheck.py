@@ -141,3 +141,35 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 1 and out["value"] > 0
     assert out["config"]["backend"] == "gloo" and out["scaling"] == "weak"
+
+
+def test_chain_timing_brackets_a_batch_and_changes_nothing():
+    """g1s_diff_set_timing(g, 2): one pair of HIP events around a batch's whole chain of kernels (bench.py's roofline.frac).
+    Every timed batch is counted, the bracket is no longer than the sum of the per-kernel event pairs of the same batches
+    (each of which puts a barrier packet between two launches), and the table is the untimed job's."""
+    from fractions import Fraction
+
+    from grav1synth_amd.diff import DiffGenerator, format_tbl
+    from grav1synth_amd.synth import SynthSpec, make_pair
+
+    spec = SynthSpec(1280, 704, 10)
+    pairs = [make_pair(spec, k, device="cuda") for k in range(8)]
+    out = {}
+    for mode in (False, True, 2):
+        g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=4)
+        for s, d in pairs[:4]:  # (one untimed batch first: the first launch of a kernel in a process loads its code object)
+            g.diff_frame(s, d, 1, 1)
+        g.sync()
+        g.set_timing(mode)
+        for rep in range(3):
+            for s, d in pairs:
+                g.diff_frame(s, d, 1, 1)
+        g.sync()
+        st = g.stats()
+        kt = g.kernel_times() if mode is True else {}
+        out[mode] = (format_tbl(g.finish()), st.ms_chain, st.chain_batches, sum(v[0] for v in kt.values()))
+        g.close()
+    assert out[False][0] == out[True][0] == out[2][0]
+    assert out[False][2] == 0 and out[True][2] == 0, "only set_timing(2) counts chain batches"
+    assert out[2][2] == 6 and out[2][1] > 0.0
+    assert out[2][1] < out[True][3] * 1.10, (out[2][1], out[True][3])

@@ -42,4 +42,16 @@ except Exception as e:
     print("error (ignored):", str(e)[:100], file=sys.stderr)
 kt = g.kernel_times()
 out = {k: round(v[0] / v[1] * 1e3, 1) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}
-print(json.dumps({"tag": os.environ.get("TAG", ""), "sum_us": round(sum(out.values()), 1), "kernels_us": out}))
+# the same batches once more with ONE pair of events around each batch's chain of kernels (set_timing(2))
+chain_us = None
+try:
+    g.set_timing(2)
+    for k in range(nb * B):
+        s, d = pairs[k % nd]
+        g.diff_frame(s, d, xd, yd, sync_torch=False)
+    g.sync()
+    st = g.stats()
+    chain_us = round(st.ms_chain / st.chain_batches * 1e3, 1) if st.chain_batches else None
+except Exception as e:
+    print("error (ignored):", str(e)[:100], file=sys.stderr)
+print(json.dumps({"tag": os.environ.get("TAG", ""), "sum_us": round(sum(out.values()), 1), "chain_us": chain_us, "kernels_us": out}))
