@@ -520,26 +520,44 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
     }
     return r;
   };
+  // (buffer form of the same loads for the units that lie inside the plane: descriptor of the plane in SGPRs, the lane's constant
+  //  offset as the instruction's VGPR offset, the row's 32-bit offset from the plane's origin as its SGPR offset -- no 64-bit
+  //  address arithmetic a row and no copy of the lane offset into the destination registers)
+  const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(psrc), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bden = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(pden), 0, 0x7fffffff, 0x00020000);
+  auto bload8 = [&](__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, bool wide) __attribute__((always_inline)) -> w_u4 {
+    w_u4 r = {0u, 0u, 0u, 0u};
+    if (wide) {
+      r = __builtin_bit_cast(w_u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 2));  // (aux 2: non-temporal)
+    } else {
+      const w_u2 a = __builtin_bit_cast(w_u2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, 0));
+      r.x = a.x, r.y = a.y;
+    }
+    return r;
+  };
   auto request = [&](uint32_t ex) __attribute__((always_inline)) {
     if (G1S_W_DBGBIT(1)) return;
     const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
     const int X0 = c * kWUnitW, Y0 = by * BH - 4;
-    // (scalar origin + the lane's constant offset)
-    const uint8_t *sb = psrc + ((ptrdiff_t)Y0 * (ptrdiff_t)sst + (ptrdiff_t)(X0 * BPS));
-    const uint8_t *vb = pden + ((ptrdiff_t)Y0 * (ptrdiff_t)dst_ + (ptrdiff_t)(X0 * BPD));
-    if ((ex >> 25) & 1u) {  // every row and word of the tile inside the plane
+    if ((ex >> 25) & 1u) {  // every row and word of the tile inside the plane (Y0 >= 0)
+      const uint32_t so_s = (uint32_t)Y0 * sst + (uint32_t)(X0 * BPS), so_v = (uint32_t)Y0 * dst_ + (uint32_t)(X0 * BPD);
 #pragma unroll
       for (int i = 0; i < NOWN; ++i)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          rs[i][r] = load8(sb + (size_t)(8 * i + r) * sst, lo_s, BPS == 2);
-          rv[i][r] = load8(vb + (size_t)(8 * i + r) * dst_, lo_v, BPD == 2);
+          rs[i][r] = bload8(bsrc, lo_s, so_s + (uint32_t)(8 * i + r) * sst, BPS == 2);
+          rv[i][r] = bload8(bden, lo_v, so_v + (uint32_t)(8 * i + r) * dst_, BPD == 2);
         }
       if (h_wave) {
-        hs = load8(sb, lo_hs, BPS == 2);
-        hv = load8(vb, lo_hv, BPD == 2);
+        hs = bload8(bsrc, lo_hs, so_s, BPS == 2);
+        hv = bload8(bden, lo_hv, so_v, BPD == 2);
       }
-    } else {
+      return;
+    }
+    // (scalar origin + the lane's constant offset)
+    const uint8_t *sb = psrc + ((ptrdiff_t)Y0 * (ptrdiff_t)sst + (ptrdiff_t)(X0 * BPS));
+    const uint8_t *vb = pden + ((ptrdiff_t)Y0 * (ptrdiff_t)dst_ + (ptrdiff_t)(X0 * BPD));
+    {
       const bool xok = X0 + 8 * w + 8 <= pw;
 #pragma unroll
       for (int i = 0; i < NOWN; ++i)
