@@ -103,6 +103,7 @@ __host__ __device__ constexpr int w_lds_bytes(int KIND, int BH) { return (KIND =
 typedef int w_v4 __attribute__((ext_vector_type(4)));
 typedef uint32_t w_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t w_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t w_store2 __attribute__((ext_vector_type(2)));  // (the operand type of the 64-bit buffer store builtin)
 
 __device__ __forceinline__ uint32_t w_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
 
@@ -442,6 +443,9 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
 
   // the L plane of the frame; this thread's word(s) of a unit's L tile (chroma launch) / this lane's L bytes (luma launch)
   uint8_t *lframe = wp.lplane + (size_t)frame * wp.lframe_bytes;
+  // (its descriptor: the L stores of the luma launch and the L-tile loads of the chroma launch are buffer instructions like the
+  //  loads of the planes -- the unit's 32-bit offset in an SGPR, the lane's constant offset in a VGPR)
+  const __amdgpu_buffer_rsrc_t bL = __builtin_amdgcn_make_buffer_rsrc(lframe, 0, 0x7fffffff, 0x00020000);
   uint32_t l_off[CHR ? (BH / 16) : NOWN];
   if (CHR) {
 #pragma unroll
@@ -588,14 +592,10 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
     if (G1S_W_DBGBIT(128)) return;
     if constexpr (CHR) {
       const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
-      const uint8_t *lb = lframe + ((size_t)(by * BH) * wp.lpitch + (size_t)(c * kWUnitW));
+      const uint32_t so = (uint32_t)(by * BH) * wp.lpitch + (uint32_t)(c * kWUnitW);
 #pragma unroll
-      for (int q = 0; q < BH / 16; ++q) {
-        uint32_t o = l_off[q];
-        asm volatile("" : "+v"(o));
-        if (BPS == 2) Lc[q] = __builtin_nontemporal_load((gptr_u2)(as_global(lb) + o));
-        else Lc[q] = *(gptr_u2)(as_global(lb) + o);
-      }
+      for (int q = 0; q < BH / 16; ++q)
+        Lc[q] = __builtin_bit_cast(w_u2, __builtin_amdgcn_raw_buffer_load_b64(bL, (int)l_off[q], (int)so, BPS == 2 ? 2 : 0));  // (16-bit jobs: non-temporal)
     }
   };
 
@@ -636,12 +636,11 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
         if constexpr (LOUT) {
           // ---- the chroma regressor L of this lane's samples -> the L plane ----
           const int c = (int)(ex & 0x3ffu), by = (int)((ex >> 10) & 0xfffu);
-          uint32_t lo_ = l_off[i];
-          asm volatile("" : "+v"(lo_));
-          uint8_t *lp = lframe + ((size_t)(by * SH::LBH) * wp.lpitch + (size_t)(c * (kWUnitW >> (SX > 0 ? 1 : 0)))) + lo_;
+          const uint32_t lso = (uint32_t)(by * SH::LBH) * wp.lpitch + (uint32_t)(c * (kWUnitW >> (SX > 0 ? 1 : 0)));
           if (SX == 0 && SY == 0) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) *reinterpret_cast<uint2 *>(lp + (size_t)r * wp.lpitch) = make_uint2(Dn[i][r][0], Dn[i][r][1]);
+            for (int r = 0; r < 2; ++r)
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(w_store2, w_u2{Dn[i][r][0], Dn[i][r][1]}), bL, (int)l_off[i], (int)(lso + (uint32_t)r * wp.lpitch), 0);
             lacc = racc;  // (L is the residual itself: outside int8 exactly where the residual is)
           } else {
 #pragma unroll
@@ -665,7 +664,7 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
                 constexpr uint32_t add = (640u - 2u * bias1) * 0x00010001u;
                 const uint32_t y01 = x01 + add, y23 = x23 + add;  // halves: L + 640; inside int8 <=> high byte 2
                 lacc |= (y01 ^ 0x02000200u) | (y23 ^ 0x02000200u);
-                *reinterpret_cast<uint32_t *>(lp + (size_t)r * wp.lpitch) = __builtin_amdgcn_perm(y23, y01, 0x06040200u) ^ 0x80808080u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(y23, y01, 0x06040200u) ^ 0x80808080u, bL, (int)l_off[i], (int)(lso + (uint32_t)r * wp.lpitch), 0);
               } else {
                 // (SY = 1, SX = 0: eight values a row pair, laid out like T)
                 constexpr uint32_t add = (640u - bias1) * 0x00010001u;
@@ -676,8 +675,9 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
                   lacc |= y[q] ^ 0x02000200u;
                 }
                 constexpr uint32_t sel = LAY == 2 ? 0x06040200u : 0x06020400u;
-                *reinterpret_cast<uint2 *>(lp + (size_t)r * wp.lpitch) =
-                    make_uint2(__builtin_amdgcn_perm(y[1], y[0], sel) ^ 0x80808080u, __builtin_amdgcn_perm(y[3], y[2], sel) ^ 0x80808080u);
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    __builtin_bit_cast(w_store2, w_u2{__builtin_amdgcn_perm(y[1], y[0], sel) ^ 0x80808080u, __builtin_amdgcn_perm(y[3], y[2], sel) ^ 0x80808080u}), bL,
+                    (int)l_off[i], (int)(lso + (uint32_t)r * wp.lpitch), 0);
               }
             }
           }
