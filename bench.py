@@ -115,40 +115,56 @@ def main() -> None:
         # `python bench.py --gpus N` by itself: start the N ranks the way the driver would (one process per GPU under
         # torch.distributed.run, rendezvous on 127.0.0.1), hand the one JSON line of rank 0 through, leave with its exit code
         raise SystemExit(self_launch(args.gpus))
+    # (G1S_BENCH_FORCE_DIST=1, a test aid: ONE rank through the N > 1 code path -- process group over RCCL, the streaming frame
+    #  shards, the rounds' transport, the collectives of the timed region -- which a single-GPU box can otherwise not run)
+    multi = world > 1 or os.environ.get("G1S_BENCH_FORCE_DIST") == "1"
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the diff path has no CPU fallback)")
+    # The line this command prints is the ONLY thing on its standard output: libraries write there too (RCCL prints a five-line
+    # version banner from its first communicator), so from here on file descriptor 1 is the error stream and the line goes to
+    # the saved descriptor at the end.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     # one rank per GPU; G1S_BENCH_SHARE_GPU=1 lets several ranks share a device (single-GPU smoke test of
     # the N > 1 code path, with the gloo backend: RCCL refuses two ranks on one device)
     share = os.environ.get("G1S_BENCH_SHARE_GPU") == "1"
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    numa = bind_to_gpu_numa_node(dev_index) if world > 1 and not share else None
+    numa = bind_to_gpu_numa_node(dev_index) if multi and not share else None
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # (no launcher around a forced one-rank job)
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if world > 1:  # the host fold pools of the ranks share the node's cores
+    if multi:  # the host fold pools of the ranks share the node's cores
         lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         from grav1synth_amd import _lib
 
         # (usable = hardware threads cut to the cgroup CPU quota: the ranks of a node share it)
-        share = int(_lib.lib().g1s_usable_cpus()) // max(lws, 1)
-        os.environ.setdefault("G1S_FOLD_THREADS", str(max(2, min(32, share))))
+        # (a name of its own: `share` above says whether the ranks share ONE device -- it picks gloo / CPU tensors further down)
+        cores_per_rank = int(_lib.lib().g1s_usable_cpus()) // max(lws, 1)
+        os.environ.setdefault("G1S_FOLD_THREADS", str(max(2, min(32, cores_per_rank))))
         # A rank's per-frame half wants ~5.5 cores at 4K (72 us of a core per frame next to the merge and the copies:
         # profiles/r04_host_budget_8ranks.txt).  A job whose CPU quota gives a rank less is bound by the host at (share / 5.5) of
         # a GPU; the half on the device (k4_latest, rebuilt in round 5: profiles/r05_device_latest.txt) runs a GPU at 0.90 - 0.95 x
         # of its host-half rate and leaves the host the launches, 27 KB a frame and the merge: the faster job below ~5 cores.
-        if share < 5:
+        if cores_per_rank < 5:
             os.environ.setdefault("G1S_LATEST", "device")
     from grav1synth_amd.diff import DiffGenerator, format_tbl
     from grav1synth_amd.dist import ShardedDiff, StreamingShardedDiff
@@ -167,7 +183,7 @@ def main() -> None:
     B = max(1, args.batch)  # (frames per launch, the same at any N; what the line reports as config.batch_frames)
     frames = []
     for k in range(F):
-        gid = ((k // B) * world + rank) * B + (k % B) if world > 1 else k
+        gid = ((k // B) * world + rank) * B + (k % B) if multi else k
         s, d = make_pair(spec, gid, device=dev)
         if not chroma:
             s, d = s[:1], d[:1]
@@ -176,7 +192,7 @@ def main() -> None:
     # FFI frame descriptors (pointers, strides) are built once, outside the timed region:
     # a native caller hands over an array of frame structs just like this
     prepared = DiffGenerator.prepare_frames(frames, xdec, ydec)
-    prepared_batches = [DiffGenerator.prepare_frames(frames[i:i + B], xdec, ydec) for i in range(0, F, B)] if world > 1 else []
+    prepared_batches = [DiffGenerator.prepare_frames(frames[i:i + B], xdec, ydec) for i in range(0, F, B)] if multi else []
     nplanes = 3 if chroma else 1
 
     stats_total = None
@@ -190,7 +206,7 @@ def main() -> None:
         nonlocal stats_total, last_tbl, window_samples, kernel_times, exchange_s, exchange_rounds
         cycles = cycles or args.cycles
         prep = prep if prep is not None else prepared
-        if world > 1:
+        if multi:
             # streaming frame shards: per batch one small all-gather of latest states, rank 0 merges in order
             sd = StreamingShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
                                       batch_frames=B, group=dist)
@@ -210,7 +226,7 @@ def main() -> None:
             for _ in range(cycles):
                 sd.diff_prepared(prep, W, H, nplanes, sync_torch=False)
         segs = sd.finish()  # (exchange +) ordered fold; rank 0 holds the table
-        if world > 1 and not timing:
+        if multi and not timing:
             exchange_s += sd.exchange_s
             exchange_rounds += cycles * len(prepared_batches) + sd.PIPELINE_BATCHES
         st = sd.generator.stats()
@@ -229,7 +245,7 @@ def main() -> None:
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -247,7 +263,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     host_cores_busy = (sum(os.times()[:2]) - cpu0) / max(elapsed, 1e-9)
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=torch.device("cpu") if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -321,7 +337,7 @@ def main() -> None:
     # ---- SURVEY 8(d) asks for both content variants: the timed-kernels job once more on the all-flat stress variant (no
     #      textured region: every unit of every frame is staged and multiplied), 64 resident frame pairs, rank 0 of N = 1 ----
     frac_all_flat = flat_fraction_all_flat = batch_ms_all_flat = None
-    if world == 1 and not args.flat and not args.no_all_flat:
+    if not multi and not args.flat and not args.no_all_flat:
         fl_spec = SynthSpec(W, H, bd, xdec, ydec, textured=False)
         nfl = min(F, max(args.batch, 64))
         fl_frames = []
@@ -376,12 +392,12 @@ def main() -> None:
                              "stream": "exact int8 SYRK on the matrix cores (v_mfma_i32_16x16x64_i8 on operand pairs, one LDS operand read per 64 samples), residual fused into the consumer, two tile buffers -- a deviation from north_star's 'no MFMA', signed off in VERDICT r01"}[os.environ.get("G1S_K3", "wide")],
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "flat_finder_literal_fraction": (st.literal_blocks / st.blocks) if st.blocks else None,
-            "rccl_ranks": (dist.get_world_size() if (world > 1 and not share) else (1 if world == 1 else 0)),
-            "backend": (dist.get_backend() if world > 1 else "none (one process)"),
+            "rccl_ranks": (dist.get_world_size() if (multi and not share) else (1 if not multi else 0)),
+            "backend": (dist.get_backend() if multi else "none (one process)"),
             "numa_node_rank0": numa,  # (N > 1: the NUMA node rank 0 bound itself to -- its GPU's; None: the host does not say)
             "exchange_ms_per_round": (exchange_s * 1e3 / exchange_rounds) if exchange_rounds else None,  # (N > 1: pack + gather + hand-over, on the feeding thread of this rank)
             "per_frame_fold_half": ("device (k4_latest)" if os.environ.get("G1S_LATEST") == "device" else "host pool"),
-            "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if world > 1 else "single GPU",
+            "parallelism": f"frame-shard x{world} (batches dealt round-robin), one small RCCL all-gather of per-frame latest states per batch, ordered merge on rank 0" if multi else "single GPU",
         },
         "hbm_roofline_frac_whole_job": (value * bpp * 1e6 / 1e9) / (HBM_PEAK_GBS * world),
         "roofline": {
@@ -417,7 +433,7 @@ def main() -> None:
             },
             "kernels_us_per_launch": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
             "families_ms_per_frame": {k: v[0] / FT for k, v in families.items()},
-            "host_fold_ms_per_frame": st.ms_host_fold / (F * (TC + (1 if world == 1 else 0))),  # (every frame the job fed, its untimed first pass too)
+            "host_fold_ms_per_frame": st.ms_host_fold / (F * (TC + (0 if multi else 1))),  # (every frame the job fed, its untimed first pass too)
             "accumulation": os.environ.get("G1S_K3", "wide"),
         },
     }
@@ -425,7 +441,7 @@ def main() -> None:
     # ---- CPU baseline: the oracle (a port: scalar f64, the reference's operation order) on a bounded sample,
     #      one thread, then T = all host cores (T independent generators, one per thread -- the reference's `diff`
     #      is sequential per video, so all cores means T videos / frame shards at once) ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         from concurrent.futures import ThreadPoolExecutor
 
         from tests.oracle_binding import OracleDiff
@@ -472,10 +488,12 @@ def main() -> None:
                       f"reference operation order) per thread, {all_s:.1f} s",
             "one_thread": {"value": W * H * n_cpu / one_s / 1e6, "cores": 1, "sample": f"{n_cpu} frame pair(s), {one_s:.1f} s"},
         }
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
+    os.close(line_fd)
 
 
 if __name__ == "__main__":

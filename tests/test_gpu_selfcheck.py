@@ -143,6 +143,27 @@ def test_bench_launches_its_own_ranks():
     assert out["config"]["backend"] == "gloo" and out["scaling"] == "weak"
 
 
+def test_bench_one_rank_through_the_rccl_code_path():
+    """G1S_BENCH_FORCE_DIST=1: ONE rank through everything `bench.py --gpus N` does over RCCL -- the process group on "nccl", the
+    streaming frame shards with the rounds' transport (pinned rings, the gather on its own stream), the barrier and the MAX
+    all-reduce of the timed region on DEVICE tensors -- which the two-rank test above (two ranks on one GPU: gloo, CPU tensors)
+    cannot reach.  (A variable of the N > 1 branch once shadowed the flag that picks CPU tensors for gloo: the all-reduce of
+    the step time would have been handed a CPU tensor on RCCL.  Nothing on a one-GPU box ran that line.)  The table of the
+    job is the one-process job's: `value` > 0 and a finished line."""
+    env = dict(os.environ, G1S_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "G1S_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--cycles", "24",
+                        "--frames", "64", "--no-all-flat", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["config"]["backend"] == "nccl" and out["config"]["rccl_ranks"] == 1
+    assert out["roofline"]["frac"] > 0
+
+
 def test_chain_timing_brackets_a_batch_and_changes_nothing():
     """g1s_diff_set_timing(g, 2): one pair of HIP events around a batch's whole chain of kernels (bench.py's roofline.frac).
     Every timed batch is counted, the bracket is no longer than the sum of the per-kernel event pairs of the same batches
