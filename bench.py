@@ -160,11 +160,13 @@ def main() -> None:
         # (a name of its own: `share` above says whether the ranks share ONE device -- it picks gloo / CPU tensors further down)
         cores_per_rank = int(_lib.lib().g1s_usable_cpus()) // max(lws, 1)
         os.environ.setdefault("G1S_FOLD_THREADS", str(max(2, min(32, cores_per_rank))))
-        # A rank's per-frame half wants ~5.5 cores at 4K (72 us of a core per frame next to the merge and the copies:
-        # profiles/r04_host_budget_8ranks.txt).  A job whose CPU quota gives a rank less is bound by the host at (share / 5.5) of
-        # a GPU; the half on the device (k4_latest, rebuilt in round 5: profiles/r05_device_latest.txt) runs a GPU at 0.90 - 0.95 x
-        # of its host-half rate and leaves the host the launches, 27 KB a frame and the merge: the faster job below ~5 cores.
-        if cores_per_rank < 5:
+        # A rank's per-frame half keeps ~9 cores busy at 4K next to the launches, the copies and the merge (profiles/
+        # r05_host_budget_8ranks.txt); a job whose CPU quota gives a rank fewer is bound by the host.  The half on the device
+        # (k4_latest, rebuilt in round 5: profiles/r05_device_latest.txt) runs a GPU at 0.90 - 0.95 x of its unconstrained
+        # host-half rate and leaves the host the launches, 27 KB a frame and the merge.  Measured with one rank held to n CPUs
+        # (profiles/r05z_half_by_cores.txt): 8 CPUs 453 k (host) / 549 k (device) Mpx/s, 10 CPUs 542 / 548, 12 CPUs 553 / 485 - 549:
+        # the device half below 10 cores a rank (two ranks on a 16-core quota have 8).
+        if cores_per_rank < 10:
             os.environ.setdefault("G1S_LATEST", "device")
     from grav1synth_amd.diff import DiffGenerator, format_tbl
     from grav1synth_amd.dist import ShardedDiff, StreamingShardedDiff
