@@ -281,3 +281,36 @@ def test_planes_sharing_the_strength_matrix_equals_every_plane_on_its_own():
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(p.stdout.strip().splitlines()[-1])
     assert len(outs[0]) == 64 and outs[0] == outs[1]
+
+
+def test_ctypes_mirrors_have_the_headers_struct_sizes(tmp_path):
+    """The Python side fills and reads the ABI's structs through ctypes mirrors (`_lib.py`); `g1s_diff_get_stats` and its
+    siblings write sizeof(struct) bytes into them.  A field added to the header and not to the mirror (or the other way
+    round) is a memory overrun no test of values would see: compile the header with the C compiler and compare the sizes
+    and the offset of each struct's last field."""
+    import ctypes as C
+    import shutil
+    import subprocess
+
+    from grav1synth_amd import _lib
+
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    pairs = [("g1s_frame_t", _lib.G1SFrame, "on_device"), ("g1s_segment_t", _lib.G1SSegment, None), ("g1s_opts_t", _lib.G1SOpts, None),
+             ("g1s_stats_t", _lib.G1SStats, "chain_batches"), ("g1s_filter_desc_t", _lib.G1SFilterDesc, "alg"),
+             ("g1s_y4m_info_t", _lib.G1SY4MInfo, "fps_den")]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "g1s_diff.h"', "int main(void) {"]
+    for name, _, last in pairs:
+        src.append(f'  printf("{name} %zu %zu\\n", sizeof({name}), {f"offsetof({name}, {last})" if last else "(size_t)0"});')
+    src += ["  return 0;", "}"]
+    c_file = tmp_path / "sizes.c"
+    c_file.write_text("\n".join(src))
+    exe = tmp_path / "sizes"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([cc, "-std=c11", "-I", os.path.join(root, "include"), str(c_file), "-o", str(exe)])
+    got = {ln.split()[0]: (int(ln.split()[1]), int(ln.split()[2])) for ln in subprocess.check_output([str(exe)], text=True).splitlines()}
+    for name, mirror, last in pairs:
+        assert C.sizeof(mirror) == got[name][0], f"{name}: header {got[name][0]} bytes, ctypes mirror {C.sizeof(mirror)}"
+        if last:
+            assert getattr(mirror, last).offset == got[name][1], f"{name}.{last}: header offset {got[name][1]}, mirror {getattr(mirror, last).offset}"
