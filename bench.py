@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -200,10 +201,11 @@ def main() -> None:
     stats_total = None
     kernel_times = {}
     last_tbl = None
+    tbl_digests = []  # SHA-256 of the table of every job that ended in one (rank 0 at N > 1), in order
     window_samples = None  # per plane, of the last frame of the timed-kernels step
     exchange_s, exchange_rounds = 0.0, 0  # N > 1: the feeding thread's time in the rounds' exchange
 
-    def one_step(timing, cycles: int = 0, prep=None):  # timing: False | True (an event a kernel) | 2 (one pair a batch)
+    def one_step(timing, cycles: int = 0, prep=None, batch: int = 0):  # timing: False | True (an event a kernel) | 2 (one pair a batch)
         """one job: the resident frames `cycles` times over through a fresh generator, up to the finished table"""
         nonlocal stats_total, last_tbl, window_samples, kernel_times, exchange_s, exchange_rounds
         cycles = cycles or args.cycles
@@ -218,7 +220,7 @@ def main() -> None:
                     sd.diff_prepared(pb, sync_torch=False)
         else:
             sd = ShardedDiff(fps, bd, bd, ar_coeff_lag=lag, luma_only=not chroma, device=dev_index,
-                             batch_frames=args.batch, group=None)
+                             batch_frames=batch or args.batch, group=None)
             if timing:
                 # (one untimed pass first: the first batch of a generator carries one-off costs -- 1.3 ms in the last kernel
                 #  of its chain -- that are not the kernels')
@@ -230,12 +232,13 @@ def main() -> None:
         segs = sd.finish()  # (exchange +) ordered fold; rank 0 holds the table
         if multi and not timing:
             exchange_s += sd.exchange_s
-            exchange_rounds += cycles * len(prepared_batches) + sd.PIPELINE_BATCHES
+            exchange_rounds += sd.exchange_rounds  # (feeds + flush rounds + the last group's padding: counted where they happen)
         st = sd.generator.stats()
         if timing is True:
             kernel_times = sd.generator.kernel_times()
         if segs is not None:
             last_tbl = format_tbl(segs)
+            tbl_digests.append(hashlib.sha256(last_tbl).hexdigest())
         if timing:
             try:
                 r = sd.generator.last_record()
@@ -251,9 +254,17 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The table of the timed job is checked, not dropped: the same 30 720 frames once through a generator with HALF the frames a
+    # launch (another partition of the video into launches, other slices a workgroup: the integer records do not depend on it), untimed;
+    # every warm-up and timed step must end in the same bytes.
+    check_tbl = None
+    if not multi:
+        one_step(False, batch=max(1, B // 2))
+        check_tbl = tbl_digests.pop()
     for _ in range(args.warmup):
         one_step(False)
     barrier()
+    n_untimed = len(tbl_digests)
     t0 = time.perf_counter()
     cpu0 = sum(os.times()[:2])  # (this process' user + system seconds, every thread: the host cores a rank keeps busy)
     step_ms, step_fold_ms = [], []
@@ -265,6 +276,11 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     host_cores_busy = (sum(os.times()[:2]) - cpu0) / max(elapsed, 1e-9)
+    timed_digests = tbl_digests[n_untimed:]
+    if rank == 0:
+        assert len(timed_digests) == args.steps and len(set(timed_digests)) == 1, "the timed steps did not all end in one table"
+        assert check_tbl is None or timed_digests[0] == check_tbl, "the timed job's table differs from the untimed half-batch job's"
+        assert last_tbl.startswith(b"filmgrn1\n") and last_tbl.count(b"\nE ") + last_tbl.startswith(b"E ") >= 1
     if multi:
         t = torch.tensor([elapsed], device=torch.device("cpu") if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,8 +336,10 @@ def main() -> None:
         return None
 
     ob = own_bytes(dom)
+    dom_flat = (st.flat_blocks / st.blocks) if st.blocks else 1.0
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     traffic = None
+    traffic_source = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
@@ -333,6 +351,10 @@ def main() -> None:
                     traffic = tj[mode + "_per_frame"] * frames_per_launch
                 else:
                     traffic = tj.get(mode)
+                if traffic is not None:
+                    traffic_source = ("static: profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/diff_pmc.py, FETCH_SIZE x 2 + "
+                                      "WRITE_SIZE per the guide's gfx950 correction), " + str(tj.get("measured", "commit not recorded")) +
+                                      "; not collected in this run")
         except Exception:
             traffic = None
 
@@ -383,6 +405,11 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
+        # the timed job really ends in a grain table: SHA-256 of its .tbl bytes (every timed step: one value, asserted), and of the
+        # same frames' table through an untimed job with half the frames a launch (N = 1; asserted equal)
+        "tbl_sha256": timed_digests[0] if timed_digests else None,
+        "tbl_sha256_untimed_half_batch_job": check_tbl,
+        "tbl_bytes": len(last_tbl) if last_tbl is not None else None,
         "dtype": "i8 x i8 -> i32 matrix-core products, i64 sums (exact integers) + f64 flat-block features",
         "data": "synthetic (deterministic integer generator, grav1synth_amd/synth.py), device-resident",
         "config": {
@@ -415,6 +442,9 @@ def main() -> None:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
+            "timing_method": "one HIP-event pair around a batch's chain of kernels (g1s_diff_set_timing 2; since the end of round 5); "
+                             "rounds 1-5 summed per-kernel event pairs: compare rounds on frac_kernel_events",
             # the same fraction on the all-flat stress variant (every unit staged and multiplied), its flat fraction, its batch
             "frac_all_flat": frac_all_flat,
             "flat_fraction_all_flat": flat_fraction_all_flat,
@@ -429,9 +459,12 @@ def main() -> None:
                 "name": dom,
                 "avg_launch_ms": dom_avg_ms,
                 "share_of_batch": dom_avg_ms / batch_ms_events if batch_ms_events > 0 else None,
-                # the bytes this one kernel exists to read (its planes), against its own duration
-                "alg_bytes_per_launch": ob * frames_per_launch if ob else None,
-                "achieved": (ob * frames_per_launch / (dom_avg_ms * 1e-3) / 1e9) if ob and dom_avg_ms > 0 else None,
+                # the planes this one kernel is launched over, and the share of them it loads: an accumulation launch only reads the
+                # units that hold a flat block, so its bandwidth is planes x flat fraction / duration (a lower bound: a unit of four
+                # blocks is loaded when ONE of them is flat; the PMC figure per kernel is in profiles/r06_pmc_traffic.txt)
+                "plane_bytes_per_launch": ob * frames_per_launch if ob else None,
+                "achieved_flat_weighted": (ob * frames_per_launch * (dom_flat if dom.startswith("k3") else 1.0) / (dom_avg_ms * 1e-3) / 1e9)
+                if ob and dom_avg_ms > 0 else None,
             },
             "kernels_us_per_launch": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
             "families_ms_per_frame": {k: v[0] / FT for k, v in families.items()},
@@ -486,6 +519,7 @@ def main() -> None:
             "cores": nproc,
             "nproc": nproc,
             "kind": "port",
+            "kind_note": "oracle/diff_oracle.c: a C restatement of the algorithm av1-grain 0.4.2 ports; there is no Rust toolchain in the image to build the reference itself",
             "sample": f"{nproc} threads x {n_cpu} frame pair(s) of the same workload cut to a {W}x{strip} strip, one oracle generator (oracle/liborc_diff.so: scalar f64, "
                       f"reference operation order) per thread, {all_s:.1f} s",
             "one_thread": {"value": W * H * n_cpu / one_s / 1e6, "cores": 1, "sample": f"{n_cpu} frame pair(s), {one_s:.1f} s"},

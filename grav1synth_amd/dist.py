@@ -251,10 +251,7 @@ class StreamingShardedDiff:
             self._rccl = _RCCL_ROUNDS[key]
         self._group_buf, self._group_n = None, 0
         self.exchange_s = 0.0  # seconds the feeding thread spent in the rounds' exchange (bench.py prints it)
-
-    # batches that can still be inside a generator when the last frame has been queued (csrc/engine.hip, kSlots: the library says
-    # how many -- g1s_shard_flush_rounds; the constant is what a build without that entry point had)
-    PIPELINE_BATCHES = 4
+        self.exchange_rounds = 0  # rounds this rank took part in: feeds, idle rounds, the flush rounds and the last group's padding
 
     # Rounds per gather: every rank packs one message a round (the library's protocol, unchanged), the transport moves
     # ROUNDS_PER_GATHER of them at a time.  A collective next to the accumulation launches costs the GPU ~0.2 ms whatever it
@@ -291,6 +288,7 @@ class StreamingShardedDiff:
                     # the merge itself runs on a thread of its own (the C call drops the GIL): this thread goes back to feeding its GPU
                     self._merge_q.put(gathered)
         self.exchange_s += _time.perf_counter() - t0
+        self.exchange_rounds += 1
 
     def _merge_main(self) -> None:
         L = self.generator._L
@@ -338,8 +336,8 @@ class StreamingShardedDiff:
             self._exchange_one(flush=True)
         while self._group_n:  # (the last group goes out full: empty messages behind the last states)
             self._exchange_one(flush=True)
-        # every frame fed by any rank must have been merged: PIPELINE_BATCHES is what a generator's slots can hold, and a change
-        # there must fail here, loudly, not drop the video's last batches
+        # every frame fed by any rank must have been merged: g1s_shard_flush_rounds() is what a generator's slots can hold, and a
+        # change there must fail here, loudly, not drop the video's last batches
         if self.dist.get_world_size() > 1:
             # (a CPU tensor unless the backend only moves device memory: a gloo job without a GPU is checked too)
             on_dev = self._dev is not None and self.dist.get_backend() == "nccl"

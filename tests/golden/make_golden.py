@@ -37,8 +37,53 @@ FULL_SIZE = {
     "oracle_full_3840x2160_10b_420_lag3_cut.tbl": dict(spec=SynthSpec(3840, 2160, 10), frames=8, lag=3, chroma=True, cut=4, fps=(24, 1)),
 }
 
+# configs[3] at its stated size: 3840x2160 10-bit 4:2:0, lag 3, chroma, 1000 frames (125 a shard x 8).  Two scene cuts: frame 500
+# is a boundary of the 125-frame shards (and lies inside a 64-frame batch), frame 768 is a boundary of the 64-frame batches the
+# streaming job deals (and lies inside a 125-frame shard).  About an hour of oracle time on one core:
+# `python -m tests.golden.make_golden long` writes it; the `-m gpu` suite compares the sharded HIP jobs with the committed bytes.
+LONG = {
+    "oracle_full_3840x2160_10b_420_lag3_1000frames.tbl": dict(spec=SynthSpec(3840, 2160, 10), frames=1000, lag=3, chroma=True,
+                                                              cuts=(500, 768), fps=(24, 1)),
+}
+
+
+def frame_specs(g):
+    """the SynthSpec of every frame of a golden's job: the noise gain triples between an odd and the next even cut"""
+    spec = g["spec"]
+    cuts = tuple(g["cuts"]) if "cuts" in g else ((g["cut"],) if "cut" in g else ())
+    b = SynthSpec(spec.width, spec.height, spec.bit_depth, xdec=spec.xdec, ydec=spec.ydec, gain_scale=3)
+    return [b if sum(k >= c for c in cuts) & 1 else spec for k in range(g["frames"])]
+
+
+def generate_long(name, workers=3):
+    """a LONG golden: the frames are made ahead on a few threads (a 4K pair is a second of integer torch work), the oracle takes
+    them in order"""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests.helpers import np_pair
+    from tests.oracle_binding import OracleDiff, format_tbl
+
+    g = LONG[name]
+    specs = frame_specs(g)
+    o = OracleDiff(g["fps"][0], g["fps"][1], g["spec"].bit_depth, g["spec"].bit_depth, g["lag"], g["chroma"])
+    t0 = time.time()
+    with ThreadPoolExecutor(workers) as ex:
+        ahead = workers + 1
+        futs = {k: ex.submit(np_pair, specs[k], k) for k in range(min(ahead, len(specs)))}
+        for k in range(len(specs)):
+            s, d = futs.pop(k).result()
+            if k + ahead < len(specs):
+                futs[k + ahead] = ex.submit(np_pair, specs[k + ahead], k + ahead)
+            o.diff_frame(s, d, specs[k].xdec, specs[k].ydec)
+            if k % 25 == 24:
+                print(f"  frame {k + 1}/{len(specs)}  {time.time() - t0:.0f} s  segments so far {o.num_segments()}", flush=True)
+    return format_tbl(o.finish())
+
 
 def generate(name):
+    if name in LONG:
+        return generate_long(name)
     g = GOLDEN[name] if name in GOLDEN else FULL_SIZE[name]
     spec = g["spec"]
     specs = None
@@ -52,7 +97,7 @@ def generate(name):
 
 
 if __name__ == "__main__":
-    names = FULL_SIZE if sys.argv[1:2] == ["full"] else GOLDEN
+    names = FULL_SIZE if sys.argv[1:2] == ["full"] else LONG if sys.argv[1:2] == ["long"] else GOLDEN
     if len(sys.argv) > 2:  # `full NAME ...`: only those
         names = sys.argv[2:]
     for name in names:

@@ -143,6 +143,32 @@ def test_bench_launches_its_own_ranks():
     assert out["config"]["backend"] == "gloo" and out["scaling"] == "weak"
 
 
+def test_bench_eight_ranks_on_one_device_end_in_the_one_rank_jobs_table():
+    """The rehearsal of `python bench.py --gpus 8` a one-GPU box allows: eight ranks on this device (gloo), the per-frame half of the
+    fold on the device (G1S_LATEST=device: what bench.py picks when a 16-core quota gives a rank two cores), three timed steps.
+    finish() refuses a job whose merged frame count is not what the ranks fed; the line's tbl_sha256 (every timed step ended in
+    these bytes) must be the one-rank job's over the same video: rank r's 64 resident frames are frames 64 r .. 64 r + 63 of a
+    512-frame cycle, so `--gpus 1 --frames 512` feeds the same frames in the same order."""
+    def line(gpus, frames, extra_env):
+        env = dict(os.environ, **extra_env)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--cycles", "3",
+                            "--frames", str(frames), "--no-all-flat", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200,
+                           cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        return json.loads(lines[0])
+
+    eight = line(8, 64, {"G1S_BENCH_SHARE_GPU": "1", "G1S_LATEST": "device"})
+    assert eight["n_gpus"] == 8 and eight["config"]["backend"] == "gloo" and eight["config"]["per_frame_fold_half"].startswith("device")
+    assert eight["config"]["frames_per_rank_per_step"] == 192 and eight["value"] > 0
+    one = line(1, 512, {})
+    assert one["tbl_sha256"] == one["tbl_sha256_untimed_half_batch_job"]
+    assert eight["tbl_sha256"] == one["tbl_sha256"] and eight["tbl_bytes"] == one["tbl_bytes"] > 100
+
+
 def test_bench_one_rank_through_the_rccl_code_path():
     """G1S_BENCH_FORCE_DIST=1: ONE rank through everything `bench.py --gpus N` does over RCCL -- the process group on "nccl", the
     streaming frame shards with the rounds' transport (pinned rings, the gather on its own stream), the barrier and the MAX

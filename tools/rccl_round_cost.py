@@ -25,7 +25,7 @@ for mode in ("rounds over RCCL", "plain generator", "rounds over RCCL", "plain g
         for _ in range(NB):
             sd.diff_prepared(prep, sync_torch=False)
         tbl = format_tbl(sd.finish())
-        ex = sd.exchange_s * 1e3 / (NB + sd.PIPELINE_BATCHES)
+        ex = sd.exchange_s * 1e3 / max(sd.exchange_rounds, 1)
         sd.close()
     else:
         g = DiffGenerator(Fraction(24, 1), 10, 10, batch_frames=B)
