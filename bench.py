@@ -435,8 +435,9 @@ def main() -> None:
             "kernel": dom,
             "family": "k3_ar_accumulate" if dom.startswith(("k3", "k0")) else "k1_flat_features" if dom.startswith("k1") else "k2_flat_select",
             "scope": "all kernels of one batch (the pass needs every one of them to have read a frame pair once): algorithmic bytes "
-                     "of the batch / HIP-event time from its first kernel's start to its last kernel's end, one stream, alone on the "
-                     "chip (frac_kernel_events: / the sum of per-kernel event pairs, each of which adds a barrier packet between two launches)",
+                     "of the batch / HIP-event time from its first kernel's start to its last kernel's end, the batch alone on the "
+                     "chip, one stream (frac_kernel_events: / the sum of per-kernel event pairs, each of which adds a "
+                     "barrier packet between two launches)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -452,7 +453,6 @@ def main() -> None:
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "avg_launch_ms": batch_ms,
             "avg_launch_ms_kernel_events": batch_ms_events,
-            "frac_kernel_events": (alg_bytes_per_launch / (batch_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS) if batch_ms_events > 0 else None,
             "alg_bytes_per_launch": alg_bytes_per_launch,
             "frames_per_launch": frames_per_launch,
             "dominant_kernel": {

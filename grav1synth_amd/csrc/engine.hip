@@ -339,6 +339,8 @@ struct StreamSet {
   // it, a batch's half would only start when the half of the batch before had been copied out (period >= 1 040 us at 4K)
   hipStream_t latest = nullptr, latest2 = nullptr;
   hipStream_t mom = nullptr;  // (G1S_MOM_STREAM: a tuning aid)
+  hipStream_t coread = nullptr;  // (G1S_DBG_COREAD: a measurement aid)
+  hipEvent_t coread_go = nullptr;
   hipEvent_t latest_done[kSlots] = {};
   int prio_side = 0;
   hipEvent_t kernels_done[kSlots] = {};
@@ -1143,12 +1145,34 @@ int g1s_diff::launch_back(int si) {
     else G1S_WB(KIND, 0, 0);                         \
   } while (0)
     const bool gen = wide_gen(g);
+    // G1S_DBG_COREAD=1|2|3 (a measurement aid, profiles/r06b_coread.txt): a pass over the batch's luma source by a kernel of few
+    // registers on a stream of its own, started with the luma launch (1), the chroma launch (2) or both (3): what a finder pass
+    // costs UNDER an accumulation launch when one of its waves fits beside the launch's four on a SIMD -- three times its own length
+    static const int coread = getenv("G1S_DBG_COREAD") ? atoi(getenv("G1S_DBG_COREAD")) : 0;
+    auto coread_with_next_launch = [&]() -> int {
+      if (!ss.coread) {
+        HIP_TRY(hipStreamCreateWithFlags(&ss.coread, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ss.coread_go, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(ss.coread_go, stream));
+      HIP_TRY(hipStreamWaitEvent(ss.coread, ss.coread_go, 0));
+      hipLaunchKernelGGL(k_dbg_coread, dim3((g.nblocks + 7) / 8, B), dim3(256), 0, ss.coread, ft, g, sl.d_k1);
+      return G1S_OK;
+    };
+    if (coread & 1) {
+      const int rc = coread_with_next_launch();
+      if (rc) return rc;
+    }
     if (!chroma) {
       if (gen) G1S_WGEN(0, -1, -1);
       else G1S_WB(0, -1, -1);
     } else {
       if (gen) G1S_WGEN(0, 1, 1);
       else G1S_WK(0);
+      if (coread & 2) {
+        const int rc = coread_with_next_launch();
+        if (rc) return rc;
+      }
       // The chroma launch stays on the main stream behind the luma launch.  Round 3's chain moved it (and what follows) to the
       // copy stream, next to the luma launch of the batch after; with this chain both launches fill every register of the
       // chip and only stretch each other: serial is +2 - 5 % on the 4K job, +10 % at 8K 4:4:4 (profiles/r04_streams.txt).

@@ -87,6 +87,31 @@ __global__ __launch_bounds__(256) void k1_moments(const FrameTable ft, Geom g, i
   }
 }
 
+// ---------------------------------------------------------------------------------
+// k_dbg_coread (G1S_DBG_COREAD, a measurement aid; profiles/r06b_coread.txt): reads the luma source of the batch the way
+// k1_moments does (lane = a block row of 64 bytes, 256-thread workgroups) with 12 registers and no LDS, so that one of its
+// waves fits on a SIMD beside the four waves of an accumulation launch: what a pass over the planes costs UNDER that launch
+// (three times what it costs behind it).  Writes nothing (the store's condition is never true; the loads cannot be dropped for it).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dbg_coread(const FrameTable ft, Geom g, int32_t *__restrict__ sink) {
+  const int frame = blockIdx.y;
+  const int tid = threadIdx.x, yi = tid & 31;
+  const int blk = (int)blockIdx.x * 8 + (tid >> 5);
+  if (blk >= g.nblocks) return;
+  const int bx = blk % g.nbw, by = blk / g.nbw;
+  const int ox = bx * kBlock, y = min(by * kBlock + yi, g.H - 1);
+  if (ox + kBlock > g.W) return;
+  const FramePlanes fp = ft.f[frame];
+  gptr_u4 p = (gptr_u4)(as_global(fp.src[0]) + (size_t)y * fp.src_stride[0] + (size_t)ox * g.src_bps);
+  uint4 a = gload4(p), b = gload4(p + 1);
+  uint32_t x = a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w;
+  if (g.src_bps == 2) {
+    a = gload4(p + 2), b = gload4(p + 3);
+    x ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w;
+  }
+  if (x == 0x9e3779b9u && sink[0] == 0x12345678) sink[1] = (int32_t)x;
+}
+
 // ---- a value the way the reference computes it, known up to a bound ----
 // v: this kernel's f64 evaluation; e: bound on |reference's rounded evaluation - v|.
 struct VE {

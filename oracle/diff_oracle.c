@@ -29,6 +29,26 @@
  * memory of av1-grain's lib.rs). */
 #define DEFAULT_GRAIN_SEED 10956
 
+/* ---- pin-sensitivity variants (tools/pin_sensitivity.py; oracle/Makefile `variants`) ------------------------------------
+ * The oracle the tests and goldens use is built with NEITHER macro: every product and every sum is its own rounding, and the
+ * normal equations are accumulated per sample.  What cannot be checked here is where av1-grain 0.4.2 writes
+ * f64::mul_add -- a Rust port kept clean under clippy's `suboptimal_flops` has one at every a * b + c -- so the study builds
+ * this file again with fused multiply-adds at groups of sites and counts what moves in the masks, scores, cuts and tables:
+ *   ORC_FMA_SITES  bit mask of the groups below; MA(g, a, b, c) is fma(a, b, c) when g is in it and a * b + c otherwise
+ *                  (identical code to the plain expression when the mask is 0: -ffp-contract=off).
+ *   ORC_DIVIDE_ONCE  the frame's normal equations as ONE division of the exact integer sums (what the HIP path's fold does,
+ *                  grav1synth_amd/csrc/fold.cpp `exact integer sums -> f64 normal equations`) instead of a division a sample. */
+#ifndef ORC_FMA_SITES
+#define ORC_FMA_SITES 0
+#endif
+#define G_LINSOLVE 1  /* linsolve: row updates, back substitution */
+#define G_MATMUL 2    /* multiply_mat, the finder's AtA */
+#define G_FINDER 4    /* gradient covariance sums, var - mean^2, det, disc, the weighted score sum */
+#define G_STRENGTH 8  /* strength solver: lerps, the measurement's products, piecewise fit */
+#define G_NOISE 16    /* block noise variance, the luma-correlated part, ar_equation_system_solve */
+#define G_MODEL 32    /* cross correlation, is_different, the quantisation's weighted means */
+#define MA(g, a, b, c) (((ORC_FMA_SITES) & (g)) ? fma((a), (b), (c)) : ((a) * (b) + (c)))
+
 /* ------------------------------------------------------------------------ */
 /* libaom aom_dsp/mathutils.h linsolve == av1-grain solver/util.rs linsolve  */
 /* ------------------------------------------------------------------------ */
@@ -53,15 +73,15 @@ static int linsolve(int n, double *A, int stride, double *b, double *x) {
     for (i = k; i < n - 1; i++) {
       if (fabs(A[k * stride + k]) < TINY_NEAR_ZERO) return 0;
       c = A[(i + 1) * stride + k] / A[k * stride + k];
-      for (j = 0; j < n; j++) A[(i + 1) * stride + j] -= c * A[k * stride + j];
-      b[i + 1] -= c * b[k];
+      for (j = 0; j < n; j++) A[(i + 1) * stride + j] = MA(G_LINSOLVE, -c, A[k * stride + j], A[(i + 1) * stride + j]);
+      b[i + 1] = MA(G_LINSOLVE, -c, b[k], b[i + 1]);
     }
   }
   /* Backward substitution */
   for (i = n - 1; i >= 0; i--) {
     if (fabs(A[i * stride + i]) < TINY_NEAR_ZERO) return 0;
     c = 0;
-    for (j = i + 1; j <= n - 1; j++) c += A[i * stride + j] * x[j];
+    for (j = i + 1; j <= n - 1; j++) c = MA(G_LINSOLVE, A[i * stride + j], x[j], c);
     x[i] = (b[i] - c) / A[i * stride + i];
   }
   return 1;
@@ -74,7 +94,7 @@ static void multiply_mat(const double *m1, const double *m2, double *res,
     for (int col = 0; col < m2_cols; ++col) {
       double sum = 0;
       for (int inner = 0; inner < inner_dim; ++inner)
-        sum += m1[row * inner_dim + inner] * m2[inner * m2_cols + col];
+        sum = MA(G_MATMUL, m1[row * inner_dim + inner], m2[inner * m2_cols + col], sum);
       *(res++) = sum;
     }
   }
@@ -159,7 +179,7 @@ static double ss_get_value(const strength_solver *s, double x) {
   const int bin_i0 = (int)floor(bin);
   const int bin_i1 = (s->num_bins - 1) < (bin_i0 + 1) ? (s->num_bins - 1) : (bin_i0 + 1);
   const double a = bin - bin_i0;
-  return (1.0 - a) * s->eqns.x[bin_i0] + a * s->eqns.x[bin_i1];
+  return MA(G_STRENGTH, 1.0 - a, s->eqns.x[bin_i0], a * s->eqns.x[bin_i1]);
 }
 static void ss_add_measurement(strength_solver *s, double block_mean, double noise_std) {
   const double bin = ss_bin_index(s, block_mean);
@@ -167,12 +187,12 @@ static void ss_add_measurement(strength_solver *s, double block_mean, double noi
   const int bin_i1 = (s->num_bins - 1) < (bin_i0 + 1) ? (s->num_bins - 1) : (bin_i0 + 1);
   const double a = bin - bin_i0;
   const int n = s->num_bins;
-  s->eqns.A[bin_i0 * n + bin_i0] += (1.0 - a) * (1.0 - a);
-  s->eqns.A[bin_i1 * n + bin_i0] += a * (1.0 - a);
-  s->eqns.A[bin_i1 * n + bin_i1] += a * a;
-  s->eqns.A[bin_i0 * n + bin_i1] += a * (1.0 - a);
-  s->eqns.b[bin_i0] += (1.0 - a) * noise_std;
-  s->eqns.b[bin_i1] += a * noise_std;
+  s->eqns.A[bin_i0 * n + bin_i0] = MA(G_STRENGTH, 1.0 - a, 1.0 - a, s->eqns.A[bin_i0 * n + bin_i0]);
+  s->eqns.A[bin_i1 * n + bin_i0] = MA(G_STRENGTH, a, 1.0 - a, s->eqns.A[bin_i1 * n + bin_i0]);
+  s->eqns.A[bin_i1 * n + bin_i1] = MA(G_STRENGTH, a, a, s->eqns.A[bin_i1 * n + bin_i1]);
+  s->eqns.A[bin_i0 * n + bin_i1] = MA(G_STRENGTH, a, 1.0 - a, s->eqns.A[bin_i0 * n + bin_i1]);
+  s->eqns.b[bin_i0] = MA(G_STRENGTH, 1.0 - a, noise_std, s->eqns.b[bin_i0]);
+  s->eqns.b[bin_i1] = MA(G_STRENGTH, a, noise_std, s->eqns.b[bin_i1]);
   s->total += noise_std;
   s->num_equations++;
 }
@@ -231,8 +251,7 @@ static void update_piecewise_linear_residual(const strength_solver *s,
       const double y = s->eqns.x[j];
       const double a = (x - lut->points[i - 1][0]) /
                        (lut->points[i + 1][0] - lut->points[i - 1][0]);
-      const double estimate_y =
-          lut->points[i - 1][1] * (1.0 - a) + lut->points[i + 1][1] * a;
+      const double estimate_y = MA(G_STRENGTH, lut->points[i - 1][1], 1.0 - a, lut->points[i + 1][1] * a);
       r += fabs(y - estimate_y);
     }
     residual[i] = r * dx;
@@ -294,7 +313,7 @@ static void ff_init(flat_finder *f) {
       f->A[n * row + 1] = xd;
       f->A[n * row + 2] = 1;
       for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) eqns.A[n * i + j] += coords[i] * coords[j];
+        for (int j = 0; j < n; ++j) eqns.A[n * i + j] = MA(G_MATMUL, coords[i], coords[j], eqns.A[n * i + j]);
     }
   }
   /* Lazy inverse using existing equation solver. */
@@ -363,11 +382,11 @@ static int ff_run(const flat_finder *f, const uint8_t *data, int w, int h,
         for (int xi = 1; xi < BLOCK_SIZE - 1; ++xi) {
           const double gx = (block[yi * BLOCK_SIZE + xi + 1] - block[yi * BLOCK_SIZE + xi - 1]) / 2;
           const double gy = (block[yi * BLOCK_SIZE + xi + BLOCK_SIZE] - block[yi * BLOCK_SIZE + xi - BLOCK_SIZE]) / 2;
-          Gxx += gx * gx;
-          Gxy += gx * gy;
-          Gyy += gy * gy;
+          Gxx = MA(G_FINDER, gx, gx, Gxx);
+          Gxy = MA(G_FINDER, gx, gy, Gxy);
+          Gyy = MA(G_FINDER, gy, gy, Gyy);
           mean += block[yi * BLOCK_SIZE + xi];
-          var += block[yi * BLOCK_SIZE + xi] * block[yi * BLOCK_SIZE + xi];
+          var = MA(G_FINDER, block[yi * BLOCK_SIZE + xi], block[yi * BLOCK_SIZE + xi], var);
         }
       }
       mean /= norm_factor;
@@ -375,13 +394,13 @@ static int ff_run(const flat_finder *f, const uint8_t *data, int w, int h,
       Gxx /= norm_factor;
       Gxy /= norm_factor;
       Gyy /= norm_factor;
-      var = var / norm_factor - mean * mean;
+      var = MA(G_FINDER, -mean, mean, var / norm_factor);
       {
         const double trace = Gxx + Gyy;
-        const double det = Gxx * Gyy - Gxy * Gxy;
+        const double det = MA(G_FINDER, Gxx, Gyy, -(Gxy * Gxy));
         /* av1-grain guards the discriminant with max(.,0) (libaom does not);
          * from memory, see SURVEY.md Appendix A.4. */
-        double disc = trace * trace - 4 * det;
+        double disc = MA(G_FINDER, trace, trace, -(4 * det));
         if (!(disc > 0.0)) disc = 0.0;
         const double e1 = (trace + sqrt(disc)) / 2.;
         const double e2 = (trace - sqrt(disc)) / 2.;
@@ -391,8 +410,8 @@ static int ff_run(const flat_finder *f, const uint8_t *data, int w, int h,
                             (norm < kNormThreshold) && (var > kVarThreshold);
         /* weights: [{var}, {ratio}, {trace}, {norm}, offset] */
         const double weights[5] = { -6682, -0.2056, 13087, -12434, 2.5694 };
-        double sum_weights = weights[0] * var + weights[1] * ratio +
-                             weights[2] * trace + weights[3] * norm + weights[4];
+        double sum_weights =
+            MA(G_FINDER, weights[3], norm, MA(G_FINDER, weights[2], trace, MA(G_FINDER, weights[1], ratio, weights[0] * var))) + weights[4];
         /* clamp the value to [-25.0, 100.0] to prevent overflow */
         sum_weights = fclamp(sum_weights, -25.0, 100.0);
         const float score = (float)(1.0 / (1 + exp(-sum_weights)));
@@ -482,7 +501,7 @@ static int ar_equation_system_solve(noise_state *s, int is_chroma) {
   double sum_covar = 0;
   for (int i = 0; i < n - is_chroma; ++i) {
     double bi = s->eqns.b[i];
-    if (is_chroma) bi -= s->eqns.A[i * n + (n - 1)] * s->eqns.x[n - 1];
+    if (is_chroma) bi = MA(G_NOISE, -s->eqns.A[i * n + (n - 1)], s->eqns.x[n - 1], bi);
     sum_covar += (bi * s->eqns.x[i]) / s->num_observations;
   }
   const double t = var - sum_covar;
@@ -589,6 +608,23 @@ static void add_block_observations(noise_model *m, int c, const planes8 *P,
       }
     }
   }
+#ifdef ORC_DIVIDE_ONCE
+  /* the frame's system from the exact integer sums, one division an entry (the chroma regressor's sum is ns x the average the
+   * per-sample form uses): needs the integer shadow, which every caller of this file passes */
+  if (sh) {
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < n; ++j) {
+        double den = normalization * normalization;
+        if (c > 0 && i == n - 1) den *= ns;
+        if (c > 0 && j == n - 1) den *= ns;
+        A[i * n + j] = (double)sh->S[c][i * n + j] / den;
+      }
+      double den = normalization * normalization;
+      if (c > 0 && i == n - 1) den *= ns;
+      b[i] = (double)sh->Sb[c][i] / den;
+    }
+  }
+#endif
   (void)ns;
 }
 
@@ -613,13 +649,13 @@ static double get_noise_var(const uint8_t *data, const uint8_t *denoised, int st
     for (int x = 0; x < max_w; ++x) {
       double noise = (double)data[(y_o + y) * stride + x_o + x] - denoised[(y_o + y) * stride + x_o + x];
       noise_mean += noise;
-      noise_var += noise * noise;
+      noise_var = MA(G_NOISE, noise, noise, noise_var);
     }
   }
   if (isd) *isd = (int32_t)noise_mean;
   if (isd2) *isd2 = (uint32_t)noise_var;
   noise_mean /= (max_w * max_h);
-  return noise_var / (max_w * max_h) - noise_mean * noise_mean;
+  return MA(G_NOISE, -noise_mean, noise_mean, noise_var / (max_w * max_h));
 }
 
 /* libaom add_noise_std_observations */
@@ -663,7 +699,7 @@ static void add_noise_std_observations(noise_model *m, int c, const double *coef
         /* don't allow fully correlated noise (hence the max) */
         const double t0 = noise_var / 16;
         const double cl = corr * luma_strength; /* Rust powi(2) == x*x */
-        const double t1 = noise_var - cl * cl;
+        const double t1 = MA(G_NOISE, -cl, cl, noise_var);
         const double uncorr_std = sqrt(t0 > t1 ? t0 : t1);
         /* undo the gain of the IIR filter */
         const double adjusted_strength = uncorr_std / noise_gain;
@@ -676,9 +712,9 @@ static void add_noise_std_observations(noise_model *m, int c, const double *coef
 static double normalized_cross_correlation(const double *a, const double *b, int n) {
   double c = 0, a_len = 0, b_len = 0;
   for (int i = 0; i < n; ++i) {
-    a_len += a[i] * a[i];
-    b_len += b[i] * b[i];
-    c += a[i] * b[i];
+    a_len = MA(G_MODEL, a[i], a[i], a_len);
+    b_len = MA(G_MODEL, b[i], b[i], b_len);
+    c = MA(G_MODEL, a[i], b[i], c);
   }
   return c / (sqrt(a_len) * sqrt(b_len));
 }
@@ -697,7 +733,7 @@ static int is_noise_model_different(const noise_model *m) {
     double weight = 0;
     for (int i = 0; i < le->n; ++i) weight += le->A[i * le->n + j];
     weight = sqrt(weight);
-    diff += weight * fabs(le->x[j] - ce->x[j]);
+    diff = MA(G_MODEL, weight, fabs(le->x[j] - ce->x[j]), diff);
     total_weight += weight;
   }
   if (diff * dx / total_weight > kStrengthThreshold) return 1;
@@ -812,7 +848,7 @@ static void nm_get_grain_parameters(const noise_model *m, uint64_t start_ts,
   for (int c = 0; c < 3; c++) {
     for (int i = 0; i < scaling_points[c].num_points; ++i) {
       dst[c][i][0] = (uint8_t)clampi((int)(scaling_points[c].points[i][0] + 0.5), 0, 255);
-      dst[c][i][1] = (uint8_t)clampi((int)(scale_factor * scaling_points[c].points[i][1] + 0.5), 0, 255);
+      dst[c][i][1] = (uint8_t)clampi((int)MA(G_MODEL, scale_factor, scaling_points[c].points[i][1], 0.5), 0, 255);
     }
   }
 
@@ -833,7 +869,7 @@ static void nm_get_grain_parameters(const noise_model *m, uint64_t start_ts,
       double w = 0;
       for (int j = 0; j < solver->eqns.n; ++j) w += solver->eqns.A[i * solver->eqns.n + j];
       w = sqrt(w);
-      average_strength += solver->eqns.x[i] * w;
+      average_strength = MA(G_MODEL, solver->eqns.x[i], w, average_strength);
       total_weight += w;
     }
     if (total_weight == 0)
