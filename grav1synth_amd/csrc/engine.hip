@@ -28,7 +28,7 @@
 #include "kernels.hip.h"
 #include "k1f.hip.h"
 #include "k3m.hip.h"
-#include "k3f.hip.h"
+#include "k3s_params.hip.h"
 #include "k3s.hip.h"
 #include "k3w.hip.h"
 #include "latest_dev.h"
@@ -491,7 +491,8 @@ struct g1s_diff {
   std::mutex ktimes_mutex;
   // timed batches run on one stream: an event before each launch (and one after the last), named after the kernel
   int kmark(Slot &sl, hipStream_t st, const char *name) {
-    if ((!sl.timed || sl.chain) && !trace) return G1S_OK;
+    if (sl.chain) return G1S_OK;  // (a chain-timed batch: nothing between two of its launches, trace mode or not)
+    if (!sl.timed && !trace) return G1S_OK;
     if (sl.nk == sl.kev.size()) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return fail(G1S_ERR_HIP, "hipEventCreate failed");
@@ -1373,11 +1374,23 @@ int g1s_diff::launch_back(int si) {
         static const int lp = getenv("G1S_LATEST_PRIO") ? atoi(getenv("G1S_LATEST_PRIO")) : 1;
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-        for (hipStream_t *st : {&ss.latest, &ss.latest2}) {
-          if (lp == 0) HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-          else HIP_TRY(hipStreamCreateWithPriority(st, hipStreamNonBlocking, lp == 1 ? plo : phi));
+        // (made into locals and handed to the stream set -- which goes back to the process-wide cache -- only when ALL of them
+        //  exist: a failure half way must not leave a set that looks complete with a null stream or event in it)
+        hipStream_t made[2] = {nullptr, nullptr};
+        hipEvent_t made_ev[kSlots] = {};
+        bool ok = true;
+        for (hipStream_t &st : made)
+          ok = ok && (lp == 0 ? hipStreamCreateWithFlags(&st, hipStreamNonBlocking) : hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lp == 1 ? plo : phi)) == hipSuccess;
+        for (int i = 0; i < kSlots; ++i) ok = ok && hipEventCreateWithFlags(&made_ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+          for (hipStream_t st : made)
+            if (st) (void)hipStreamDestroy(st);
+          for (hipEvent_t e : made_ev)
+            if (e) (void)hipEventDestroy(e);
+          return fail_hip("the device half's streams / events could not be created");
         }
-        for (int i = 0; i < kSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&ss.latest_done[i], hipEventDisableTiming));
+        ss.latest = made[0], ss.latest2 = made[1];
+        for (int i = 0; i < kSlots; ++i) ss.latest_done[i] = made_ev[i];
       }
       static const bool one_latest = getenv("G1S_LATEST_ONE_STREAM") != nullptr;  // (tuning aid: round 4's placement)
       hipStream_t lst = (si & 1) && !one_latest ? ss.latest2 : ss.latest;
@@ -1666,13 +1679,6 @@ int g1s_diff::drain_all() {
 }
 
 void g1s_diff::release() {
-  if (trace && !trace_lines.empty()) {
-    if (FILE *f = fopen(getenv("G1S_TRACE"), "a")) {
-      for (const auto &l : trace_lines) fprintf(f, "%s\n", l.c_str());
-      fclose(f);
-    }
-    trace_lines.clear();
-  }
   if (drainer.joinable()) {
     {
       std::lock_guard<std::mutex> lk(dm);
@@ -1697,6 +1703,18 @@ void g1s_diff::release() {
   if (ss.flat2) (void)hipStreamSynchronize(ss.flat2);
   if (ss.mom) (void)hipStreamSynchronize(ss.mom);
   if (ss.upload) (void)hipStreamSynchronize(ss.upload);
+  if (ss.coread) (void)hipStreamSynchronize(ss.coread);
+  // (the trace: written when nothing can add to it any more -- the drainer and the folder are joined, the streams idle)
+  if (trace) {
+    std::lock_guard<std::mutex> lk(trace_mutex);
+    if (!trace_lines.empty()) {
+      if (FILE *f = fopen(getenv("G1S_TRACE"), "a")) {
+        for (const auto &l : trace_lines) fprintf(f, "%s\n", l.c_str());
+        fclose(f);
+      }
+      trace_lines.clear();
+    }
+  }
   release_streams(ss);
   for (Slot &sl : slots) {
     if (sl.h_planes && geometry_set) {  // park the buffers for the next generator of this geometry

@@ -22,7 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "k0.hip.h"
+#include "pixel_helpers.hip.h"
 #include "kernels.hip.h"
 
 namespace g1s {

@@ -20,13 +20,13 @@
 // flat block, listed per frame by k3m_units together with the observation windows of its blocks.  This
 // file holds the scheme's shared parts (matrix row map, tile geometry, the copy writer, the multiply
 // loops, the unit lists, the reducer); the kernel that stages the tiles straight from the source /
-// denoised planes and multiplies them is k3f.hip.h.  Any lag 1..3 (the lag-L neighbourhood and window
+// denoised planes and multiplies them is k3s.hip.h (round 2: k3f_fused, removed).  Any lag 1..3 (the lag-L neighbourhood and window
 // border; the other matrix rows are ignored).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "k0.hip.h"
+#include "pixel_helpers.hip.h"
 #include "kernels.hip.h"
 
 namespace g1s {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
     if (!((bits >> b) & 1u) || (kind && !chroma)) continue;
     const int bw = kind ? (kBlock >> g.xdec) : kBlock, bh = kind ? (kBlock >> g.ydec) : kBlock;
     const int pw = kind ? (g.W >> g.xdec) : g.W, ph = kind ? (g.H >> g.ydec) : g.H;
-    // block_window (k0.hip.h) on the bytes read above
+    // block_window (pixel_helpers.hip.h) on the bytes read above
     const int left = b ? m_0 : m_l, right = b ? m_r : m_1, up = b ? u_1 : u_0;
     Win w{1, 0, 0, 0, 0};
     w.ys = up ? 0 : g.lag;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k3m_units(Geom g, const uint8_t *__restri
     if (!w.flat || w.xs != 0 || w.ys != 0 || w.xe != bw || w.ye != bh) plain = false;
     if (!w.flat) continue;
     // (a pixel pass may have flagged residuals outside int8: the tile reaches into the left / right / upper neighbours;
-    //  the fused pass, k3f.hip.h, finds them itself)
+    //  the fused pass finds them itself)
     bool defer = false;
     if (mp.bad) {
       const uint8_t *bad = mp.bad + ((size_t)frame * 2 + kind) * g.nblocks;

@@ -1,6 +1,6 @@
 // k3s.hip.h -- the fused accumulation pass, second generation (G1S_K3=stream).
 //
-// Same job as k3f.hip.h (source / denoised planes of the flat blocks' tiles -> residual tiles in LDS -> exact int8 SYRK on
+// Same job as k3s_params.hip.h (source / denoised planes of the flat blocks' tiles -> residual tiles in LDS -> exact int8 SYRK on
 // the matrix cores -> one partial system per workgroup and plane; block statistics, L plane and out-of-int8 deferrals on
 // the way), same lists (k3m_units), same finisher (k3m_finish), same records.  What differs is how a unit moves through
 // the workgroup -- and how many instructions that takes: the SQ counters of k3f and of this kernel's first form
@@ -24,15 +24,15 @@
 //    takes the general path (predicated loads, halo lanes, flags), a wave-uniform branch away.
 //  * One LDS read per iteration for everything uniform a unit needs (a control word built when the entries are parked).
 //
-// Bit-exact against k3f.hip.h and the oracle (tests/test_gpu_parity.py::test_accumulation_modes_agree).
+// Bit-exact against k3s_params.hip.h and the oracle (tests/test_gpu_parity.py::test_accumulation_modes_agree).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <type_traits>
 
-#include "k0.hip.h"
-#include "k3f.hip.h"
+#include "pixel_helpers.hip.h"
+#include "k3s_params.hip.h"
 #include "k3m.hip.h"
 #include "kernels.hip.h"
 

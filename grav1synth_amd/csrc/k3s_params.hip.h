@@ -1,4 +1,4 @@
-// k3f.hip.h -- what is left of round 2's fused accumulation pass (the k3f_fused kernel itself was removed in round 4): the launch
+// k3s_params.hip.h -- what is left of round 2's fused accumulation pass (the k3f_fused kernel itself was removed in round 4): the launch
 // parameters and the load / narrowing helpers k3s.hip.h (the stream chain, the wide chain's fallback) is built on.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -6,7 +6,7 @@
 
 #include <type_traits>
 
-#include "k0.hip.h"
+#include "pixel_helpers.hip.h"
 #include "k3m.hip.h"
 #include "kernels.hip.h"
 

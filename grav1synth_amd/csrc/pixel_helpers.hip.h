@@ -1,4 +1,4 @@
-// k0.hip.h -- shared helpers of the pixel kernels: packed 16-bit arithmetic, the block-window rule of
+// pixel_helpers.hip.h -- shared helpers of the pixel kernels: packed 16-bit arithmetic, the block-window rule of
 // add_block_observations, the flat-block finder's row moments (k1f.hip.h), the per-batch zero fill.
 // (The streaming pixel pass K0 of rounds 1 and 2 -- int8 residual / L / window-bit planes in front of the accumulation -- and
 // its window kernel were removed in round 4; the name of the file stayed.)

@@ -1072,6 +1072,47 @@ int orc_diff_finish(orc_diff *g, orc_segment *out, int cap) {
   return g->ntable;
 }
 
+/* ---- checkpoint of a generator between two frames (tests/golden/make_golden.py long: an hour-long job that must survive an
+ * interrupted session).  The state that crosses frames is the noise model (plain arrays), the frame counter, the last cut's
+ * timestamp and the segments emitted so far; everything else is scratch of the frame in hand. ---- */
+size_t orc_diff_state_size(const orc_diff *g) {
+  return sizeof(uint64_t) * 3 + sizeof(noise_model) + sizeof(orc_segment) * (size_t)g->ntable;
+}
+long orc_diff_save(const orc_diff *g, void *buf, size_t cap) {
+  const size_t need = orc_diff_state_size(g);
+  if (cap < need) return -1;
+  uint8_t *p = (uint8_t *)buf;
+  const uint64_t head[3] = { g->frame_count, g->prev_timestamp, (uint64_t)g->ntable };
+  memcpy(p, head, sizeof(head));
+  p += sizeof(head);
+  memcpy(p, &g->model, sizeof(noise_model));
+  p += sizeof(noise_model);
+  if (g->ntable) memcpy(p, g->table, sizeof(orc_segment) * (size_t)g->ntable);
+  return (long)need;
+}
+int orc_diff_restore(orc_diff *g, const void *buf, size_t size) {
+  const uint8_t *p = (const uint8_t *)buf;
+  uint64_t head[3];
+  if (size < sizeof(head) + sizeof(noise_model)) return -1;
+  memcpy(head, p, sizeof(head));
+  p += sizeof(head);
+  if (size != sizeof(head) + sizeof(noise_model) + sizeof(orc_segment) * (size_t)head[2]) return -1;
+  noise_model m;
+  memcpy(&m, p, sizeof(m));
+  if (m.lag != g->model.lag) return -2;
+  p += sizeof(noise_model);
+  g->model = m;
+  g->frame_count = head[0];
+  g->prev_timestamp = head[1];
+  g->ntable = 0;
+  for (uint64_t i = 0; i < head[2]; ++i) {
+    orc_segment sgm;
+    memcpy(&sgm, p + sizeof(orc_segment) * i, sizeof(sgm));
+    push_segment(g, &sgm);
+  }
+  return 0;
+}
+
 const uint8_t *orc_last_flat_mask(const orc_diff *g, int *nbw, int *nbh) {
   if (nbw) *nbw = g->nbw;
   if (nbh) *nbh = g->nbh;

@@ -79,6 +79,12 @@ int orc_diff_finish(orc_diff *, orc_segment *out, int cap);
 void orc_diff_free(orc_diff *);
 const char *orc_diff_last_error(const orc_diff *);
 
+/* ---- checkpoint between two frames (the state that crosses frames: noise model, counters, segments so far); restore into a
+ * generator made with the same arguments.  save returns the bytes written or <0 (cap too small); restore 0 or <0. ---- */
+size_t orc_diff_state_size(const orc_diff *);
+long orc_diff_save(const orc_diff *, void *buf, size_t cap);
+int orc_diff_restore(orc_diff *, const void *buf, size_t size);
+
 /* ---- introspection of the LAST frame (for pinning GPU intermediates) ---- */
 /* flat mask bytes (0 / 1 / 255 / 255|1) in block raster order */
 const uint8_t *orc_last_flat_mask(const orc_diff *, int *nbw, int *nbh);

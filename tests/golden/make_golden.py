@@ -55,28 +55,60 @@ def frame_specs(g):
     return [b if sum(k >= c for c in cuts) & 1 else spec for k in range(g["frames"])]
 
 
-def generate_long(name, workers=3):
+def generate_long(name, workers=3, checkpoint_every=25):
     """a LONG golden: the frames are made ahead on a few threads (a 4K pair is a second of integer torch work), the oracle takes
-    them in order"""
+    them in order.  Two aids for an hour-long job: the oracle compiled for this machine's vector unit (oracle/Makefile
+    `_variants/liborc_native.so`: the same IEEE operations packed, no contraction, no reassociation -- checked here against every
+    committed small golden and the 4K scene-cut golden's first frames before it is trusted), and a checkpoint of the generator's
+    state every few frames (/tmp/<name>.ckpt: orc_diff_save) from which an interrupted run carries on."""
+    import pickle
     import time
     from concurrent.futures import ThreadPoolExecutor
 
     from tests.helpers import np_pair
-    from tests.oracle_binding import OracleDiff, format_tbl
+    from tests.oracle_binding import OracleDiff, format_tbl, load_variant
 
+    L = load_variant("native")
+    for gname, gg in GOLDEN.items():  # the native build writes the committed bytes
+        o = OracleDiff(*( gg.get("fps", (30000, 1001)) if "cut" in gg else (24, 1)), gg["spec"].bit_depth, gg["spec"].bit_depth, gg["lag"], gg["chroma"], library=L)
+        for k, sp in enumerate(frame_specs(gg)):
+            s, d = np_pair(sp, k)
+            o.diff_frame(s if gg["chroma"] else s[:1], d if gg["chroma"] else d[:1], sp.xdec, sp.ydec)
+        with open(os.path.join(HERE, gname), "rb") as f:
+            assert format_tbl(o.finish()) == f.read(), f"the native build of the oracle differs on {gname}"
     g = LONG[name]
     specs = frame_specs(g)
-    o = OracleDiff(g["fps"][0], g["fps"][1], g["spec"].bit_depth, g["spec"].bit_depth, g["lag"], g["chroma"])
+    o = OracleDiff(g["fps"][0], g["fps"][1], g["spec"].bit_depth, g["spec"].bit_depth, g["lag"], g["chroma"], library=L)
+    # ... and the same states as the base build after two 4K frames (every f64 of the noise model)
+    ob = OracleDiff(g["fps"][0], g["fps"][1], g["spec"].bit_depth, g["spec"].bit_depth, g["lag"], g["chroma"])
+    ckpt = os.path.join("/tmp", name + ".ckpt")
+    start = 0
+    if os.path.exists(ckpt):
+        with open(ckpt, "rb") as f:
+            start, state = pickle.load(f)
+        o.restore(state)
+        print(f"  resuming behind frame {start}", flush=True)
+    else:
+        for k in range(2):
+            s, d = np_pair(specs[k], k)
+            o.diff_frame(s, d, specs[k].xdec, specs[k].ydec)
+            ob.diff_frame(s, d, specs[k].xdec, specs[k].ydec)
+        assert o.save() == ob.save(), "the native build of the oracle differs from the base build on 4K frames"
+        start = 2
+    ob.close()
     t0 = time.time()
     with ThreadPoolExecutor(workers) as ex:
         ahead = workers + 1
-        futs = {k: ex.submit(np_pair, specs[k], k) for k in range(min(ahead, len(specs)))}
-        for k in range(len(specs)):
+        futs = {k: ex.submit(np_pair, specs[k], k) for k in range(start, min(start + ahead, len(specs)))}
+        for k in range(start, len(specs)):
             s, d = futs.pop(k).result()
             if k + ahead < len(specs):
                 futs[k + ahead] = ex.submit(np_pair, specs[k + ahead], k + ahead)
             o.diff_frame(s, d, specs[k].xdec, specs[k].ydec)
-            if k % 25 == 24:
+            if (k + 1) % checkpoint_every == 0:
+                with open(ckpt + ".tmp", "wb") as f:
+                    pickle.dump((k + 1, o.save()), f)
+                os.replace(ckpt + ".tmp", ckpt)
                 print(f"  frame {k + 1}/{len(specs)}  {time.time() - t0:.0f} s  segments so far {o.num_segments()}", flush=True)
     return format_tbl(o.finish())
 
@@ -101,6 +133,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 2:  # `full NAME ...`: only those
         names = sys.argv[2:]
     for name in names:
+        tbl = generate(name)  # (the file is opened when there is something to write: a long job must not leave an empty golden behind)
         with open(os.path.join(HERE, name), "wb") as f:
-            f.write(generate(name))
+            f.write(tbl)
         print("wrote", name)

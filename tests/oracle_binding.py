@@ -68,17 +68,7 @@ def build() -> None:
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_LIB_PATH):
-        build()
-    L = C.CDLL(_LIB_PATH)
-    if not hasattr(L, "orc_estimate_plane_noise") or not hasattr(L, "orc_resize_plane"):  # a library from before these were added
-        del L
-        build()
-        L = C.CDLL(_LIB_PATH)
+def _prototypes(L):
     L.orc_estimate_plane_noise.restype = C.c_double
     L.orc_estimate_plane_noise.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]
     L.orc_resize_plan.restype = C.c_int
@@ -106,8 +96,37 @@ def lib():
     L.orc_num_segments.argtypes = [C.c_void_p]
     L.orc_format_tbl.restype = C.c_long
     L.orc_format_tbl.argtypes = [C.POINTER(OrcSegment), C.c_int, C.c_char_p, C.c_size_t]
-    _lib = L
+    if hasattr(L, "orc_diff_save"):
+        L.orc_diff_state_size.restype = C.c_size_t
+        L.orc_diff_state_size.argtypes = [C.c_void_p]
+        L.orc_diff_save.restype = C.c_long
+        L.orc_diff_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_diff_restore.restype = C.c_int
+        L.orc_diff_restore.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     return L
+
+
+def load_variant(name: str):
+    """A pin-sensitivity build of the oracle (oracle/Makefile `variants`; tools/pin_sensitivity.py): the same restatement with fused
+    multiply-adds at a group of sites / contraction left to the compiler / one division of the exact sums a frame."""
+    path = os.path.join(ORACLE_DIR, "_variants", f"liborc_{name}.so")
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, f"_variants/liborc_{name}.so"])
+    return _prototypes(C.CDLL(path))
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    if not hasattr(L, "orc_estimate_plane_noise") or not hasattr(L, "orc_resize_plane") or not hasattr(L, "orc_diff_save"):  # a library from before these were added
+        del L
+        build()
+        L = C.CDLL(_LIB_PATH)
+    _lib = _prototypes(L)
+    return _lib
 
 
 def estimate_plane_noise(plane: np.ndarray, bit_depth: int) -> Optional[float]:
@@ -162,8 +181,8 @@ class OracleDiff:
     """The oracle behind the same three-method shape as av1_grain::DiffGenerator
     (reference src/main.rs:420-427, :442, :524)."""
 
-    def __init__(self, fps_num: int, fps_den: int, src_bd: int, den_bd: int, lag: int = 3, chroma: bool = True):
-        self.L = lib()
+    def __init__(self, fps_num: int, fps_den: int, src_bd: int, den_bd: int, lag: int = 3, chroma: bool = True, library=None):
+        self.L = library if library is not None else lib()  # (library: a pin-sensitivity variant, load_variant)
         self.h = self.L.orc_diff_new(fps_num, fps_den, src_bd, den_bd, lag, int(chroma))
         if not self.h:
             raise ValueError("orc_diff_new failed (lag must be 1..3)")
@@ -213,6 +232,18 @@ class OracleDiff:
 
     def num_segments(self) -> int:
         return self.L.orc_num_segments(self.h)
+
+    def save(self) -> bytes:
+        """the state that crosses frames (checkpoint of a long job)"""
+        n = self.L.orc_diff_state_size(self.h)
+        buf = C.create_string_buffer(n)
+        assert self.L.orc_diff_save(self.h, buf, n) == n
+        return buf.raw
+
+    def restore(self, state: bytes) -> None:
+        rc = self.L.orc_diff_restore(self.h, state, len(state))
+        if rc:
+            raise ValueError(f"orc_diff_restore failed ({rc})")
 
     def close(self):
         if self.h:
