@@ -320,6 +320,8 @@ __device__ __forceinline__ void w_multiply(w_v4 &aS, w_v4 &aP, w_v4 &aX, w_v4 &a
   constexpr int P = kWUnitW;
   w_v4 q = *reinterpret_cast<const w_v4 *>(smem + a0 - P);
   if constexpr (MODE == 1) aQ = __builtin_amdgcn_mfma_i32_16x16x64_i8(q & cm, q, aQ, 0, 0, 0);
+  // (measured and dropped, profiles/r06f_halo_rotation.txt: the plain chain with FOUR operand reads in flight, pinned with scheduling
+  //  barriers -- same registers, same time: the SIMD has three other waves to issue from while one waits for its operands)
   constexpr int H = MODE == 2 ? 1 : 2;  // operand reads in flight (the general form holds three masked copies besides)
 #pragma unroll
   for (int j0 = 0; j0 < NSTEP; j0 += H) {
@@ -422,8 +424,10 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
   const uint32_t sst = CHR ? (s_plane ? fp.src_stride[2] : fp.src_stride[1]) : fp.src_stride[0];
   const uint32_t dst_ = CHR ? (s_plane ? fp.den_stride[2] : fp.den_stride[1]) : fp.den_stride[0];
   // own iteration i: tile rows t = 4 + own_row0 + 8 i + 2 p + r
-  // (measured and dropped: the halo wave rotating with the workgroup -- pseudo-randomly, so that the four workgroups of a CU
-  //  would not all load the same SIMD with it: luma 399 - 429 -> 430 - 441 us, tools/r4_rot.sh)
+  // (measured and dropped, twice: the halo wave rotating with the workgroup so that the four workgroups of a CU would not all
+  //  load the same SIMD with it -- round 4, pseudo-randomly: luma 399 - 429 -> 430 - 441 us; round 6, by the bits of the workgroup
+  //  index that differ between the workgroups dealt to one CU: 363 - 367 -> 367 - 374, chroma 217 -> 216 - 220, all-flat 537 -> 543:
+  //  nothing.  The halo wave's extra row is not what the workgroup's barriers wait for.  profiles/r06f_halo_rotation.txt)
   const int swave = wave;
   const int own_row0 = CHR ? (swave & 1) * (BH / 2) : 8 * swave;
   // the halo rows (tile rows 0 .. 3) of a plane: one more QUARTER iteration on the plane's last wave -- its 64 lanes are the
