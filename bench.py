@@ -107,6 +107,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-all-flat", action="store_true", help="skip the all-flat variant's timed-kernels job (roofline.frac_all_flat)")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--no-table-check", action="store_true", help="skip the untimed half-batch job the timed job's table is checked against "
+                    "(profiling runs: its launches are half the size and would halve the profiler's per-kernel averages)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -258,7 +260,7 @@ def main() -> None:
     # launch (another partition of the video into launches, other slices a workgroup: the integer records do not depend on it), untimed;
     # every warm-up and timed step must end in the same bytes.
     check_tbl = None
-    if not multi:
+    if not multi and not args.no_table_check:
         one_step(False, batch=max(1, B // 2))
         check_tbl = tbl_digests.pop()
     for _ in range(args.warmup):
@@ -453,6 +455,7 @@ def main() -> None:
             "flat_fraction": (st.flat_blocks / st.blocks) if st.blocks else None,
             "avg_launch_ms": batch_ms,
             "avg_launch_ms_kernel_events": batch_ms_events,
+            "frac_kernel_events": (alg_bytes_per_launch / (batch_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS) if batch_ms_events > 0 else None,
             "alg_bytes_per_launch": alg_bytes_per_launch,
             "frames_per_launch": frames_per_launch,
             "dominant_kernel": {

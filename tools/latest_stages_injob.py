@@ -12,6 +12,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "grav1synth_amd", "libg1s_v_lprof.so")
+if not os.path.exists(lib):  # (no profiling build: the job's rate and cores only)
+    lib = os.path.join(ROOT, "grav1synth_amd", "libg1s_diff.so")
 os.environ["G1S_LIB"] = lib
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from fractions import Fraction  # noqa: E402
@@ -30,8 +32,8 @@ pairs = [make_pair(spec, k, device="cuda") for k in range(2 * B)]
 prep = [DiffGenerator.prepare_frames(pairs[i:i + B], 1, 1) for i in (0, B)]
 torch.cuda.synchronize()
 L = _lib.lib()
-sym = [s for s in os.popen(f"nm -D {lib}").read().split() if "latest_stage" in s][0]
-arr = (C.c_double * 8).in_dll(L, sym)
+syms = [s for s in os.popen(f"nm -D {lib}").read().split() if "latest_stage" in s]
+arr = (C.c_double * 8).in_dll(L, syms[0]) if syms else (C.c_double * 8)()
 for rep in range(2):
     for i in range(8):
         arr[i] = 0.0

@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 python tools/ktime.py 2 > /dev/null 2>&1   # (warm the box: the first process runs slow)
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 400 gpurun_out/${TAG}_bench.json; echo
-B="python $ROOT/bench.py --steps 2 --warmup 1 --cycles 8 --no-cpu-baseline --no-all-flat"
+B="python $ROOT/bench.py --steps 2 --warmup 1 --cycles 8 --no-cpu-baseline --no-all-flat --no-table-check"
 bash tools/prof.sh ${TAG}_kt --kernel-trace --stats -- $B > /dev/null
 G1S_ONE_STREAM=1 G1S_D2H_SYNC=1 bash tools/prof.sh ${TAG}_kt1 --kernel-trace --stats -- $B > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do

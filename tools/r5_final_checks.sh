@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 {
-echo "# final build of round 5 (commit $(cat .gpurun_head 2>/dev/null || echo unknown)), 1x MI355X"
+echo "# final build (OUT=${OUT:-r06}; commit $(cat .gpurun_head 2>/dev/null || echo unknown)), 1x MI355X"
 echo "## tools/check_large.py 3840 2160 10 1 1 3 (the bench workload's format, three frames, every record field and the table vs the oracle)"
 timeout 900 python tools/check_large.py 3840 2160 10 1 1 3 2>&1 | tail -1
 echo "## tools/check_large.py (8K 10-bit 4:4:4, two frames)"
@@ -17,5 +17,5 @@ G1S_LATEST=device timeout 1500 python tools/fuzz_parity.py 300 73 2>&1 | tail -2
 echo "## tools/debug_damage3.py 400 75 (prints failures only)"
 timeout 1500 python tools/debug_damage3.py 400 75 2>&1 | grep -v amdgpu.ids | tail -5
 echo "(end)"
-} > gpurun_out/r05_final_checks.txt 2>&1
-grep -v "amdgpu.ids" gpurun_out/r05_final_checks.txt
+} > gpurun_out/${OUT:-r06}_final_checks.txt 2>&1
+grep -v "amdgpu.ids" gpurun_out/${OUT:-r06}_final_checks.txt

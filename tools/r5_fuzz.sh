@@ -6,7 +6,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 S=${1:-1}
 {
-echo "# tools/r5_fuzz.sh $S on commit $(cat .gpurun_head 2>/dev/null || echo unknown), 1x MI355X"
+echo "# tools/r5_fuzz.sh $S (OUT=${OUT:-r06}) on commit $(cat .gpurun_head 2>/dev/null || echo unknown), 1x MI355X"
 echo "## $((600*S)) small cases (<= 420 x 300) with widths that are multiples of 16 (FUZZ_ALIGN=16: the wide chain every time), seed 60"; FUZZ_ALIGN=16 timeout 2400 python tools/fuzz_parity.py $((600*S)) 60 2>&1 | tail -3
 echo "## $((300*S)) small cases, random widths (one in sixteen the wide chain, the others the fallback), seed 61"; timeout 2400 python tools/fuzz_parity.py $((300*S)) 61 2>&1 | tail -3
 echo "## $((160*S)) large cases (<= 1500 x 700), widths multiples of 16, seed 62"; FUZZ_ALIGN=16 timeout 2400 python tools/fuzz_parity.py $((160*S)) 62 1500 700 2>&1 | tail -3
@@ -17,5 +17,5 @@ FUZZ_ALIGN=16 G1S_LATEST=device timeout 2400 python tools/fuzz_parity.py $((400*
 G1S_LATEST=device timeout 2400 python tools/fuzz_parity.py $((100*S)) 67 1500 700 2>&1 | tail -2
 echo "## damaged frames (isolated residuals outside int8): $((300*S)) cases, seed 65"; timeout 2400 python tools/debug_damage3.py $((300*S)) 65 2>&1 | grep -v amdgpu.ids | tail -4
 echo "(end)"
-} > gpurun_out/r05_fuzz_parity.txt 2>&1
-grep -v amdgpu.ids gpurun_out/r05_fuzz_parity.txt
+} > gpurun_out/${OUT:-r06}_fuzz_parity.txt 2>&1
+grep -v amdgpu.ids gpurun_out/${OUT:-r06}_fuzz_parity.txt
