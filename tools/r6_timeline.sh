@@ -10,7 +10,7 @@ cd "$ROOT"; mkdir -p gpurun_out/$TAG
 python - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/$TAG/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "g1s" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "g1s" in r["Kernel_Name"] or "ALL" in "${TL_ALL:-}"]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = len(rows)
 mid = rows[n * 3 // 8 - 10: n * 3 // 8 + 20]
