@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/r5_other_workloads.sh -- the other BASELINE workloads, the all-flat variant, the fallback chain and the two-rank
-# shared-GPU line on the current build (parity-test cases, not bench lines) -> gpurun_out/r05_other_workloads.txt
+# shared-GPU line on the current build (parity-test cases, not bench lines) -> gpurun_out/${OUT:-r06}_other_workloads.txt
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 python tools/ktime.py 2 > /dev/null 2>&1
@@ -19,8 +19,8 @@ echo "== 4k10 G1S_K3=stream (round 3's chain, the fallback)"; G1S_K3=stream one
 echo "== 4k10 --batch 32"; one --batch 32
 echo "== 4k10 G1S_LATEST=device (the per-frame half on the device)"; G1S_LATEST=device one
 echo "== 4k10, two ranks sharing the one GPU (G1S_BENCH_SHARE_GPU=1, torch.distributed.run --nproc-per-node 2, bench.py --gpus 2)"
-G1S_BENCH_SHARE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 2>/dev/null | tail -1 | tee gpurun_out/r05_bench_2ranks_shared_gpu.json | python -c "
+G1S_BENCH_SHARE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 2>/dev/null | tail -1 | tee gpurun_out/${OUT:-r06}_bench_2ranks_shared_gpu.json | python -c "
 import json,sys
 j=json.loads(sys.stdin.readline()); print(round(j['value']), 'Mpx/s', j['n_gpus'], 'ranks', round(j['ms_per_step'],2), 'ms/step', j['config']['parallelism'])"
-} > gpurun_out/r05_other_workloads.txt 2>&1
-cat gpurun_out/r05_other_workloads.txt
+} > gpurun_out/${OUT:-r06}_other_workloads.txt 2>&1
+cat gpurun_out/${OUT:-r06}_other_workloads.txt
