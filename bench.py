@@ -256,13 +256,10 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The table of the timed job is checked, not dropped: the same 30 720 frames once through a generator with HALF the frames a
-    # launch (another partition of the video into launches, other slices a workgroup: the integer records do not depend on it), untimed;
-    # every warm-up and timed step must end in the same bytes.
+    # The table of the timed job is checked, not dropped: behind the timed steps the same 30 720 frames go once more through a generator
+    # with HALF the frames a launch (another partition of the video into launches, other slices a workgroup: the integer records do not
+    # depend on it), untimed; every timed step must have ended in those bytes.
     check_tbl = None
-    if not multi and not args.no_table_check:
-        one_step(False, batch=max(1, B // 2))
-        check_tbl = tbl_digests.pop()
     for _ in range(args.warmup):
         one_step(False)
     barrier()
@@ -279,6 +276,9 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     host_cores_busy = (sum(os.times()[:2]) - cpu0) / max(elapsed, 1e-9)
     timed_digests = tbl_digests[n_untimed:]
+    if not multi and not args.no_table_check:  # (behind the timed region: nothing but the W warm-up steps runs in front of it)
+        one_step(False, batch=max(1, B // 2))
+        check_tbl = tbl_digests.pop()
     if rank == 0:
         assert len(timed_digests) == args.steps and len(set(timed_digests)) == 1, "the timed steps did not all end in one table"
         assert check_tbl is None or timed_digests[0] == check_tbl, "the timed job's table differs from the untimed half-batch job's"
