@@ -11,6 +11,9 @@ Three jobs over the same 1000 frames (tests/golden/make_golden.py LONG: scene cu
   streaming_device.tbl  the same with the per-frame half on the device (k4_latest, G1S_LATEST=device: what a 16-core quota takes).
   contiguous.tbl        ShardedDiff: 125 consecutive frames a rank ("125 per GPU x 8"), ONE all-gather of the integer records at
                         the end, the whole fold on rank 0.  Frame 500 is a shard boundary, frame 768 lies inside shard 6.
+
+G1S_LONG_NAME picks the job (tests/golden/make_golden.py LONG).  The second one is configs[4]'s format in eight shards: 7680x4320 10-bit
+4:4:4, 32 frames, batches and shards of 4 (one batch a rank), cuts at frame 16 (a boundary of both) and 22 (inside batch / shard 5).
 """
 import os
 import sys
@@ -23,8 +26,8 @@ from grav1synth_amd.dist import ShardedDiff, StreamingShardedDiff
 from grav1synth_amd.synth import make_pair
 from tests.golden import make_golden
 
-NAME = "oracle_full_3840x2160_10b_420_lag3_1000frames.tbl"
-BATCH = 64
+NAME = os.environ.get("G1S_LONG_NAME", "oracle_full_3840x2160_10b_420_lag3_1000frames.tbl")  # (the 8K 4:4:4 job of configs[4]: 32 frames, 4 a batch and shard)
+BATCH = int(make_golden.LONG[NAME].get("batch", 64))
 
 
 def job():

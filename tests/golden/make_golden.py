@@ -44,6 +44,10 @@ FULL_SIZE = {
 LONG = {
     "oracle_full_3840x2160_10b_420_lag3_1000frames.tbl": dict(spec=SynthSpec(3840, 2160, 10), frames=1000, lag=3, chroma=True,
                                                               cuts=(500, 768), fps=(24, 1)),
+    # configs[4]'s format in eight shards: 7680x4320 10-bit 4:4:4, lag 3, chroma, 32 frames (4 a shard x 8; 398 MB a frame pair).  Cuts at
+    # frame 16 (a boundary of the 4-frame shards and batches) and at frame 22 (inside one).  Ten minutes of oracle time.
+    "oracle_full_7680x4320_10b_444_lag3_32frames.tbl": dict(spec=SynthSpec(7680, 4320, 10, xdec=0, ydec=0), frames=32, lag=3, chroma=True,
+                                                            cuts=(16, 22), fps=(24, 1), batch=4),
 }
 
 
@@ -81,6 +85,7 @@ def generate_long(name, workers=3, checkpoint_every=25):
     o = OracleDiff(g["fps"][0], g["fps"][1], g["spec"].bit_depth, g["spec"].bit_depth, g["lag"], g["chroma"], library=L)
     # ... and the same states as the base build after two 4K frames (every f64 of the noise model)
     ob = OracleDiff(g["fps"][0], g["fps"][1], g["spec"].bit_depth, g["spec"].bit_depth, g["lag"], g["chroma"])
+    checkpoint_every = min(checkpoint_every, max(1, len(specs) // 8))
     ckpt = os.path.join("/tmp", name + ".ckpt")
     start = 0
     if os.path.exists(ckpt):

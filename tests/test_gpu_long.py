@@ -1,8 +1,11 @@
-"""BASELINE.json configs[3] at its stated size -- diff 3840x2160 10-bit 4:2:0, lag 3, chroma, 1000 frames sharded eight ways -- on the
+"""BASELINE.json configs[3] at its stated size -- diff 3840x2160 10-bit 4:2:0, lag 3, chroma, 1000 frames sharded eight ways -- and configs[4]'s
+format in eight shards -- 7680x4320 10-bit 4:4:4, 32 frames, four a shard, cuts at frame 16 (a shard boundary) and 22 (inside one) -- on the
 ONE device a test box has, against a table the oracle wrote for the same seeded frames (tests/golden/make_golden.py long: an hour
 and a half of oracle time, committed as data).  Two scene cuts: frame 500 (a boundary of the 125-frame shards, inside a 64-frame
 batch) and frame 768 (a boundary of the 64-frame batches, inside a 125-frame shard).  The reference's loop is strictly ordered
 (/root/reference/src/main.rs:432-521): whatever deals the frames, the table must be the ordered job's, byte for byte.
+
+(Both jobs run all of what follows; sizes below are the 4K job's.)
 
   * one generator, 1000 frames in order                                          (the plain path at this length)
   * eight gloo ranks sharing device 0: the streaming job with the per-frame half on the host and on the device, and contiguous
@@ -27,15 +30,20 @@ from tests.golden import make_golden
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAME = "oracle_full_3840x2160_10b_420_lag3_1000frames.tbl"
+NAMES = ["oracle_full_3840x2160_10b_420_lag3_1000frames.tbl", "oracle_full_7680x4320_10b_444_lag3_32frames.tbl"]
 
 
-@pytest.fixture(scope="module")
-def want():
-    with open(os.path.join(ROOT, "tests", "golden", NAME), "rb") as f:
+@pytest.fixture(scope="module", params=NAMES, ids=["4K_420_1000_frames", "8K_444_32_frames"])
+def job(request):
+    """(golden's name, its job, the frames' specs, fps, the golden's bytes)"""
+    from fractions import Fraction
+
+    name = request.param
+    g = make_golden.LONG[name]
+    with open(os.path.join(ROOT, "tests", "golden", name), "rb") as f:
         tbl = f.read()
-    assert tbl.count(b"\nE ") == 3, "the golden holds three segments (cuts at frames 500 and 768)"
-    return tbl
+    assert tbl.count(b"\nE ") == 3, "the golden holds three segments (two scene cuts)"
+    return name, g, make_golden.frame_specs(g), Fraction(*g["fps"]), tbl
 
 
 def _keep(name, tbl):
@@ -47,15 +55,8 @@ def _keep(name, tbl):
             f.write(tbl)
 
 
-def _job():
-    from fractions import Fraction
-
-    g = make_golden.LONG[NAME]
-    return g, make_golden.frame_specs(g), Fraction(*g["fps"])
-
-
-def test_one_generator_over_1000_frames_matches_the_oracle_golden(want):
-    g, specs, fps = _job()
+def test_one_generator_over_the_whole_job_matches_the_oracle_golden(job):
+    name, g, specs, fps, want = job
     spec = g["spec"]
     gen = DiffGenerator(fps, spec.bit_depth, spec.bit_depth, ar_coeff_lag=g["lag"])  # (the engine's own launch group: 64 frames at 4K)
     keep = []
@@ -74,14 +75,15 @@ def test_one_generator_over_1000_frames_matches_the_oracle_golden(want):
     assert got == want
 
 
-def test_eight_ranks_on_one_device_match_the_oracle_golden(tmp_path, want):
+def test_eight_ranks_on_one_device_match_the_oracle_golden(tmp_path, job):
+    name, g, specs, fps, want = job
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
     for rank in range(8):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="8", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   G1S_FOLD_THREADS="2", OMP_NUM_THREADS="1", GPU_MAX_HW_QUEUES="8")
+                   G1S_FOLD_THREADS="2", OMP_NUM_THREADS="1", GPU_MAX_HW_QUEUES="8", G1S_LONG_NAME=name)
         env.pop("G1S_LATEST", None)
         procs.append(subprocess.Popen([sys.executable, "-m", "tests.dist_gpu_long_worker", str(tmp_path)], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -105,10 +107,10 @@ def _y4m_frame(planes) -> bytes:
     return b"FRAME\n" + b"".join(p.cpu().numpy().astype("<u2", copy=False).tobytes() for p in planes)
 
 
-def test_the_sharded_command_over_two_pipes_matches_the_oracle_golden(tmp_path, want):
+def test_the_sharded_command_over_two_pipes_matches_the_oracle_golden(tmp_path, job):
     from grav1synth_amd.ingest import diff_y4m_files
 
-    g, specs, fps = _job()
+    name, g, specs, fps, want = job
     spec = g["spec"]
     fifos = {k: str(tmp_path / f"{k}.pipe") for k in ("src", "den")}
     for f in fifos.values():
@@ -136,7 +138,7 @@ def test_the_sharded_command_over_two_pipes_matches_the_oracle_golden(tmp_path, 
                 fcntl.fcntl(dst.fileno(), 1031, 1 << 20)  # F_SETPIPE_SZ
             except OSError:
                 pass
-            dst.write(f"YUV4MPEG2 W{spec.width} H{spec.height} F{fps.numerator}:{fps.denominator} Ip A1:1 C420p10\n".encode())
+            dst.write(f"YUV4MPEG2 W{spec.width} H{spec.height} F{fps.numerator}:{fps.denominator} Ip A1:1 C{'420' if spec.xdec else '444'}p10\n".encode())
             while True:
                 b = qs[name].get()
                 if b is None:
@@ -149,7 +151,7 @@ def test_the_sharded_command_over_two_pipes_matches_the_oracle_golden(tmp_path, 
     for t in ts:
         t.start()
     out = tmp_path / "out.tbl"
-    frames, unequal = diff_y4m_files(fifos["src"], fifos["den"], str(out), devices=[0] * 8)
+    frames, unequal = diff_y4m_files(fifos["src"], fifos["den"], str(out), devices=[0] * 8, batch_frames=int(g.get("batch", 0)))
     for t in ts:
         t.join(timeout=60)
         assert not t.is_alive()
