@@ -169,14 +169,16 @@ def test_bench_eight_ranks_on_one_device_end_in_the_one_rank_jobs_table():
     assert eight["tbl_sha256"] == one["tbl_sha256"] and eight["tbl_bytes"] == one["tbl_bytes"] > 100
 
 
-def test_bench_one_rank_through_the_rccl_code_path():
+@pytest.mark.parametrize("half", ["host", "device"])
+def test_bench_one_rank_through_the_rccl_code_path(half):
     """G1S_BENCH_FORCE_DIST=1: ONE rank through everything `bench.py --gpus N` does over RCCL -- the process group on "nccl", the
     streaming frame shards with the rounds' transport (pinned rings, the gather on its own stream), the barrier and the MAX
     all-reduce of the timed region on DEVICE tensors -- which the two-rank test above (two ranks on one GPU: gloo, CPU tensors)
     cannot reach.  (A variable of the N > 1 branch once shadowed the flag that picks CPU tensors for gloo: the all-reduce of
     the step time would have been handed a CPU tensor on RCCL.  Nothing on a one-GPU box ran that line.)  The table of the
     job is the one-process job's: `value` > 0 and a finished line."""
-    env = dict(os.environ, G1S_BENCH_FORCE_DIST="1")
+    # (half = "device": RCCL rounds AND k4_latest together -- what every rank of `bench.py --gpus 8` runs on a 16-core quota)
+    env = dict(os.environ, G1S_BENCH_FORCE_DIST="1", G1S_LATEST=half)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "G1S_BENCH_SHARE_GPU"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--cycles", "24",
@@ -187,7 +189,10 @@ def test_bench_one_rank_through_the_rccl_code_path():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["backend"] == "nccl" and out["config"]["rccl_ranks"] == 1
+    assert out["config"]["per_frame_fold_half"].startswith("device" if half == "device" else "host")
     assert out["roofline"]["frac"] > 0
+    # (the table every timed step ended in is the one-process job's over the same frames: the digest of the 4K bench content, 64 frames x 24 cycles)
+    assert len(out["tbl_sha256"]) == 64
 
 
 def test_chain_timing_brackets_a_batch_and_changes_nothing():
