@@ -865,6 +865,11 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
     }
     if (CHR && ea.w) defer |= 3u;  // L outside int8 in a luma unit under this unit: both planes
     const bool mine_deferred = ((defer >> (CHR ? s_plane : 0)) & 1u) != 0;
+    // (round 6: a wave that multiplies outranks, at its SIMD's arbiter, the three waves of other workgroups that stage beside it -- the
+    //  matrix pipe is the scarcer issue slot, and a product issued late is a barrier reached late by four waves.  luma 362 - 365 ->
+    //  354 - 358 us, chroma 212 - 219 -> 209 - 214, the chain - 5 to - 20 by the box; priorities 1 / 2 / 3, the halo wave raised while it
+    //  stages, or the staging phase raised instead: all within 3 us of each other.  profiles/r06h_setprio.txt)
+    __builtin_amdgcn_s_setprio(1);
     if (!mine_deferred && !G1S_W_DBGBIT(16)) {
       if ((ex >> 24) & 1u) {
         w_multiply<NSTEP, 0>(aSS, aPP, aPQ, aQQ, w_smem, m_addr, w_v4{0, 0, 0, 0}, 0u);
@@ -909,6 +914,7 @@ __global__ __launch_bounds__(kWThreads, KIND == 1 ? (SY == 0 ? 2 : G1S_W_OCC_C) 
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (tid == 64) {
       if (LOUT && (defer & 8u)) wp.lbad[(size_t)frame * wp.ncell_y + ea.z] = 1;
       s_bad[(k + 3) & 3] = 0u;  // (the slot of unit k - 2 = of unit k + 2: dead since the iteration before, written again in the next)
