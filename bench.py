@@ -169,7 +169,10 @@ def main() -> None:
         # host-half rate and leaves the host the launches, 27 KB a frame and the merge.  Measured with one rank held to n CPUs
         # (profiles/r05z_half_by_cores.txt): 8 CPUs 453 k (host) / 549 k (device) Mpx/s, 10 CPUs 542 / 548, 12 CPUs 553 / 485 - 549:
         # the device half below 10 cores a rank (two ranks on a 16-core quota have 8).
-        if cores_per_rank < 10:
+        # (not when the ranks SHARE one device -- the single-GPU rehearsal of this code path: two processes' low-priority k4_latest
+        #  streams on one GPU starve each other, 109 k Mpx/s where the host half reads 606 k, profiles/r06_other_workloads.txt; a
+        #  rehearsal that wants the device half says G1S_LATEST=device)
+        if cores_per_rank < 10 and not share:
             os.environ.setdefault("G1S_LATEST", "device")
     from grav1synth_amd.diff import DiffGenerator, format_tbl
     from grav1synth_amd.dist import ShardedDiff, StreamingShardedDiff
